@@ -1,0 +1,148 @@
+"""ctypes binding of oracle/libsilent_oracle.so (the C restatement) -- TEST INFRASTRUCTURE ONLY.
+
+Same import restrictions as silent_oracle.py: tests/, __graft_entry__.smoke() and bench.py's
+cpu_baseline leg only.
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_SO = os.path.join(_HERE, "libsilent_oracle.so")
+_lib = None
+
+_f = C.POINTER(C.c_float)
+
+
+def build(force=False):
+    if force or not os.path.exists(_SO) or os.path.getmtime(_SO) < os.path.getmtime(os.path.join(_HERE, "silent_oracle.c")):
+        subprocess.check_call(["make", "-C", _HERE, "-s"] + (["-B"] if force else []))
+    return _SO
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        build()
+        L = C.CDLL(_SO)
+        L.so_num_threads.restype = C.c_int
+        L.so_max_value_indices_region.restype = C.c_int64
+        L.so_max_value_indices_region.argtypes = [_f, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
+                                                  C.POINTER(C.c_int64), C.c_int64]
+        L.so_conv2d_same.argtypes = [_f, C.c_int, C.c_int, C.c_int, C.c_int, _f, C.c_int, C.c_int, C.c_int,
+                                     C.c_int, C.c_float, _f]
+        L.so_regulate.argtypes = [_f, C.c_int, C.c_int, C.c_int, C.c_int, _f, C.c_int, C.c_int, C.c_float,
+                                  C.c_float, C.c_int, _f]
+        L.so_pad_inwards.argtypes = [_f] + [C.c_int] * 8 + [_f]
+        L.so_value_from_color.argtypes = [_f, C.c_size_t, C.c_int, _f]
+        L.so_nms3x3.argtypes = [_f] + [C.c_int] * 5 + [_f]
+        L.so_top_value_points.argtypes = [_f, _f] + [C.c_int] * 4 + [C.c_float, _f]
+        L.so_zoom_level.argtypes = [_f] + [C.c_int] * 11 + [_f]
+        L.so_gray_line_end_level.argtypes = [_f, C.c_int, C.c_int, _f, _f, C.c_int, C.c_float, _f, _f]
+        _lib = L
+    return _lib
+
+
+def _p(a):
+    return a.ctypes.data_as(_f)
+
+
+def _c32(a):
+    return np.ascontiguousarray(a, dtype=np.float32)
+
+
+def num_threads():
+    return lib().so_num_threads()
+
+
+def set_num_threads(n):
+    lib().so_set_num_threads(C.c_int(n))
+
+
+def conv2d_same(x, k, relu=False, clip_hi=None):
+    x, k = _c32(x), _c32(k)
+    n, h, w, ci = x.shape
+    kh, kw, ki, co = k.shape
+    assert ki == ci and co <= 16
+    out = np.empty((n, h, w, co), np.float32)
+    flags = (1 if relu else 0) | (2 if clip_hi is not None else 0)
+    lib().so_conv2d_same(_p(x), n, h, w, ci, _p(k), kh, kw, co, flags, float(clip_hi or 0.0), _p(out))
+    return out
+
+
+def regulate(x, blur, rv, root=0.5, flat_policy="ieee"):
+    x, blur = _c32(x), _c32(blur)
+    n, h, w, c = x.shape
+    out = np.empty_like(x)
+    lib().so_regulate(_p(x), n, h, w, c, _p(blur), blur.shape[0], blur.shape[1], float(rv), float(root),
+                      {"ieee": 0, "zero": 1}[flat_policy], _p(out))
+    return out
+
+
+def pad_inwards(x, paddings):
+    x = _c32(x)
+    n, h, w, c = x.shape
+    out = np.empty_like(x)
+    lib().so_pad_inwards(_p(x), n, h, w, c, int(paddings[1][0]), int(paddings[1][1]), int(paddings[2][0]),
+                         int(paddings[2][1]), _p(out))
+    return out
+
+
+def value_from_color(x):
+    x = _c32(x)
+    out = np.empty(x.shape[:-1] + (1,), np.float32)
+    lib().so_value_from_color(_p(x), x.size // x.shape[-1], x.shape[-1], _p(out))
+    return out
+
+
+def nms3x3(x, mode="product"):
+    x = _c32(x)
+    n, h, w, c = x.shape
+    out = np.empty_like(x)
+    lib().so_nms3x3(_p(x), n, h, w, c, {"product": 0, "fired": 1}[mode], _p(out))
+    return out
+
+
+def top_value_points(color, top_percent=0.1, value=None):
+    color = _c32(color)
+    value = value_from_color(color) if value is None else _c32(value)
+    n, h, w, c = color.shape
+    out = np.empty_like(color)
+    lib().so_top_value_points(_p(color), _p(value), n, h, w, c, float(np.float32(top_percent)), _p(out))
+    return out
+
+
+def max_value_indices_region(color, region_shape, value=None):
+    value = value_from_color(_c32(color)) if value is None else _c32(value)
+    n, h, w, _ = value.shape
+    cap = n * h * w
+    idx = np.empty((cap, 4), np.int64)
+    cnt = lib().so_max_value_indices_region(_p(value), n, h, w, int(region_shape[1]), int(region_shape[2]),
+                                            idx.ctypes.data_as(C.POINTER(C.c_int64)), cap)
+    return idx[:cnt].copy()
+
+
+def zoom_level(frame, y0, x0, ch, cw, zh, zw, oh, ow):
+    frame = _c32(frame)
+    H, W, Cc = frame.shape
+    out = np.empty((oh, ow, Cc), np.float32)
+    lib().so_zoom_level(_p(frame), H, W, Cc, y0, x0, ch, cw, zh, zw, oh, ow, _p(out))
+    return out
+
+
+def classic_pyramid(frame, extents):
+    frame = _c32(frame)
+    H, W, _ = frame.shape
+    return [zoom_level(frame, 0, 0, H, W, zh, zw, zh, zw)[None] for zh, zw in extents]
+
+
+def gray_line_end_level(lev, cs_k, end_k, clip_hi=255.0):
+    lev, cs_k, end_k = _c32(lev), _c32(cs_k), _c32(end_k)
+    _, h, w, _ = lev.shape
+    K = end_k.shape[-1]
+    cs = np.empty((1, h, w, 1), np.float32)
+    end = np.empty((1, h, w, K), np.float32)
+    lib().so_gray_line_end_level(_p(lev), h, w, _p(cs_k), _p(end_k), K, float(clip_hi), _p(cs), _p(end))
+    return cs, end
