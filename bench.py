@@ -1,0 +1,174 @@
+#!/usr/bin/env python3
+"""bench.py -- Mpx/s of the full pyramid line-end pass @1080p (BASELINE.json metric), one rank per GPU.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--frames B] [--workload config2|config3|config5]
+
+A "step" is one pass of the hot path over one batch of B device-resident synthetic frames per rank:
+zoom pyramid -> center-surround -> ReLU -> oriented line-end bank -> ReLU -> clip (config 2/5) or the
+reference's RGB chain + keypoints (config 3).  Frames shard over ranks (frame i -> rank i mod N, no
+per-frame collective); the constant kernels are generated on rank 0 and broadcast once over RCCL.
+
+Rank 0 prints ONE JSON line.  ``value`` = input-frame megapixels per second over all ranks, inputs
+resident in HBM when the timed region starts.  ``roofline`` prices the dominant kernel (the fused filter
+pass) against HBM; ``cpu_baseline`` is the C port of the oracle timed on the host cores (N = 1 only).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import numpy as np  # noqa: E402
+
+WORKLOADS = {
+    # BASELINE.json configs[1]: 1080p grayscale, 5-level pyramid, center-surround + 4-orientation line-end
+    "config2": dict(hw=(1080, 1920), mode="gray", n_levels=5, n_orient=4,
+                    name="1080p gray, 5-level pyramid (scale 2), CS + 4-orientation line-end"),
+    # configs[2]: 1080p RGB, 6-level pyramid, normalize + peak extraction
+    "config3": dict(hw=(1080, 1920), mode="rgb", n_levels=6, n_orient=3,
+                    name="1080p RGB, 6-level pyramid (scale 2), rgc>rgby>stripe>regulate>end + keypoints"),
+    # configs[4]: 4K, 8-level pyramid, 8-orientation bank
+    "config5": dict(hw=(2160, 3840), mode="gray", n_levels=8, n_orient=8,
+                    name="4K gray, 8-level pyramid (scale 2), CS + 8-orientation line-end"),
+}
+HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+
+
+def cpu_baseline(wl, consts, budget_s=12.0):
+    """Time the C port of the oracle (oracle/silent_oracle.c, OpenMP over the host cores) on a bounded sample
+    of the same workload.  The oracle is the thing timed here, never part of the GPU path."""
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import c_oracle as co
+    import silent_oracle as so
+    from pysilent_amd.distributed import synthetic_frame
+    h, w = wl["hw"]
+    if wl["mode"] != "gray":
+        return None
+    extents = so.classic_extents(h, w, 2.0, wl["n_levels"])
+
+    def one(i):
+        frame = synthetic_frame(i, h, w, 1)
+        t = time.perf_counter()
+        pyr = co.classic_pyramid(frame, extents)
+        for lev in pyr:
+            co.gray_line_end_level(lev, consts["cs"], consts["end"])
+        return time.perf_counter() - t
+
+    one(0)                       # warm (page faults, OpenMP team start)
+    t1 = one(1)
+    n = int(max(4, min(512, budget_s / max(t1, 1e-3))))
+    total = sum(one(2 + i) for i in range(n))
+    return {"value": round(n * h * w / total / 1e6, 3), "unit": "Mpx/s", "cores": co.num_threads(), "kind": "port",
+            "sample": "%d synthetic %dx%d frames, whole pass (pyramid + CS + %d-orientation line-end), "
+                      "oracle/silent_oracle.c -O3 -fopenmp float64 accumulation, %.1f s of CPU work"
+                      % (n, w, h, wl["n_orient"], total),
+            "host_cpus": os.cpu_count(), "affinity": len(os.sched_getaffinity(0))}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--frames", type=int, default=0, help="frames per rank per step (0 = workload default)")
+    ap.add_argument("--workload", default="config2", choices=sorted(WORKLOADS))
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+    wl = WORKLOADS[args.workload]
+
+    import torch
+    from pysilent_amd import distributed as D
+    from pysilent_amd.pipeline import LineEndPipeline
+
+    rank, world, local = D.init()
+    if world != args.gpus:
+        raise SystemExit("--gpus %d but WORLD_SIZE is %d: launch with torch.distributed.run --nproc-per-node %d"
+                         % (args.gpus, world, args.gpus))
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+
+    # one RCCL broadcast of the constant kernels at init; nothing crosses GPUs per frame
+    consts = D.broadcast_constants(wl["mode"], wl["n_orient"], device=local)
+
+    h, w = wl["hw"]
+    c = 1 if wl["mode"] == "gray" else 3
+    # working set per rank well beyond the 256 MiB Infinity Cache (hard part 6)
+    B = args.frames or {"config2": 64, "config3": 32, "config5": 16}[args.workload]
+    pipe = LineEndPipeline((h, w), mode=wl["mode"], n_levels=wl["n_levels"], n_orient=wl["n_orient"], batch=B,
+                           device=local, constants=consts, max_keypoints_per_frame=1 << 16)
+    frames = torch.empty((B, h, w, c), dtype=torch.float32, device=dev)
+    for j, gi in enumerate(D.shard_frame_indices(B * world, rank, world)):
+        frames[j] = torch.from_numpy(D.synthetic_frame(gi, h, w, c)).to(dev)
+    torch.cuda.synchronize(dev)
+
+    for _ in range(args.warmup):
+        pipe.step(frames)
+    torch.cuda.synchronize(dev)
+    D.barrier()
+
+    # HIP events on the stream the kernels are launched on (torch's current stream), around the filter launch
+    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True),
+           torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
+    torch.cuda.synchronize(dev)
+    t0 = time.perf_counter()
+    for k in range(args.steps):
+        a, b, e = ev[k]
+        a.record()
+        pipe.run_pyramid(frames)
+        b.record()
+        pipe.run_filters()
+        e.record()
+        if wl["mode"] == "rgb":
+            pipe.run_keypoints()
+    torch.cuda.synchronize(dev)
+    elapsed = time.perf_counter() - t0
+    D.barrier()
+    elapsed = D.max_over_ranks(elapsed)
+
+    pyr_ms = float(np.mean([a.elapsed_time(b) for a, b, _ in ev]))
+    filt_ms = float(np.mean([b.elapsed_time(e) for _, b, e in ev]))
+
+    if rank != 0:
+        return
+    total_frames = B * world * args.steps
+    mpx_in = total_frames * h * w / elapsed / 1e6
+    mpx_pyr = total_frames * pipe.frame_px / elapsed / 1e6
+    filt_bytes = pipe.filter_bytes_per_frame() * B
+    out = {
+        "metric": "Mpx/s full pyramid line-end pass @1080p" if h == 1080 else "Mpx/s full pyramid line-end pass @4K",
+        "value": round(mpx_in, 2),
+        "unit": "Mpx/s",
+        "n_gpus": world,
+        "steps": args.steps,
+        "warmup": args.warmup,
+        "ms_per_step": round(elapsed / args.steps * 1e3, 4),
+        "higher_is_better": True,
+        "scaling": "weak",
+        "vs_baseline": None,
+        "dtype": "f32",
+        "data": "synthetic",
+        "config": {"workload": wl["name"], "frames_per_gpu_per_step": B, "frame": "%dx%dx%d f32" % (w, h, c),
+                   "pyramid_px_per_frame": pipe.frame_px, "level_extents": pipe.extents,
+                   "mpx_pyramid_per_s": round(mpx_pyr, 2), "frames_per_s": round(total_frames / elapsed, 1),
+                   "algorithmic_bytes_per_frame": pipe.algorithmic_bytes_per_frame(),
+                   "whole_pass_algorithmic_GBs_per_gpu": round(pipe.algorithmic_bytes_per_frame() * B * args.steps
+                                                               / elapsed / 1e9, 1),
+                   "pyramid_kernel_ms": round(pyr_ms, 4), "filter_kernel_ms": round(filt_ms, 4),
+                   "sharding": "frame i -> rank i mod N; one RCCL broadcast of constants at init"},
+        "roofline": {"bound": "hbm", "kernel": "gray_line_end_kernel" if wl["mode"] == "gray" else "rgb chain (5 launches)",
+                     "achieved": round(filt_bytes / (filt_ms * 1e-3) / 1e9, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                     "frac": round(filt_bytes / (filt_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4), "traffic": None,
+                     "algorithmic_bytes_per_launch": filt_bytes, "avg_launch_ms": round(filt_ms, 4)},
+    }
+    if world == 1 and not args.no_cpu_baseline:
+        out["cpu_baseline"] = cpu_baseline(wl, consts)
+    else:
+        out["cpu_baseline"] = None
+    print(json.dumps(out))
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,221 @@
+/* silent_hip.h -- C ABI of libsilent_hip.so: the MI355X (gfx950) implementation of pySILEnT's
+ * scale-space center-surround / oriented line-end detector hot path.
+ *
+ * The reference (SimLeek/pySILEnT, /root/reference) has NO plugin / operator / FFI layer: its
+ * boundary is a set of plain Python functions that build TensorFlow-1.x graph nodes
+ * (SURVEY.md section 8b).  Each entry point below therefore cites the reference *function* it
+ * replaces (path:line relative to /root/reference); the Python binding a maintainer would add
+ * (ctypes) is shown in INTEGRATION.md and implemented in pysilent_amd/_lib.py.
+ *
+ * Conventions
+ *   - Activations: float32, NHWC, "packed pyramid batch": n_frames consecutive pyramids, each
+ *     pyramid = level 0 .. level n_levels-1 back to back, level l = h_l x w_l x C row-major.
+ *     The reference's fixed-size layout [L, h, w, C] (util/zoom/from_image.py:47) is the special
+ *     case n_frames = 1, all extents equal -- byte-identical to the NumPy array it feeds TF.
+ *   - Kernels: float32, HWIO [kh, kw, C_in, C_out] (what tf.constant(k, dtype=tf.float32) holds).
+ *   - Convolutions: stride 1, SAME zero padding (pad_before = (k-1)/2), cross-correlation.
+ *   - Every function returns SILENT_OK (0) or a negative silent_status; the message is available
+ *     from silent_last_error().  Nothing throws or aborts across the ABI.
+ *   - Ownership: the caller owns every buffer; the library never keeps a caller pointer past
+ *     return.  silent_ctx / silent_pyramid_plan are library-owned handles.
+ *   - Threading: a silent_ctx is not thread-safe; use one per (host thread, GPU).
+ *   - Entry points without suffix take HOST pointers and are synchronous (they stage through the
+ *     context's device arena).  The *_dev twins take DEVICE pointers plus a hipStream_t (passed as
+ *     void*; NULL = the legacy default stream), are stream-ordered and do not synchronise.
+ */
+#ifndef SILENT_HIP_H
+#define SILENT_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SILENT_ABI_VERSION 1
+#define SILENT_MAX_LEVELS 16
+#define SILENT_MAX_KERNEL_FLOATS 784 /* kh*kw*C_in*C_out limit (weights travel as kernel arguments) */
+
+typedef enum silent_status {
+    SILENT_OK = 0,
+    SILENT_E_INVALID = -1,     /* bad argument (NULL pointer, extent <= 0, channel mismatch ...)  -> ValueError */
+    SILENT_E_HIP = -2,         /* a HIP runtime call failed                                       -> RuntimeError */
+    SILENT_E_CAPACITY = -3,    /* caller-provided index buffer too small; counts hold the need    -> ValueError */
+    SILENT_E_UNSUPPORTED = -4, /* shape outside the compiled set                                  -> ValueError */
+    SILENT_E_NOMEM = -5        /* device allocation failed                                        -> MemoryError */
+} silent_status;
+
+typedef struct silent_ctx silent_ctx;
+typedef struct silent_pyramid_plan silent_pyramid_plan;
+typedef void* silent_stream; /* hipStream_t */
+
+typedef struct silent_extent {
+    int32_t h, w;
+} silent_extent;
+
+/* conv flags */
+#define SILENT_RELU 1u /* tf.maximum(x, [0])            filters/rgc.py:13-16 */
+#define SILENT_CLIP 2u /* tf.clip_by_value(x, 0, hi)    recognition_testing.py:74 */
+
+/* regulate_tensor flat-region policy (hard part 3) */
+#define SILENT_FLAT_IEEE 0 /* literal: 0 * (rv / pow(0, root)) = NaN */
+#define SILENT_FLAT_ZERO 1 /* output 0 where the input is exactly 0 */
+
+/* nms modes */
+#define SILENT_NMS_PRODUCT 0 /* x * where(x == maxpool3x3(x), x, 0)   _experimental/vision_filter.py:88-89 */
+#define SILENT_NMS_FIRED 1   /* where(x == maxpool3x3(x), 1, 0)       util/energy/boosting.py:18-22 */
+
+/* ---------------------------------------------------------------------------- context */
+
+int silent_abi_version(void);
+/* Number of HIP devices visible (0 and SILENT_E_HIP when the runtime cannot initialise). */
+int silent_device_count(int* count);
+int silent_create(int device, silent_ctx** out);
+void silent_destroy(silent_ctx* ctx);
+/* Last error text of this context; ctx may be NULL (then: the last error of a failed silent_create). */
+const char* silent_last_error(const silent_ctx* ctx);
+int silent_device_name(const silent_ctx* ctx, char* buf, size_t len);
+
+/* Device-memory helpers so that a host without PyTorch can stay device-resident. */
+int silent_malloc(silent_ctx* ctx, size_t bytes, void** dptr);
+int silent_free(silent_ctx* ctx, void* dptr);
+int silent_memcpy_h2d(silent_ctx* ctx, void* dst_dev, const void* src_host, size_t bytes, silent_stream stream);
+int silent_memcpy_d2h(silent_ctx* ctx, void* dst_host, const void* src_dev, size_t bytes, silent_stream stream);
+int silent_synchronize(silent_ctx* ctx, silent_stream stream);
+
+/* ---------------------------------------------------------------------------- a-1 pyramid
+ * Replaces image_to_zoom_tensor, slam_recognition/util/zoom/from_image.py:10-69: per level a crop of
+ * the frame resampled by scipy.ndimage.zoom(plane, z, prefilter=False, order=5) (from_image.py:55-59:
+ * un-prefiltered quintic B-spline, output o -> o*(in-1)/(out-1), mirror tap extension, mode
+ * 'constant' out-of-range rule) and copied to the top-left of a canvas (from_image.py:61-64).
+ * Canvas pixels the zoomed crop does not cover are uninitialised in the reference; here they are 0.
+ * The HOST decides crop and zoom extents (Python's round() is part of scipy's contract) and passes
+ * them explicitly; "classic" whole-frame levels are the case crop = frame, out = zoom extents. */
+typedef struct silent_pyr_level {
+    int32_t src_y0, src_x0, src_h, src_w; /* crop of the frame that the resampler sees        */
+    int32_t zoom_h, zoom_w;               /* resampler output extents = round(src * zoom)     */
+    int32_t out_h, out_w;                 /* canvas (level) extents; copied region = min(zoom, out) */
+} silent_pyr_level;
+
+int silent_pyramid_plan_create(silent_ctx* ctx, int frame_h, int frame_w, int channels,
+                               const silent_pyr_level* levels, int n_levels, silent_pyramid_plan** out);
+void silent_pyramid_plan_destroy(silent_pyramid_plan* plan);
+/* frames: n_frames x [H, W, C] float32 (values as the reference feeds them: uint8 range cast to f32,
+ * recognition_testing.py:141).  pyr: packed pyramid batch with the plan's canvas extents. */
+int silent_pyramid(silent_ctx* ctx, const silent_pyramid_plan* plan, const float* frames, int n_frames, float* pyr);
+int silent_pyramid_dev(silent_ctx* ctx, const silent_pyramid_plan* plan, const float* frames, int n_frames,
+                       float* pyr, silent_stream stream);
+
+/* ---------------------------------------------------------------------------- a-2..a-5 convolution
+ * Replaces the tf.nn.conv2d(+tf.maximum(+tf.clip_by_value)) call sites:
+ *   rgc_filter          slam_recognition/filters/rgc.py:6-18
+ *   rgby_filter         slam_recognition/filters/rgby.py:6-14
+ *   orientation_filter  slam_recognition/filters/orientation.py:17-29 (the stripe conv)
+ *   apply_filter        slam_recognition/util/apply_filter.py:4-7 (+ relu/clip recognition_testing.py:73-74)
+ * flags: SILENT_RELU | SILENT_CLIP (clip to [0, clip_hi]); NaN handling is Eigen's (x < 0 ? 0 : x). */
+int silent_conv2d_same(silent_ctx* ctx, const float* in, const silent_extent* levels, int n_levels, int n_frames,
+                       int c_in, const float* kernel_hwio, int kh, int kw, int c_out, unsigned flags,
+                       float clip_hi, float* out);
+int silent_conv2d_same_dev(silent_ctx* ctx, const float* in, const silent_extent* levels, int n_levels,
+                           int n_frames, int c_in, const float* kernel_hwio, int kh, int kw, int c_out,
+                           unsigned flags, float clip_hi, float* out, silent_stream stream);
+
+/* ---------------------------------------------------------------------------- fused grayscale pass
+ * BASELINE configs 1/2/5: per level
+ *     cs  = relu(conv3x3(x,  cs_kernel[3,3,1,1]))
+ *     end = clip(relu(conv3x3(cs, end_bank[3,3,1,K])), 0, clip_hi)
+ * i.e. the reference chain order recognition_testing.py:69-74 restricted to one input channel, in one
+ * kernel launch (the CS map never leaves LDS between the two convolutions).  K in {3, 4, 8}.
+ * cs_out: packed [.., h_l, w_l, 1]; end_out: packed [.., h_l, w_l, K]; either may be NULL to skip it. */
+int silent_gray_line_end(silent_ctx* ctx, const float* pyr, const silent_extent* levels, int n_levels, int n_frames,
+                         const float* cs_kernel, const float* end_bank, int n_orient, float clip_hi,
+                         float* cs_out, float* end_out);
+int silent_gray_line_end_dev(silent_ctx* ctx, const float* pyr, const silent_extent* levels, int n_levels,
+                             int n_frames, const float* cs_kernel, const float* end_bank, int n_orient,
+                             float clip_hi, float* cs_out, float* end_out, silent_stream stream);
+
+/* ---------------------------------------------------------------------------- a-6 regulator
+ * Replaces regulate_tensor, slam_recognition/util/regulator/gaussian_regulator_tensor.py:10-36:
+ *   y = x * (rv / pow(min(conv(x, blur), 1), root)); blur is HWIO [kh, kw, C, C]. */
+int silent_regulate(silent_ctx* ctx, const float* in, const silent_extent* levels, int n_levels, int n_frames,
+                    int channels, const float* blur_hwio, int kh, int kw, float regulation_value,
+                    float regulation_root, int flat_policy, float* out);
+int silent_regulate_dev(silent_ctx* ctx, const float* in, const silent_extent* levels, int n_levels, int n_frames,
+                        int channels, const float* blur_hwio, int kh, int kw, float regulation_value,
+                        float regulation_root, int flat_policy, float* out, silent_stream stream);
+
+/* ---------------------------------------------------------------------------- a-7 / a-8 pointwise
+ * pad_inwards            slam_recognition/util/selection/isolate_rectangle.py:19-23 (multiply by a 0/1 mask)
+ * get_value_from_color   slam_recognition/util/color/get_value.py:6-12 (channel sum * float32(1/C)) */
+int silent_pad_inwards(silent_ctx* ctx, const float* in, const silent_extent* levels, int n_levels, int n_frames,
+                       int channels, int pad_top, int pad_bottom, int pad_left, int pad_right, float* out);
+int silent_pad_inwards_dev(silent_ctx* ctx, const float* in, const silent_extent* levels, int n_levels,
+                           int n_frames, int channels, int pad_top, int pad_bottom, int pad_left, int pad_right,
+                           float* out, silent_stream stream);
+int silent_value_from_color(silent_ctx* ctx, const float* in, const silent_extent* levels, int n_levels,
+                            int n_frames, int channels, float* out);
+int silent_value_from_color_dev(silent_ctx* ctx, const float* in, const silent_extent* levels, int n_levels,
+                                int n_frames, int channels, float* out, silent_stream stream);
+
+/* ---------------------------------------------------------------------------- a-9 non-max suppression */
+int silent_nms3x3(silent_ctx* ctx, const float* in, const silent_extent* levels, int n_levels, int n_frames,
+                  int channels, int mode, float* out);
+int silent_nms3x3_dev(silent_ctx* ctx, const float* in, const silent_extent* levels, int n_levels, int n_frames,
+                      int channels, int mode, float* out, silent_stream stream);
+
+/* ---------------------------------------------------------------------------- a-10 top-percent threshold
+ * Replaces top_value_points, slam_recognition/util/selection/top_value_points.py:8-29: per level
+ * (= per batch item of the reference) thr = (1-p)*max(value) + p*min(value), out = color * (value >= thr).
+ * value: packed 1-channel map (NULL -> computed from color as get_value_from_color does). */
+int silent_top_value_points(silent_ctx* ctx, const float* color, const float* value, const silent_extent* levels,
+                            int n_levels, int n_frames, int channels, double top_percent, float* out);
+int silent_top_value_points_dev(silent_ctx* ctx, const float* color, const float* value,
+                                const silent_extent* levels, int n_levels, int n_frames, int channels,
+                                double top_percent, float* out, silent_stream stream);
+
+/* ---------------------------------------------------------------------------- a-11 keypoint indices
+ * Replaces max_value_indices_region, slam_recognition/util/selection/top_value_points.py:32-45:
+ * tf.where(value >= resize_nearest(max_pool(value, k=(H,W), strides=(rH,rW), SAME))) with the TF1
+ * SAME / NEAREST index rules.  regions[l] = (rH, rW) of level l; at most
+ * 4 x 4 windows per level (ceil(h/rH), ceil(w/rW) <= 4; the reference uses 2 x 2).
+ * idx: n_frames x cap_per_frame x 4 int64 rows (level, y, x, 0), ROW-MAJOR SORTED within a frame like
+ * tf.where; counts[f] = number of rows frame f produced.  If any count exceeds cap_per_frame only the
+ * first cap_per_frame rows of that frame are written and the host call returns SILENT_E_CAPACITY.
+ * The _dev twin leaves counts on the device and cannot report capacity: check counts yourself. */
+int silent_max_value_indices_region(silent_ctx* ctx, const float* value, const silent_extent* levels, int n_levels,
+                                    int n_frames, const silent_extent* regions, int64_t* idx,
+                                    size_t cap_per_frame, int64_t* counts);
+int silent_max_value_indices_region_dev(silent_ctx* ctx, const float* value, const silent_extent* levels,
+                                        int n_levels, int n_frames, const silent_extent* regions, int64_t* idx,
+                                        size_t cap_per_frame, int64_t* counts, silent_stream stream);
+
+/* ---------------------------------------------------------------------------- fused RGB chain
+ * The reference graph recognition_testing.py:69-77 on 3-channel levels, in two launches:
+ *   orient   = regulate(relu(conv(relu(conv(relu(conv(x, rgc)), rgby)), stripe)), blur, rv, root)   (:69-71)
+ *   line_end = pad_inwards(clip(relu(conv(orient, end)), 0, clip_hi), pad)                          (:73-75)
+ *   value    = get_value_from_color(line_end)                                                        (:77)
+ * Every kernel is HWIO [3,3,3,3] except blur [7,7,3,3].  Any of the three outputs may be NULL. */
+typedef struct silent_rgb_chain_params {
+    const float* rgc;    /* midget_rgc(2)              filters/rgc.py:9      */
+    const float* rgby;   /* rgby_3(2)                  filters/rgby.py:9     */
+    const float* stripe; /* rgb_2d_stripe_tensors()    filters/orientation.py:19 */
+    const float* blur;   /* blur_tensor(2, 7)          filters/orientation.py:20 */
+    const float* end;    /* rgb_2d_end_tensors()       recognition_testing.py:29 */
+    float regulation_value, regulation_root; /* 1.0, 0.1   filters/orientation.py:33 */
+    int32_t flat_policy;
+    float clip_hi;       /* 255                        recognition_testing.py:74 */
+    int32_t pad;         /* 2                          recognition_testing.py:75 */
+} silent_rgb_chain_params;
+
+int silent_rgb_line_end(silent_ctx* ctx, const float* pyr, const silent_extent* levels, int n_levels, int n_frames,
+                        const silent_rgb_chain_params* params, float* orient_out, float* line_end_out,
+                        float* value_out);
+int silent_rgb_line_end_dev(silent_ctx* ctx, const float* pyr, const silent_extent* levels, int n_levels,
+                            int n_frames, const silent_rgb_chain_params* params, float* orient_out,
+                            float* line_end_out, float* value_out, silent_stream stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SILENT_HIP_H */

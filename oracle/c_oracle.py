@@ -38,7 +38,7 @@ def lib():
         L.so_pad_inwards.argtypes = [_f] + [C.c_int] * 8 + [_f]
         L.so_value_from_color.argtypes = [_f, C.c_size_t, C.c_int, _f]
         L.so_nms3x3.argtypes = [_f] + [C.c_int] * 5 + [_f]
-        L.so_top_value_points.argtypes = [_f, _f] + [C.c_int] * 4 + [C.c_float, _f]
+        L.so_top_value_points.argtypes = [_f, _f] + [C.c_int] * 4 + [C.c_double, _f]
         L.so_zoom_level.argtypes = [_f] + [C.c_int] * 11 + [_f]
         L.so_gray_line_end_level.argtypes = [_f, C.c_int, C.c_int, _f, _f, C.c_int, C.c_float, _f, _f]
         _lib = L
@@ -110,7 +110,7 @@ def top_value_points(color, top_percent=0.1, value=None):
     value = value_from_color(color) if value is None else _c32(value)
     n, h, w, c = color.shape
     out = np.empty_like(color)
-    lib().so_top_value_points(_p(color), _p(value), n, h, w, c, float(np.float32(top_percent)), _p(out))
+    lib().so_top_value_points(_p(color), _p(value), n, h, w, c, float(top_percent), _p(out))
     return out
 
 

@@ -158,15 +158,16 @@ SO_API void so_level_max_min(const float* v, int n, size_t npx, float* mx, float
 }
 
 SO_API void so_top_value_points(const float* color, const float* value, int n, int h, int w, int c,
-                                float top_percent, float* out) {
+                                double top_percent, float* out) {
     const size_t npx = (size_t)h * w;
     float* mx = (float*)malloc(sizeof(float) * n * 2);
     float* mn = mx + n;
     so_level_max_min(value, n, npx, mx, mn);
-    const float a = (float)(1.0 - (double)top_percent); /* python: float32(1.0 - p) */
+    const float a = (float)(1.0 - top_percent); /* python: float32(1.0 - p) */
+    const float pf = (float)top_percent;
     for (int b = 0; b < n; ++b) {
         volatile float t0 = a * mx[b];
-        volatile float t1 = top_percent * mn[b];
+        volatile float t1 = pf * mn[b];
         const float thr = t0 + t1;
 #pragma omp parallel for schedule(static)
         for (size_t p = 0; p < npx; ++p) {

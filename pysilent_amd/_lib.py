@@ -1,0 +1,157 @@
+"""ctypes binding of libsilent_hip.so (include/silent_hip.h) -- the only way the package reaches the GPU.
+
+There is no CPU fallback anywhere in this package: if the shared library is missing, or no
+gfx950 device is visible, the filters raise.  (The CPU oracle lives in ``oracle/`` and is test
+infrastructure; nothing under ``pysilent_amd`` imports it.)
+"""
+import ctypes as C
+import importlib.util
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libsilent_hip.so")
+
+SILENT_OK = 0
+SILENT_E_INVALID = -1
+SILENT_E_HIP = -2
+SILENT_E_CAPACITY = -3
+SILENT_E_UNSUPPORTED = -4
+SILENT_E_NOMEM = -5
+
+RELU = 1
+CLIP = 2
+FLAT_IEEE = 0
+FLAT_ZERO = 1
+NMS_PRODUCT = 0
+NMS_FIRED = 1
+MAX_LEVELS = 16
+ABI_VERSION = 1
+
+
+class Extent(C.Structure):
+    _fields_ = [("h", C.c_int32), ("w", C.c_int32)]
+
+
+class PyrLevel(C.Structure):
+    _fields_ = [("src_y0", C.c_int32), ("src_x0", C.c_int32), ("src_h", C.c_int32), ("src_w", C.c_int32),
+                ("zoom_h", C.c_int32), ("zoom_w", C.c_int32), ("out_h", C.c_int32), ("out_w", C.c_int32)]
+
+
+class RgbChainParams(C.Structure):
+    _fields_ = [("rgc", C.POINTER(C.c_float)), ("rgby", C.POINTER(C.c_float)), ("stripe", C.POINTER(C.c_float)),
+                ("blur", C.POINTER(C.c_float)), ("end", C.POINTER(C.c_float)),
+                ("regulation_value", C.c_float), ("regulation_root", C.c_float), ("flat_policy", C.c_int32),
+                ("clip_hi", C.c_float), ("pad", C.c_int32)]
+
+
+class SilentLibraryError(RuntimeError):
+    """libsilent_hip.so is missing or cannot be loaded."""
+
+
+_lib = None
+
+_vp = C.c_void_p
+_fp = C.c_void_p          # float* passed as an address (host ndarray.ctypes.data or a device pointer)
+_ep = C.POINTER(Extent)
+_i, _u, _f, _d, _sz = C.c_int, C.c_uint, C.c_float, C.c_double, C.c_size_t
+
+# name -> argtypes (restype is int unless listed in _RESTYPES)
+_SIGNATURES = {
+    "silent_abi_version": [],
+    "silent_device_count": [C.POINTER(_i)],
+    "silent_create": [_i, C.POINTER(_vp)],
+    "silent_destroy": [_vp],
+    "silent_last_error": [_vp],
+    "silent_device_name": [_vp, C.c_char_p, _sz],
+    "silent_malloc": [_vp, _sz, C.POINTER(_vp)],
+    "silent_free": [_vp, _vp],
+    "silent_memcpy_h2d": [_vp, _vp, _vp, _sz, _vp],
+    "silent_memcpy_d2h": [_vp, _vp, _vp, _sz, _vp],
+    "silent_synchronize": [_vp, _vp],
+    "silent_pyramid_plan_create": [_vp, _i, _i, _i, C.POINTER(PyrLevel), _i, C.POINTER(_vp)],
+    "silent_pyramid_plan_destroy": [_vp],
+    "silent_pyramid": [_vp, _vp, _fp, _i, _fp],
+    "silent_pyramid_dev": [_vp, _vp, _fp, _i, _fp, _vp],
+    "silent_conv2d_same": [_vp, _fp, _ep, _i, _i, _i, _fp, _i, _i, _i, _u, _f, _fp],
+    "silent_conv2d_same_dev": [_vp, _fp, _ep, _i, _i, _i, _fp, _i, _i, _i, _u, _f, _fp, _vp],
+    "silent_gray_line_end": [_vp, _fp, _ep, _i, _i, _fp, _fp, _i, _f, _fp, _fp],
+    "silent_gray_line_end_dev": [_vp, _fp, _ep, _i, _i, _fp, _fp, _i, _f, _fp, _fp, _vp],
+    "silent_regulate": [_vp, _fp, _ep, _i, _i, _i, _fp, _i, _i, _f, _f, _i, _fp],
+    "silent_regulate_dev": [_vp, _fp, _ep, _i, _i, _i, _fp, _i, _i, _f, _f, _i, _fp, _vp],
+    "silent_pad_inwards": [_vp, _fp, _ep, _i, _i, _i, _i, _i, _i, _i, _fp],
+    "silent_pad_inwards_dev": [_vp, _fp, _ep, _i, _i, _i, _i, _i, _i, _i, _fp, _vp],
+    "silent_value_from_color": [_vp, _fp, _ep, _i, _i, _i, _fp],
+    "silent_value_from_color_dev": [_vp, _fp, _ep, _i, _i, _i, _fp, _vp],
+    "silent_nms3x3": [_vp, _fp, _ep, _i, _i, _i, _i, _fp],
+    "silent_nms3x3_dev": [_vp, _fp, _ep, _i, _i, _i, _i, _fp, _vp],
+    "silent_top_value_points": [_vp, _fp, _fp, _ep, _i, _i, _i, _d, _fp],
+    "silent_top_value_points_dev": [_vp, _fp, _fp, _ep, _i, _i, _i, _d, _fp, _vp],
+    "silent_max_value_indices_region": [_vp, _fp, _ep, _i, _i, _ep, _vp, _sz, _vp],
+    "silent_max_value_indices_region_dev": [_vp, _fp, _ep, _i, _i, _ep, _vp, _sz, _vp, _vp],
+    "silent_rgb_line_end": [_vp, _fp, _ep, _i, _i, C.POINTER(RgbChainParams), _fp, _fp, _fp],
+    "silent_rgb_line_end_dev": [_vp, _fp, _ep, _i, _i, C.POINTER(RgbChainParams), _fp, _fp, _fp, _vp],
+}
+_RESTYPES = {"silent_destroy": None, "silent_pyramid_plan_destroy": None, "silent_last_error": C.c_char_p}
+
+EXPORTED_SYMBOLS = tuple(sorted(_SIGNATURES))
+
+
+def _preload_hip_runtime():
+    """One HIP runtime per process.  PyTorch-ROCm wheels bundle their own libamdhip64.so with the same
+    SONAME as /opt/rocm's; if torch is installed, load ITS copy first (by path, RTLD_GLOBAL) so that our
+    DT_NEEDED libamdhip64.so.7 binds to the very file ``import torch`` will map later.  Without torch the
+    library's RUNPATH (/opt/rocm/lib) applies."""
+    try:
+        spec = importlib.util.find_spec("torch")
+    except (ImportError, ValueError):
+        spec = None
+    if spec is None or not spec.origin:
+        return
+    cand = os.path.join(os.path.dirname(spec.origin), "lib", "libamdhip64.so")
+    if os.path.exists(cand):
+        try:
+            C.CDLL(cand, mode=C.RTLD_GLOBAL)
+        except OSError:
+            pass
+
+
+def load():
+    """Load (once) and return the ctypes handle; raises SilentLibraryError when the .so is absent."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise SilentLibraryError(
+            "%s not found: build it with `python pysilent_amd/csrc/build.py` (hipcc --offload-arch=gfx950). "
+            "pysilent_amd has no CPU fallback." % LIB_PATH)
+    _preload_hip_runtime()
+    try:
+        lib = C.CDLL(LIB_PATH)
+    except OSError as e:
+        raise SilentLibraryError("cannot load %s: %s" % (LIB_PATH, e))
+    for name, argtypes in _SIGNATURES.items():
+        fn = getattr(lib, name)          # AttributeError here = header / library mismatch
+        fn.argtypes = argtypes
+        fn.restype = _RESTYPES.get(name, C.c_int)
+    got = lib.silent_abi_version()
+    if got != ABI_VERSION:
+        raise SilentLibraryError("libsilent_hip.so ABI %d != binding ABI %d" % (got, ABI_VERSION))
+    _lib = lib
+    return lib
+
+
+def last_error(ctx_handle):
+    msg = load().silent_last_error(ctx_handle)
+    return msg.decode("utf-8", "replace") if msg else ""
+
+
+def check(rc, ctx_handle=None):
+    """Map a silent_status to the Python exception the reference's callers would see."""
+    if rc == SILENT_OK:
+        return
+    msg = last_error(ctx_handle) or ("silent_status %d" % rc)
+    if rc in (SILENT_E_INVALID, SILENT_E_UNSUPPORTED, SILENT_E_CAPACITY):
+        raise ValueError(msg)
+    if rc == SILENT_E_NOMEM:
+        raise MemoryError(msg)
+    raise RuntimeError(msg)

@@ -1,0 +1,416 @@
+"""Host-side runtime above the C ABI: contexts, tensor adapters, one thin wrapper per entry point.
+
+Tensors the wrappers accept (the reference accepts ``tf.Tensor`` or ``np.ndarray``, get_dimensions.py:9-12):
+  * ``np.ndarray`` rank 4 NHWC  -> host-pointer entry points, result is a fresh float32 ndarray
+  * ``torch.Tensor`` on a ROCm device, rank 4 NHWC -> ``*_dev`` entry points on torch's current stream,
+    result is a torch tensor on the same device (PyTorch is only the allocator / stream provider)
+  * ``PackedPyramid`` (ragged levels, host or device) -> same, result is a PackedPyramid
+Anything else raises the reference's TypeError.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+from . import _lib
+
+TYPE_ERROR_MESSAGE = "Input to orientation filter must either be tensor or numpy array."
+
+
+# ----------------------------------------------------------------------------- context
+
+class Context(object):
+    """One silent_ctx: one per (host thread, GPU); not thread-safe."""
+
+    def __init__(self, device=0):
+        lib = _lib.load()
+        self._lib = lib
+        self.device = int(device)
+        self.handle = C.c_void_p()
+        rc = lib.silent_create(self.device, C.byref(self.handle))
+        if rc != _lib.SILENT_OK:
+            msg = _lib.last_error(None)
+            self.handle = C.c_void_p()
+            raise RuntimeError("pysilent_amd needs an MI355X (gfx950) GPU and has no CPU fallback: " + msg)
+
+    @property
+    def name(self):
+        buf = C.create_string_buffer(256)
+        self._lib.silent_device_name(self.handle, buf, 256)
+        return buf.value.decode()
+
+    def check(self, rc):
+        _lib.check(rc, self.handle)
+
+    def close(self):
+        if self.handle:
+            self._lib.silent_destroy(self.handle)
+            self.handle = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+_contexts = {}
+
+
+def default_device():
+    if "SILENT_DEVICE" in os.environ:
+        return int(os.environ["SILENT_DEVICE"])
+    return int(os.environ.get("LOCAL_RANK", "0"))
+
+
+def get_context(device=None):
+    device = default_device() if device is None else int(device)
+    ctx = _contexts.get(device)
+    if ctx is None:
+        ctx = _contexts[device] = Context(device)
+    return ctx
+
+
+def device_count():
+    n = C.c_int(0)
+    _lib.load().silent_device_count(C.byref(n))
+    return n.value
+
+
+# ----------------------------------------------------------------------------- tensors
+
+def is_torch_tensor(x):
+    return type(x).__module__.split(".")[0] == "torch" and hasattr(x, "data_ptr")
+
+
+class PackedPyramid(object):
+    """A batch of pyramids with per-level extents, packed as the C ABI wants it.
+
+    ``data`` is a flat float32 buffer (np.ndarray, or torch tensor on the GPU) of
+    ``n_frames * sum(h_l * w_l) * channels`` elements: frames outermost, then levels, NHWC inside."""
+
+    def __init__(self, data, extents, channels, n_frames=1):
+        self.extents = [(int(h), int(w)) for h, w in extents]
+        self.channels = int(channels)
+        self.n_frames = int(n_frames)
+        self.frame_px = sum(h * w for h, w in self.extents)
+        n = self.n_frames * self.frame_px * self.channels
+        if is_torch_tensor(data):
+            data = data.reshape(-1)
+        else:
+            data = np.ascontiguousarray(data, dtype=np.float32).reshape(-1)
+        if data.shape[0] != n:
+            raise ValueError("PackedPyramid: buffer holds %d floats, extents need %d" % (data.shape[0], n))
+        self.data = data
+
+    @property
+    def on_device(self):
+        return is_torch_tensor(self.data)
+
+    @classmethod
+    def from_levels(cls, levels):
+        """levels: list of [n_frames, h_l, w_l, C] float32 ndarrays."""
+        n_frames, c = levels[0].shape[0], levels[0].shape[-1]
+        ext = [l.shape[1:3] for l in levels]
+        per_frame = [np.concatenate([np.ascontiguousarray(l[f], np.float32).reshape(-1) for l in levels])
+                     for f in range(n_frames)]
+        return cls(np.concatenate(per_frame), ext, c, n_frames)
+
+    def level(self, l):
+        """[n_frames, h_l, w_l, C] view (host: NumPy view; device: torch view)."""
+        h, w = self.extents[l]
+        off = sum(eh * ew for eh, ew in self.extents[:l]) * self.channels
+        n = h * w * self.channels
+        return self.data.reshape(self.n_frames, -1)[:, off:off + n].reshape(self.n_frames, h, w, self.channels)
+
+    def levels(self):
+        return [self.level(l) for l in range(len(self.extents))]
+
+    def like(self, channels, data=None):
+        """Same geometry, other channel count; allocates when data is None."""
+        n = self.n_frames * self.frame_px * channels
+        if data is None:
+            if self.on_device:
+                import torch
+                data = torch.empty(n, dtype=torch.float32, device=self.data.device)
+            else:
+                data = np.empty(n, dtype=np.float32)
+        return PackedPyramid(data, self.extents, channels, self.n_frames)
+
+
+class _Operand(object):
+    """Normalised view of an input tensor: geometry + pointer + how to allocate results."""
+
+    def __init__(self, x, channels=None):
+        self.packed = isinstance(x, PackedPyramid)
+        if self.packed:
+            self.src = x
+            buf = x.data
+            self.extents, self.n_frames, self.c = x.extents, x.n_frames, x.channels
+            self.dev = x.on_device
+        elif isinstance(x, np.ndarray) or is_torch_tensor(x):
+            if x.ndim != 4:
+                raise ValueError("expected a rank-4 NHWC tensor, got shape %s" % (tuple(x.shape),))
+            n, h, w, c = (int(s) for s in x.shape)
+            if min(n, h, w, c) < 1:
+                raise ValueError("empty tensor: shape %s" % (tuple(x.shape),))
+            self.extents, self.n_frames, self.c = [(h, w)], n, c
+            self.dev = is_torch_tensor(x)
+            buf = x
+        else:
+            raise TypeError(TYPE_ERROR_MESSAGE)
+        if channels is not None and self.c != channels:
+            raise ValueError("tensor has %d channels, expected %d" % (self.c, channels))
+        if self.dev:
+            import torch
+            if not buf.is_cuda:
+                raise TypeError("torch tensors must live on the GPU (use a numpy array for host data)")
+            buf = buf.to(torch.float32).contiguous()
+            self.device = buf.device.index or 0
+            self.stream = C.c_void_p(torch.cuda.current_stream(buf.device).cuda_stream)
+            self.ptr = C.c_void_p(buf.data_ptr())
+            self._torch_device = buf.device
+        else:
+            buf = np.ascontiguousarray(buf, dtype=np.float32)
+            self.device = None
+            self.stream = None
+            self.ptr = C.c_void_p(buf.ctypes.data)
+        self.buf = buf                                  # keep alive
+        self.frame_px = sum(h * w for h, w in self.extents)
+        self.levels = (_lib.Extent * len(self.extents))(*[_lib.Extent(h, w) for h, w in self.extents])
+        self.n_levels = len(self.extents)
+        self.ctx = get_context(self.device)
+
+    def alloc(self, channels, dtype=np.float32):
+        n = self.n_frames * self.frame_px * channels
+        if self.dev:
+            import torch
+            tdt = {np.float32: torch.float32, np.int64: torch.int64}[dtype]
+            out = torch.empty(n, dtype=tdt, device=self._torch_device)
+            return out, C.c_void_p(out.data_ptr())
+        out = np.empty(n, dtype=dtype)
+        return out, C.c_void_p(out.ctypes.data)
+
+    def wrap(self, flat, channels):
+        if self.packed:
+            return PackedPyramid(flat, self.extents, channels, self.n_frames)
+        h, w = self.extents[0]
+        return flat.reshape(self.n_frames, h, w, channels)
+
+    def geom(self):
+        return (self.levels, self.n_levels, self.n_frames)
+
+
+def _kernel_arg(k, c_in=None):
+    k = np.ascontiguousarray(np.asarray(k, dtype=np.float64).astype(np.float32))   # tf.constant(k, float32)
+    if k.ndim != 4:
+        raise ValueError("filter must be HWIO rank 4, got shape %s" % (k.shape,))
+    if c_in is not None and k.shape[2] != c_in:
+        raise ValueError("filter C_in %d does not match tensor channels %d" % (k.shape[2], c_in))
+    return k
+
+
+def _same_geometry(a, b, what):
+    if a.extents != b.extents or a.n_frames != b.n_frames or a.dev != b.dev:
+        raise ValueError("%s: tensors differ in geometry or placement" % what)
+
+
+# ----------------------------------------------------------------------------- op wrappers
+
+def conv2d_same(x, kernel_hwio, relu=False, clip_hi=None):
+    op = _Operand(x)
+    k = _kernel_arg(kernel_hwio, op.c)
+    kh, kw, _, co = k.shape
+    out, optr = op.alloc(co)
+    flags = (_lib.RELU if relu else 0) | (_lib.CLIP if clip_hi is not None else 0)
+    lib, ctx = _lib.load(), op.ctx
+    args = (ctx.handle, op.ptr) + op.geom() + (op.c, C.c_void_p(k.ctypes.data), kh, kw, co, flags,
+                                                  float(clip_hi or 0.0), optr)
+    ctx.check(lib.silent_conv2d_same_dev(*(args + (op.stream,))) if op.dev else lib.silent_conv2d_same(*args))
+    return op.wrap(out, co)
+
+
+def regulate(x, blur_hwio, regulation_value, regulation_root=0.5, flat_policy="ieee"):
+    op = _Operand(x)
+    k = _kernel_arg(blur_hwio, op.c)
+    if k.shape[3] != op.c:
+        raise ValueError("blur tensor must be [kh, kw, C, C]")
+    try:
+        pol = {"ieee": _lib.FLAT_IEEE, "zero": _lib.FLAT_ZERO}[flat_policy]
+    except KeyError:
+        raise ValueError("flat_policy must be 'ieee' or 'zero'")
+    out, optr = op.alloc(op.c)
+    lib, ctx = _lib.load(), op.ctx
+    args = (ctx.handle, op.ptr) + op.geom() + (op.c, C.c_void_p(k.ctypes.data), k.shape[0], k.shape[1],
+                                                  float(regulation_value), float(regulation_root), pol, optr)
+    ctx.check(lib.silent_regulate_dev(*(args + (op.stream,))) if op.dev else lib.silent_regulate(*args))
+    return op.wrap(out, op.c)
+
+
+def gray_line_end(x, cs_kernel, end_bank, clip_hi=255.0, want_cs=True, want_end=True):
+    op = _Operand(x, channels=1)
+    cs = _kernel_arg(cs_kernel, 1)
+    eb = _kernel_arg(end_bank, 1)
+    if cs.shape != (3, 3, 1, 1) or eb.shape[:3] != (3, 3, 1):
+        raise ValueError("gray_line_end needs a [3,3,1,1] CS kernel and a [3,3,1,K] end bank")
+    K = eb.shape[3]
+    cs_out, cs_ptr = op.alloc(1) if want_cs else (None, None)
+    end_out, end_ptr = op.alloc(K) if want_end else (None, None)
+    lib, ctx = _lib.load(), op.ctx
+    args = (ctx.handle, op.ptr) + op.geom() + (C.c_void_p(cs.ctypes.data), C.c_void_p(eb.ctypes.data), K,
+                                                  float(clip_hi), cs_ptr, end_ptr)
+    ctx.check(lib.silent_gray_line_end_dev(*(args + (op.stream,))) if op.dev else lib.silent_gray_line_end(*args))
+    return (op.wrap(cs_out, 1) if want_cs else None, op.wrap(end_out, K) if want_end else None)
+
+
+def pad_inwards(x, pt, pb, pl, pr):
+    op = _Operand(x)
+    out, optr = op.alloc(op.c)
+    lib, ctx = _lib.load(), op.ctx
+    args = (ctx.handle, op.ptr) + op.geom() + (op.c, int(pt), int(pb), int(pl), int(pr), optr)
+    ctx.check(lib.silent_pad_inwards_dev(*(args + (op.stream,))) if op.dev else lib.silent_pad_inwards(*args))
+    return op.wrap(out, op.c)
+
+
+def value_from_color(x):
+    op = _Operand(x)
+    out, optr = op.alloc(1)
+    lib, ctx = _lib.load(), op.ctx
+    args = (ctx.handle, op.ptr) + op.geom() + (op.c, optr)
+    ctx.check(lib.silent_value_from_color_dev(*(args + (op.stream,))) if op.dev else lib.silent_value_from_color(*args))
+    return op.wrap(out, 1)
+
+
+def nms3x3(x, mode="product"):
+    op = _Operand(x)
+    try:
+        m = {"product": _lib.NMS_PRODUCT, "fired": _lib.NMS_FIRED}[mode]
+    except KeyError:
+        raise ValueError("mode must be 'product' or 'fired'")
+    out, optr = op.alloc(op.c)
+    lib, ctx = _lib.load(), op.ctx
+    args = (ctx.handle, op.ptr) + op.geom() + (op.c, m, optr)
+    ctx.check(lib.silent_nms3x3_dev(*(args + (op.stream,))) if op.dev else lib.silent_nms3x3(*args))
+    return op.wrap(out, op.c)
+
+
+def top_value_points(color, top_percent=0.1, value=None):
+    op = _Operand(color)
+    vptr = None
+    if value is not None:
+        vop = _Operand(value, channels=1)
+        _same_geometry(op, vop, "top_value_points")
+        vptr = vop.ptr
+    out, optr = op.alloc(op.c)
+    lib, ctx = _lib.load(), op.ctx
+    args = (ctx.handle, op.ptr, vptr) + op.geom() + (op.c, float(top_percent), optr)
+    ctx.check(lib.silent_top_value_points_dev(*(args + (op.stream,))) if op.dev else lib.silent_top_value_points(*args))
+    return op.wrap(out, op.c)
+
+
+def max_value_indices_region(value, regions, cap_per_frame=None):
+    """value: 1-channel tensor.  regions: one (rH, rW) per level.  Returns (idx [n_frames, cap, 4] int64,
+    counts [n_frames] int64) -- host arrays for host input, torch tensors for device input."""
+    op = _Operand(value, channels=1)
+    if len(regions) != op.n_levels:
+        raise ValueError("need one (rH, rW) region per level")
+    reg = (_lib.Extent * op.n_levels)(*[_lib.Extent(int(rh), int(rw)) for rh, rw in regions])
+    cap = op.frame_px if cap_per_frame is None else int(cap_per_frame)
+    lib, ctx = _lib.load(), op.ctx
+    if op.dev:
+        import torch
+        idx = torch.empty((op.n_frames, cap, 4), dtype=torch.int64, device=op._torch_device)
+        counts = torch.empty(op.n_frames, dtype=torch.int64, device=op._torch_device)
+        ctx.check(lib.silent_max_value_indices_region_dev(ctx.handle, op.ptr, op.levels, op.n_levels, op.n_frames, reg,
+                                                          C.c_void_p(idx.data_ptr()), cap,
+                                                          C.c_void_p(counts.data_ptr()), op.stream))
+        return idx, counts
+    idx = np.empty((op.n_frames, cap, 4), dtype=np.int64)
+    counts = np.empty(op.n_frames, dtype=np.int64)
+    ctx.check(lib.silent_max_value_indices_region(ctx.handle, op.ptr, op.levels, op.n_levels, op.n_frames, reg,
+                                                  C.c_void_p(idx.ctypes.data), cap, C.c_void_p(counts.ctypes.data)))
+    return idx, counts
+
+
+def rgb_line_end(x, kernels, regulation_value=1.0, regulation_root=0.1, flat_policy="ieee", clip_hi=255.0, pad=2,
+                 want=("orient", "line_end", "value")):
+    """The reference graph recognition_testing.py:69-77 on 3-channel levels.  ``kernels``: dict with
+    rgc, rgby, stripe, end ([3,3,3,3]) and blur ([7,7,3,3]).  Returns dict of the requested outputs."""
+    op = _Operand(x, channels=3)
+    ks = {}
+    for name, shape in (("rgc", (3, 3, 3, 3)), ("rgby", (3, 3, 3, 3)), ("stripe", (3, 3, 3, 3)),
+                        ("blur", (7, 7, 3, 3)), ("end", (3, 3, 3, 3))):
+        k = _kernel_arg(kernels[name], 3)
+        if k.shape != shape:
+            raise ValueError("kernel %s must have shape %s, got %s" % (name, shape, k.shape))
+        ks[name] = k
+    fp = C.POINTER(C.c_float)
+    params = _lib.RgbChainParams(*[ks[n].ctypes.data_as(fp) for n in ("rgc", "rgby", "stripe", "blur", "end")],
+                                 float(regulation_value), float(regulation_root),
+                                 {"ieee": _lib.FLAT_IEEE, "zero": _lib.FLAT_ZERO}[flat_policy], float(clip_hi), int(pad))
+    outs, ptrs = {}, {}
+    for name, ch in (("orient", 3), ("line_end", 3), ("value", 1)):
+        if name in want:
+            outs[name], ptrs[name] = op.alloc(ch)
+        else:
+            ptrs[name] = None
+    lib, ctx = _lib.load(), op.ctx
+    args = (ctx.handle, op.ptr) + op.geom() + (C.byref(params), ptrs["orient"], ptrs["line_end"], ptrs["value"])
+    ctx.check(lib.silent_rgb_line_end_dev(*(args + (op.stream,))) if op.dev else lib.silent_rgb_line_end(*args))
+    return {n: op.wrap(o, 1 if n == "value" else 3) for n, o in outs.items()}
+
+
+# ----------------------------------------------------------------------------- pyramid plans
+
+class PyramidPlan(object):
+    """Tap tables of one (frame size, level geometry) on the device.  ``levels`` is a list of dicts / tuples
+    (src_y0, src_x0, src_h, src_w, zoom_h, zoom_w, out_h, out_w)."""
+
+    def __init__(self, frame_h, frame_w, channels, levels, device=None):
+        self.ctx = get_context(device)
+        self.frame_shape = (int(frame_h), int(frame_w), int(channels))
+        self.levels = [tuple(int(v) for v in l) for l in levels]
+        self.extents = [(l[6], l[7]) for l in self.levels]
+        arr = (_lib.PyrLevel * len(self.levels))(*[_lib.PyrLevel(*l) for l in self.levels])
+        self.handle = C.c_void_p()
+        self.ctx.check(_lib.load().silent_pyramid_plan_create(self.ctx.handle, self.frame_shape[0], self.frame_shape[1],
+                                                              self.frame_shape[2], arr, len(self.levels),
+                                                              C.byref(self.handle)))
+        self.frame_px = sum(h * w for h, w in self.extents)
+
+    def run(self, frames):
+        """frames: [n, H, W, C] ndarray (host) or torch GPU tensor.  Returns a PackedPyramid."""
+        h, w, c = self.frame_shape
+        lib = _lib.load()
+        if is_torch_tensor(frames):
+            import torch
+            if tuple(frames.shape[1:]) != (h, w, c):
+                raise ValueError("frames must be [n, %d, %d, %d]" % (h, w, c))
+            f = frames.to(torch.float32).contiguous()
+            n = int(f.shape[0])
+            out = torch.empty(n * self.frame_px * c, dtype=torch.float32, device=f.device)
+            stream = C.c_void_p(torch.cuda.current_stream(f.device).cuda_stream)
+            self.ctx.check(lib.silent_pyramid_dev(self.ctx.handle, self.handle, C.c_void_p(f.data_ptr()), n,
+                                                  C.c_void_p(out.data_ptr()), stream))
+            return PackedPyramid(out, self.extents, c, n)
+        if not isinstance(frames, np.ndarray):
+            raise TypeError(TYPE_ERROR_MESSAGE)
+        if tuple(frames.shape[1:]) != (h, w, c):
+            raise ValueError("frames must be [n, %d, %d, %d], got %s" % (h, w, c, frames.shape))
+        f = np.ascontiguousarray(frames, dtype=np.float32)
+        n = f.shape[0]
+        out = np.empty(n * self.frame_px * c, dtype=np.float32)
+        self.ctx.check(lib.silent_pyramid(self.ctx.handle, self.handle, C.c_void_p(f.ctypes.data), n,
+                                          C.c_void_p(out.ctypes.data)))
+        return PackedPyramid(out, self.extents, c, n)
+
+    def close(self):
+        if self.handle:
+            _lib.load().silent_pyramid_plan_destroy(self.handle)
+            self.handle = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

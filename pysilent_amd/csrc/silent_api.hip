@@ -1,0 +1,964 @@
+// libsilent_hip.so -- C ABI (include/silent_hip.h) over the gfx950 kernels.
+// Host side: argument validation, tile tables, tap tables (float64, scipy-identical), staging arena.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <new>
+#include <string>
+#include <vector>
+
+#include "silent_common.h"
+#include "silent_conv.h"
+#include "silent_peaks.h"
+#include "silent_pyramid.h"
+
+using namespace silent;
+
+#define SILENT_EXPORT extern "C" __attribute__((visibility("default")))
+
+// ------------------------------------------------------------------------------------------ context
+
+struct DevBuf {
+    void* p = nullptr;
+    size_t cap = 0;
+};
+
+struct silent_ctx {
+    int device = 0;
+    std::string err;
+    std::string name;
+    DevBuf arena;  // staging for the host-pointer entry points
+    DevBuf ws;     // scratch for reductions / compaction / the RGB chain temporaries
+};
+
+struct silent_pyramid_plan {
+    silent_ctx* ctx = nullptr;
+    PyrTab tab{};
+    std::vector<silent_extent> extents;
+    void* tables = nullptr;
+};
+
+static thread_local std::string g_create_err;
+
+static int fail(silent_ctx* ctx, int code, const std::string& msg) {
+    if (ctx)
+        ctx->err = msg;
+    else
+        g_create_err = msg;
+    return code;
+}
+
+#define HIP_TRY(ctx, call)                                                                            \
+    do {                                                                                              \
+        hipError_t e_ = (call);                                                                       \
+        if (e_ != hipSuccess) {                                                                       \
+            (void)hipGetLastError();                                                                  \
+            return fail(ctx, e_ == hipErrorOutOfMemory ? SILENT_E_NOMEM : SILENT_E_HIP,               \
+                        std::string(#call) + ": " + hipGetErrorString(e_));                           \
+        }                                                                                             \
+    } while (0)
+
+#define TRY(expr)                   \
+    do {                            \
+        int rc_ = (expr);           \
+        if (rc_ != SILENT_OK) return rc_; \
+    } while (0)
+
+static int grow(silent_ctx* ctx, DevBuf& b, size_t bytes) {
+    if (bytes <= b.cap) return SILENT_OK;
+    if (b.p) {
+        HIP_TRY(ctx, hipFree(b.p));  // synchronises with work still using the old block
+        b.p = nullptr;
+        b.cap = 0;
+    }
+    const size_t want = bytes + bytes / 4 + (1u << 20);
+    HIP_TRY(ctx, hipMalloc(&b.p, want));
+    b.cap = want;
+    return SILENT_OK;
+}
+
+static inline size_t align_up(size_t v, size_t a = 256) { return (v + a - 1) / a * a; }
+
+SILENT_EXPORT int silent_abi_version(void) { return SILENT_ABI_VERSION; }
+
+SILENT_EXPORT int silent_device_count(int* count) {
+    if (!count) return fail(nullptr, SILENT_E_INVALID, "silent_device_count: count is NULL");
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess) {
+        (void)hipGetLastError();
+        *count = 0;
+        return fail(nullptr, SILENT_E_HIP, std::string("hipGetDeviceCount: ") + hipGetErrorString(e));
+    }
+    *count = n;
+    return SILENT_OK;
+}
+
+SILENT_EXPORT int silent_create(int device, silent_ctx** out) {
+    if (!out) return fail(nullptr, SILENT_E_INVALID, "silent_create: out is NULL");
+    *out = nullptr;
+    int n = 0;
+    HIP_TRY(nullptr, hipGetDeviceCount(&n));
+    if (device < 0 || device >= n)
+        return fail(nullptr, SILENT_E_INVALID,
+                    "silent_create: device " + std::to_string(device) + " out of range (" + std::to_string(n) +
+                        " visible)");
+    HIP_TRY(nullptr, hipSetDevice(device));
+    hipDeviceProp_t prop;
+    HIP_TRY(nullptr, hipGetDeviceProperties(&prop, device));
+    silent_ctx* ctx = new (std::nothrow) silent_ctx();
+    if (!ctx) return fail(nullptr, SILENT_E_NOMEM, "silent_create: out of host memory");
+    ctx->device = device;
+    ctx->name = std::string(prop.name) + " (" + prop.gcnArchName + ")";
+    if (std::string(prop.gcnArchName).rfind("gfx950", 0) != 0) {
+        std::string m = "silent_create: device is " + ctx->name + "; this library holds gfx950 code objects only";
+        delete ctx;
+        return fail(nullptr, SILENT_E_UNSUPPORTED, m);
+    }
+    *out = ctx;
+    return SILENT_OK;
+}
+
+SILENT_EXPORT void silent_destroy(silent_ctx* ctx) {
+    if (!ctx) return;
+    (void)hipSetDevice(ctx->device);
+    if (ctx->arena.p) (void)hipFree(ctx->arena.p);
+    if (ctx->ws.p) (void)hipFree(ctx->ws.p);
+    delete ctx;
+}
+
+SILENT_EXPORT const char* silent_last_error(const silent_ctx* ctx) {
+    return ctx ? ctx->err.c_str() : g_create_err.c_str();
+}
+
+SILENT_EXPORT int silent_device_name(const silent_ctx* ctx, char* buf, size_t len) {
+    if (!ctx || !buf || len == 0) return SILENT_E_INVALID;
+    std::snprintf(buf, len, "%s", ctx->name.c_str());
+    return SILENT_OK;
+}
+
+#define NEED_CTX(ctx)                  \
+    if (!(ctx)) return fail(nullptr, SILENT_E_INVALID, std::string(__func__) + ": ctx is NULL"); \
+    HIP_TRY(ctx, hipSetDevice((ctx)->device))
+
+SILENT_EXPORT int silent_malloc(silent_ctx* ctx, size_t bytes, void** dptr) {
+    NEED_CTX(ctx);
+    if (!dptr) return fail(ctx, SILENT_E_INVALID, "silent_malloc: dptr is NULL");
+    *dptr = nullptr;
+    HIP_TRY(ctx, hipMalloc(dptr, bytes ? bytes : 1));
+    return SILENT_OK;
+}
+
+SILENT_EXPORT int silent_free(silent_ctx* ctx, void* dptr) {
+    NEED_CTX(ctx);
+    if (dptr) HIP_TRY(ctx, hipFree(dptr));
+    return SILENT_OK;
+}
+
+SILENT_EXPORT int silent_memcpy_h2d(silent_ctx* ctx, void* dst, const void* src, size_t bytes, silent_stream stream) {
+    NEED_CTX(ctx);
+    if (bytes && (!dst || !src)) return fail(ctx, SILENT_E_INVALID, "silent_memcpy_h2d: NULL pointer");
+    HIP_TRY(ctx, hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, (hipStream_t)stream));
+    HIP_TRY(ctx, hipStreamSynchronize((hipStream_t)stream));
+    return SILENT_OK;
+}
+
+SILENT_EXPORT int silent_memcpy_d2h(silent_ctx* ctx, void* dst, const void* src, size_t bytes, silent_stream stream) {
+    NEED_CTX(ctx);
+    if (bytes && (!dst || !src)) return fail(ctx, SILENT_E_INVALID, "silent_memcpy_d2h: NULL pointer");
+    HIP_TRY(ctx, hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, (hipStream_t)stream));
+    HIP_TRY(ctx, hipStreamSynchronize((hipStream_t)stream));
+    return SILENT_OK;
+}
+
+SILENT_EXPORT int silent_synchronize(silent_ctx* ctx, silent_stream stream) {
+    NEED_CTX(ctx);
+    HIP_TRY(ctx, hipStreamSynchronize((hipStream_t)stream));
+    return SILENT_OK;
+}
+
+// ------------------------------------------------------------------------------------------ tile tables
+
+// tile_h == 0 selects the 1-D "chunk" decomposition (kChunk flattened pixels per block).
+static int build_level_tab(silent_ctx* ctx, const char* who, const silent_extent* levels, int n_levels, int n_frames,
+                           int tile_w, int tile_h, LevelTab* tab, long long* n_blocks) {
+    if (!levels) return fail(ctx, SILENT_E_INVALID, std::string(who) + ": levels is NULL");
+    if (n_levels < 1 || n_levels > kMaxLevels)
+        return fail(ctx, SILENT_E_INVALID, std::string(who) + ": n_levels must be in [1, " + std::to_string(kMaxLevels) + "]");
+    if (n_frames < 1) return fail(ctx, SILENT_E_INVALID, std::string(who) + ": n_frames must be >= 1");
+    std::memset(tab, 0, sizeof(*tab));
+    tab->n_levels = n_levels;
+    long long px = 0, tiles = 0;
+    for (int l = 0; l < n_levels; ++l) {
+        const long long h = levels[l].h, w = levels[l].w;
+        if (h < 1 || w < 1 || h * w > (1ll << 30))
+            return fail(ctx, SILENT_E_INVALID, std::string(who) + ": level " + std::to_string(l) + " extent " +
+                                                   std::to_string(h) + "x" + std::to_string(w) + " is invalid");
+        tab->h[l] = (int)h;
+        tab->w[l] = (int)w;
+        tab->px_off[l] = px;
+        tab->tile_start[l] = (int)tiles;
+        long long tx, ty;
+        if (tile_h == 0) {
+            tx = (h * w + kChunk - 1) / kChunk;
+            ty = 1;
+        } else {
+            tx = (w + tile_w - 1) / tile_w;
+            ty = (h + tile_h - 1) / tile_h;
+        }
+        tab->tiles_x[l] = (int)tx;
+        tiles += tx * ty;
+        px += h * w;
+    }
+    tab->tile_start[n_levels] = (int)tiles;
+    tab->tiles_per_frame = (int)tiles;
+    tab->frame_px = px;
+    const long long total = tiles * (long long)n_frames;
+    if (total > 0x7fffffffll) return fail(ctx, SILENT_E_INVALID, std::string(who) + ": too many tiles for one launch");
+    *n_blocks = total;
+    return SILENT_OK;
+}
+
+static int check_launch(silent_ctx* ctx, const char* what) {
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return fail(ctx, SILENT_E_HIP, std::string(what) + " launch: " + hipGetErrorString(e));
+    return SILENT_OK;
+}
+
+static long long pyramid_px(const silent_extent* levels, int n_levels) {
+    long long px = 0;
+    for (int l = 0; l < n_levels; ++l) px += (long long)levels[l].h * levels[l].w;
+    return px;
+}
+
+// ------------------------------------------------------------------------------------------ convolution
+
+template <int KH, int KW, int CIN, int COUT, bool REG>
+static void launch_conv(const float* in, float* out, const LevelTab& tab, const ConvW& w, const Epilogue& ep,
+                        long long blocks, hipStream_t s) {
+    hipLaunchKernelGGL((conv2d_same_kernel<KH, KW, CIN, COUT, REG>), dim3((unsigned)blocks), dim3(256), 0, s, in, out,
+                       tab, w, ep);
+}
+
+template <int KH, int KW, int CI, int CO>
+static void conv_case(bool reg, const float* in, float* out, const LevelTab& tab, const ConvW& w, const Epilogue& ep,
+                      long long blocks, hipStream_t s) {
+    if constexpr (CI == CO) {
+        if (reg) {
+            launch_conv<KH, KW, CI, CO, true>(in, out, tab, w, ep, blocks, s);
+            return;
+        }
+    }
+    launch_conv<KH, KW, CI, CO, false>(in, out, tab, w, ep, blocks, s);
+}
+
+static int conv_dispatch(silent_ctx* ctx, const char* who, const float* in, const silent_extent* levels, int n_levels,
+                         int n_frames, int cin, const float* k, int kh, int kw, int cout, bool reg,
+                         const Epilogue& ep, float* out, hipStream_t s) {
+    if (!in || !out || !k) return fail(ctx, SILENT_E_INVALID, std::string(who) + ": NULL pointer");
+    if (kh < 1 || kw < 1 || cin < 1 || cout < 1 || kh > 15 || kw > 15 || cin > 16 || cout > 16)
+        return fail(ctx, SILENT_E_UNSUPPORTED, std::string(who) + ": kernel shape out of range (k <= 15, channels <= 16)");
+    if ((long long)kh * kw * cin * cout > SILENT_MAX_KERNEL_FLOATS)
+        return fail(ctx, SILENT_E_UNSUPPORTED,
+                    std::string(who) + ": kh*kw*C_in*C_out exceeds " + std::to_string(SILENT_MAX_KERNEL_FLOATS));
+    if (reg && cin != cout) return fail(ctx, SILENT_E_INVALID, std::string(who) + ": blur must be [kh,kw,C,C]");
+    LevelTab tab;
+    long long blocks;
+    TRY(build_level_tab(ctx, who, levels, n_levels, n_frames, kConvTW, kConvTH, &tab, &blocks));
+    ConvW w;
+    std::memset(&w, 0, sizeof(w));
+    std::memcpy(w.w, k, sizeof(float) * kh * kw * cin * cout);
+
+#define CONV_CASE(KH_, KW_, CI_, CO_)                                      \
+    if (kh == KH_ && kw == KW_ && cin == CI_ && cout == CO_) {             \
+        conv_case<KH_, KW_, CI_, CO_>(reg, in, out, tab, w, ep, blocks, s); \
+        return check_launch(ctx, who);                                     \
+    }
+    CONV_CASE(3, 3, 1, 1)
+    CONV_CASE(3, 3, 1, 3)
+    CONV_CASE(3, 3, 1, 4)
+    CONV_CASE(3, 3, 1, 8)
+    CONV_CASE(3, 3, 3, 1)
+    CONV_CASE(3, 3, 3, 3)
+    CONV_CASE(3, 3, 3, 4)
+    CONV_CASE(7, 7, 1, 1)
+    CONV_CASE(7, 7, 3, 3)
+#undef CONV_CASE
+    const int IW = kConvTW + kw - 1, IH = kConvTH + kh - 1;
+    const size_t lds = sizeof(float) * (size_t)IW * IH * cin;
+    if (lds > 64 * 1024) return fail(ctx, SILENT_E_UNSUPPORTED, std::string(who) + ": halo tile exceeds 64 KiB of LDS");
+    hipLaunchKernelGGL(conv2d_same_generic_kernel, dim3((unsigned)blocks), dim3(256), lds, s, in, out, tab, w, kh, kw,
+                       cin, cout, reg ? 1 : 0, ep);
+    return check_launch(ctx, who);
+}
+
+SILENT_EXPORT int silent_conv2d_same_dev(silent_ctx* ctx, const float* in, const silent_extent* levels, int n_levels,
+                                         int n_frames, int c_in, const float* kernel_hwio, int kh, int kw, int c_out,
+                                         unsigned flags, float clip_hi, float* out, silent_stream stream) {
+    NEED_CTX(ctx);
+    Epilogue ep{flags, clip_hi, 0.f, 0.f, 0};
+    return conv_dispatch(ctx, "silent_conv2d_same", in, levels, n_levels, n_frames, c_in, kernel_hwio, kh, kw, c_out,
+                         false, ep, out, (hipStream_t)stream);
+}
+
+SILENT_EXPORT int silent_regulate_dev(silent_ctx* ctx, const float* in, const silent_extent* levels, int n_levels,
+                                      int n_frames, int channels, const float* blur_hwio, int kh, int kw,
+                                      float regulation_value, float regulation_root, int flat_policy, float* out,
+                                      silent_stream stream) {
+    NEED_CTX(ctx);
+    if (flat_policy != SILENT_FLAT_IEEE && flat_policy != SILENT_FLAT_ZERO)
+        return fail(ctx, SILENT_E_INVALID, "silent_regulate: flat_policy must be SILENT_FLAT_IEEE or SILENT_FLAT_ZERO");
+    Epilogue ep{0u, 0.f, regulation_value, regulation_root, flat_policy};
+    return conv_dispatch(ctx, "silent_regulate", in, levels, n_levels, n_frames, channels, blur_hwio, kh, kw, channels,
+                         true, ep, out, (hipStream_t)stream);
+}
+
+// ------------------------------------------------------------------------------------------ fused gray pass
+
+SILENT_EXPORT int silent_gray_line_end_dev(silent_ctx* ctx, const float* pyr, const silent_extent* levels,
+                                           int n_levels, int n_frames, const float* cs_kernel, const float* end_bank,
+                                           int n_orient, float clip_hi, float* cs_out, float* end_out,
+                                           silent_stream stream) {
+    NEED_CTX(ctx);
+    const char* who = "silent_gray_line_end";
+    if (!pyr || !cs_kernel) return fail(ctx, SILENT_E_INVALID, std::string(who) + ": NULL pointer");
+    if (!cs_out && !end_out) return fail(ctx, SILENT_E_INVALID, std::string(who) + ": both outputs are NULL");
+    if (end_out && !end_bank) return fail(ctx, SILENT_E_INVALID, std::string(who) + ": end_bank is NULL");
+    if (n_orient != 3 && n_orient != 4 && n_orient != 8)
+        return fail(ctx, SILENT_E_UNSUPPORTED, std::string(who) + ": n_orient must be 3, 4 or 8");
+    LevelTab tab;
+    long long blocks;
+    TRY(build_level_tab(ctx, who, levels, n_levels, n_frames, kGrayTW, kGrayTH, &tab, &blocks));
+    GrayW w;
+    std::memset(&w, 0, sizeof(w));
+    std::memcpy(w.cs, cs_kernel, sizeof(float) * 9);
+    if (end_bank) std::memcpy(w.end, end_bank, sizeof(float) * 9 * n_orient);
+    hipStream_t s = (hipStream_t)stream;
+    switch (n_orient) {
+        case 3:
+            hipLaunchKernelGGL(gray_line_end_kernel<3>, dim3((unsigned)blocks), dim3(256), 0, s, pyr, cs_out, end_out, tab, w, clip_hi);
+            break;
+        case 4:
+            hipLaunchKernelGGL(gray_line_end_kernel<4>, dim3((unsigned)blocks), dim3(256), 0, s, pyr, cs_out, end_out, tab, w, clip_hi);
+            break;
+        default:
+            hipLaunchKernelGGL(gray_line_end_kernel<8>, dim3((unsigned)blocks), dim3(256), 0, s, pyr, cs_out, end_out, tab, w, clip_hi);
+            break;
+    }
+    return check_launch(ctx, who);
+}
+
+// ------------------------------------------------------------------------------------------ pointwise / nms
+
+SILENT_EXPORT int silent_pad_inwards_dev(silent_ctx* ctx, const float* in, const silent_extent* levels, int n_levels,
+                                         int n_frames, int channels, int pt, int pb, int pl, int pr, float* out,
+                                         silent_stream stream) {
+    NEED_CTX(ctx);
+    const char* who = "silent_pad_inwards";
+    if (!in || !out) return fail(ctx, SILENT_E_INVALID, std::string(who) + ": NULL pointer");
+    if (channels < 1 || pt < 0 || pb < 0 || pl < 0 || pr < 0)
+        return fail(ctx, SILENT_E_INVALID, std::string(who) + ": channels must be >= 1 and paddings >= 0");
+    LevelTab tab;
+    long long blocks;
+    TRY(build_level_tab(ctx, who, levels, n_levels, n_frames, 0, 0, &tab, &blocks));
+    hipLaunchKernelGGL(pad_inwards_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, in, out, tab,
+                       channels, pt, pb, pl, pr);
+    return check_launch(ctx, who);
+}
+
+SILENT_EXPORT int silent_value_from_color_dev(silent_ctx* ctx, const float* in, const silent_extent* levels,
+                                              int n_levels, int n_frames, int channels, float* out,
+                                              silent_stream stream) {
+    NEED_CTX(ctx);
+    const char* who = "silent_value_from_color";
+    if (!in || !out) return fail(ctx, SILENT_E_INVALID, std::string(who) + ": NULL pointer");
+    if (channels < 1) return fail(ctx, SILENT_E_INVALID, std::string(who) + ": channels must be >= 1");
+    LevelTab tab;
+    long long blocks;
+    TRY(build_level_tab(ctx, who, levels, n_levels, n_frames, 0, 0, &tab, &blocks));
+    const long long npx = tab.frame_px * n_frames;
+    const long long grid = std::min<long long>((npx + 255) / 256, 256 * 32);
+    hipLaunchKernelGGL(value_from_color_kernel, dim3((unsigned)grid), dim3(256), 0, (hipStream_t)stream, in, out, npx,
+                       channels);
+    return check_launch(ctx, who);
+}
+
+SILENT_EXPORT int silent_nms3x3_dev(silent_ctx* ctx, const float* in, const silent_extent* levels, int n_levels,
+                                    int n_frames, int channels, int mode, float* out, silent_stream stream) {
+    NEED_CTX(ctx);
+    const char* who = "silent_nms3x3";
+    if (!in || !out) return fail(ctx, SILENT_E_INVALID, std::string(who) + ": NULL pointer");
+    if (channels < 1) return fail(ctx, SILENT_E_INVALID, std::string(who) + ": channels must be >= 1");
+    if (mode != SILENT_NMS_PRODUCT && mode != SILENT_NMS_FIRED)
+        return fail(ctx, SILENT_E_INVALID, std::string(who) + ": mode must be SILENT_NMS_PRODUCT or SILENT_NMS_FIRED");
+    LevelTab tab;
+    long long blocks;
+    TRY(build_level_tab(ctx, who, levels, n_levels, n_frames, 0, 0, &tab, &blocks));
+    hipLaunchKernelGGL(nms3x3_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, in, out, tab, channels,
+                       mode);
+    return check_launch(ctx, who);
+}
+
+// ------------------------------------------------------------------------------------------ top-percent threshold
+
+SILENT_EXPORT int silent_top_value_points_dev(silent_ctx* ctx, const float* color, const float* value,
+                                              const silent_extent* levels, int n_levels, int n_frames, int channels,
+                                              double top_percent, float* out, silent_stream stream) {
+    NEED_CTX(ctx);
+    const char* who = "silent_top_value_points";
+    if (!color || !out) return fail(ctx, SILENT_E_INVALID, std::string(who) + ": NULL pointer");
+    if (channels < 1) return fail(ctx, SILENT_E_INVALID, std::string(who) + ": channels must be >= 1");
+    LevelTab tab;
+    long long blocks;
+    TRY(build_level_tab(ctx, who, levels, n_levels, n_frames, 0, 0, &tab, &blocks));
+    const int nmm = n_frames * n_levels;
+    TRY(grow(ctx, ctx->ws, sizeof(unsigned) * 2 * (size_t)nmm));
+    unsigned* mm = (unsigned*)ctx->ws.p;
+    hipStream_t s = (hipStream_t)stream;
+    hipLaunchKernelGGL(init_maxmin_kernel, dim3((nmm + 255) / 256), dim3(256), 0, s, mm, nmm);
+    hipLaunchKernelGGL(level_maxmin_kernel, dim3((unsigned)blocks), dim3(256), 0, s, value, value ? nullptr : color,
+                       channels, tab, mm);
+    // python: (1.0 - top_percent) and top_percent are doubles that TF casts to float32 constants
+    const float a = (float)(1.0 - top_percent), b = (float)top_percent;
+    hipLaunchKernelGGL(top_value_points_kernel, dim3((unsigned)blocks), dim3(256), 0, s, color, value, out, tab,
+                       channels, a, b, mm);
+    return check_launch(ctx, who);
+}
+
+// ------------------------------------------------------------------------------------------ keypoint indices
+
+// TF1 max_pool SAME geometry with window == full extent
+static int region_axis(int size, int stride, int* n_win, int* nseg, int* cut, int* w_lo, int* w_hi, float* scale) {
+    if (stride < 1) return -1;
+    const int out = (size + stride - 1) / stride;
+    if (out > kMaxWin) return -2;
+    const int pad_before = ((out - 1) * stride) / 2;
+    int lo[kMaxWin], hi[kMaxWin];
+    std::vector<int> cuts = {0, size};
+    for (int j = 0; j < out; ++j) {
+        const int a = j * stride - pad_before, b = a + size;
+        lo[j] = a < 0 ? 0 : a;
+        hi[j] = b > size ? size : b;
+        cuts.push_back(lo[j]);
+        cuts.push_back(hi[j]);
+    }
+    std::sort(cuts.begin(), cuts.end());
+    cuts.erase(std::unique(cuts.begin(), cuts.end()), cuts.end());
+    const int ns = (int)cuts.size() - 1;
+    if (ns > kMaxSeg) return -2;
+    for (int i = 0; i <= ns; ++i) cut[i] = cuts[i];
+    for (int j = 0; j < out; ++j) {
+        int a = 0, b = 0;
+        for (int i = 0; i <= ns; ++i) {
+            if (cuts[i] == lo[j]) a = i;
+            if (cuts[i] == hi[j]) b = i;
+        }
+        w_lo[j] = a;
+        w_hi[j] = b;
+    }
+    *n_win = out;
+    *nseg = ns;
+    *scale = (float)out / (float)size;
+    return 0;
+}
+
+SILENT_EXPORT int silent_max_value_indices_region_dev(silent_ctx* ctx, const float* value, const silent_extent* levels,
+                                                      int n_levels, int n_frames, const silent_extent* regions,
+                                                      int64_t* idx, size_t cap_per_frame, int64_t* counts,
+                                                      silent_stream stream) {
+    NEED_CTX(ctx);
+    const char* who = "silent_max_value_indices_region";
+    if (!value || !regions || !counts || (!idx && cap_per_frame))
+        return fail(ctx, SILENT_E_INVALID, std::string(who) + ": NULL pointer");
+    LevelTab tab;
+    long long blocks;
+    TRY(build_level_tab(ctx, who, levels, n_levels, n_frames, 0, 0, &tab, &blocks));
+    RegionTab rt;
+    std::memset(&rt, 0, sizeof(rt));
+    for (int l = 0; l < n_levels; ++l) {
+        RegionLevel& r = rt.lv[l];
+        int rc = region_axis(levels[l].h, regions[l].h, &r.oh, &r.nrs, r.rcut, r.wy_lo, r.wy_hi, &r.yscale);
+        if (rc == 0) rc = region_axis(levels[l].w, regions[l].w, &r.ow, &r.ncs, r.ccut, r.wx_lo, r.wx_hi, &r.xscale);
+        if (rc == -1) return fail(ctx, SILENT_E_INVALID, std::string(who) + ": region extents must be >= 1");
+        if (rc == -2)
+            return fail(ctx, SILENT_E_UNSUPPORTED,
+                        std::string(who) + ": more than " + std::to_string(kMaxWin) + " windows per axis at level " + std::to_string(l));
+    }
+    // workspace: cells | chunk_counts | chunk_offsets
+    const size_t n_cells = (size_t)n_frames * n_levels * kCells;
+    const size_t off_counts = align_up(n_cells * sizeof(unsigned));
+    const size_t off_offsets = off_counts + align_up((size_t)blocks * sizeof(int));
+    const size_t total = off_offsets + align_up((size_t)blocks * sizeof(long long));
+    TRY(grow(ctx, ctx->ws, total));
+    unsigned* cells = (unsigned*)ctx->ws.p;
+    int* chunk_counts = (int*)((char*)ctx->ws.p + off_counts);
+    long long* chunk_offsets = (long long*)((char*)ctx->ws.p + off_offsets);
+    hipStream_t s = (hipStream_t)stream;
+    hipLaunchKernelGGL(init_cells_kernel, dim3((unsigned)((n_cells + 255) / 256)), dim3(256), 0, s, cells, (long long)n_cells);
+    hipLaunchKernelGGL(region_cell_max_kernel, dim3((unsigned)blocks), dim3(256), 0, s, value, tab, rt, cells);
+    hipLaunchKernelGGL(region_count_kernel, dim3((unsigned)blocks), dim3(256), 0, s, value, tab, rt, cells, chunk_counts);
+    hipLaunchKernelGGL(region_scan_kernel, dim3((unsigned)n_frames), dim3(256), 0, s, chunk_counts, chunk_offsets,
+                       tab.tiles_per_frame, counts);
+    if (cap_per_frame)
+        hipLaunchKernelGGL(region_write_kernel, dim3((unsigned)blocks), dim3(256), 0, s, value, tab, rt, cells,
+                           chunk_offsets, idx, (long long)cap_per_frame);
+    return check_launch(ctx, who);
+}
+
+// ------------------------------------------------------------------------------------------ RGB chain
+
+SILENT_EXPORT int silent_rgb_line_end_dev(silent_ctx* ctx, const float* pyr, const silent_extent* levels, int n_levels,
+                                          int n_frames, const silent_rgb_chain_params* p, float* orient_out,
+                                          float* line_end_out, float* value_out, silent_stream stream) {
+    NEED_CTX(ctx);
+    const char* who = "silent_rgb_line_end";
+    if (!pyr || !p) return fail(ctx, SILENT_E_INVALID, std::string(who) + ": NULL pointer");
+    if (!p->rgc || !p->rgby || !p->stripe || !p->blur || !p->end)
+        return fail(ctx, SILENT_E_INVALID, std::string(who) + ": a kernel pointer in params is NULL");
+    if (!orient_out && !line_end_out && !value_out) return fail(ctx, SILENT_E_INVALID, std::string(who) + ": all outputs are NULL");
+    if (p->pad < 0) return fail(ctx, SILENT_E_INVALID, std::string(who) + ": pad must be >= 0");
+    if (!levels || n_levels < 1 || n_levels > kMaxLevels || n_frames < 1)
+        return fail(ctx, SILENT_E_INVALID, std::string(who) + ": bad levels / n_frames");
+    for (int l = 0; l < n_levels; ++l)
+        if (levels[l].h < 1 || levels[l].w < 1) return fail(ctx, SILENT_E_INVALID, std::string(who) + ": bad level extent");
+    // Stage-per-launch composition (round 1): two ping-pong temporaries in the context workspace.
+    const size_t n = (size_t)pyramid_px(levels, n_levels) * n_frames * 3;
+    const size_t bytes = align_up(n * sizeof(float));
+    TRY(grow(ctx, ctx->ws, 3 * bytes));
+    float* t0 = (float*)ctx->ws.p;
+    float* t1 = (float*)((char*)ctx->ws.p + bytes);
+    float* t2 = (float*)((char*)ctx->ws.p + 2 * bytes);
+    hipStream_t s = (hipStream_t)stream;
+    const Epilogue relu{SILENT_RELU, 0.f, 0.f, 0.f, 0};
+    TRY(conv_dispatch(ctx, who, pyr, levels, n_levels, n_frames, 3, p->rgc, 3, 3, 3, false, relu, t0, s));
+    TRY(conv_dispatch(ctx, who, t0, levels, n_levels, n_frames, 3, p->rgby, 3, 3, 3, false, relu, t1, s));
+    TRY(conv_dispatch(ctx, who, t1, levels, n_levels, n_frames, 3, p->stripe, 3, 3, 3, false, relu, t0, s));
+    float* orient = orient_out ? orient_out : t1;
+    const Epilogue reg{0u, 0.f, p->regulation_value, p->regulation_root, p->flat_policy};
+    TRY(conv_dispatch(ctx, who, t0, levels, n_levels, n_frames, 3, p->blur, 7, 7, 3, true, reg, orient, s));
+    if (!line_end_out && !value_out) return SILENT_OK;
+    const Epilogue rc{SILENT_RELU | SILENT_CLIP, p->clip_hi, 0.f, 0.f, 0};
+    TRY(conv_dispatch(ctx, who, orient, levels, n_levels, n_frames, 3, p->end, 3, 3, 3, false, rc, t0, s));
+    float* padded = line_end_out ? line_end_out : t2;
+    LevelTab tab;
+    long long blocks;
+    TRY(build_level_tab(ctx, who, levels, n_levels, n_frames, 0, 0, &tab, &blocks));
+    hipLaunchKernelGGL(pad_inwards_kernel, dim3((unsigned)blocks), dim3(256), 0, s, t0, padded, tab, 3, p->pad, p->pad,
+                       p->pad, p->pad);
+    if (value_out) {
+        const long long npx = tab.frame_px * n_frames;
+        const long long grid = std::min<long long>((npx + 255) / 256, 256 * 32);
+        hipLaunchKernelGGL(value_from_color_kernel, dim3((unsigned)grid), dim3(256), 0, s, padded, value_out, npx, 3);
+    }
+    return check_launch(ctx, who);
+}
+
+// ------------------------------------------------------------------------------------------ pyramid plan
+
+static void spline5_weights(double t, double* w) {
+    // quintic cardinal B-spline at taps floor(c)-2 .. floor(c)+3; last tap by partition of unity
+    const double y = t, z = 1.0 - t;
+    double t2 = y * y;
+    w[2] = t2 * (t2 * (0.25 - y / 12.0) - 0.5) + 0.55;
+    t2 = z * z;
+    w[3] = t2 * (t2 * (0.25 - z / 12.0) - 0.5) + 0.55;
+    const double y1 = y + 1.0;
+    w[1] = y1 * (y1 * (y1 * (y1 * (y1 / 24.0 - 0.375) + 1.25) - 1.75) + 0.625) + 0.425;
+    const double z1 = z + 1.0;
+    w[4] = z1 * (z1 * (z1 * (z1 * (z1 / 24.0 - 0.375) + 1.25) - 1.75) + 0.625) + 0.425;
+    const double y2 = 1.0 - y;
+    w[0] = y2 * y2 * y2 * y2 * y2 / 120.0;
+    w[5] = 1.0 - w[0] - w[1] - w[2] - w[3] - w[4];
+}
+
+static int host_mirror(long i, int n) {
+    if (n == 1) return 0;
+    const long period = 2L * (n - 1);
+    if (i < 0) i = -i;
+    i %= period;
+    return (int)(i >= n ? period - i : i);
+}
+
+// scipy.ndimage.zoom, grid_mode=False: output o samples o * (n_in-1)/(n_out-1); mode 'constant'
+// declares a coordinate outside [0, n_in-1] out of bounds (-> cval 0 for the whole row/column).
+static void axis_table(int n_in, int n_out, int* base, int* idx, float* wts) {
+    const double step = n_out > 1 ? (double)(n_in - 1) / (double)(n_out - 1) : 1.0;
+    for (int o = 0; o < n_out; ++o) {
+        const double c = (double)o * step;
+        const long b = (long)std::floor(c);
+        double w[6] = {0, 0, 0, 0, 0, 0};
+        if (c >= 0.0 && c <= (double)(n_in - 1)) spline5_weights(c - (double)b, w);
+        if (base) base[o] = (int)b;
+        for (int j = 0; j < 6; ++j) {
+            wts[6 * o + j] = (float)w[j];
+            if (idx) idx[6 * o + j] = host_mirror(b - 2 + j, n_in);
+        }
+    }
+}
+
+SILENT_EXPORT int silent_pyramid_plan_create(silent_ctx* ctx, int frame_h, int frame_w, int channels,
+                                             const silent_pyr_level* levels, int n_levels,
+                                             silent_pyramid_plan** out) {
+    NEED_CTX(ctx);
+    const char* who = "silent_pyramid_plan_create";
+    if (!out || !levels) return fail(ctx, SILENT_E_INVALID, std::string(who) + ": NULL pointer");
+    *out = nullptr;
+    if (frame_h < 1 || frame_w < 1 || (long long)frame_h * frame_w > (1ll << 30))
+        return fail(ctx, SILENT_E_INVALID, std::string(who) + ": bad frame extent");
+    if (channels != 1 && channels != 3)
+        return fail(ctx, SILENT_E_UNSUPPORTED, std::string(who) + ": channels must be 1 or 3");
+    if (n_levels < 1 || n_levels > kMaxLevels)
+        return fail(ctx, SILENT_E_INVALID, std::string(who) + ": n_levels must be in [1, " + std::to_string(kMaxLevels) + "]");
+    silent_pyramid_plan* plan = new (std::nothrow) silent_pyramid_plan();
+    if (!plan) return fail(ctx, SILENT_E_NOMEM, std::string(who) + ": out of host memory");
+    plan->ctx = ctx;
+    PyrTab& tab = plan->tab;
+    tab.n_levels = n_levels;
+    tab.H = frame_h;
+    tab.W = frame_w;
+    tab.C = channels;
+    long long cols = 0, rows = 0, px = 0, tiles = 0;
+    for (int l = 0; l < n_levels; ++l) {
+        const silent_pyr_level& L = levels[l];
+        const bool ok = L.src_h >= 1 && L.src_w >= 1 && L.src_y0 >= 0 && L.src_x0 >= 0 &&
+                        (long long)L.src_y0 + L.src_h <= frame_h && (long long)L.src_x0 + L.src_w <= frame_w &&
+                        L.zoom_h >= 1 && L.zoom_w >= 1 && L.out_h >= 1 && L.out_w >= 1 &&
+                        (long long)L.out_h * L.out_w <= (1ll << 30) && (long long)L.zoom_h * L.zoom_w <= (1ll << 30);
+        if (!ok) {
+            delete plan;
+            return fail(ctx, SILENT_E_INVALID, std::string(who) + ": level " + std::to_string(l) + " geometry is invalid");
+        }
+        PyrLevelDev& d = tab.lv[l];
+        d.src_y0 = L.src_y0; d.src_x0 = L.src_x0; d.src_h = L.src_h; d.src_w = L.src_w;
+        d.zoom_h = L.zoom_h; d.zoom_w = L.zoom_w; d.out_h = L.out_h; d.out_w = L.out_w;
+        d.xtab_off = (int)cols;
+        d.ytab_off = (int)rows;
+        cols += L.zoom_w;
+        rows += L.zoom_h;
+        plan->extents.push_back(silent_extent{L.out_h, L.out_w});
+    }
+    std::vector<int> xidx(cols * 6), ybase(rows);
+    std::vector<float> xw(cols * 6), yw(rows * 6);
+    for (int l = 0; l < n_levels; ++l) {
+        PyrLevelDev& d = tab.lv[l];
+        axis_table(d.src_w, d.zoom_w, nullptr, xidx.data() + (size_t)d.xtab_off * 6, xw.data() + (size_t)d.xtab_off * 6);
+        axis_table(d.src_h, d.zoom_h, ybase.data() + d.ytab_off, nullptr, yw.data() + (size_t)d.ytab_off * 6);
+        // rows per tile: the source lines a tile touches must fit the LDS slab
+        const int* yb = ybase.data() + d.ytab_off;
+        int th = kPyrMaxTH;
+        for (;;) {
+            int worst = 0;
+            const int zrows = std::min(d.zoom_h, d.out_h);
+            for (int oy0 = 0; oy0 < zrows; oy0 += th) {
+                const int oy1 = std::min(oy0 + th, zrows) - 1;
+                worst = std::max(worst, yb[oy1] + 3 - (yb[oy0] - 2) + 1);
+            }
+            if (worst <= kPyrMaxRows || th == 1) break;
+            th = th > 2 ? th / 2 : 1;
+        }
+        d.tile_h = th;
+        tab.px_off[l] = px;
+        tab.tile_start[l] = (int)tiles;
+        tab.tiles_x[l] = (d.out_w + kPyrTW - 1) / kPyrTW;
+        tiles += (long long)tab.tiles_x[l] * ((d.out_h + th - 1) / th);
+        px += (long long)d.out_h * d.out_w;
+    }
+    if (tiles > 0x7fffffffll) {
+        delete plan;
+        return fail(ctx, SILENT_E_INVALID, std::string(who) + ": too many tiles");
+    }
+    tab.tile_start[n_levels] = (int)tiles;
+    tab.tiles_per_frame = (int)tiles;
+    tab.frame_px_out = px;
+    const size_t b_xidx = align_up(xidx.size() * sizeof(int)), b_xw = align_up(xw.size() * sizeof(float));
+    const size_t b_yb = align_up(ybase.size() * sizeof(int)), b_yw = align_up(yw.size() * sizeof(float));
+    hipError_t e = hipMalloc(&plan->tables, b_xidx + b_xw + b_yb + b_yw);
+    if (e != hipSuccess) {
+        (void)hipGetLastError();
+        delete plan;
+        return fail(ctx, SILENT_E_NOMEM, std::string(who) + ": hipMalloc: " + hipGetErrorString(e));
+    }
+    char* base = (char*)plan->tables;
+    tab.xidx = (const int*)base;
+    tab.xw = (const float*)(base + b_xidx);
+    tab.ybase = (const int*)(base + b_xidx + b_xw);
+    tab.yw = (const float*)(base + b_xidx + b_xw + b_yb);
+    e = hipMemcpy((void*)tab.xidx, xidx.data(), xidx.size() * sizeof(int), hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipMemcpy((void*)tab.xw, xw.data(), xw.size() * sizeof(float), hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipMemcpy((void*)tab.ybase, ybase.data(), ybase.size() * sizeof(int), hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipMemcpy((void*)tab.yw, yw.data(), yw.size() * sizeof(float), hipMemcpyHostToDevice);
+    if (e != hipSuccess) {
+        (void)hipGetLastError();
+        (void)hipFree(plan->tables);
+        delete plan;
+        return fail(ctx, SILENT_E_HIP, std::string(who) + ": hipMemcpy: " + hipGetErrorString(e));
+    }
+    *out = plan;
+    return SILENT_OK;
+}
+
+SILENT_EXPORT void silent_pyramid_plan_destroy(silent_pyramid_plan* plan) {
+    if (!plan) return;
+    if (plan->ctx) (void)hipSetDevice(plan->ctx->device);
+    if (plan->tables) (void)hipFree(plan->tables);
+    delete plan;
+}
+
+SILENT_EXPORT int silent_pyramid_dev(silent_ctx* ctx, const silent_pyramid_plan* plan, const float* frames,
+                                     int n_frames, float* pyr, silent_stream stream) {
+    NEED_CTX(ctx);
+    const char* who = "silent_pyramid";
+    if (!plan || !frames || !pyr) return fail(ctx, SILENT_E_INVALID, std::string(who) + ": NULL pointer");
+    if (plan->ctx != ctx) return fail(ctx, SILENT_E_INVALID, std::string(who) + ": plan belongs to another context");
+    if (n_frames < 1) return fail(ctx, SILENT_E_INVALID, std::string(who) + ": n_frames must be >= 1");
+    const long long blocks = (long long)plan->tab.tiles_per_frame * n_frames;
+    if (blocks > 0x7fffffffll) return fail(ctx, SILENT_E_INVALID, std::string(who) + ": too many tiles for one launch");
+    hipStream_t s = (hipStream_t)stream;
+    if (plan->tab.C == 1)
+        hipLaunchKernelGGL(pyramid_kernel<1>, dim3((unsigned)blocks), dim3(256), 0, s, frames, pyr, plan->tab);
+    else
+        hipLaunchKernelGGL(pyramid_kernel<3>, dim3((unsigned)blocks), dim3(256), 0, s, frames, pyr, plan->tab);
+    return check_launch(ctx, who);
+}
+
+// ------------------------------------------------------------------------------------------ host-pointer twins
+// Synchronous: stage inputs into the context arena, run the *_dev twin on the default stream, copy back.
+
+struct Stage {
+    silent_ctx* ctx;
+    size_t used = 0;
+    std::vector<size_t> offs;
+    explicit Stage(silent_ctx* c) : ctx(c) {}
+    size_t add(size_t bytes) {
+        offs.push_back(used);
+        used += align_up(bytes ? bytes : 1);
+        return offs.size() - 1;
+    }
+    int commit() { return grow(ctx, ctx->arena, used); }
+    template <class T>
+    T* ptr(size_t i) const { return (T*)((char*)ctx->arena.p + offs[i]); }
+};
+
+static int h2d(silent_ctx* ctx, void* d, const void* h, size_t bytes) {
+    HIP_TRY(ctx, hipMemcpy(d, h, bytes, hipMemcpyHostToDevice));
+    return SILENT_OK;
+}
+static int d2h(silent_ctx* ctx, void* h, const void* d, size_t bytes) {
+    HIP_TRY(ctx, hipMemcpy(h, d, bytes, hipMemcpyDeviceToHost));
+    return SILENT_OK;
+}
+static int sync0(silent_ctx* ctx) {
+    HIP_TRY(ctx, hipStreamSynchronize(nullptr));
+    return SILENT_OK;
+}
+
+static int check_levels(silent_ctx* ctx, const char* who, const silent_extent* levels, int n_levels, int n_frames,
+                        long long* px) {
+    LevelTab tab;
+    long long blocks;
+    TRY(build_level_tab(ctx, who, levels, n_levels, n_frames, 0, 0, &tab, &blocks));
+    *px = tab.frame_px * n_frames;
+    return SILENT_OK;
+}
+
+SILENT_EXPORT int silent_conv2d_same(silent_ctx* ctx, const float* in, const silent_extent* levels, int n_levels,
+                                     int n_frames, int c_in, const float* k, int kh, int kw, int c_out, unsigned flags,
+                                     float clip_hi, float* out) {
+    NEED_CTX(ctx);
+    if (!in || !out || !k) return fail(ctx, SILENT_E_INVALID, "silent_conv2d_same: NULL pointer");
+    if (c_in < 1 || c_out < 1) return fail(ctx, SILENT_E_INVALID, "silent_conv2d_same: channels must be >= 1");
+    long long px;
+    TRY(check_levels(ctx, "silent_conv2d_same", levels, n_levels, n_frames, &px));
+    Stage st(ctx);
+    const size_t bi = (size_t)px * c_in * 4, bo = (size_t)px * c_out * 4;
+    const size_t i_in = st.add(bi), i_out = st.add(bo);
+    TRY(st.commit());
+    TRY(h2d(ctx, st.ptr<float>(i_in), in, bi));
+    TRY(silent_conv2d_same_dev(ctx, st.ptr<float>(i_in), levels, n_levels, n_frames, c_in, k, kh, kw, c_out, flags,
+                               clip_hi, st.ptr<float>(i_out), nullptr));
+    TRY(sync0(ctx));
+    return d2h(ctx, out, st.ptr<float>(i_out), bo);
+}
+
+SILENT_EXPORT int silent_regulate(silent_ctx* ctx, const float* in, const silent_extent* levels, int n_levels,
+                                  int n_frames, int channels, const float* blur, int kh, int kw, float rv, float root,
+                                  int flat_policy, float* out) {
+    NEED_CTX(ctx);
+    if (!in || !out || !blur) return fail(ctx, SILENT_E_INVALID, "silent_regulate: NULL pointer");
+    if (channels < 1) return fail(ctx, SILENT_E_INVALID, "silent_regulate: channels must be >= 1");
+    long long px;
+    TRY(check_levels(ctx, "silent_regulate", levels, n_levels, n_frames, &px));
+    Stage st(ctx);
+    const size_t b = (size_t)px * channels * 4;
+    const size_t i_in = st.add(b), i_out = st.add(b);
+    TRY(st.commit());
+    TRY(h2d(ctx, st.ptr<float>(i_in), in, b));
+    TRY(silent_regulate_dev(ctx, st.ptr<float>(i_in), levels, n_levels, n_frames, channels, blur, kh, kw, rv, root,
+                            flat_policy, st.ptr<float>(i_out), nullptr));
+    TRY(sync0(ctx));
+    return d2h(ctx, out, st.ptr<float>(i_out), b);
+}
+
+SILENT_EXPORT int silent_gray_line_end(silent_ctx* ctx, const float* pyr, const silent_extent* levels, int n_levels,
+                                       int n_frames, const float* cs_kernel, const float* end_bank, int n_orient,
+                                       float clip_hi, float* cs_out, float* end_out) {
+    NEED_CTX(ctx);
+    if (!pyr) return fail(ctx, SILENT_E_INVALID, "silent_gray_line_end: NULL pointer");
+    if (n_orient < 1 || n_orient > 8) return fail(ctx, SILENT_E_UNSUPPORTED, "silent_gray_line_end: n_orient must be 3, 4 or 8");
+    long long px;
+    TRY(check_levels(ctx, "silent_gray_line_end", levels, n_levels, n_frames, &px));
+    Stage st(ctx);
+    const size_t b1 = (size_t)px * 4, bk = (size_t)px * n_orient * 4;
+    const size_t i_in = st.add(b1), i_cs = st.add(b1), i_end = st.add(bk);
+    TRY(st.commit());
+    TRY(h2d(ctx, st.ptr<float>(i_in), pyr, b1));
+    TRY(silent_gray_line_end_dev(ctx, st.ptr<float>(i_in), levels, n_levels, n_frames, cs_kernel, end_bank, n_orient,
+                                 clip_hi, cs_out ? st.ptr<float>(i_cs) : nullptr,
+                                 end_out ? st.ptr<float>(i_end) : nullptr, nullptr));
+    TRY(sync0(ctx));
+    if (cs_out) TRY(d2h(ctx, cs_out, st.ptr<float>(i_cs), b1));
+    if (end_out) TRY(d2h(ctx, end_out, st.ptr<float>(i_end), bk));
+    return SILENT_OK;
+}
+
+SILENT_EXPORT int silent_pad_inwards(silent_ctx* ctx, const float* in, const silent_extent* levels, int n_levels,
+                                     int n_frames, int channels, int pt, int pb, int pl, int pr, float* out) {
+    NEED_CTX(ctx);
+    if (!in || !out) return fail(ctx, SILENT_E_INVALID, "silent_pad_inwards: NULL pointer");
+    if (channels < 1) return fail(ctx, SILENT_E_INVALID, "silent_pad_inwards: channels must be >= 1");
+    long long px;
+    TRY(check_levels(ctx, "silent_pad_inwards", levels, n_levels, n_frames, &px));
+    Stage st(ctx);
+    const size_t b = (size_t)px * channels * 4;
+    const size_t i_in = st.add(b), i_out = st.add(b);
+    TRY(st.commit());
+    TRY(h2d(ctx, st.ptr<float>(i_in), in, b));
+    TRY(silent_pad_inwards_dev(ctx, st.ptr<float>(i_in), levels, n_levels, n_frames, channels, pt, pb, pl, pr,
+                               st.ptr<float>(i_out), nullptr));
+    TRY(sync0(ctx));
+    return d2h(ctx, out, st.ptr<float>(i_out), b);
+}
+
+SILENT_EXPORT int silent_value_from_color(silent_ctx* ctx, const float* in, const silent_extent* levels, int n_levels,
+                                          int n_frames, int channels, float* out) {
+    NEED_CTX(ctx);
+    if (!in || !out) return fail(ctx, SILENT_E_INVALID, "silent_value_from_color: NULL pointer");
+    if (channels < 1) return fail(ctx, SILENT_E_INVALID, "silent_value_from_color: channels must be >= 1");
+    long long px;
+    TRY(check_levels(ctx, "silent_value_from_color", levels, n_levels, n_frames, &px));
+    Stage st(ctx);
+    const size_t bi = (size_t)px * channels * 4, bo = (size_t)px * 4;
+    const size_t i_in = st.add(bi), i_out = st.add(bo);
+    TRY(st.commit());
+    TRY(h2d(ctx, st.ptr<float>(i_in), in, bi));
+    TRY(silent_value_from_color_dev(ctx, st.ptr<float>(i_in), levels, n_levels, n_frames, channels,
+                                    st.ptr<float>(i_out), nullptr));
+    TRY(sync0(ctx));
+    return d2h(ctx, out, st.ptr<float>(i_out), bo);
+}
+
+SILENT_EXPORT int silent_nms3x3(silent_ctx* ctx, const float* in, const silent_extent* levels, int n_levels,
+                                int n_frames, int channels, int mode, float* out) {
+    NEED_CTX(ctx);
+    if (!in || !out) return fail(ctx, SILENT_E_INVALID, "silent_nms3x3: NULL pointer");
+    if (channels < 1) return fail(ctx, SILENT_E_INVALID, "silent_nms3x3: channels must be >= 1");
+    long long px;
+    TRY(check_levels(ctx, "silent_nms3x3", levels, n_levels, n_frames, &px));
+    Stage st(ctx);
+    const size_t b = (size_t)px * channels * 4;
+    const size_t i_in = st.add(b), i_out = st.add(b);
+    TRY(st.commit());
+    TRY(h2d(ctx, st.ptr<float>(i_in), in, b));
+    TRY(silent_nms3x3_dev(ctx, st.ptr<float>(i_in), levels, n_levels, n_frames, channels, mode, st.ptr<float>(i_out),
+                          nullptr));
+    TRY(sync0(ctx));
+    return d2h(ctx, out, st.ptr<float>(i_out), b);
+}
+
+SILENT_EXPORT int silent_top_value_points(silent_ctx* ctx, const float* color, const float* value,
+                                          const silent_extent* levels, int n_levels, int n_frames, int channels,
+                                          double top_percent, float* out) {
+    NEED_CTX(ctx);
+    if (!color || !out) return fail(ctx, SILENT_E_INVALID, "silent_top_value_points: NULL pointer");
+    if (channels < 1) return fail(ctx, SILENT_E_INVALID, "silent_top_value_points: channels must be >= 1");
+    long long px;
+    TRY(check_levels(ctx, "silent_top_value_points", levels, n_levels, n_frames, &px));
+    Stage st(ctx);
+    const size_t bc = (size_t)px * channels * 4, bv = (size_t)px * 4;
+    const size_t i_c = st.add(bc), i_v = st.add(bv), i_o = st.add(bc);
+    TRY(st.commit());
+    TRY(h2d(ctx, st.ptr<float>(i_c), color, bc));
+    if (value) TRY(h2d(ctx, st.ptr<float>(i_v), value, bv));
+    TRY(silent_top_value_points_dev(ctx, st.ptr<float>(i_c), value ? st.ptr<float>(i_v) : nullptr, levels, n_levels,
+                                    n_frames, channels, top_percent, st.ptr<float>(i_o), nullptr));
+    TRY(sync0(ctx));
+    return d2h(ctx, out, st.ptr<float>(i_o), bc);
+}
+
+SILENT_EXPORT int silent_max_value_indices_region(silent_ctx* ctx, const float* value, const silent_extent* levels,
+                                                  int n_levels, int n_frames, const silent_extent* regions,
+                                                  int64_t* idx, size_t cap_per_frame, int64_t* counts) {
+    NEED_CTX(ctx);
+    if (!value || !counts) return fail(ctx, SILENT_E_INVALID, "silent_max_value_indices_region: NULL pointer");
+    long long px;
+    TRY(check_levels(ctx, "silent_max_value_indices_region", levels, n_levels, n_frames, &px));
+    Stage st(ctx);
+    const size_t bv = (size_t)px * 4, bi = (size_t)n_frames * cap_per_frame * 4 * sizeof(int64_t);
+    const size_t bc = (size_t)n_frames * sizeof(int64_t);
+    const size_t i_v = st.add(bv), i_i = st.add(bi), i_c = st.add(bc);
+    TRY(st.commit());
+    TRY(h2d(ctx, st.ptr<float>(i_v), value, bv));
+    TRY(silent_max_value_indices_region_dev(ctx, st.ptr<float>(i_v), levels, n_levels, n_frames, regions,
+                                            st.ptr<int64_t>(i_i), cap_per_frame, st.ptr<int64_t>(i_c), nullptr));
+    TRY(sync0(ctx));
+    TRY(d2h(ctx, counts, st.ptr<int64_t>(i_c), bc));
+    bool over = false;
+    for (int f = 0; f < n_frames; ++f) {
+        const size_t n = (size_t)std::min<int64_t>(counts[f], (int64_t)cap_per_frame);
+        if (counts[f] > (int64_t)cap_per_frame) over = true;
+        if (n) TRY(d2h(ctx, idx + (size_t)f * cap_per_frame * 4, st.ptr<int64_t>(i_i) + (size_t)f * cap_per_frame * 4, n * 4 * sizeof(int64_t)));
+    }
+    if (over) return fail(ctx, SILENT_E_CAPACITY, "silent_max_value_indices_region: cap_per_frame too small; counts hold the need");
+    return SILENT_OK;
+}
+
+SILENT_EXPORT int silent_rgb_line_end(silent_ctx* ctx, const float* pyr, const silent_extent* levels, int n_levels,
+                                      int n_frames, const silent_rgb_chain_params* p, float* orient_out,
+                                      float* line_end_out, float* value_out) {
+    NEED_CTX(ctx);
+    if (!pyr || !p) return fail(ctx, SILENT_E_INVALID, "silent_rgb_line_end: NULL pointer");
+    long long px;
+    TRY(check_levels(ctx, "silent_rgb_line_end", levels, n_levels, n_frames, &px));
+    Stage st(ctx);
+    const size_t b3 = (size_t)px * 3 * 4, b1 = (size_t)px * 4;
+    const size_t i_in = st.add(b3), i_o = st.add(b3), i_l = st.add(b3), i_v = st.add(b1);
+    TRY(st.commit());
+    TRY(h2d(ctx, st.ptr<float>(i_in), pyr, b3));
+    TRY(silent_rgb_line_end_dev(ctx, st.ptr<float>(i_in), levels, n_levels, n_frames, p,
+                                orient_out ? st.ptr<float>(i_o) : nullptr, line_end_out ? st.ptr<float>(i_l) : nullptr,
+                                value_out ? st.ptr<float>(i_v) : nullptr, nullptr));
+    TRY(sync0(ctx));
+    if (orient_out) TRY(d2h(ctx, orient_out, st.ptr<float>(i_o), b3));
+    if (line_end_out) TRY(d2h(ctx, line_end_out, st.ptr<float>(i_l), b3));
+    if (value_out) TRY(d2h(ctx, value_out, st.ptr<float>(i_v), b1));
+    return SILENT_OK;
+}
+
+SILENT_EXPORT int silent_pyramid(silent_ctx* ctx, const silent_pyramid_plan* plan, const float* frames, int n_frames,
+                                 float* pyr) {
+    NEED_CTX(ctx);
+    if (!plan || !frames || !pyr) return fail(ctx, SILENT_E_INVALID, "silent_pyramid: NULL pointer");
+    if (n_frames < 1) return fail(ctx, SILENT_E_INVALID, "silent_pyramid: n_frames must be >= 1");
+    Stage st(ctx);
+    const size_t bi = (size_t)plan->tab.H * plan->tab.W * plan->tab.C * 4 * n_frames;
+    const size_t bo = (size_t)plan->tab.frame_px_out * plan->tab.C * 4 * n_frames;
+    const size_t i_in = st.add(bi), i_out = st.add(bo);
+    TRY(st.commit());
+    TRY(h2d(ctx, st.ptr<float>(i_in), frames, bi));
+    TRY(silent_pyramid_dev(ctx, plan, st.ptr<float>(i_in), n_frames, st.ptr<float>(i_out), nullptr));
+    TRY(sync0(ctx));
+    return d2h(ctx, pyr, st.ptr<float>(i_out), bo);
+}

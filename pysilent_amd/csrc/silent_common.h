@@ -1,0 +1,50 @@
+// Shared host/device declarations for libsilent_hip.so (gfx950 only).
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/silent_hip.h"
+
+namespace silent {
+
+constexpr int kMaxLevels = SILENT_MAX_LEVELS;
+constexpr int kWave = 64;  // CDNA wavefront
+
+// Tile -> (frame, level, tile_y, tile_x) lookup for one launch over a packed pyramid batch.
+// Travels as a kernel argument (SGPR-resident after s_load), so the lookup is scalar work.
+struct LevelTab {
+    int n_levels;
+    int tiles_per_frame;
+    long long frame_px;  // pixels of one whole pyramid (all levels)
+    int h[kMaxLevels];
+    int w[kMaxLevels];
+    int tiles_x[kMaxLevels];
+    int tile_start[kMaxLevels + 1];  // prefix sum of tiles per level
+    long long px_off[kMaxLevels];    // pixel offset of level l inside one pyramid
+};
+
+struct TileCoord {
+    int frame, level, ty, tx;
+};
+
+__device__ __forceinline__ TileCoord locate_tile(const LevelTab& tab, unsigned bid) {
+    TileCoord t;
+    t.frame = (int)(bid / (unsigned)tab.tiles_per_frame);
+    int rem = (int)(bid - (unsigned)t.frame * (unsigned)tab.tiles_per_frame);
+    int l = 0;
+#pragma unroll
+    for (int i = 1; i < kMaxLevels; ++i)
+        if (i < tab.n_levels && rem >= tab.tile_start[i]) l = i;
+    t.level = l;
+    rem -= tab.tile_start[l];
+    t.ty = rem / tab.tiles_x[l];
+    t.tx = rem - t.ty * tab.tiles_x[l];
+    return t;
+}
+
+// tf.maximum(x, [0]) with Eigen's CPU functor: a NaN stays a NaN (oracle: relu_tf).
+__device__ __forceinline__ float relu_tf(float v) { return v < 0.0f ? 0.0f : v; }
+__device__ __forceinline__ float clip_hi_tf(float v, float hi) { return v > hi ? hi : v; }
+
+}  // namespace silent

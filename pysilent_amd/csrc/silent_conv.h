@@ -1,0 +1,283 @@
+// Stencil kernels: generic SAME conv2d (NHWC x HWIO) and the fused grayscale CS -> end-bank pass.
+// HBM-bound stencil/pointwise work: coalesced tile loads into LDS, filters unrolled in registers,
+// weights held in SGPRs (they arrive as kernel arguments), no MFMA.
+#pragma once
+
+#include "silent_common.h"
+
+namespace silent {
+
+struct ConvW {
+    float w[SILENT_MAX_KERNEL_FLOATS];
+};
+
+constexpr int kConvTW = 64;  // one wave spans a tile row: 64 consecutive pixels
+constexpr int kConvTH = 16;
+
+// out[y,x,o] = sum_{dy,dx,i} in[y+dy-PH, x+dx-PW, i] * K[dy,dx,i,o]   (zero outside the level)
+// Block = 256 threads = 4 waves; lane = column, each wave owns 4 rows of the 64 x 16 tile.
+//
+// REG = true turns the kernel into regulate_tensor (gaussian_regulator_tensor.py:34-36): the
+// convolution is the blur (C_out == C_in) and the epilogue is y = x * (rv / pow(min(b, 1), root)),
+// x taken from the already staged tile.
+struct Epilogue {
+    unsigned flags;   // SILENT_RELU | SILENT_CLIP           (REG = false)
+    float clip_hi;
+    float rv, root;   // regulation value / root             (REG = true)
+    int flat_policy;  // SILENT_FLAT_*
+};
+
+__device__ __forceinline__ float regulate_px(float x, float b, const Epilogue& ep) {
+    const float m = b > 1.0f ? 1.0f : b;  // tf.minimum(b, [1])
+    const float p = powf(m, ep.root);
+    const float r = ep.rv / p;
+    float y = x * r;
+    if (ep.flat_policy == SILENT_FLAT_ZERO && x == 0.0f) y = 0.0f;
+    return y;
+}
+
+template <int KH, int KW, int CIN, int COUT, bool REG>
+__global__ __launch_bounds__(256) void conv2d_same_kernel(const float* __restrict__ in, float* __restrict__ out,
+                                                          const LevelTab tab, const ConvW wts, const Epilogue ep) {
+    static_assert(!REG || CIN == COUT, "regulate needs a square blur");
+    constexpr int TW = kConvTW, TH = kConvTH;
+    constexpr int PH = (KH - 1) / 2, PW = (KW - 1) / 2;
+    constexpr int IW = TW + KW - 1, IH = TH + KH - 1;
+    constexpr int ROWF = IW * CIN;  // floats per LDS row
+    __shared__ float s_in[IH * ROWF];
+
+    const TileCoord tc = locate_tile(tab, blockIdx.x);
+    const int H = tab.h[tc.level], W = tab.w[tc.level];
+    const long long base_px = (long long)tc.frame * tab.frame_px + tab.px_off[tc.level];
+    const float* __restrict__ src = in + base_px * CIN;
+    float* __restrict__ dst = out + base_px * COUT;
+    const int x0 = tc.tx * TW, y0 = tc.ty * TH;
+    const int tid = threadIdx.x;
+
+    // stage the (TH+KH-1) x (TW+KW-1) x CIN halo tile; consecutive threads read consecutive floats
+    for (int p = tid; p < IH * ROWF; p += 256) {
+        const int r = p / ROWF;
+        const int rem = p - r * ROWF;
+        const int c = rem / CIN;
+        const int ch = rem - c * CIN;
+        const int y = y0 + r - PH, x = x0 + c - PW;
+        float v = 0.0f;
+        if (y >= 0 && y < H && x >= 0 && x < W) v = src[((long long)y * W + x) * CIN + ch];
+        s_in[p] = v;
+    }
+    __syncthreads();
+
+    const int col = tid & 63, wave = tid >> 6;
+    const int x = x0 + col;
+    if (x >= W) return;
+#pragma unroll 1
+    for (int rr = 0; rr < TH / 4; ++rr) {
+        const int r = wave * (TH / 4) + rr;
+        const int y = y0 + r;
+        if (y >= H) break;
+        float acc[COUT];
+#pragma unroll
+        for (int o = 0; o < COUT; ++o) acc[o] = 0.0f;
+#pragma unroll
+        for (int dy = 0; dy < KH; ++dy)
+#pragma unroll
+            for (int dx = 0; dx < KW; ++dx)
+#pragma unroll
+                for (int i = 0; i < CIN; ++i) {
+                    const float v = s_in[(r + dy) * ROWF + (col + dx) * CIN + i];
+#pragma unroll
+                    for (int o = 0; o < COUT; ++o)
+                        acc[o] = __builtin_fmaf(v, wts.w[((dy * KW + dx) * CIN + i) * COUT + o], acc[o]);
+                }
+        float* __restrict__ po = dst + ((long long)y * W + x) * COUT;
+#pragma unroll
+        for (int o = 0; o < COUT; ++o) {
+            float v = acc[o];
+            if constexpr (REG) {
+                v = regulate_px(s_in[(r + PH) * ROWF + (col + PW) * CIN + o], v, ep);
+            } else {
+                if (ep.flags & SILENT_RELU) v = relu_tf(v);
+                if (ep.flags & SILENT_CLIP) v = clip_hi_tf(relu_tf(v), ep.clip_hi);
+            }
+            acc[o] = v;
+        }
+        if constexpr (COUT == 4) {
+            *reinterpret_cast<float4*>(po) = make_float4(acc[0], acc[1], acc[2], acc[3]);
+        } else if constexpr (COUT == 8) {
+            reinterpret_cast<float4*>(po)[0] = make_float4(acc[0], acc[1], acc[2], acc[3]);
+            reinterpret_cast<float4*>(po)[1] = make_float4(acc[4], acc[5], acc[6], acc[7]);
+        } else {
+#pragma unroll
+            for (int o = 0; o < COUT; ++o) po[o] = acc[o];
+        }
+    }
+}
+
+// Any other (kh, kw, C_in, C_out) within the weight budget: same tiling, runtime loops,
+// dynamic LDS.  Correct, not tuned -- the compiled set above covers every reference call site.
+__global__ __launch_bounds__(256) void conv2d_same_generic_kernel(const float* __restrict__ in,
+                                                                  float* __restrict__ out, const LevelTab tab,
+                                                                  const ConvW wts, int KH, int KW, int CIN,
+                                                                  int COUT, int reg, const Epilogue ep) {
+    constexpr int TW = kConvTW, TH = kConvTH;
+    extern __shared__ __attribute__((aligned(16))) float s_dyn[];
+    const int PH = (KH - 1) / 2, PW = (KW - 1) / 2;
+    const int IW = TW + KW - 1, IH = TH + KH - 1;
+    const int ROWF = IW * CIN;
+
+    const TileCoord tc = locate_tile(tab, blockIdx.x);
+    const int H = tab.h[tc.level], W = tab.w[tc.level];
+    const long long base_px = (long long)tc.frame * tab.frame_px + tab.px_off[tc.level];
+    const float* __restrict__ src = in + base_px * CIN;
+    float* __restrict__ dst = out + base_px * COUT;
+    const int x0 = tc.tx * TW, y0 = tc.ty * TH;
+    const int tid = threadIdx.x;
+
+    for (int p = tid; p < IH * ROWF; p += 256) {
+        const int r = p / ROWF;
+        const int rem = p - r * ROWF;
+        const int c = rem / CIN;
+        const int ch = rem - c * CIN;
+        const int y = y0 + r - PH, x = x0 + c - PW;
+        float v = 0.0f;
+        if (y >= 0 && y < H && x >= 0 && x < W) v = src[((long long)y * W + x) * CIN + ch];
+        s_dyn[p] = v;
+    }
+    __syncthreads();
+
+    const int col = tid & 63, wave = tid >> 6;
+    const int x = x0 + col;
+    if (x >= W) return;
+    for (int rr = 0; rr < TH / 4; ++rr) {
+        const int r = wave * (TH / 4) + rr;
+        const int y = y0 + r;
+        if (y >= H) break;
+        float* __restrict__ po = dst + ((long long)y * W + x) * COUT;
+        for (int o = 0; o < COUT; ++o) {
+            float acc = 0.0f;
+            for (int dy = 0; dy < KH; ++dy)
+                for (int dx = 0; dx < KW; ++dx)
+                    for (int i = 0; i < CIN; ++i)
+                        acc = __builtin_fmaf(s_dyn[(r + dy) * ROWF + (col + dx) * CIN + i],
+                                             wts.w[((dy * KW + dx) * CIN + i) * COUT + o], acc);
+            if (reg) {
+                acc = regulate_px(s_dyn[(r + PH) * ROWF + (col + PW) * CIN + o], acc, ep);
+            } else {
+                if (ep.flags & SILENT_RELU) acc = relu_tf(acc);
+                if (ep.flags & SILENT_CLIP) acc = clip_hi_tf(relu_tf(acc), ep.clip_hi);
+            }
+            po[o] = acc;
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Fused grayscale pass (BASELINE configs 1/2/5):  cs = relu(conv3x3(x, cs_k));
+//                                                 end = clip(relu(conv3x3(cs, end_bank)), 0, hi)
+// One 64 x 32 output tile per 256-thread block.  The input tile (halo 2) and the CS tile (halo 1)
+// live in LDS; CS values outside the level are forced to 0 because the second convolution's SAME
+// padding pads the CS MAP, not the input.  In phase C a lane owns one column and slides a 3x3
+// register window down 8 rows, so the dominant traffic (K floats per pixel, NHWC) leaves as one
+// contiguous 64 x 4K-byte row per wave instruction.
+struct GrayW {
+    float cs[9];
+    float end[9 * 8];  // [dy][dx][k], k < K
+};
+
+constexpr int kGrayTW = 64;
+constexpr int kGrayTH = 32;
+
+template <int K>
+__global__ __launch_bounds__(256) void gray_line_end_kernel(const float* __restrict__ pyr,
+                                                            float* __restrict__ cs_out,
+                                                            float* __restrict__ end_out, const LevelTab tab,
+                                                            const GrayW wts, float clip_hi) {
+    constexpr int TW = kGrayTW, TH = kGrayTH;
+    constexpr int IW = TW + 4, IH = TH + 4;  // input tile, halo 2
+    constexpr int CW = TW + 2, CH = TH + 2;  // CS tile, halo 1
+    __shared__ float s_in[IH * IW];
+    __shared__ float s_cs[CH * CW];
+
+    const TileCoord tc = locate_tile(tab, blockIdx.x);
+    const int H = tab.h[tc.level], W = tab.w[tc.level];
+    const long long base_px = (long long)tc.frame * tab.frame_px + tab.px_off[tc.level];
+    const float* __restrict__ src = pyr + base_px;
+    const int x0 = tc.tx * TW, y0 = tc.ty * TH;
+    const int tid = threadIdx.x;
+
+    for (int p = tid; p < IH * IW; p += 256) {
+        const int r = p / IW, c = p - r * IW;
+        const int y = y0 + r - 2, x = x0 + c - 2;
+        float v = 0.0f;
+        if (y >= 0 && y < H && x >= 0 && x < W) v = src[(long long)y * W + x];
+        s_in[p] = v;
+    }
+    __syncthreads();
+
+    for (int p = tid; p < CH * CW; p += 256) {
+        const int r = p / CW, c = p - r * CW;
+        const int y = y0 + r - 1, x = x0 + c - 1;
+        float v = 0.0f;
+        if (y >= 0 && y < H && x >= 0 && x < W) {
+            float acc = 0.0f;
+#pragma unroll
+            for (int dy = 0; dy < 3; ++dy)
+#pragma unroll
+                for (int dx = 0; dx < 3; ++dx)
+                    acc = __builtin_fmaf(s_in[(r + dy) * IW + c + dx], wts.cs[dy * 3 + dx], acc);
+            v = relu_tf(acc);
+        }
+        s_cs[p] = v;
+    }
+    __syncthreads();
+
+    const int col = tid & 63, wave = tid >> 6;
+    const int x = x0 + col;
+    if (x >= W) return;
+    constexpr int R = TH / 4;
+    const int r0 = wave * R;
+    float win[3][3];
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int i = 0; i < 3; ++i) win[j + 1][i] = s_cs[(r0 + j) * CW + col + i];
+#pragma unroll
+    for (int rr = 0; rr < R; ++rr) {
+        const int y = y0 + r0 + rr;
+        if (y >= H) break;
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+            win[0][i] = win[1][i];
+            win[1][i] = win[2][i];
+            win[2][i] = s_cs[(r0 + rr + 2) * CW + col + i];
+        }
+        const long long px = base_px + (long long)y * W + x;
+        if (cs_out) cs_out[px] = win[1][1];
+        if (end_out) {
+            float acc[K];
+#pragma unroll
+            for (int k = 0; k < K; ++k) acc[k] = 0.0f;
+#pragma unroll
+            for (int dy = 0; dy < 3; ++dy)
+#pragma unroll
+                for (int dx = 0; dx < 3; ++dx)
+#pragma unroll
+                    for (int k = 0; k < K; ++k)
+                        acc[k] = __builtin_fmaf(win[dy][dx], wts.end[(dy * 3 + dx) * K + k], acc[k]);
+#pragma unroll
+            for (int k = 0; k < K; ++k) acc[k] = clip_hi_tf(relu_tf(acc[k]), clip_hi);
+            float* __restrict__ po = end_out + px * K;
+            if constexpr (K == 4) {
+                *reinterpret_cast<float4*>(po) = make_float4(acc[0], acc[1], acc[2], acc[3]);
+            } else if constexpr (K == 8) {
+                reinterpret_cast<float4*>(po)[0] = make_float4(acc[0], acc[1], acc[2], acc[3]);
+                reinterpret_cast<float4*>(po)[1] = make_float4(acc[4], acc[5], acc[6], acc[7]);
+            } else {
+#pragma unroll
+                for (int k = 0; k < K; ++k) po[k] = acc[k];
+            }
+        }
+    }
+}
+
+}  // namespace silent

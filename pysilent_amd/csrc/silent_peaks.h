@@ -1,0 +1,377 @@
+// Pointwise ops, per-level reductions, 3x3 NMS and ordered keypoint compaction.
+#pragma once
+
+#include "silent_common.h"
+
+namespace silent {
+
+constexpr int kChunk = 1024;  // pixels per block for the 1-D (flattened level) kernels: 256 threads x 4
+
+// order-preserving float <-> uint map so that integer atomics give float max / min
+__device__ __forceinline__ unsigned f2ord(float f) {
+    const unsigned u = __float_as_uint(f);
+    return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+}
+__device__ __forceinline__ float ord2f(unsigned u) {
+    return __uint_as_float((u & 0x80000000u) ? (u & 0x7fffffffu) : ~u);
+}
+
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        const float t = __shfl_xor(v, o);
+        v = v < t ? t : v;
+    }
+    return v;
+}
+__device__ __forceinline__ float wave_min(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        const float t = __shfl_xor(v, o);
+        v = t < v ? t : v;
+    }
+    return v;
+}
+
+// ---- a-7 pad_inwards: out = mask * in (multiplication, like the reference: 0 * NaN stays NaN)
+__global__ __launch_bounds__(256) void pad_inwards_kernel(const float* __restrict__ in, float* __restrict__ out,
+                                                          const LevelTab tab, int C, int pt, int pb, int pl,
+                                                          int pr) {
+    const TileCoord tc = locate_tile(tab, blockIdx.x);
+    const int H = tab.h[tc.level], W = tab.w[tc.level];
+    const long long base_px = (long long)tc.frame * tab.frame_px + tab.px_off[tc.level];
+    const int npx = H * W;
+    for (int k = 0; k < 4; ++k) {
+        const int p = tc.tx * kChunk + k * 256 + threadIdx.x;
+        if (p >= npx) break;
+        const int y = p / W, x = p - y * W;
+        const float m = (y >= pt && y < H - pb && x >= pl && x < W - pr) ? 1.0f : 0.0f;
+        for (int c = 0; c < C; ++c) out[(base_px + p) * C + c] = m * in[(base_px + p) * C + c];
+    }
+}
+
+// ---- a-8 get_value_from_color: ((x0 + x1) + x2 ...) * float32(1/C)
+__global__ __launch_bounds__(256) void value_from_color_kernel(const float* __restrict__ in,
+                                                               float* __restrict__ out, long long npx, int C) {
+    const float inv = 1.0f / (float)C;
+    for (long long p = (long long)blockIdx.x * 256 + threadIdx.x; p < npx; p += (long long)gridDim.x * 256) {
+        float s = in[p * C];
+        for (int c = 1; c < C; ++c) s = __fadd_rn(s, in[p * C + c]);
+        out[p] = __fmul_rn(s, inv);
+    }
+}
+
+// ---- a-9 3x3 non-max suppression (max-pool SAME ignores out-of-level taps)
+__global__ __launch_bounds__(256) void nms3x3_kernel(const float* __restrict__ in, float* __restrict__ out,
+                                                     const LevelTab tab, int C, int mode) {
+    const TileCoord tc = locate_tile(tab, blockIdx.x);
+    const int H = tab.h[tc.level], W = tab.w[tc.level];
+    const long long base_px = (long long)tc.frame * tab.frame_px + tab.px_off[tc.level];
+    const float* __restrict__ src = in + base_px * C;
+    float* __restrict__ dst = out + base_px * C;
+    const int npx = H * W;
+    for (int k = 0; k < 4; ++k) {
+        const int p = tc.tx * kChunk + k * 256 + threadIdx.x;
+        if (p >= npx) break;
+        const int y = p / W, x = p - y * W;
+        for (int c = 0; c < C; ++c) {
+            float m = -INFINITY;
+            for (int dy = -1; dy <= 1; ++dy) {
+                const int yy = y + dy;
+                if (yy < 0 || yy >= H) continue;
+                for (int dx = -1; dx <= 1; ++dx) {
+                    const int xx = x + dx;
+                    if (xx < 0 || xx >= W) continue;
+                    const float v = src[((long long)yy * W + xx) * C + c];
+                    m = m < v ? v : m;
+                }
+            }
+            const float v = src[(long long)p * C + c];
+            const bool is_max = v == m;
+            dst[(long long)p * C + c] = mode == SILENT_NMS_FIRED ? (is_max ? 1.0f : 0.0f) : v * (is_max ? v : 0.0f);
+        }
+    }
+}
+
+// ---- a-10 per-level max / min: wave shuffle reduction -> LDS -> one atomic pair per block.
+// mm[(frame * n_levels + level) * 2 + {0,1}] = ordered-uint max / min; pre-set by init_maxmin_kernel.
+__global__ void init_maxmin_kernel(unsigned* mm, int n) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i < n) {
+        mm[2 * i] = 0u;            // below every float
+        mm[2 * i + 1] = 0xffffffffu;  // above every float
+    }
+}
+
+// If `color` is non-null the value is computed on the fly as get_value_from_color does.
+__global__ __launch_bounds__(256) void level_maxmin_kernel(const float* __restrict__ value,
+                                                           const float* __restrict__ color, int C,
+                                                           const LevelTab tab, unsigned* __restrict__ mm) {
+    __shared__ float s_mx[4], s_mn[4];
+    const TileCoord tc = locate_tile(tab, blockIdx.x);
+    const int npx = tab.h[tc.level] * tab.w[tc.level];
+    const long long base_px = (long long)tc.frame * tab.frame_px + tab.px_off[tc.level];
+    const float inv = 1.0f / (float)C;
+    float mx = -INFINITY, mn = INFINITY;
+    for (int k = 0; k < 4; ++k) {
+        const int p = tc.tx * kChunk + k * 256 + threadIdx.x;
+        if (p >= npx) break;
+        float v;
+        if (value) {
+            v = value[base_px + p];
+        } else {
+            v = color[(base_px + p) * C];
+            for (int c = 1; c < C; ++c) v = __fadd_rn(v, color[(base_px + p) * C + c]);
+            v = __fmul_rn(v, inv);
+        }
+        mx = mx < v ? v : mx;
+        mn = v < mn ? v : mn;
+    }
+    mx = wave_max(mx);
+    mn = wave_min(mn);
+    const int wave = threadIdx.x >> 6;
+    if ((threadIdx.x & 63) == 0) {
+        s_mx[wave] = mx;
+        s_mn[wave] = mn;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int i = 1; i < 4; ++i) {
+            mx = mx < s_mx[i] ? s_mx[i] : mx;
+            mn = s_mn[i] < mn ? s_mn[i] : mn;
+        }
+        unsigned* slot = mm + ((long long)tc.frame * tab.n_levels + tc.level) * 2;
+        atomicMax(slot, f2ord(mx));
+        atomicMin(slot + 1, f2ord(mn));
+    }
+}
+
+// thr = (1-p)*max + p*min with every op rounded to float32 and NOT fused (TF runs mul, mul, add)
+__global__ __launch_bounds__(256) void top_value_points_kernel(const float* __restrict__ color,
+                                                               const float* __restrict__ value,
+                                                               float* __restrict__ out, const LevelTab tab, int C,
+                                                               float one_minus_p, float p_f,
+                                                               const unsigned* __restrict__ mm) {
+    const TileCoord tc = locate_tile(tab, blockIdx.x);
+    const int npx = tab.h[tc.level] * tab.w[tc.level];
+    const long long base_px = (long long)tc.frame * tab.frame_px + tab.px_off[tc.level];
+    const unsigned* slot = mm + ((long long)tc.frame * tab.n_levels + tc.level) * 2;
+    const float mx = ord2f(slot[0]), mn = ord2f(slot[1]);
+    const float thr = __fadd_rn(__fmul_rn(one_minus_p, mx), __fmul_rn(p_f, mn));
+    const float inv = 1.0f / (float)C;
+    for (int k = 0; k < 4; ++k) {
+        const int p = tc.tx * kChunk + k * 256 + threadIdx.x;
+        if (p >= npx) break;
+        float v;
+        if (value) {
+            v = value[base_px + p];
+        } else {
+            v = color[(base_px + p) * C];
+            for (int c = 1; c < C; ++c) v = __fadd_rn(v, color[(base_px + p) * C + c]);
+            v = __fmul_rn(v, inv);
+        }
+        const float m = v >= thr ? 1.0f : 0.0f;
+        for (int c = 0; c < C; ++c) out[(base_px + p) * C + c] = color[(base_px + p) * C + c] * m;
+    }
+}
+
+// ---- a-11 max_value_indices_region
+// The TF1 op is max_pool(k = full extent, stride = region, SAME): every window is the level clipped to
+// a shifted copy of itself, i.e. a PREFIX or a SUFFIX of rows (and of columns).  The distinct window
+// edges cut each axis into <= kMaxSeg segments; one pass computes the max of every (row segment x
+// column segment) cell, and a window maximum is the max over the cells it covers.
+constexpr int kMaxWin = 4;  // windows per axis (the reference uses 2); keeps RegionTab inside the kernarg budget
+constexpr int kMaxSeg = 8;  // segments per axis (<= 2 * windows)
+
+struct RegionLevel {
+    int oh, ow;          // windows per axis
+    int nrs, ncs;        // segments per axis
+    int rcut[kMaxSeg + 1];  // row segment s = [rcut[s], rcut[s+1])
+    int ccut[kMaxSeg + 1];
+    int wy_lo[kMaxWin], wy_hi[kMaxWin];  // window j covers row SEGMENTS [lo, hi)
+    int wx_lo[kMaxWin], wx_hi[kMaxWin];
+    float yscale, xscale;  // float32 (windows / extent): TF1 CalculateResizeScale
+};
+
+struct RegionTab {
+    RegionLevel lv[kMaxLevels];
+};
+
+constexpr int kCells = kMaxSeg * kMaxSeg;
+
+__global__ void init_cells_kernel(unsigned* cells, long long n) {
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i < n) cells[i] = 0u;
+}
+
+// cells[(frame * n_levels + level) * kCells + rs * kMaxSeg + cs] = ordered-uint max of the cell
+__global__ __launch_bounds__(256) void region_cell_max_kernel(const float* __restrict__ value, const LevelTab tab,
+                                                              const RegionTab rt, unsigned* __restrict__ cells) {
+    __shared__ unsigned s_cell[kCells];
+    const TileCoord tc = locate_tile(tab, blockIdx.x);
+    const RegionLevel& rl = rt.lv[tc.level];
+    const int W = tab.w[tc.level];
+    const int npx = tab.h[tc.level] * W;
+    const long long base_px = (long long)tc.frame * tab.frame_px + tab.px_off[tc.level];
+    for (int i = threadIdx.x; i < kCells; i += 256) s_cell[i] = 0u;
+    __syncthreads();
+    for (int k = 0; k < 4; ++k) {
+        const int p = tc.tx * kChunk + k * 256 + threadIdx.x;
+        const bool live = p < npx;
+        int cell = -1;
+        float v = -INFINITY;
+        if (live) {
+            const int y = p / W, x = p - y * W;
+            int rs = 0, cs = 0;
+            for (int s = 1; s < rl.nrs; ++s) rs = y >= rl.rcut[s] ? s : rs;
+            for (int s = 1; s < rl.ncs; ++s) cs = x >= rl.ccut[s] ? s : cs;
+            cell = rs * kMaxSeg + cs;
+            v = value[base_px + p];
+        }
+        // common case: the whole wave sits in one cell -> one LDS atomic per wave
+        const int first = __builtin_amdgcn_readfirstlane(cell);
+        if (__all(cell == first)) {
+            const float m = wave_max(v);
+            if ((threadIdx.x & 63) == 0 && first >= 0) atomicMax(&s_cell[first], f2ord(m));
+        } else if (live) {
+            atomicMax(&s_cell[cell], f2ord(v));
+        }
+    }
+    __syncthreads();
+    unsigned* dst = cells + ((long long)tc.frame * tab.n_levels + tc.level) * kCells;
+    for (int i = threadIdx.x; i < kCells; i += 256)
+        if (s_cell[i] != 0u) atomicMax(dst + i, s_cell[i]);
+}
+
+// window maxima of one (frame, level) into LDS: pooled[j * kMaxWin + i]
+__device__ __forceinline__ void load_pooled(const unsigned* __restrict__ cells, const RegionLevel& rl,
+                                            float* s_pooled) {
+    for (int wi = threadIdx.x; wi < rl.oh * rl.ow; wi += 256) {
+        const int j = wi / rl.ow, i = wi - j * rl.ow;
+        unsigned m = 0u;
+        for (int rs = rl.wy_lo[j]; rs < rl.wy_hi[j]; ++rs)
+            for (int cs = rl.wx_lo[i]; cs < rl.wx_hi[i]; ++cs) {
+                const unsigned c = cells[rs * kMaxSeg + cs];
+                m = c > m ? c : m;
+            }
+        s_pooled[j * kMaxWin + i] = ord2f(m);
+    }
+}
+
+__device__ __forceinline__ bool region_pred(const float* __restrict__ value, long long base_px, int p, int W,
+                                            const RegionLevel& rl, const float* s_pooled) {
+    const int y = p / W, x = p - y * W;
+    // TF1 ResizeNearestNeighbor: min(floorf(dst * scale), in - 1), float32
+    int sy = (int)floorf(__fmul_rn((float)y, rl.yscale));
+    int sx = (int)floorf(__fmul_rn((float)x, rl.xscale));
+    sy = sy > rl.oh - 1 ? rl.oh - 1 : sy;
+    sx = sx > rl.ow - 1 ? rl.ow - 1 : sx;
+    return value[base_px + p] >= s_pooled[sy * kMaxWin + sx];
+}
+
+// pass 1: matches per chunk (thread t owns 4 CONSECUTIVE pixels so ranks stay row-major)
+__global__ __launch_bounds__(256) void region_count_kernel(const float* __restrict__ value, const LevelTab tab,
+                                                           const RegionTab rt, const unsigned* __restrict__ cells,
+                                                           int* __restrict__ chunk_counts) {
+    __shared__ float s_pooled[kMaxWin * kMaxWin];
+    __shared__ int s_cnt[4];
+    const TileCoord tc = locate_tile(tab, blockIdx.x);
+    const RegionLevel& rl = rt.lv[tc.level];
+    const int W = tab.w[tc.level];
+    const int npx = tab.h[tc.level] * W;
+    const long long base_px = (long long)tc.frame * tab.frame_px + tab.px_off[tc.level];
+    load_pooled(cells + ((long long)tc.frame * tab.n_levels + tc.level) * kCells, rl, s_pooled);
+    __syncthreads();
+    int n = 0;
+    for (int k = 0; k < 4; ++k) {
+        const int p = tc.tx * kChunk + threadIdx.x * 4 + k;
+        if (p < npx && region_pred(value, base_px, p, W, rl, s_pooled)) ++n;
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) n += __shfl_xor(n, o);
+    if ((threadIdx.x & 63) == 0) s_cnt[threadIdx.x >> 6] = n;
+    __syncthreads();
+    if (threadIdx.x == 0) chunk_counts[blockIdx.x] = s_cnt[0] + s_cnt[1] + s_cnt[2] + s_cnt[3];
+}
+
+// pass 2: exclusive scan of the chunk counts of one frame (one block per frame)
+__global__ __launch_bounds__(256) void region_scan_kernel(const int* __restrict__ chunk_counts,
+                                                          long long* __restrict__ chunk_offsets,
+                                                          int chunks_per_frame, int64_t* __restrict__ counts) {
+    __shared__ long long s_part[256];
+    const int f = blockIdx.x;
+    const int* cc = chunk_counts + (long long)f * chunks_per_frame;
+    long long* off = chunk_offsets + (long long)f * chunks_per_frame;
+    const int per = (chunks_per_frame + 255) / 256;
+    const int lo = min((int)threadIdx.x * per, chunks_per_frame), hi = min(lo + per, chunks_per_frame);
+    long long s = 0;
+    for (int i = lo; i < hi; ++i) s += cc[i];
+    s_part[threadIdx.x] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        long long run = 0;
+        for (int i = 0; i < 256; ++i) {
+            const long long t = s_part[i];
+            s_part[i] = run;
+            run += t;
+        }
+        counts[f] = run;
+    }
+    __syncthreads();
+    long long run = s_part[threadIdx.x];
+    for (int i = lo; i < hi; ++i) {
+        off[i] = run;
+        run += cc[i];
+    }
+}
+
+// pass 3: ordered write of (level, y, x, 0) rows
+__global__ __launch_bounds__(256) void region_write_kernel(const float* __restrict__ value, const LevelTab tab,
+                                                           const RegionTab rt, const unsigned* __restrict__ cells,
+                                                           const long long* __restrict__ chunk_offsets,
+                                                           int64_t* __restrict__ idx, long long cap_per_frame) {
+    __shared__ float s_pooled[kMaxWin * kMaxWin];
+    __shared__ int s_wave[4];
+    const TileCoord tc = locate_tile(tab, blockIdx.x);
+    const RegionLevel& rl = rt.lv[tc.level];
+    const int W = tab.w[tc.level];
+    const int npx = tab.h[tc.level] * W;
+    const long long base_px = (long long)tc.frame * tab.frame_px + tab.px_off[tc.level];
+    load_pooled(cells + ((long long)tc.frame * tab.n_levels + tc.level) * kCells, rl, s_pooled);
+    __syncthreads();
+    bool hit[4];
+    int n = 0;
+    for (int k = 0; k < 4; ++k) {
+        const int p = tc.tx * kChunk + threadIdx.x * 4 + k;
+        hit[k] = p < npx && region_pred(value, base_px, p, W, rl, s_pooled);
+        n += hit[k] ? 1 : 0;
+    }
+    // exclusive prefix of n over the block: inclusive wave scan, then wave offsets through LDS
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    int incl = n;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const int t = __shfl_up(incl, o);
+        if (lane >= o) incl += t;
+    }
+    if (lane == 63) s_wave[wave] = incl;
+    __syncthreads();
+    int rank = incl - n;
+    for (int i = 0; i < wave; ++i) rank += s_wave[i];
+    long long pos = chunk_offsets[blockIdx.x] + rank;
+    int64_t* dst = idx + (long long)tc.frame * cap_per_frame * 4;
+    for (int k = 0; k < 4; ++k) {
+        if (!hit[k]) continue;
+        if (pos < cap_per_frame) {
+            const int p = tc.tx * kChunk + threadIdx.x * 4 + k;
+            const int y = p / W, x = p - y * W;
+            dst[pos * 4 + 0] = tc.level;
+            dst[pos * 4 + 1] = y;
+            dst[pos * 4 + 2] = x;
+            dst[pos * 4 + 3] = 0;
+        }
+        ++pos;
+    }
+}
+
+}  // namespace silent

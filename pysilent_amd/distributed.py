@@ -1,0 +1,83 @@
+"""Frame sharding across the GPUs of one node: one process per GPU, no per-frame collectives.
+
+The path shards by independent units (frames), so the only communication is ONE
+broadcast of the packed constant kernels from rank 0 at init (RCCL when the backend is "nccl", gloo on
+CPU in the tests).  The reference itself has no multi-device code at all
+(slam_recognition/recognition_testing.py:64 hard-codes '/device:GPU:0').
+"""
+import os
+
+import numpy as np
+
+from .pipeline import default_constants, pack_constants, unpack_constants
+
+
+def world():
+    """(rank, world_size, local_rank) from the torchrun environment (1 process -> (0, 1, 0))."""
+    return (int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1")),
+            int(os.environ.get("LOCAL_RANK", "0")))
+
+
+def init(backend=None):
+    """Initialise torch.distributed when launched with more than one rank.  Returns (rank, world_size, local_rank)."""
+    rank, size, local = world()
+    if size > 1:
+        import torch
+        import torch.distributed as dist
+        if not dist.is_initialized():
+            if backend is None:
+                backend = "nccl" if torch.cuda.is_available() else "gloo"
+            if backend == "nccl":
+                torch.cuda.set_device(local)
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            dist.init_process_group(backend=backend, rank=rank, world_size=size)
+    return rank, size, local
+
+
+def shard_frame_indices(n_frames_total, rank, world_size):
+    """Frame i goes to rank i mod G."""
+    return list(range(rank, n_frames_total, world_size))
+
+
+def broadcast_constants(mode, n_orient=4, device=None):
+    """Rank 0 generates the constant kernels; everyone receives one flat float32 blob (< 8 KB).
+
+    The layout (names + shapes) is a pure function of (mode, n_orient), so only the floats travel."""
+    import torch
+    import torch.distributed as dist
+    local = default_constants(mode, n_orient)
+    blob, layout = pack_constants(local)
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+        return unpack_constants(blob, layout)
+    on_gpu = dist.get_backend() == "nccl"
+    dev = torch.device("cuda", int(os.environ.get("LOCAL_RANK", "0")) if device is None else device) if on_gpu else "cpu"
+    if dist.get_rank() == 0:
+        t = torch.from_numpy(blob.copy()).to(dev)
+    else:
+        t = torch.zeros(blob.shape[0], dtype=torch.float32, device=dev)    # receivers do NOT keep their own copy
+    dist.broadcast(t, src=0)
+    return unpack_constants(t.cpu().numpy(), layout)
+
+
+def max_over_ranks(value):
+    """MAX all-reduce of a Python float (step time of the slowest rank)."""
+    import torch
+    import torch.distributed as dist
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+        return float(value)
+    on_gpu = dist.get_backend() == "nccl"
+    t = torch.tensor([float(value)], dtype=torch.float64,
+                     device=torch.device("cuda", int(os.environ.get("LOCAL_RANK", "0"))) if on_gpu else "cpu")
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    return float(t.item())
+
+
+def barrier():
+    import torch.distributed as dist
+    if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+        dist.barrier()
+
+
+def synthetic_frame(index, h, w, c):
+    """noise frame with seed = global frame index."""
+    return np.random.default_rng(index).integers(0, 256, (h, w, c)).astype(np.float32)

@@ -1,0 +1,176 @@
+"""LineEndPipeline: the whole per-frame hot path, batched and device-resident.
+
+Op order = the reference's graph, slam_recognition/recognition_testing.py:136-144 (callback: frame ->
+zoom pyramid) and :69-90 (compile: rgc -> rgby -> orientation -> line-end -> clip -> pad -> value ->
+keypoint indices), restated for the two workloads of BASELINE.json:
+
+  mode "gray"  (configs 1, 2, 5)  frame[H,W,1] -> pyramid -> CS -> ReLU -> K-orientation end bank -> ReLU -> clip
+  mode "rgb"   (config 3)         frame[H,W,3] -> pyramid -> rgc -> rgby -> stripe -> regulate -> end -> clip
+                                   -> pad_inwards -> value -> per-region keypoint indices
+
+All buffers are torch GPU tensors allocated once; every launch goes to torch's current stream through the
+``*_dev`` C-ABI entry points, so a step is pure kernel launches (no allocation, no synchronisation).
+PyTorch is used for device memory and streams only.
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import _lib, _runtime
+from . import constant_convolutions as cc
+from .util.normalize import normalize_tensor_positive_negative
+from .util.zoom.from_image import classic_levels, reference_levels
+
+
+def default_constants(mode, n_orient=4):
+    """The constant kernels of a pipeline as one dict of float32 HWIO arrays (what gets broadcast)."""
+    if mode == "gray":
+        cs = normalize_tensor_positive_negative(cc.center_surround_tensor(2, [1], [1], [1], [-1]))
+        return {"cs": cs.astype(np.float32), "end": cc.end_bank(n_orient).astype(np.float32)}
+    if mode == "rgb":
+        return {"rgc": cc.midget_rgc(2).astype(np.float32), "rgby": cc.rgby_3(2).astype(np.float32),
+                "stripe": cc.rgb_2d_stripe_tensors().astype(np.float32), "blur": cc.blur_tensor(2, 7).astype(np.float32),
+                "end": cc.rgb_2d_end_tensors().astype(np.float32)}
+    raise ValueError("mode must be 'gray' or 'rgb'")
+
+
+def pack_constants(consts):
+    """dict of arrays -> (flat float32 blob, layout) for a single broadcast."""
+    layout, parts = [], []
+    for name in sorted(consts):
+        a = np.ascontiguousarray(consts[name], dtype=np.float32)
+        layout.append((name, a.shape))
+        parts.append(a.reshape(-1))
+    return np.concatenate(parts), layout
+
+
+def unpack_constants(blob, layout):
+    out, off = {}, 0
+    for name, shape in layout:
+        n = int(np.prod(shape))
+        out[name] = np.asarray(blob[off:off + n], dtype=np.float32).reshape(shape).copy()
+        off += n
+    return out
+
+
+class LineEndPipeline(object):
+    def __init__(self, frame_hw, mode="gray", n_levels=5, scale=2.0, n_orient=4, batch=1, device=None,
+                 constants=None, center_dimensions=None, clip_hi=255.0, flat_policy="ieee", pad=2,
+                 max_keypoints_per_frame=None):
+        import torch
+        self.torch = torch
+        self.mode = mode
+        self.channels = 1 if mode == "gray" else 3
+        self.device_index = _runtime.default_device() if device is None else int(device)
+        self.tdev = torch.device("cuda", self.device_index)
+        self.ctx = _runtime.get_context(self.device_index)
+        self.batch = int(batch)
+        h, w = int(frame_hw[0]), int(frame_hw[1])
+        self.frame_shape = (h, w, self.channels)
+        levels = (reference_levels((h, w), center_dimensions, scale) if center_dimensions is not None
+                  else classic_levels((h, w), scale, n_levels))
+        self.plan = _runtime.PyramidPlan(h, w, self.channels, levels, self.device_index)
+        self.extents = self.plan.extents
+        self.frame_px = self.plan.frame_px
+        self.n_levels = len(self.extents)
+        self.levels_c = (_lib.Extent * self.n_levels)(*[_lib.Extent(eh, ew) for eh, ew in self.extents])
+        self.consts = {k: np.ascontiguousarray(v, np.float32) for k, v in
+                       (constants or default_constants(mode, n_orient)).items()}
+        self.clip_hi, self.flat_policy, self.pad = float(clip_hi), flat_policy, int(pad)
+        n = self.batch * self.frame_px
+        f32 = dict(dtype=torch.float32, device=self.tdev)
+        self.pyr = torch.empty(n * self.channels, **f32)
+        if mode == "gray":
+            self.n_orient = int(self.consts["end"].shape[3])
+            self.cs = torch.empty(n, **f32)
+            self.end = torch.empty(n * self.n_orient, **f32)
+        else:
+            self.orient = torch.empty(n * 3, **f32)
+            self.line_end = torch.empty(n * 3, **f32)
+            self.value = torch.empty(n, **f32)
+            self.regions = (_lib.Extent * self.n_levels)(*[_lib.Extent(max(eh // 2, 1), max(ew // 2, 1))
+                                                           for eh, ew in self.extents])
+            self.kp_cap = int(max_keypoints_per_frame or self.frame_px)
+            self.kp_idx = torch.empty((self.batch, self.kp_cap, 4), dtype=torch.int64, device=self.tdev)
+            self.kp_counts = torch.zeros(self.batch, dtype=torch.int64, device=self.tdev)
+            fp = C.POINTER(C.c_float)
+            self._params = _lib.RgbChainParams(
+                *[self.consts[k].ctypes.data_as(fp) for k in ("rgc", "rgby", "stripe", "blur", "end")],
+                1.0, 0.1, {"ieee": _lib.FLAT_IEEE, "zero": _lib.FLAT_ZERO}[flat_policy], self.clip_hi, self.pad)
+        self._lib = _lib.load()
+
+    # -- byte accounting -------------------------------------------------------
+    def algorithmic_bytes_per_frame(self):
+        """4*[H*W*C (frame read) + P*C (pyramid written) + P*C (pyramid read) + P*sum(C_out returned)]"""
+        h, w, c = self.frame_shape
+        outs = (1 + self.n_orient) if self.mode == "gray" else (3 + 3 + 1)
+        return 4 * (h * w * c + 2 * self.frame_px * c + self.frame_px * outs)
+
+    def filter_bytes_per_frame(self):
+        """The filter pass alone: pyramid read once + every returned map written once."""
+        c = self.channels
+        outs = (1 + self.n_orient) if self.mode == "gray" else (3 + 3 + 1)
+        return 4 * self.frame_px * (c + outs)
+
+    def pyramid_bytes_per_frame(self):
+        h, w, c = self.frame_shape
+        return 4 * c * (h * w + self.frame_px)
+
+    # -- launches --------------------------------------------------------------------------------------
+    def _stream(self):
+        return C.c_void_p(self.torch.cuda.current_stream(self.tdev).cuda_stream)
+
+    def _check_frames(self, frames):
+        if tuple(frames.shape) != (self.batch,) + self.frame_shape or frames.dtype != self.torch.float32 \
+                or not frames.is_cuda or not frames.is_contiguous():
+            raise ValueError("frames must be a contiguous float32 GPU tensor of shape %s" %
+                             ((self.batch,) + self.frame_shape,))
+
+    def run_pyramid(self, frames, stream=None):
+        self._check_frames(frames)
+        self.ctx.check(self._lib.silent_pyramid_dev(self.ctx.handle, self.plan.handle, C.c_void_p(frames.data_ptr()),
+                                                    self.batch, C.c_void_p(self.pyr.data_ptr()),
+                                                    stream or self._stream()))
+
+    def run_filters(self, stream=None):
+        s = stream or self._stream()
+        if self.mode == "gray":
+            self.ctx.check(self._lib.silent_gray_line_end_dev(
+                self.ctx.handle, C.c_void_p(self.pyr.data_ptr()), self.levels_c, self.n_levels, self.batch,
+                C.c_void_p(self.consts["cs"].ctypes.data), C.c_void_p(self.consts["end"].ctypes.data), self.n_orient,
+                self.clip_hi, C.c_void_p(self.cs.data_ptr()), C.c_void_p(self.end.data_ptr()), s))
+        else:
+            self.ctx.check(self._lib.silent_rgb_line_end_dev(
+                self.ctx.handle, C.c_void_p(self.pyr.data_ptr()), self.levels_c, self.n_levels, self.batch,
+                C.byref(self._params), C.c_void_p(self.orient.data_ptr()), C.c_void_p(self.line_end.data_ptr()),
+                C.c_void_p(self.value.data_ptr()), s))
+
+    def run_keypoints(self, stream=None):
+        self.ctx.check(self._lib.silent_max_value_indices_region_dev(
+            self.ctx.handle, C.c_void_p(self.value.data_ptr()), self.levels_c, self.n_levels, self.batch, self.regions,
+            C.c_void_p(self.kp_idx.data_ptr()), self.kp_cap, C.c_void_p(self.kp_counts.data_ptr()),
+            stream or self._stream()))
+
+    def step(self, frames):
+        """One pass of the hot path over one batch of frames (asynchronous)."""
+        s = self._stream()
+        self.run_pyramid(frames, s)
+        self.run_filters(s)
+        if self.mode == "rgb":
+            self.run_keypoints(s)
+
+    # -- results as PackedPyramids over the pipeline's buffers ---------------------------------------
+    def outputs(self):
+        P = _runtime.PackedPyramid
+        out = {"pyramid": P(self.pyr, self.extents, self.channels, self.batch)}
+        if self.mode == "gray":
+            out["cs"] = P(self.cs, self.extents, 1, self.batch)
+            out["end"] = P(self.end, self.extents, self.n_orient, self.batch)
+        else:
+            out["orient"] = P(self.orient, self.extents, 3, self.batch)
+            out["line_end"] = P(self.line_end, self.extents, 3, self.batch)
+            out["value"] = P(self.value, self.extents, 1, self.batch)
+            counts = self.kp_counts.cpu().numpy()
+            idx = self.kp_idx.cpu().numpy()
+            out["keypoints"] = [idx[f, :min(int(counts[f]), self.kp_cap)].copy() for f in range(self.batch)]
+        return out

@@ -1,0 +1,76 @@
+import os
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+ORACLE = os.path.join(ROOT, "oracle")
+if ORACLE not in sys.path:
+    sys.path.insert(0, ORACLE)
+
+GOLDEN = os.path.join(ROOT, "tests", "golden")
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+@pytest.fixture(scope="session")
+def golden():
+    return dict(np.load(os.path.join(GOLDEN, "kernels.npz")))
+
+
+@pytest.fixture(scope="session")
+def kernels(golden):
+    """The constant kernels of the chain, from the PRODUCT generators (checked against the goldens in
+    test_generators.py), HWIO float64."""
+    from pysilent_amd import constant_convolutions as cc
+    from pysilent_amd.util.normalize import normalize_tensor_positive_negative
+    return dict(
+        rgc=cc.midget_rgc(2), rgby=cc.rgby_3(2), stripe=cc.rgb_2d_stripe_tensors(), blur=cc.blur_tensor(2, 7),
+        end=cc.rgb_2d_end_tensors(),
+        cs_gray=normalize_tensor_positive_negative(cc.center_surround_tensor(2, [1], [1], [1], [-1])),
+        end4=cc.end_bank(4), end8=cc.end_bank(8), end3=cc.end_bank(3),
+    )
+
+
+def noise_frame(seed, h, w, c):
+    """SURVEY.md section 8d synthetic input: uint8-range noise cast to float32."""
+    return np.random.default_rng(seed).integers(0, 256, (h, w, c)).astype(np.float32)
+
+
+def structured_frame(seed, h, w, c, n_lines=200):
+    """Black background + random 1-3 px wide bright line segments: real line ends and flat regions."""
+    rng = np.random.default_rng(1000 + seed)
+    img = np.zeros((h, w, c), np.float32)
+    for _ in range(n_lines):
+        x0, y0 = rng.integers(0, w), rng.integers(0, h)
+        ang = rng.uniform(0, 2 * np.pi)
+        length = rng.integers(5, max(6, min(h, w) // 3))
+        width = rng.integers(1, 4)
+        col = rng.integers(128, 256, c).astype(np.float32)
+        for t in range(length):
+            x, y = int(round(x0 + t * np.cos(ang))), int(round(y0 + t * np.sin(ang)))
+            img[max(0, y):min(h, y + width), max(0, x):min(w, x + width)] = col
+    return img
+
+
+def assert_close(got, want, rtol=1e-5, scale=None, what=""):
+    """Response-map tolerance of BASELINE.json: 1e-5 relative.  The absolute floor is 1e-5 times the
+    dynamic range of the expected map (|a-b| <= rtol * (|b| + range)), so values that cancel to ~0 are
+    judged against the magnitude of the terms that produced them, not against 0."""
+    got, want = np.asarray(got), np.asarray(want)
+    assert got.shape == want.shape, (what, got.shape, want.shape)
+    nan_g, nan_w = np.isnan(got), np.isnan(want)
+    assert np.array_equal(nan_g, nan_w), "%s: NaN pattern differs (%d vs %d)" % (what, nan_g.sum(), nan_w.sum())
+    fin = ~nan_w
+    if scale is None:
+        scale = float(np.max(np.abs(want[fin]))) if fin.any() else 1.0
+    err = np.abs(got[fin].astype(np.float64) - want[fin].astype(np.float64))
+    tol = rtol * (np.abs(want[fin].astype(np.float64)) + scale)
+    bad = err > tol
+    assert not bad.any(), "%s: %d / %d elements off; max err %.3e (tol %.3e)" % (
+        what, bad.sum(), bad.size, err.max(), tol[np.argmax(err)])

@@ -1,0 +1,354 @@
+"""GPU parity: the HIP path (through the C ABI) against the CPU oracle on the same seeded inputs.
+
+Tolerances (BASELINE.json north_star): response maps within 1e-5 relative (see conftest.assert_close
+for the exact statement), keypoint indices and every other integer / mask result bit-exact.
+"""
+import math
+
+import numpy as np
+import pytest
+
+import silent_oracle as so
+import c_oracle as co
+from conftest import assert_close, noise_frame, structured_frame
+
+pytestmark = pytest.mark.gpu
+
+RTOL = 1e-5
+
+
+@pytest.fixture(scope="module")
+def rt():
+    from pysilent_amd import _runtime
+    _runtime.get_context()          # fails loudly if there is no gfx950 device
+    return _runtime
+
+
+def f32(k):
+    return np.asarray(k, np.float64).astype(np.float32)
+
+
+# ----------------------------------------------------------------------------- convolution
+
+@pytest.mark.parametrize("name", ["rgc", "rgby", "stripe", "end", "blur"])
+@pytest.mark.parametrize("shape", [(2, 37, 53, 3), (1, 5, 3, 3), (3, 16, 64, 3), (1, 1, 1, 3), (1, 17, 130, 3)])
+def test_conv2d_reference_kernels(rt, kernels, name, shape):
+    x = np.random.default_rng(7).integers(0, 256, shape).astype(np.float32)
+    got = rt.conv2d_same(x, kernels[name], relu=True)
+    assert_close(got, so.conv2d_same(x, kernels[name], relu=True), RTOL, what=name)
+
+
+@pytest.mark.parametrize("kshape", [(3, 3, 1, 1), (3, 3, 1, 3), (3, 3, 1, 4), (3, 3, 1, 8), (3, 3, 3, 1), (3, 3, 3, 4),
+                                    (7, 7, 1, 1), (5, 5, 3, 2), (2, 2, 3, 3), (1, 3, 3, 3), (4, 6, 2, 5)])
+def test_conv2d_shapes_including_generic_path(rt, kshape):
+    rng = np.random.default_rng(11)
+    x = (rng.standard_normal((2, 23, 71, kshape[2])) * 40).astype(np.float32)
+    k = rng.standard_normal(kshape)
+    assert_close(rt.conv2d_same(x, k), so.conv2d_same(x, k), RTOL, what=str(kshape))
+    assert_close(rt.conv2d_same(x, k, relu=True, clip_hi=30.0), so.conv2d_same(x, k, relu=True, clip_hi=30.0), RTOL)
+
+
+def test_conv2d_known_answers(rt, kernels):
+    # impulse: output = kernel flipped around the impulse (cross-correlation), independent of the oracle
+    k = f32(kernels["end"])
+    x = np.zeros((1, 9, 9, 3), np.float32)
+    x[0, 4, 4, 1] = 1.0
+    out = rt.conv2d_same(x, k)
+    for dy in range(3):
+        for dx in range(3):
+            np.testing.assert_array_equal(out[0, 4 - (dy - 1), 4 - (dx - 1)], k[dy, dx, 1])
+    # constant image: interior = c * sum of taps (midget_rgc: 4/3 - 2/3 per diagonal channel); border from SAME zeros
+    rgc = f32(kernels["rgc"])
+    x = np.full((1, 8, 8, 3), 30.0, np.float32)
+    out = rt.conv2d_same(x, rgc)
+    np.testing.assert_allclose(out[0, 1:-1, 1:-1], 30.0 * 2.0 / 3.0, rtol=1e-6)
+    corner = 30.0 * rgc[1:, 1:, 0, 0].astype(np.float64).sum()
+    np.testing.assert_allclose(out[0, 0, 0, 0], corner, rtol=1e-6)
+
+
+def test_filters_api_matches_reference_chain(rt, kernels):
+    from pysilent_amd import filters
+    from pysilent_amd.util.apply_filter import apply_filter
+    x = noise_frame(3, 48, 64, 3)[None]
+    rgc = filters.rgc_filter(x)
+    assert_close(rgc, so.conv2d_same(x, kernels["rgc"], relu=True), RTOL, what="rgc_filter")
+    rgby = filters.rgby_filter(rgc)
+    assert_close(rgby, so.conv2d_same(rgc, kernels["rgby"], relu=True), RTOL, what="rgby_filter")
+    orient = filters.orientation_filter(rgby)
+    want = so.regulate(so.conv2d_same(rgby, kernels["stripe"], relu=True), kernels["blur"], 1.0, 0.1)
+    assert_close(orient, want, RTOL, what="orientation_filter")
+    le = apply_filter(orient, kernels["end"], relu=True, clip_hi=255.0)
+    assert_close(le, so.conv2d_same(orient, kernels["end"], relu=True, clip_hi=255.0), RTOL, what="apply_filter")
+    assert rgc.dtype == np.float32 and rgc.shape == x.shape
+
+
+def test_bad_arguments_raise_value_error(rt, kernels):
+    x = np.zeros((1, 8, 8, 3), np.float32)
+    with pytest.raises(ValueError):
+        rt.conv2d_same(x, np.zeros((3, 3, 1, 3)))              # C_in mismatch
+    with pytest.raises(ValueError):
+        rt.conv2d_same(x[0], kernels["rgc"])                   # rank 3
+    with pytest.raises(ValueError):
+        rt.conv2d_same(x, np.zeros((17, 17, 3, 3)))            # outside the supported set
+    with pytest.raises(ValueError):
+        rt.regulate(x, kernels["blur"], 1.0, 0.1, flat_policy="bogus")
+    with pytest.raises(ValueError):
+        rt.gray_line_end(np.zeros((1, 8, 8, 1), np.float32), kernels["cs_gray"], np.zeros((3, 3, 1, 5)))
+
+
+# ----------------------------------------------------------------------------- regulator
+
+@pytest.mark.parametrize("policy", ["ieee", "zero"])
+def test_regulate(rt, kernels, policy):
+    x = so.conv2d_same(noise_frame(5, 40, 56, 3)[None], kernels["stripe"], relu=True)
+    x[0, :18, :20] = 0          # an all-zero window: 0 * inf = NaN under "ieee"
+    want = so.regulate(x, kernels["blur"], 1.0, 0.1, policy)
+    got = rt.regulate(x, kernels["blur"], 1.0, 0.1, policy)
+    assert np.isnan(want).any() == (policy == "ieee")
+    assert_close(got, want, RTOL, what="regulate " + policy)
+    small = (x * np.float32(1e-3)).astype(np.float32)      # blur < 1: the pow branch is live
+    assert_close(rt.regulate(small, kernels["blur"], 1.0, 0.5, policy),
+                 so.regulate(small, kernels["blur"], 1.0, 0.5, policy), RTOL, what="regulate small")
+
+
+def test_regulate_gray_blur(rt):
+    from pysilent_amd.constant_convolutions import blur_tensor
+    x = (noise_frame(6, 33, 47, 1)[None] / 255.0).astype(np.float32)
+    for size in (3, 7, 5):
+        b = blur_tensor(2, size, 1, 1)
+        assert_close(rt.regulate(x, b, 2.0, 0.5), so.regulate(x, b, 2.0, 0.5), RTOL, what="blur %d" % size)
+
+
+# ----------------------------------------------------------------------------- fused gray pass
+
+def ragged_pyramid(rt, seed, extents, c=1, n_frames=2):
+    rng = np.random.default_rng(seed)
+    levels = [rng.integers(0, 256, (n_frames, h, w, c)).astype(np.float32) for h, w in extents]
+    return rt.PackedPyramid.from_levels(levels), levels
+
+
+@pytest.mark.parametrize("K", [3, 4, 8])
+def test_gray_line_end_fused(rt, kernels, K):
+    extents = [(70, 131), (35, 66), (18, 33), (9, 17), (1, 1), (32, 64), (33, 65)]
+    packed, levels = ragged_pyramid(rt, 20 + K, extents)
+    bank = kernels["end%d" % K]
+    cs, end = rt.gray_line_end(packed, kernels["cs_gray"], bank)
+    for l, lev in enumerate(levels):
+        want_cs = so.conv2d_same(lev, kernels["cs_gray"], relu=True)
+        want_end = so.conv2d_same(want_cs, bank, relu=True, clip_hi=255.0)
+        assert_close(cs.level(l), want_cs, RTOL, what="cs level %d" % l)
+        # the second conv reads the GPU's own cs map: compare against the oracle applied to that map too
+        assert_close(end.level(l), so.conv2d_same(np.ascontiguousarray(cs.level(l)), bank, relu=True, clip_hi=255.0),
+                     RTOL, what="end|gpu-cs level %d" % l)
+        assert_close(end.level(l), want_end, RTOL, scale=255.0, what="end level %d" % l)
+
+
+def test_gray_line_end_equals_two_convs(rt, kernels):
+    x = noise_frame(9, 45, 70, 1)[None]
+    cs, end = rt.gray_line_end(x, kernels["cs_gray"], kernels["end4"], clip_hi=20.0)
+    cs2 = rt.conv2d_same(x, kernels["cs_gray"], relu=True)
+    end2 = rt.conv2d_same(cs2, kernels["end4"], relu=True, clip_hi=20.0)
+    np.testing.assert_array_equal(cs, cs2)            # same fma order -> bit-identical
+    np.testing.assert_array_equal(end, end2)
+    only_cs, none = rt.gray_line_end(x, kernels["cs_gray"], kernels["end4"], want_end=False)
+    assert none is None
+    np.testing.assert_array_equal(only_cs, cs)
+
+
+def test_config1_640x480_three_levels_center_surround(rt, kernels):
+    """BASELINE config 1: one 640x480 gray frame, 3-level pyramid, center-surround only."""
+    from pysilent_amd.util.zoom import classic_pyramid
+    frame = noise_frame(0, 480, 640, 1)
+    pyr = classic_pyramid(frame, 2.0, 3)
+    assert pyr.extents == [(480, 640), (240, 320), (120, 160)]
+    want_pyr = so.classic_pyramid(frame, 2.0, 3)
+    cs, _ = rt.gray_line_end(pyr, kernels["cs_gray"], kernels["end4"], want_end=False)
+    for l in range(3):
+        assert_close(pyr.level(l), want_pyr[l], RTOL, what="pyramid level %d" % l)
+        assert_close(cs.level(l), so.conv2d_same(want_pyr[l], kernels["cs_gray"], relu=True), RTOL, scale=255.0,
+                     what="cs level %d" % l)
+    # the 3-channel kernel of the reference's own test on the frame replicated to 3 channels
+    from pysilent_amd.constant_convolutions import center_surround_tensor
+    k3 = center_surround_tensor(2, [0, 1, 0], [1, 0, 0], [0, 0, 1], [1, 0, 0])
+    x3 = np.repeat(want_pyr[2], 3, axis=3)
+    assert_close(rt.conv2d_same(x3, k3, relu=True), so.conv2d_same(x3, k3, relu=True), RTOL, what="cs 3ch")
+
+
+# ----------------------------------------------------------------------------- pyramid
+
+@pytest.mark.parametrize("shape,center,scale", [((480, 640, 3), (288, 192), math.e ** .5),
+                                                ((480, 640, 3), (160, 120), math.e ** .5),
+                                                ((120, 160, 1), (40, 30), 2.0),
+                                                ((97, 131, 3), (32, 24), 1.7)])
+def test_from_image_reference_layout(rt, shape, center, scale):
+    from pysilent_amd.util import zoom
+    img = noise_frame(1, *shape)
+    got = zoom.from_image(img, shape[2], center, scale)
+    want = so.zoom_from_image(img, shape[2], center, scale)     # calls scipy.ndimage.zoom like the reference
+    assert got.shape == want.shape and got.dtype == np.float32
+    assert_close(got, want, RTOL, scale=255.0, what="from_image")
+
+
+@pytest.mark.parametrize("shape,scale,n", [((135, 240, 1), 2.0, 5), ((135, 240, 3), 2.0, 4), ((270, 480, 1), math.e ** .5, 6),
+                                           ((48, 64, 1), 2.0, 2), ((100, 37, 1), 1.3, 7)])
+def test_classic_pyramid(rt, shape, scale, n):
+    from pysilent_amd.util.zoom import classic_pyramid
+    frames = np.stack([noise_frame(s, *shape) for s in range(2)])
+    got = classic_pyramid(frames, scale, n)
+    for f in range(2):
+        want = so.classic_pyramid(frames[f], scale, n)
+        for l in range(n):
+            assert_close(got.level(l)[f:f + 1], want[l], RTOL, scale=255.0, what="frame %d level %d" % (f, l))
+
+
+def test_pyramid_known_answers(rt):
+    from pysilent_amd.util.zoom import classic_pyramid
+    img = np.zeros((11, 11, 1), np.float32)
+    img[5, 5, 0] = 120.0 * 120.0
+    lvl0 = classic_pyramid(img, 2.0, 1).level(0)[0, :, :, 0]
+    np.testing.assert_allclose(lvl0[5, 3:8], [66., 1716., 4356., 1716., 66.], rtol=1e-6)   # [1,26,66,26,1]^2 row
+    const = np.full((41, 57, 1), 77.0, np.float32)      # mirror taps: a constant image stays constant
+    for lev, want in zip(classic_pyramid(const, 2.0, 3).levels(), so.classic_pyramid(const, 2.0, 3)):
+        assert (want == 77.0).all()                      # (sizes chosen so that scipy's last-row rule stays out)
+        np.testing.assert_allclose(lev, 77.0, rtol=1e-6)
+    # scipy's mode='constant' rule: 23 * (47/23) lands one ulp above 47 -> the last output row is cval = 0
+    img = noise_frame(2, 48, 64, 1)
+    lvl1 = classic_pyramid(img, 2.0, 2).level(1)[0, :, :, 0]
+    assert (lvl1[-1] == 0).all() and (lvl1[:-1] != 0).any()
+
+
+# ----------------------------------------------------------------------------- pointwise, nms, selection
+
+def test_pad_value_nms_bit_exact(rt):
+    x = noise_frame(4, 29, 43, 3)[None]
+    x[0, 3:9, 4:12] = 0                         # a zero plateau: every pixel of it "fires"
+    pads = [[0, 0], [2, 2], [2, 2], [0, 0]]
+    from pysilent_amd.util.selection import pad_inwards
+    from pysilent_amd.util.color import get_value_from_color
+    from pysilent_amd.util.energy import has_fired, local_maxima
+    np.testing.assert_array_equal(pad_inwards(x, pads), so.pad_inwards(x, pads))
+    np.testing.assert_array_equal(pad_inwards(x, [[0, 0], [1, 3], [0, 5], [0, 0]]),
+                                  so.pad_inwards(x, [[0, 0], [1, 3], [0, 5], [0, 0]]))
+    np.testing.assert_array_equal(get_value_from_color(x), so.value_from_color(x))
+    np.testing.assert_array_equal(local_maxima(x), so.nms3x3(x, "product"))
+    np.testing.assert_array_equal(has_fired(x), so.nms3x3(x, "fired"))
+    v = so.value_from_color(x)
+    np.testing.assert_array_equal(has_fired(v), so.nms3x3(v, "fired"))
+
+
+@pytest.mark.parametrize("p", [0.1, 0.5, 0.0, 1.0, 0.37])
+def test_top_value_points_bit_exact(rt, p):
+    from pysilent_amd.util.selection import top_value_points
+    x = np.stack([noise_frame(s, 31, 45, 3) for s in (0, 1, 2)])
+    x[1] *= 0.25
+    np.testing.assert_array_equal(top_value_points(x, p), so.top_value_points(x, p))
+    v = (so.value_from_color(x) - np.float32(100)).astype(np.float32)           # negative values too
+    np.testing.assert_array_equal(top_value_points(x, p, v), so.top_value_points(x, p, v))
+
+
+@pytest.mark.parametrize("shape,region", [((2, 192, 288, 3), (1, 96, 144, 3)), ((3, 37, 53, 3), (1, 18, 26, 3)),
+                                          ((1, 37, 53, 3), (1, 37, 53, 3)), ((2, 40, 40, 3), (1, 10, 14, 3)),
+                                          ((1, 19, 27, 1), (1, 7, 9, 1))])
+def test_max_value_indices_region_bit_exact(rt, shape, region):
+    from pysilent_amd.util.selection import max_value_indices_region
+    x = np.random.default_rng(8).integers(0, 256, shape).astype(np.float32)
+    x[0, :shape[1] // 2, :shape[2] // 2] = 0     # an all-zero quadrant: every pixel of it is emitted
+    got = max_value_indices_region(x, region)
+    want = so.max_value_indices_region(x, region)
+    assert got.dtype == np.int64
+    np.testing.assert_array_equal(got, want)
+    v = so.value_from_color(x)
+    np.testing.assert_array_equal(max_value_indices_region(x, region, v), co.max_value_indices_region(x, region, v))
+
+
+def test_max_value_indices_capacity_error(rt):
+    v = np.zeros((1, 16, 16, 1), np.float32)
+    idx, counts = rt.max_value_indices_region(v, [(8, 8)])
+    assert counts[0] == 256
+    with pytest.raises(ValueError, match="cap_per_frame"):
+        rt.max_value_indices_region(v, [(8, 8)], cap_per_frame=10)
+
+
+# ----------------------------------------------------------------------------- RGB chain
+
+@pytest.mark.parametrize("policy,frame", [("ieee", "noise"), ("zero", "structured"), ("ieee", "structured")])
+def test_rgb_chain(rt, kernels, policy, frame):
+    img = noise_frame(2, 64, 96, 3) if frame == "noise" else structured_frame(2, 64, 96, 3, 30)
+    x = img[None]
+    want = so.rgb_line_end_chain(x, kernels, policy)
+    got = rt.rgb_line_end(x, kernels, flat_policy=policy)
+    if frame == "noise":
+        assert not np.isnan(want["line_end"]).any()            # SURVEY hard part 3: noise frames stay finite
+    assert_close(got["orient"], want["orient"], RTOL, what="orient")
+    # later stages: compare against the oracle continued from the GPU's own orient (isolates each stage) ...
+    le = so.pad_inwards(so.conv2d_same(np.ascontiguousarray(got["orient"]), kernels["end"], relu=True, clip_hi=255.0),
+                        [[0, 0], [2, 2], [2, 2], [0, 0]])
+    assert_close(got["line_end"], le, RTOL, what="line_end|gpu-orient")
+    np.testing.assert_array_equal(got["value"], so.value_from_color(np.ascontiguousarray(got["line_end"])))
+    # ... and end to end
+    assert_close(got["line_end"], want["padded"], RTOL, scale=255.0, what="line_end")
+    assert_close(got["value"], want["value"], RTOL, scale=255.0, what="value")
+
+
+def test_rgb_chain_on_packed_levels_and_keypoints(rt, kernels):
+    from pysilent_amd.util.selection import max_value_indices_region
+    extents = [(64, 96), (32, 48), (16, 24)]
+    packed, levels = ragged_pyramid(rt, 31, extents, c=3, n_frames=2)
+    got = rt.rgb_line_end(packed, kernels)
+    regions = [(h // 2, w // 2) for h, w in extents]
+    kp = max_value_indices_region(got["line_end"], regions, got["value"])
+    assert len(kp) == 2
+    for f in range(2):
+        rows = []
+        for l, lev in enumerate(levels):
+            v = np.ascontiguousarray(got["value"].level(l)[f:f + 1])
+            want = so.rgb_line_end_chain(lev[f:f + 1], kernels)
+            assert_close(got["line_end"].level(l)[f:f + 1], want["padded"], RTOL, scale=255.0, what="level %d" % l)
+            r = so.max_value_indices_region(None, (1,) + regions[l] + (3,), v)
+            r[:, 0] = l
+            rows.append(r)
+        np.testing.assert_array_equal(kp[f], np.concatenate(rows))     # bit-exact, row-major, level-major
+
+
+# ----------------------------------------------------------------------------- device-resident (torch) path
+
+def test_torch_device_path_is_bit_identical(rt, kernels):
+    torch = pytest.importorskip("torch")
+    assert torch.cuda.is_available()
+    from pysilent_amd.util.zoom import classic_pyramid
+    frames = np.stack([noise_frame(s, 135, 240, 1) for s in range(3)])
+    host = classic_pyramid(frames, 2.0, 4)
+    dev = classic_pyramid(torch.from_numpy(frames).cuda(), 2.0, 4)
+    assert dev.on_device
+    np.testing.assert_array_equal(dev.data.cpu().numpy(), host.data)
+    cs_h, end_h = rt.gray_line_end(host, kernels["cs_gray"], kernels["end4"])
+    cs_d, end_d = rt.gray_line_end(dev, kernels["cs_gray"], kernels["end4"])
+    np.testing.assert_array_equal(cs_d.data.cpu().numpy(), cs_h.data)
+    np.testing.assert_array_equal(end_d.data.cpu().numpy(), end_h.data)
+    x = torch.from_numpy(noise_frame(1, 40, 60, 3)[None]).cuda()
+    from pysilent_amd import filters
+    y = filters.rgc_filter(x)
+    assert y.is_cuda
+    np.testing.assert_array_equal(y.cpu().numpy(), filters.rgc_filter(x.cpu().numpy()))
+
+
+# ----------------------------------------------------------------------------- full size (BASELINE config 2)
+
+def test_config2_1080p_full_size_against_c_oracle(rt, kernels):
+    """1080p gray, 5-level pyramid, CS + 4-orientation line-end: the bench workload, one frame."""
+    from pysilent_amd.util.zoom import classic_pyramid
+    frame = noise_frame(0, 1080, 1920, 1)
+    pyr = classic_pyramid(frame, 2.0, 5)
+    assert pyr.extents == [(1080, 1920), (540, 960), (270, 480), (135, 240), (68, 120)]
+    assert pyr.frame_px == 2762160
+    cs, end = rt.gray_line_end(pyr, kernels["cs_gray"], kernels["end4"])
+    want_pyr = co.classic_pyramid(frame, pyr.extents)
+    for l in range(5):
+        assert_close(pyr.level(l), want_pyr[l], RTOL, scale=255.0, what="pyramid %d" % l)
+        wcs, wend = co.gray_line_end_level(want_pyr[l], kernels["cs_gray"], kernels["end4"])
+        assert_close(cs.level(l), wcs, RTOL, scale=255.0, what="cs %d" % l)
+        assert_close(end.level(l), wend, RTOL, scale=255.0, what="end %d" % l)
+    # size-independent properties: linearity of the pyramid, and ReLU/clip range of the responses
+    pyr2 = classic_pyramid(frame * np.float32(0.5), 2.0, 5)
+    np.testing.assert_allclose(pyr2.data, pyr.data * np.float32(0.5), rtol=1e-6, atol=1e-4)
+    assert end.data.min() >= 0 and end.data.max() <= 255 and cs.data.min() >= 0
