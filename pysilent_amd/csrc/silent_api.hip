@@ -591,12 +591,22 @@ static void axis_table(int n_in, int n_out, int* base, int* idx, float* wts) {
         const long b = (long)std::floor(c);
         double w[6] = {0, 0, 0, 0, 0, 0};
         if (c >= 0.0 && c <= (double)(n_in - 1)) spline5_weights(c - (double)b, w);
-        if (base) base[o] = (int)b;
+        base[o] = (int)b;
         for (int j = 0; j < 6; ++j) {
             wts[6 * o + j] = (float)w[j];
-            if (idx) idx[6 * o + j] = host_mirror(b - 2 + j, n_in);
+            idx[6 * o + j] = host_mirror(b - 2 + j, n_in);
         }
     }
+}
+
+// widest unmirrored tap span [base(o0)-2, base(o1)+3] over tiles of `tile` consecutive outputs
+static int worst_span(const int* base, int n, int tile) {
+    int worst = 0;
+    for (int o0 = 0; o0 < n; o0 += tile) {
+        const int o1 = std::min(o0 + tile, n) - 1;
+        worst = std::max(worst, base[o1] + 3 - (base[o0] - 2) + 1);
+    }
+    return worst;
 }
 
 SILENT_EXPORT int silent_pyramid_plan_create(silent_ctx* ctx, int frame_h, int frame_w, int channels,
@@ -640,30 +650,35 @@ SILENT_EXPORT int silent_pyramid_plan_create(silent_ctx* ctx, int frame_h, int f
         rows += L.zoom_h;
         plan->extents.push_back(silent_extent{L.out_h, L.out_w});
     }
-    std::vector<int> xidx(cols * 6), ybase(rows);
+    std::vector<int> xbase(cols), xidx(cols * 6), ybase(rows), yidx(rows * 6);
     std::vector<float> xw(cols * 6), yw(rows * 6);
+    const int max_sw = channels == 1 ? dense_max_sw(1) : dense_max_sw(3);
     for (int l = 0; l < n_levels; ++l) {
         PyrLevelDev& d = tab.lv[l];
-        axis_table(d.src_w, d.zoom_w, nullptr, xidx.data() + (size_t)d.xtab_off * 6, xw.data() + (size_t)d.xtab_off * 6);
-        axis_table(d.src_h, d.zoom_h, ybase.data() + d.ytab_off, nullptr, yw.data() + (size_t)d.ytab_off * 6);
-        // rows per tile: the source lines a tile touches must fit the LDS slab
-        const int* yb = ybase.data() + d.ytab_off;
-        int th = kPyrMaxTH;
-        for (;;) {
-            int worst = 0;
-            const int zrows = std::min(d.zoom_h, d.out_h);
-            for (int oy0 = 0; oy0 < zrows; oy0 += th) {
-                const int oy1 = std::min(oy0 + th, zrows) - 1;
-                worst = std::max(worst, yb[oy1] + 3 - (yb[oy0] - 2) + 1);
-            }
-            if (worst <= kPyrMaxRows || th == 1) break;
-            th = th > 2 ? th / 2 : 1;
+        int* xb = xbase.data() + d.xtab_off;
+        int* yb = ybase.data() + d.ytab_off;
+        float* xwl = xw.data() + (size_t)d.xtab_off * 6;
+        float* ywl = yw.data() + (size_t)d.ytab_off * 6;
+        axis_table(d.src_w, d.zoom_w, xb, xidx.data() + (size_t)d.xtab_off * 6, xwl);
+        axis_table(d.src_h, d.zoom_h, yb, yidx.data() + (size_t)d.ytab_off * 6, ywl);
+        // path selection (see silent_pyramid.h)
+        const int zc = std::min(d.zoom_w, d.out_w), zr = std::min(d.zoom_h, d.out_h);
+        const bool unit = d.zoom_h == d.src_h && d.zoom_w == d.src_w && std::fabs(xwl[5]) < 1e-12f &&
+                          std::fabs(ywl[5]) < 1e-12f;
+        int tw = 0, th = 0;
+        for (int c : {64, 32}) if (!tw && worst_span(xb, zc, c) <= max_sw) tw = c;
+        for (int r : {16, 8}) if (!th && worst_span(yb, zr, r) <= kDenseMaxSH) th = r;
+        if (unit) {
+            d.kind = kPyrUnit; d.tile_w = kUnitTW; d.tile_h = kUnitTH;
+        } else if (tw && th) {
+            d.kind = kPyrDense; d.tile_w = tw; d.tile_h = th;
+        } else {
+            d.kind = kPyrSparse; d.tile_w = kSparseTW; d.tile_h = kSparseTH;
         }
-        d.tile_h = th;
         tab.px_off[l] = px;
         tab.tile_start[l] = (int)tiles;
-        tab.tiles_x[l] = (d.out_w + kPyrTW - 1) / kPyrTW;
-        tiles += (long long)tab.tiles_x[l] * ((d.out_h + th - 1) / th);
+        tab.tiles_x[l] = (d.out_w + d.tile_w - 1) / d.tile_w;
+        tiles += (long long)tab.tiles_x[l] * ((d.out_h + d.tile_h - 1) / d.tile_h);
         px += (long long)d.out_h * d.out_w;
     }
     if (tiles > 0x7fffffffll) {
@@ -673,28 +688,33 @@ SILENT_EXPORT int silent_pyramid_plan_create(silent_ctx* ctx, int frame_h, int f
     tab.tile_start[n_levels] = (int)tiles;
     tab.tiles_per_frame = (int)tiles;
     tab.frame_px_out = px;
-    const size_t b_xidx = align_up(xidx.size() * sizeof(int)), b_xw = align_up(xw.size() * sizeof(float));
-    const size_t b_yb = align_up(ybase.size() * sizeof(int)), b_yw = align_up(yw.size() * sizeof(float));
-    hipError_t e = hipMalloc(&plan->tables, b_xidx + b_xw + b_yb + b_yw);
+    const size_t b_xb = align_up(xbase.size() * 4), b_xi = align_up(xidx.size() * 4), b_xw = align_up(xw.size() * 4);
+    const size_t b_yb = align_up(ybase.size() * 4), b_yi = align_up(yidx.size() * 4), b_yw = align_up(yw.size() * 4);
+    hipError_t e = hipMalloc(&plan->tables, b_xb + b_xi + b_xw + b_yb + b_yi + b_yw);
     if (e != hipSuccess) {
         (void)hipGetLastError();
         delete plan;
         return fail(ctx, SILENT_E_NOMEM, std::string(who) + ": hipMalloc: " + hipGetErrorString(e));
     }
     char* base = (char*)plan->tables;
-    tab.xidx = (const int*)base;
-    tab.xw = (const float*)(base + b_xidx);
-    tab.ybase = (const int*)(base + b_xidx + b_xw);
-    tab.yw = (const float*)(base + b_xidx + b_xw + b_yb);
-    e = hipMemcpy((void*)tab.xidx, xidx.data(), xidx.size() * sizeof(int), hipMemcpyHostToDevice);
-    if (e == hipSuccess) e = hipMemcpy((void*)tab.xw, xw.data(), xw.size() * sizeof(float), hipMemcpyHostToDevice);
-    if (e == hipSuccess) e = hipMemcpy((void*)tab.ybase, ybase.data(), ybase.size() * sizeof(int), hipMemcpyHostToDevice);
-    if (e == hipSuccess) e = hipMemcpy((void*)tab.yw, yw.data(), yw.size() * sizeof(float), hipMemcpyHostToDevice);
-    if (e != hipSuccess) {
-        (void)hipGetLastError();
-        (void)hipFree(plan->tables);
-        delete plan;
-        return fail(ctx, SILENT_E_HIP, std::string(who) + ": hipMemcpy: " + hipGetErrorString(e));
+    tab.xbase = (const int*)base;
+    tab.xidx = (const int*)(base + b_xb);
+    tab.xw = (const float*)(base + b_xb + b_xi);
+    tab.ybase = (const int*)(base + b_xb + b_xi + b_xw);
+    tab.yidx = (const int*)(base + b_xb + b_xi + b_xw + b_yb);
+    tab.yw = (const float*)(base + b_xb + b_xi + b_xw + b_yb + b_yi);
+    const struct { const void* dst; const void* src; size_t bytes; } copies[] = {
+        {tab.xbase, xbase.data(), xbase.size() * 4}, {tab.xidx, xidx.data(), xidx.size() * 4},
+        {tab.xw, xw.data(), xw.size() * 4},          {tab.ybase, ybase.data(), ybase.size() * 4},
+        {tab.yidx, yidx.data(), yidx.size() * 4},    {tab.yw, yw.data(), yw.size() * 4}};
+    for (const auto& c : copies) {
+        e = hipMemcpy((void*)c.dst, c.src, c.bytes, hipMemcpyHostToDevice);
+        if (e != hipSuccess) {
+            (void)hipGetLastError();
+            (void)hipFree(plan->tables);
+            delete plan;
+            return fail(ctx, SILENT_E_HIP, std::string(who) + ": hipMemcpy: " + hipGetErrorString(e));
+        }
     }
     *out = plan;
     return SILENT_OK;

@@ -43,6 +43,17 @@ __device__ __forceinline__ TileCoord locate_tile(const LevelTab& tab, unsigned b
     return t;
 }
 
+// Neighbour exchange inside a wave by DPP wavefront shifts (VALU, no LDS round trip).
+// lane i receives lane i-1 (lane 0 keeps its own value) / lane i+1 (lane 63 keeps its own value).
+__device__ __forceinline__ float from_lane_below(float v) {
+    const int i = __float_as_int(v);
+    return __int_as_float(__builtin_amdgcn_update_dpp(i, i, 0x138 /* wave_shr:1 */, 0xf, 0xf, false));
+}
+__device__ __forceinline__ float from_lane_above(float v) {
+    const int i = __float_as_int(v);
+    return __int_as_float(__builtin_amdgcn_update_dpp(i, i, 0x130 /* wave_shl:1 */, 0xf, 0xf, false));
+}
+
 // tf.maximum(x, [0]) with Eigen's CPU functor: a NaN stays a NaN (oracle: relu_tf).
 __device__ __forceinline__ float relu_tf(float v) { return v < 0.0f ? 0.0f : v; }
 __device__ __forceinline__ float clip_hi_tf(float v, float hi) { return v > hi ? hi : v; }

@@ -174,107 +174,123 @@ __global__ __launch_bounds__(256) void conv2d_same_generic_kernel(const float* _
 // ---------------------------------------------------------------------------------------------
 // Fused grayscale pass (BASELINE configs 1/2/5):  cs = relu(conv3x3(x, cs_k));
 //                                                 end = clip(relu(conv3x3(cs, end_bank)), 0, hi)
-// One 64 x 32 output tile per 256-thread block.  The input tile (halo 2) and the CS tile (halo 1)
-// live in LDS; CS values outside the level are forced to 0 because the second convolution's SAME
-// padding pads the CS MAP, not the input.  In phase C a lane owns one column and slides a 3x3
-// register window down 8 rows, so the dominant traffic (K floats per pixel, NHWC) leaves as one
-// contiguous 64 x 4K-byte row per wave instruction.
+//
+// Wave-autonomous streaming stencil: no LDS, no barrier.  A wave owns a strip of 64 columns (60 of
+// them produce outputs) and walks down R rows.  Each lane loads its own column (one coalesced dword
+// per row, all R+4 rows requested up front), receives the left / right neighbours by a DPP wave shift,
+// keeps a 3x3 input window and a 3x3 CS window in registers, and emits one CS value and one K-vector
+// per row.  Lanes 0/63 only feed their neighbours' CS, lanes 1/62 only feed their neighbours' outputs,
+// so lanes 2..61 own the 60 output columns.  CS values outside the level are forced to 0 because the
+// second convolution's SAME padding pads the CS MAP, not the input.  The dominant traffic (K floats
+// per pixel, NHWC) leaves as one contiguous 60 x 4K-byte run per wave instruction.
 struct GrayW {
     float cs[9];
     float end[9 * 8];  // [dy][dx][k], k < K
 };
 
-constexpr int kGrayTW = 64;
-constexpr int kGrayTH = 32;
+constexpr int kGrayCols = 60;            // output columns per wave
+constexpr int kGrayTW = 4 * kGrayCols;   // 4 waves side by side
+constexpr int kGrayTH = 16;              // rows per tile (R)
 
 template <int K>
 __global__ __launch_bounds__(256) void gray_line_end_kernel(const float* __restrict__ pyr,
                                                             float* __restrict__ cs_out,
                                                             float* __restrict__ end_out, const LevelTab tab,
                                                             const GrayW wts, float clip_hi) {
-    constexpr int TW = kGrayTW, TH = kGrayTH;
-    constexpr int IW = TW + 4, IH = TH + 4;  // input tile, halo 2
-    constexpr int CW = TW + 2, CH = TH + 2;  // CS tile, halo 1
-    __shared__ float s_in[IH * IW];
-    __shared__ float s_cs[CH * CW];
-
+    constexpr int R = kGrayTH;
     const TileCoord tc = locate_tile(tab, blockIdx.x);
     const int H = tab.h[tc.level], W = tab.w[tc.level];
     const long long base_px = (long long)tc.frame * tab.frame_px + tab.px_off[tc.level];
     const float* __restrict__ src = pyr + base_px;
-    const int x0 = tc.tx * TW, y0 = tc.ty * TH;
-    const int tid = threadIdx.x;
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int xw0 = tc.tx * kGrayTW + wave * kGrayCols;  // first output column of this wave
+    if (xw0 >= W) return;                                // wave-uniform
+    const int y0 = tc.ty * R;
+    const int x = xw0 + lane - 2;
+    const bool col_ok = x >= 0 && x < W;
+    const int xc = min(max(x, 0), W - 1);
 
-    for (int p = tid; p < IH * IW; p += 256) {
-        const int r = p / IW, c = p - r * IW;
-        const int y = y0 + r - 2, x = x0 + c - 2;
-        float v = 0.0f;
-        if (y >= 0 && y < H && x >= 0 && x < W) v = src[(long long)y * W + x];
-        s_in[p] = v;
+    // all R+4 input rows of this lane's column, requested before the first use (clamped address +
+    // select: no branch around a load)
+    float in[R + 4];
+#pragma unroll
+    for (int i = 0; i < R + 4; ++i) {
+        const int y = y0 - 2 + i;
+        const bool row_ok = y >= 0 && y < H;
+        const float v = src[(long long)min(max(y, 0), H - 1) * W + xc];
+        in[i] = (row_ok && col_ok) ? v : 0.0f;
     }
-    __syncthreads();
+    // Retire every requested row here.  Loads and stores share vmcnt in issue order, so a counted wait
+    // for a late row inside the loop below would also wait for the previous rows' STORES to be
+    // acknowledged; with the loads retired up front the row loop carries no vector-memory wait at all.
+#pragma unroll
+    for (int i = 0; i < R + 4; ++i) asm volatile("" ::"v"(in[i]));
 
-    for (int p = tid; p < CH * CW; p += 256) {
-        const int r = p / CW, c = p - r * CW;
-        const int y = y0 + r - 1, x = x0 + c - 1;
-        float v = 0.0f;
-        if (y >= 0 && y < H && x >= 0 && x < W) {
+    float iw[3][3], cw[3][3];
+#pragma unroll
+    for (int a = 0; a < 3; ++a)
+#pragma unroll
+        for (int b = 0; b < 3; ++b) iw[a][b] = cw[a][b] = 0.0f;
+    const bool out_lane = lane >= 2 && lane < 2 + kGrayCols && x < W;
+
+#pragma unroll
+    for (int i = 0; i < R + 4; ++i) {
+#pragma unroll
+        for (int b = 0; b < 3; ++b) {
+            iw[0][b] = iw[1][b];
+            iw[1][b] = iw[2][b];
+        }
+        iw[2][1] = in[i];
+        iw[2][0] = from_lane_below(in[i]);
+        iw[2][2] = from_lane_above(in[i]);
+        if (i >= 2) {
+            const int cy = y0 + i - 3;  // CS row produced by this step
             float acc = 0.0f;
 #pragma unroll
             for (int dy = 0; dy < 3; ++dy)
 #pragma unroll
-                for (int dx = 0; dx < 3; ++dx)
-                    acc = __builtin_fmaf(s_in[(r + dy) * IW + c + dx], wts.cs[dy * 3 + dx], acc);
-            v = relu_tf(acc);
+                for (int dx = 0; dx < 3; ++dx) acc = __builtin_fmaf(iw[dy][dx], wts.cs[dy * 3 + dx], acc);
+            float cs = relu_tf(acc);
+            cs = (cy >= 0 && cy < H && col_ok) ? cs : 0.0f;
+#pragma unroll
+            for (int b = 0; b < 3; ++b) {
+                cw[0][b] = cw[1][b];
+                cw[1][b] = cw[2][b];
+            }
+            cw[2][1] = cs;
+            cw[2][0] = from_lane_below(cs);
+            cw[2][2] = from_lane_above(cs);
         }
-        s_cs[p] = v;
-    }
-    __syncthreads();
-
-    const int col = tid & 63, wave = tid >> 6;
-    const int x = x0 + col;
-    if (x >= W) return;
-    constexpr int R = TH / 4;
-    const int r0 = wave * R;
-    float win[3][3];
+        if (i >= 4) {
+            const int y = y0 + i - 4;  // output row
+            if (y < H && out_lane) {
+                const long long px = base_px + (long long)y * W + x;
+                if (cs_out) cs_out[px] = cw[1][1];
+                if (end_out) {
+                    float acc[K];
 #pragma unroll
-    for (int j = 0; j < 2; ++j)
+                    for (int k = 0; k < K; ++k) acc[k] = 0.0f;
 #pragma unroll
-        for (int i = 0; i < 3; ++i) win[j + 1][i] = s_cs[(r0 + j) * CW + col + i];
+                    for (int dy = 0; dy < 3; ++dy)
 #pragma unroll
-    for (int rr = 0; rr < R; ++rr) {
-        const int y = y0 + r0 + rr;
-        if (y >= H) break;
+                        for (int dx = 0; dx < 3; ++dx)
 #pragma unroll
-        for (int i = 0; i < 3; ++i) {
-            win[0][i] = win[1][i];
-            win[1][i] = win[2][i];
-            win[2][i] = s_cs[(r0 + rr + 2) * CW + col + i];
-        }
-        const long long px = base_px + (long long)y * W + x;
-        if (cs_out) cs_out[px] = win[1][1];
-        if (end_out) {
-            float acc[K];
+                            for (int k = 0; k < K; ++k)
+                                acc[k] = __builtin_fmaf(cw[dy][dx], wts.end[(dy * 3 + dx) * K + k], acc[k]);
 #pragma unroll
-            for (int k = 0; k < K; ++k) acc[k] = 0.0f;
+                    for (int k = 0; k < K; ++k) acc[k] = clip_hi_tf(relu_tf(acc[k]), clip_hi);
+                    float* __restrict__ po = end_out + px * K;
+                    if constexpr (K == 4) {
+                        *reinterpret_cast<float4*>(po) = make_float4(acc[0], acc[1], acc[2], acc[3]);
+                    } else if constexpr (K == 8) {
+                        reinterpret_cast<float4*>(po)[0] = make_float4(acc[0], acc[1], acc[2], acc[3]);
+                        reinterpret_cast<float4*>(po)[1] = make_float4(acc[4], acc[5], acc[6], acc[7]);
+                    } else {
 #pragma unroll
-            for (int dy = 0; dy < 3; ++dy)
-#pragma unroll
-                for (int dx = 0; dx < 3; ++dx)
-#pragma unroll
-                    for (int k = 0; k < K; ++k)
-                        acc[k] = __builtin_fmaf(win[dy][dx], wts.end[(dy * 3 + dx) * K + k], acc[k]);
-#pragma unroll
-            for (int k = 0; k < K; ++k) acc[k] = clip_hi_tf(relu_tf(acc[k]), clip_hi);
-            float* __restrict__ po = end_out + px * K;
-            if constexpr (K == 4) {
-                *reinterpret_cast<float4*>(po) = make_float4(acc[0], acc[1], acc[2], acc[3]);
-            } else if constexpr (K == 8) {
-                reinterpret_cast<float4*>(po)[0] = make_float4(acc[0], acc[1], acc[2], acc[3]);
-                reinterpret_cast<float4*>(po)[1] = make_float4(acc[4], acc[5], acc[6], acc[7]);
-            } else {
-#pragma unroll
-                for (int k = 0; k < K; ++k) po[k] = acc[k];
+                        for (int k = 0; k < K; ++k) po[k] = acc[k];
+                    }
+                }
             }
         }
     }
