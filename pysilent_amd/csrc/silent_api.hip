@@ -599,16 +599,6 @@ static void axis_table(int n_in, int n_out, int* base, int* idx, float* wts) {
     }
 }
 
-// widest unmirrored tap span [base(o0)-2, base(o1)+3] over tiles of `tile` consecutive outputs
-static int worst_span(const int* base, int n, int tile) {
-    int worst = 0;
-    for (int o0 = 0; o0 < n; o0 += tile) {
-        const int o1 = std::min(o0 + tile, n) - 1;
-        worst = std::max(worst, base[o1] + 3 - (base[o0] - 2) + 1);
-    }
-    return worst;
-}
-
 SILENT_EXPORT int silent_pyramid_plan_create(silent_ctx* ctx, int frame_h, int frame_w, int channels,
                                              const silent_pyr_level* levels, int n_levels,
                                              silent_pyramid_plan** out) {
@@ -630,7 +620,10 @@ SILENT_EXPORT int silent_pyramid_plan_create(silent_ctx* ctx, int frame_h, int f
     tab.H = frame_h;
     tab.W = frame_w;
     tab.C = channels;
-    long long cols = 0, rows = 0, px = 0, tiles = 0;
+    const int RW = channels == 1 ? region_w(1) : region_w(3);
+    tab.regions_x = (frame_w + RW - 1) / RW;
+    tab.regions_y = (frame_h + kRegionH - 1) / kRegionH;
+    long long cols = 0, rows = 0, px = 0;
     for (int l = 0; l < n_levels; ++l) {
         const silent_pyr_level& L = levels[l];
         const bool ok = L.src_h >= 1 && L.src_w >= 1 && L.src_y0 >= 0 && L.src_x0 >= 0 &&
@@ -648,11 +641,16 @@ SILENT_EXPORT int silent_pyramid_plan_create(silent_ctx* ctx, int frame_h, int f
         d.ytab_off = (int)rows;
         cols += L.zoom_w;
         rows += L.zoom_h;
+        tab.px_off[l] = px;
+        px += (long long)L.out_h * L.out_w;
         plan->extents.push_back(silent_extent{L.out_h, L.out_w});
     }
-    std::vector<int> xbase(cols), xidx(cols * 6), ybase(rows), yidx(rows * 6);
+    tab.frame_px_out = px;
+    std::vector<int> xbase(cols), xidx(cols * 6), ybase(rows), yidx(rows * 6), xreg, yreg;
     std::vector<float> xw(cols * 6), yw(rows * 6);
-    const int max_sw = channels == 1 ? dense_max_sw(1) : dense_max_sw(3);
+    long long unit_tiles = 0, zero_chunks = 0;
+    tab.n_general = 0;
+    bool tap_range_ok = true;
     for (int l = 0; l < n_levels; ++l) {
         PyrLevelDev& d = tab.lv[l];
         int* xb = xbase.data() + d.xtab_off;
@@ -661,61 +659,91 @@ SILENT_EXPORT int silent_pyramid_plan_create(silent_ctx* ctx, int frame_h, int f
         float* ywl = yw.data() + (size_t)d.ytab_off * 6;
         axis_table(d.src_w, d.zoom_w, xb, xidx.data() + (size_t)d.xtab_off * 6, xwl);
         axis_table(d.src_h, d.zoom_h, yb, yidx.data() + (size_t)d.ytab_off * 6, ywl);
-        // path selection (see silent_pyramid.h)
-        const int zc = std::min(d.zoom_w, d.out_w), zr = std::min(d.zoom_h, d.out_h);
+        // zoom factor exactly 1 <=> every output samples an integer coordinate: weights [1,26,66,26,1,~0]/120
         const bool unit = d.zoom_h == d.src_h && d.zoom_w == d.src_w && std::fabs(xwl[5]) < 1e-12f &&
                           std::fabs(ywl[5]) < 1e-12f;
-        int tw = 0, th = 0;
-        for (int c : {64, 32}) if (!tw && worst_span(xb, zc, c) <= max_sw) tw = c;
-        for (int r : {16, 8}) if (!th && worst_span(yb, zr, r) <= kDenseMaxSH) th = r;
+        d.kind = unit ? kPyrUnit : kPyrGeneral;
+        tab.unit_tile_start[l] = (int)unit_tiles;
+        tab.zero_chunk_start[l] = (int)zero_chunks;
+        tab.unit_tiles_x[l] = (d.out_w + kUnitTW - 1) / kUnitTW;
+        d.xreg_off = (int)xreg.size();
+        d.yreg_off = (int)yreg.size();
         if (unit) {
-            d.kind = kPyrUnit; d.tile_w = kUnitTW; d.tile_h = kUnitTH;
-        } else if (tw && th) {
-            d.kind = kPyrDense; d.tile_w = tw; d.tile_h = th;
-        } else {
-            d.kind = kPyrSparse; d.tile_w = kSparseTW; d.tile_h = kSparseTH;
+            unit_tiles += (long long)tab.unit_tiles_x[l] * ((d.out_h + kUnitTH - 1) / kUnitTH);
+            continue;
         }
-        tab.px_off[l] = px;
-        tab.tile_start[l] = (int)tiles;
-        tab.tiles_x[l] = (d.out_w + d.tile_w - 1) / d.tile_w;
-        tiles += (long long)tab.tiles_x[l] * ((d.out_h + d.tile_h - 1) / d.tile_h);
-        px += (long long)d.out_h * d.out_w;
+        ++tab.n_general;
+        // outputs are owned by the region that holds their ANCHOR = floor(source coordinate), frame coordinates
+        const int zc = std::min(d.zoom_w, d.out_w), zr = std::min(d.zoom_h, d.out_h);
+        int o = 0;
+        for (int r = 0; r <= tab.regions_x; ++r) {
+            while (o < zc && xb[o] + d.src_x0 < r * RW) ++o;
+            xreg.push_back(r == tab.regions_x ? zc : o);
+        }
+        o = 0;
+        for (int r = 0; r <= tab.regions_y; ++r) {
+            while (o < zr && yb[o] + d.src_y0 < r * kRegionH) ++o;
+            yreg.push_back(r == tab.regions_y ? zr : o);
+        }
+        // every mirrored tap of an anchored output must lie inside its region's staged tile (see the kernel)
+        const int* xi = xidx.data() + (size_t)d.xtab_off * 6;
+        const int* yi = yidx.data() + (size_t)d.ytab_off * 6;
+        for (int ox = 0; ox < zc; ++ox) {
+            const int X0 = ((xb[ox] + d.src_x0) / RW) * RW;
+            for (int j = 0; j < 6; ++j) {
+                const int p = xi[(size_t)ox * 6 + j] + d.src_x0 - (X0 - kRegionHaloL);
+                if (p < 0 || p >= RW + kRegionHaloL + kRegionHaloR) tap_range_ok = false;
+            }
+        }
+        for (int oy = 0; oy < zr; ++oy) {
+            const int Y0 = ((yb[oy] + d.src_y0) / kRegionH) * kRegionH;
+            for (int j = 0; j < 6; ++j) {
+                const int p = yi[(size_t)oy * 6 + j] + d.src_y0 - (Y0 - kRegionHaloT);
+                if (p < 0 || p >= kRegionSH) tap_range_ok = false;
+            }
+        }
+        if (d.out_h > d.zoom_h || d.out_w > d.zoom_w) zero_chunks += ((long long)d.out_h * d.out_w + 1023) / 1024;
     }
-    if (tiles > 0x7fffffffll) {
+    tab.unit_tile_start[n_levels] = (int)unit_tiles;
+    tab.unit_tiles_per_frame = (int)unit_tiles;
+    tab.zero_chunk_start[n_levels] = (int)zero_chunks;
+    tab.zero_chunks_per_frame = (int)zero_chunks;
+    if (!tap_range_ok) {
         delete plan;
-        return fail(ctx, SILENT_E_INVALID, std::string(who) + ": too many tiles");
+        return fail(ctx, SILENT_E_HIP, std::string(who) + ": internal error: a tap fell outside its staged region");
     }
-    tab.tile_start[n_levels] = (int)tiles;
-    tab.tiles_per_frame = (int)tiles;
-    tab.frame_px_out = px;
-    const size_t b_xb = align_up(xbase.size() * 4), b_xi = align_up(xidx.size() * 4), b_xw = align_up(xw.size() * 4);
-    const size_t b_yb = align_up(ybase.size() * 4), b_yi = align_up(yidx.size() * 4), b_yw = align_up(yw.size() * 4);
-    hipError_t e = hipMalloc(&plan->tables, b_xb + b_xi + b_xw + b_yb + b_yi + b_yw);
+    if (xreg.empty()) xreg.push_back(0);
+    if (yreg.empty()) yreg.push_back(0);
+    const std::vector<std::pair<const void*, size_t>> blobs = {
+        {xidx.data(), xidx.size() * 4}, {xw.data(), xw.size() * 4},     {yidx.data(), yidx.size() * 4},
+        {yw.data(), yw.size() * 4},     {xreg.data(), xreg.size() * 4}, {yreg.data(), yreg.size() * 4}};
+    size_t total = 0;
+    for (const auto& bl : blobs) total += align_up(bl.second);
+    hipError_t e = hipMalloc(&plan->tables, total);
     if (e != hipSuccess) {
         (void)hipGetLastError();
         delete plan;
         return fail(ctx, SILENT_E_NOMEM, std::string(who) + ": hipMalloc: " + hipGetErrorString(e));
     }
-    char* base = (char*)plan->tables;
-    tab.xbase = (const int*)base;
-    tab.xidx = (const int*)(base + b_xb);
-    tab.xw = (const float*)(base + b_xb + b_xi);
-    tab.ybase = (const int*)(base + b_xb + b_xi + b_xw);
-    tab.yidx = (const int*)(base + b_xb + b_xi + b_xw + b_yb);
-    tab.yw = (const float*)(base + b_xb + b_xi + b_xw + b_yb + b_yi);
-    const struct { const void* dst; const void* src; size_t bytes; } copies[] = {
-        {tab.xbase, xbase.data(), xbase.size() * 4}, {tab.xidx, xidx.data(), xidx.size() * 4},
-        {tab.xw, xw.data(), xw.size() * 4},          {tab.ybase, ybase.data(), ybase.size() * 4},
-        {tab.yidx, yidx.data(), yidx.size() * 4},    {tab.yw, yw.data(), yw.size() * 4}};
-    for (const auto& c : copies) {
-        e = hipMemcpy((void*)c.dst, c.src, c.bytes, hipMemcpyHostToDevice);
+    const void* dptr[6];
+    size_t off = 0;
+    for (size_t i = 0; i < blobs.size(); ++i) {
+        dptr[i] = (char*)plan->tables + off;
+        e = hipMemcpy((void*)dptr[i], blobs[i].first, blobs[i].second, hipMemcpyHostToDevice);
         if (e != hipSuccess) {
             (void)hipGetLastError();
             (void)hipFree(plan->tables);
             delete plan;
             return fail(ctx, SILENT_E_HIP, std::string(who) + ": hipMemcpy: " + hipGetErrorString(e));
         }
+        off += align_up(blobs[i].second);
     }
+    tab.xidx = (const int*)dptr[0];
+    tab.xw = (const float*)dptr[1];
+    tab.yidx = (const int*)dptr[2];
+    tab.yw = (const float*)dptr[3];
+    tab.xreg = (const int*)dptr[4];
+    tab.yreg = (const int*)dptr[5];
     *out = plan;
     return SILENT_OK;
 }
@@ -734,13 +762,21 @@ SILENT_EXPORT int silent_pyramid_dev(silent_ctx* ctx, const silent_pyramid_plan*
     if (!plan || !frames || !pyr) return fail(ctx, SILENT_E_INVALID, std::string(who) + ": NULL pointer");
     if (plan->ctx != ctx) return fail(ctx, SILENT_E_INVALID, std::string(who) + ": plan belongs to another context");
     if (n_frames < 1) return fail(ctx, SILENT_E_INVALID, std::string(who) + ": n_frames must be >= 1");
-    const long long blocks = (long long)plan->tab.tiles_per_frame * n_frames;
-    if (blocks > 0x7fffffffll) return fail(ctx, SILENT_E_INVALID, std::string(who) + ": too many tiles for one launch");
+    const PyrTab& tab = plan->tab;
+    const long long b_unit = (long long)tab.unit_tiles_per_frame * n_frames;
+    const long long b_region = tab.n_general ? (long long)tab.regions_x * tab.regions_y * n_frames : 0;
+    const long long b_zero = (long long)tab.zero_chunks_per_frame * n_frames;
+    if (b_unit > 0x7fffffffll || b_region > 0x7fffffffll || b_zero > 0x7fffffffll)
+        return fail(ctx, SILENT_E_INVALID, std::string(who) + ": too many tiles for one launch");
     hipStream_t s = (hipStream_t)stream;
-    if (plan->tab.C == 1)
-        hipLaunchKernelGGL(pyramid_kernel<1>, dim3((unsigned)blocks), dim3(256), 0, s, frames, pyr, plan->tab);
-    else
-        hipLaunchKernelGGL(pyramid_kernel<3>, dim3((unsigned)blocks), dim3(256), 0, s, frames, pyr, plan->tab);
+    if (tab.C == 1) {
+        if (b_unit) hipLaunchKernelGGL(pyramid_unit_kernel<1>, dim3((unsigned)b_unit), dim3(256), 0, s, frames, pyr, tab);
+        if (b_region) hipLaunchKernelGGL(pyramid_region_kernel<1>, dim3((unsigned)b_region), dim3(256), 0, s, frames, pyr, tab);
+    } else {
+        if (b_unit) hipLaunchKernelGGL(pyramid_unit_kernel<3>, dim3((unsigned)b_unit), dim3(256), 0, s, frames, pyr, tab);
+        if (b_region) hipLaunchKernelGGL(pyramid_region_kernel<3>, dim3((unsigned)b_region), dim3(256), 0, s, frames, pyr, tab);
+    }
+    if (b_zero) hipLaunchKernelGGL(pyramid_zero_kernel, dim3((unsigned)b_zero), dim3(256), 0, s, pyr, tab);
     return check_launch(ctx, who);
 }
 

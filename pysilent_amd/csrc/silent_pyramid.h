@@ -2,60 +2,70 @@
 // order=5, prefilter=False semantics; reference call site util/zoom/from_image.py:55-59),
 // separable, with the per-axis tap tables built on the host in float64.
 //
-// One launch covers every level of every frame; a tile takes one of three block-uniform paths:
-//   UNIT    zoom factor exactly 1 (level 0, 75 % of all pixels): the resampler degenerates to the fixed
-//           5-tap smoother [1,26,66,26,1]/120 per axis -> LDS-tiled separable stencil, float4 staging.
-//   DENSE   step <= ~4 source pixels per output pixel: the contiguous source footprint of the tile is
-//           staged into LDS once (coalesced), filtered vertically, then horizontally.
-//   SPARSE  larger steps (tiny levels): 36 gathered taps per output straight from L2.
+// The frame is read TWICE whatever the number of levels:
+//   pyramid_unit_kernel    levels whose zoom factor is exactly 1 (level 0, 75 % of all pixels).  The
+//                          resampler degenerates to the fixed 5-tap smoother [1,26,66,26,1]/120 per axis;
+//                          wave-autonomous streaming stencil (DPP neighbour exchange, no LDS, no barrier).
+//   pyramid_region_kernel  every other level.  One block per 128 x 32 source region: the region (+ halo)
+//                          is staged into LDS once with float4 loads, and each level's outputs ANCHORED in
+//                          the region (floor(source coordinate) inside it) are produced from that copy:
+//                          6-tap vertical pass into LDS, 6-tap horizontal pass, coalesced store.
+//                          (Variants tried on the GPU and rejected, DESIGN.md section 6: region-major tap
+//                          records staged in LDS, persistent blocks with register prefetch.)
+//   pyramid_zero_kernel    canvas pixels the zoomed crop does not cover (reference: uninitialised; here 0),
+//                          launched only when a non-unit level has such pixels.
 #pragma once
 
 #include "silent_common.h"
 
 namespace silent {
 
-enum { kPyrUnit = 0, kPyrDense = 1, kPyrSparse = 2 };
+enum { kPyrUnit = 0, kPyrGeneral = 1 };
 
-constexpr int kUnitTW = 64, kUnitTH = 32;         // UNIT output tile
-constexpr int kUnitSW = kUnitTW + 8;              // staged columns x0-4 .. x0+67 (16-byte aligned start)
-constexpr int kUnitSH = kUnitTH + 4;              // staged rows    y0-2 .. y0+33
-constexpr int kDenseMaxTW = 64, kDenseMaxTH = 16; // DENSE output tile (shrinks with the step)
-constexpr int kDenseMaxSH = 40;                   // staged source rows per tile
-__host__ __device__ constexpr int dense_max_sw(int C) { return C == 1 ? 136 : 72; }  // staged source columns
-constexpr int kSparseTW = 64, kSparseTH = 4;
+// ---- unit kernel geometry
+constexpr int kUnitCols = 60;             // output columns per wave (64 lanes - 2 halo lanes each side)
+constexpr int kUnitTW = 4 * kUnitCols;    // 4 waves side by side
+constexpr int kUnitTH = 16;               // rows per tile
 
-template <int C>
-__host__ __device__ constexpr int pyr_lds_floats() {
-    constexpr int unit = (kUnitSH * kUnitSW + kUnitSH * kUnitTW) * C;
-    constexpr int dense = (kDenseMaxSH + kDenseMaxTH) * dense_max_sw(C) * C;
-    return unit > dense ? unit : dense;
-}
+// ---- region kernel geometry
+__host__ __device__ constexpr int region_w(int C) { return C == 1 ? 128 : 64; }
+constexpr int kRegionH = 32;
+constexpr int kRegionHaloL = 4, kRegionHaloR = 4;   // staged columns [X0-4, X0+RW+4): float4 aligned, covers taps -3..+3
+constexpr int kRegionHaloT = 3, kRegionHaloB = 3;   // staged rows    [Y0-3, Y0+RH+3)
+constexpr int kRegionVR = 16;                       // output rows per vertical-pass chunk
+__host__ __device__ constexpr int region_sw(int C) { return region_w(C) + kRegionHaloL + kRegionHaloR; }
+constexpr int kRegionSH = kRegionH + kRegionHaloT + kRegionHaloB;
 
 struct PyrLevelDev {
     int src_y0, src_x0, src_h, src_w;
     int zoom_h, zoom_w, out_h, out_w;
-    int kind, tile_w, tile_h;
-    int xtab_off;  // entry offset (in output columns) of this level in the x tables
-    int ytab_off;  // entry offset (in output rows) in the y tables
+    int kind;
+    int xtab_off, ytab_off;  // entry offsets (output columns / rows) of this level in the tap tables
+    int xreg_off, yreg_off;  // entry offsets in the region-start tables (regions_x+1 / regions_y+1 entries)
 };
 
 struct PyrTab {
     int n_levels;
-    int tiles_per_frame;
     int H, W, C;
     long long frame_px_out;  // pixels of one output pyramid
     PyrLevelDev lv[kMaxLevels];
-    int tiles_x[kMaxLevels];
-    int tile_start[kMaxLevels + 1];
     long long px_off[kMaxLevels];
-    // device tables (one allocation owned by the plan); "base" = floor(coordinate), unmirrored,
-    // relative to the crop; idx = the 6 mirrored tap positions relative to the crop
-    const int* xbase;
+    // unit launch: tiles of kUnitTW x kUnitTH canvas pixels over the unit levels only
+    int unit_tiles_per_frame;
+    int unit_tiles_x[kMaxLevels];
+    int unit_tile_start[kMaxLevels + 1];
+    // region launch
+    int regions_x, regions_y, n_general;
+    // zero-fill launch (chunks of 1024 canvas pixels over the general levels that need it)
+    int zero_chunks_per_frame;
+    int zero_chunk_start[kMaxLevels + 1];
+    // device tables (one allocation owned by the plan); idx = the 6 mirrored tap positions relative to the crop
     const int* xidx;   // [cols][6]
     const float* xw;   // [cols][6]
-    const int* ybase;
     const int* yidx;   // [rows][6]
     const float* yw;   // [rows][6]
+    const int* xreg;   // per general level: first output column anchored at or right of region column rx
+    const int* yreg;
 };
 
 __device__ __forceinline__ int mirror_index(int i, int n) {
@@ -69,265 +79,232 @@ __device__ __forceinline__ int mirror_index(int i, int n) {
 }
 
 // ------------------------------------------------------------------------------------------ UNIT
+// A wave owns 64 source columns (60 outputs) and walks down kUnitTH rows: per row one coalesced load of
+// its own column (all rows requested up front), four DPP shifts for the +-1 / +-2 neighbours, 5 horizontal
+// FMAs, a 5-row register window, 5 vertical FMAs, one store.
 template <int C>
-__device__ __forceinline__ void pyr_unit_tile(const float* __restrict__ src, float* __restrict__ dst,
-                                              const PyrTab& tab, const PyrLevelDev& lv, int ty, int tx,
-                                              float* smem) {
-    constexpr int TW = kUnitTW, TH = kUnitTH, SW = kUnitSW, SH = kUnitSH;
-    float* s_src = smem;                 // [SH][SW][C]
-    float* s_h = smem + SH * SW * C;     // [SH][TW][C]
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int x0 = tx * TW, y0 = ty * TH;
+__global__ __launch_bounds__(256) void pyramid_unit_kernel(const float* __restrict__ frames,
+                                                           float* __restrict__ pyr, const PyrTab tab) {
+    constexpr int R = kUnitTH;
+    const unsigned bid = blockIdx.x;
+    const int frame = (int)(bid / (unsigned)tab.unit_tiles_per_frame);
+    int rem = (int)(bid - (unsigned)frame * (unsigned)tab.unit_tiles_per_frame);
+    int l = 0;
+#pragma unroll
+    for (int i = 1; i < kMaxLevels; ++i)
+        if (i < tab.n_levels && rem >= tab.unit_tile_start[i]) l = i;
+    rem -= tab.unit_tile_start[l];
+    const PyrLevelDev& lv = tab.lv[l];
+    const int ty = rem / tab.unit_tiles_x[l];
+    const int tx = rem - ty * tab.unit_tiles_x[l];
+
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int xw0 = tx * kUnitTW + wave * kUnitCols;
+    if (xw0 >= lv.out_w) return;  // wave-uniform
+    const int y0 = ty * R;
+    const int ox = xw0 + lane - 2;
     const int W = tab.W;
+    const float* __restrict__ src = frames + (long long)frame * tab.H * W * C;
+    float* __restrict__ dst = pyr + ((long long)frame * tab.frame_px_out + tab.px_off[l]) * C;
+
     float wx[5], wy[5];
 #pragma unroll
     for (int i = 0; i < 5; ++i) {
         wx[i] = tab.xw[(long long)lv.xtab_off * 6 + i];
         wy[i] = tab.yw[(long long)lv.ytab_off * 6 + i];
     }
+    const long long sx = (long long)(mirror_index(ox, lv.src_w) + lv.src_x0) * C;
+    float in[R + 4][C];
+#pragma unroll
+    for (int i = 0; i < R + 4; ++i) {
+        const long long sy = mirror_index(y0 - 2 + i, lv.src_h) + lv.src_y0;
+#pragma unroll
+        for (int ch = 0; ch < C; ++ch) in[i][ch] = src[sy * W * C + sx + ch];
+    }
+    // retire the loads before the first store (see gray_line_end_kernel)
+#pragma unroll
+    for (int i = 0; i < R + 4; ++i)
+#pragma unroll
+        for (int ch = 0; ch < C; ++ch) asm volatile("" ::"v"(in[i][ch]));
 
-    // stage rows y0-2 .. y0+33, columns x0-4 .. x0+67 (mirrored at the crop border)
-    const bool fast = (x0 - 4 >= 0) && (x0 + TW + 4 <= lv.src_w) && (((lv.src_x0 * C) & 3) == 0) &&
-                      (((W * C) & 3) == 0);
-    // Loads are issued in predicated batches (clamped index, no branch around a load) so that every
-    // thread has several requests in flight before the first wait.
-    if (fast) {
-        constexpr int V4 = SW * C / 4;  // float4 per staged row
-        constexpr int NB = (SH * V4 + 255) / 256;
+    const bool out_lane = lane >= 2 && lane < 2 + kUnitCols && ox < lv.out_w;
+    float hw[5][C];
+#pragma unroll
+    for (int j = 0; j < 5; ++j)
+#pragma unroll
+        for (int ch = 0; ch < C; ++ch) hw[j][ch] = 0.0f;
+#pragma unroll
+    for (int i = 0; i < R + 4; ++i) {
+#pragma unroll
+        for (int ch = 0; ch < C; ++ch) {
+            const float c0 = in[i][ch];
+            const float l1 = from_lane_below(c0), l2 = from_lane_below(l1);
+            const float r1 = from_lane_above(c0), r2 = from_lane_above(r1);
+            float h = wx[0] * l2;
+            h = __builtin_fmaf(wx[1], l1, h);
+            h = __builtin_fmaf(wx[2], c0, h);
+            h = __builtin_fmaf(wx[3], r1, h);
+            h = __builtin_fmaf(wx[4], r2, h);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) hw[j][ch] = hw[j + 1][ch];
+            hw[4][ch] = h;
+        }
+        if (i >= 4) {
+            const int oy = y0 + i - 4;
+            if (oy < lv.out_h && out_lane) {
+                const bool live = oy < lv.zoom_h && ox < lv.zoom_w;
+                float* __restrict__ po = dst + ((long long)oy * lv.out_w + ox) * C;
+#pragma unroll
+                for (int ch = 0; ch < C; ++ch) {
+                    float v = wy[0] * hw[0][ch];
+#pragma unroll
+                    for (int j = 1; j < 5; ++j) v = __builtin_fmaf(wy[j], hw[j][ch], v);
+                    po[ch] = live ? v : 0.0f;
+                }
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------ REGION
+// One block per source region: the region (+ halo) is staged into LDS once (batched float4 loads), then each
+// general level's outputs anchored in the region are produced from that copy: 6-tap vertical pass into LDS
+// for every staged column, barrier, 6-tap horizontal pass, coalesced store.  29 KB of LDS -> 5 blocks per CU
+// cover each other's table-load and barrier latencies.
+template <int C>
+__global__ __launch_bounds__(256) void pyramid_region_kernel(const float* __restrict__ frames,
+                                                             float* __restrict__ pyr, const PyrTab tab) {
+    constexpr int RW = region_w(C), SW = region_sw(C), SH = kRegionSH, ROWF = SW * C;
+    __shared__ __attribute__((aligned(16))) float s_src[SH * ROWF];
+    __shared__ __attribute__((aligned(16))) float s_v[kRegionVR * ROWF];
+
+    const int per_frame = tab.regions_x * tab.regions_y;
+    const unsigned bid = blockIdx.x;
+    const int frame = (int)(bid / (unsigned)per_frame);
+    const int rem = (int)(bid - (unsigned)frame * (unsigned)per_frame);
+    const int ry = rem / tab.regions_x, rx = rem - ry * tab.regions_x;
+    const int X0 = rx * RW, Y0 = ry * kRegionH;
+    const int W = tab.W, H = tab.H;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const float* __restrict__ src = frames + (long long)frame * H * W * C;
+
+    // stage rows [Y0-3, Y0+RH+3) x columns [X0-4, X0+RW+4).  Taps are mirrored INTO the crop, so positions
+    // outside the frame are never referenced: rows are clamped, out-of-frame column groups are skipped.
+    if (((W * C) & 3) == 0) {
+        constexpr int V4 = ROWF / 4, NB = (SH * V4 + 255) / 256;
         float4 v[NB];
-        const float* __restrict__ base = src + ((long long)lv.src_y0 * W + lv.src_x0 + x0 - 4) * C;
 #pragma unroll
         for (int k = 0; k < NB; ++k) {
             const int p = min(tid + 256 * k, SH * V4 - 1);
             const int r = p / V4, q = p - r * V4;
-            const int sy = mirror_index(y0 - 2 + r, lv.src_h);
-            v[k] = *reinterpret_cast<const float4*>(base + (long long)sy * W * C + q * 4);
+            const int sy = min(max(Y0 - kRegionHaloT + r, 0), H - 1);
+            long long f = (long long)(X0 - kRegionHaloL) * C + q * 4;  // first float of this group in the row
+            f = min(max(f, 0ll), (long long)W * C - 4);
+            v[k] = *reinterpret_cast<const float4*>(src + (long long)sy * W * C + f);
         }
 #pragma unroll
         for (int k = 0; k < NB; ++k) {
             const int p = tid + 256 * k;
             const int r = p / V4, q = p - r * V4;
-            if (p < SH * V4) *reinterpret_cast<float4*>(s_src + (r * SW) * C + q * 4) = v[k];
+            const long long f = (long long)(X0 - kRegionHaloL) * C + q * 4;
+            if (p < SH * V4 && f >= 0 && f + 4 <= (long long)W * C)
+                *reinterpret_cast<float4*>(s_src + r * ROWF + q * 4) = v[k];
         }
     } else {
-        constexpr int NB = (SH * SW + 255) / 256;
+        constexpr int NB = (SH * ROWF + 255) / 256;
+        float v[NB];
 #pragma unroll
-        for (int ch = 0; ch < C; ++ch) {
-            float v[NB];
+        for (int k = 0; k < NB; ++k) {
+            const int p = min(tid + 256 * k, SH * ROWF - 1);
+            const int r = p / ROWF, q = p - r * ROWF;
+            const int sy = min(max(Y0 - kRegionHaloT + r, 0), H - 1);
+            const long long f = min(max((long long)(X0 - kRegionHaloL) * C + q, 0ll), (long long)W * C - 1);
+            v[k] = src[(long long)sy * W * C + f];
+        }
 #pragma unroll
-            for (int k = 0; k < NB; ++k) {
-                const int p = min(tid + 256 * k, SH * SW - 1);
-                const int r = p / SW, c = p - r * SW;
-                const int sy = mirror_index(y0 - 2 + r, lv.src_h) + lv.src_y0;
-                const int sx = mirror_index(x0 - 4 + c, lv.src_w) + lv.src_x0;
-                v[k] = src[((long long)sy * W + sx) * C + ch];
-            }
-#pragma unroll
-            for (int k = 0; k < NB; ++k) {
-                const int p = tid + 256 * k;
-                if (p < SH * SW) s_src[p * C + ch] = v[k];
-            }
+        for (int k = 0; k < NB; ++k) {
+            const int p = tid + 256 * k;
+            if (p < SH * ROWF) s_src[p] = v[k];
         }
     }
     __syncthreads();
 
-    // horizontal 5 taps: output column j reads staged columns j+2 .. j+6
-    for (int r = wave; r < SH; r += 4) {
+    for (int l = 0; l < tab.n_levels; ++l) {
+        const PyrLevelDev& lv = tab.lv[l];
+        if (lv.kind != kPyrGeneral) continue;
+        const int xs = tab.xreg[lv.xreg_off + rx], xe = tab.xreg[lv.xreg_off + rx + 1];
+        const int ys = tab.yreg[lv.yreg_off + ry], ye = tab.yreg[lv.yreg_off + ry + 1];
+        if (xs >= xe || ys >= ye) continue;  // block-uniform
+        float* __restrict__ dst = pyr + ((long long)frame * tab.frame_px_out + tab.px_off[l]) * C;
+        const int xshift = lv.src_x0 - (X0 - kRegionHaloL), yshift = lv.src_y0 - (Y0 - kRegionHaloT);
+        for (int yc = ys; yc < ye; yc += kRegionVR) {
+            const int nr = min(kRegionVR, ye - yc);
+            // vertical 6 taps for every staged float of the rows this chunk needs (lanes = consecutive floats)
+            for (int orow = wave; orow < nr; orow += 4) {
+                const long long ye6 = (long long)(lv.ytab_off + yc + orow) * 6;
+                int ro[6];
+                float wy[6];
 #pragma unroll
-        for (int ch = 0; ch < C; ++ch) {
-            float acc = 0.0f;
+                for (int j = 0; j < 6; ++j) {
+                    ro[j] = min(max(tab.yidx[ye6 + j] + yshift, 0), SH - 1) * ROWF;
+                    wy[j] = tab.yw[ye6 + j];
+                }
+                for (int c = lane; c < ROWF; c += 64) {
+                    float acc = wy[0] * s_src[ro[0] + c];
 #pragma unroll
-            for (int i = 0; i < 5; ++i) acc = __builtin_fmaf(wx[i], s_src[(r * SW + lane + 2 + i) * C + ch], acc);
-            s_h[(r * TW + lane) * C + ch] = acc;
-        }
-    }
-    __syncthreads();
-
-    // vertical 5 taps, a 5-row register window sliding down the wave's 8 rows
-    const int ox = x0 + lane;
-    if (ox >= lv.out_w) return;
-    constexpr int R = TH / 4;
-    const int r0 = wave * R;
-    float win[5][C];
+                    for (int j = 1; j < 6; ++j) acc = __builtin_fmaf(wy[j], s_src[ro[j] + c], acc);
+                    s_v[orow * ROWF + c] = acc;
+                }
+            }
+            __syncthreads();
+            // horizontal 6 taps and store (lanes = consecutive output columns)
+            for (int oc = xs + lane; oc < xe; oc += 64) {
+                const long long xe6 = (long long)(lv.xtab_off + oc) * 6;
+                int co[6];
+                float wx[6];
 #pragma unroll
-    for (int j = 0; j < 4; ++j)
+                for (int i = 0; i < 6; ++i) {
+                    co[i] = min(max(tab.xidx[xe6 + i] + xshift, 0), SW - 1) * C;
+                    wx[i] = tab.xw[xe6 + i];
+                }
+                for (int orow = wave; orow < nr; orow += 4) {
+                    float* __restrict__ po = dst + ((long long)(yc + orow) * lv.out_w + oc) * C;
 #pragma unroll
-        for (int ch = 0; ch < C; ++ch) win[j + 1][ch] = s_h[((r0 + j) * TW + lane) * C + ch];
+                    for (int ch = 0; ch < C; ++ch) {
+                        float acc = wx[0] * s_v[orow * ROWF + co[0] + ch];
 #pragma unroll
-    for (int rr = 0; rr < R; ++rr) {
-        const int oy = y0 + r0 + rr;
-        if (oy >= lv.out_h) break;
-#pragma unroll
-        for (int ch = 0; ch < C; ++ch) {
-#pragma unroll
-            for (int j = 0; j < 4; ++j) win[j][ch] = win[j + 1][ch];
-            win[4][ch] = s_h[((r0 + rr + 4) * TW + lane) * C + ch];
-        }
-        const bool live = oy < lv.zoom_h && ox < lv.zoom_w;
-        float* __restrict__ po = dst + ((long long)oy * lv.out_w + ox) * C;
-#pragma unroll
-        for (int ch = 0; ch < C; ++ch) {
-            float acc = 0.0f;
-#pragma unroll
-            for (int j = 0; j < 5; ++j) acc = __builtin_fmaf(wy[j], win[j][ch], acc);
-            po[ch] = live ? acc : 0.0f;
+                        for (int i = 1; i < 6; ++i) acc = __builtin_fmaf(wx[i], s_v[orow * ROWF + co[i] + ch], acc);
+                        po[ch] = acc;
+                    }
+                }
+            }
+            __syncthreads();
         }
     }
 }
 
-// ------------------------------------------------------------------------------------------ DENSE
-template <int C>
-__device__ __forceinline__ void pyr_dense_tile(const float* __restrict__ src, float* __restrict__ dst,
-                                               const PyrTab& tab, const PyrLevelDev& lv, int ty, int tx,
-                                               float* smem) {
-    constexpr int SWM = dense_max_sw(C);
-    float* s_src = smem;                          // [kDenseMaxSH][SWM][C]
-    float* s_v = smem + kDenseMaxSH * SWM * C;    // [kDenseMaxTH][SWM][C]
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int ox0 = tx * lv.tile_w, oy0 = ty * lv.tile_h;
-    const int W = tab.W;
-    // output rows / columns of this tile that the resampler produces (the rest of the canvas is 0)
-    const int ncols = min(lv.tile_w, min(lv.zoom_w, lv.out_w) - ox0);
-    const int nrows = min(lv.tile_h, min(lv.zoom_h, lv.out_h) - oy0);
-    int cx0 = 0, SW = 0, ry0 = 0, SH = 0;
-    if (ncols > 0 && nrows > 0) {
-        cx0 = tab.xbase[lv.xtab_off + ox0] - 2;
-        SW = min(tab.xbase[lv.xtab_off + ox0 + ncols - 1] + 3 - cx0 + 1, SWM);  // host guarantees <=
-        ry0 = tab.ybase[lv.ytab_off + oy0] - 2;
-        SH = min(tab.ybase[lv.ytab_off + oy0 + nrows - 1] + 3 - ry0 + 1, kDenseMaxSH);
-    }
-    // per-thread horizontal taps (column = lane; tile_w <= 64); loads are unconditional on a clamped index
-    const int oxc = lv.xtab_off + min(ox0 + lane, max(lv.zoom_w - 1, 0));
-    const int xo = tab.xbase[oxc] - 2 - cx0;
-    float wx[6];
-#pragma unroll
-    for (int i = 0; i < 6; ++i) wx[i] = tab.xw[(long long)oxc * 6 + i];
-
-    // A: stage the contiguous source footprint (mirrored at the crop border).  Lanes = consecutive staged
-    // floats, the wave's rows are wave-uniform; loads go out in predicated batches of KR per thread.
-    if (SH > 0 && SW > 0) {
-        constexpr int KC = (SWM * C + 63) / 64;
-        constexpr int KR = kDenseMaxSH / 4;
-        long long rowoff[KR];
-#pragma unroll
-        for (int j = 0; j < KR; ++j)
-            rowoff[j] = (long long)(mirror_index(ry0 + min(wave + 4 * j, SH - 1), lv.src_h) + lv.src_y0) * W;
-#pragma unroll
-        for (int k = 0; k < KC; ++k) {
-            const int cf = lane + 64 * k;
-            const int c = cf / C, ch = cf - c * C;
-            const int sx = mirror_index(cx0 + min(c, SW - 1), lv.src_w) + lv.src_x0;
-            float v[KR];
-#pragma unroll
-            for (int j = 0; j < KR; ++j) v[j] = src[(rowoff[j] + sx) * C + ch];
-#pragma unroll
-            for (int j = 0; j < KR; ++j) {
-                const int r = wave + 4 * j;
-                if (c < SW && r < SH) s_src[(r * SWM) * C + cf] = v[j];
-            }
-        }
-    }
-    __syncthreads();
-    // B: vertical 6 taps for every staged column (conflict-free: lanes = consecutive columns)
-    for (int orow = wave; orow < nrows; orow += 4) {
-        const int oy = lv.ytab_off + oy0 + orow;
-        const int s0 = min(max(tab.ybase[oy] - 2 - ry0, 0), kDenseMaxSH - 6);
-        float wy[6];
-#pragma unroll
-        for (int j = 0; j < 6; ++j) wy[j] = tab.yw[(long long)oy * 6 + j];
-        for (int c = lane; c < SW; c += 64) {
-#pragma unroll
-            for (int ch = 0; ch < C; ++ch) {
-                float acc = 0.0f;
-#pragma unroll
-                for (int j = 0; j < 6; ++j) acc = __builtin_fmaf(wy[j], s_src[((s0 + j) * SWM + c) * C + ch], acc);
-                s_v[(orow * SWM + c) * C + ch] = acc;
-            }
-        }
-    }
-    __syncthreads();
-    // C: horizontal 6 taps and store
-    const int ox = ox0 + lane;
-    if (lane >= lv.tile_w || ox >= lv.out_w) return;
-    const int xs = min(max(xo, 0), SWM - 6);
-    for (int orow = wave; orow < lv.tile_h; orow += 4) {
-        const int oy = oy0 + orow;
-        if (oy >= lv.out_h) break;
-        const bool live = orow < nrows && lane < ncols;
-        float* __restrict__ po = dst + ((long long)oy * lv.out_w + ox) * C;
-#pragma unroll
-        for (int ch = 0; ch < C; ++ch) {
-            float acc = 0.0f;
-#pragma unroll
-            for (int i = 0; i < 6; ++i) acc = __builtin_fmaf(wx[i], s_v[(orow * SWM + xs + i) * C + ch], acc);
-            po[ch] = live ? acc : 0.0f;
-        }
-    }
-}
-
-// ------------------------------------------------------------------------------------------ SPARSE
-template <int C>
-__device__ __forceinline__ void pyr_sparse_tile(const float* __restrict__ src, float* __restrict__ dst,
-                                                const PyrTab& tab, const PyrLevelDev& lv, int ty, int tx) {
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int ox = tx * kSparseTW + lane, oy = ty * kSparseTH + wave;
-    if (ox >= lv.out_w || oy >= lv.out_h) return;
-    const bool live = ox < lv.zoom_w && oy < lv.zoom_h;
-    const long long xe = lv.xtab_off + min(ox, lv.zoom_w - 1), ye = lv.ytab_off + min(oy, lv.zoom_h - 1);
-    int xi[6], yi[6];
-    float wx[6], wy[6];
-#pragma unroll
-    for (int i = 0; i < 6; ++i) {
-        xi[i] = (tab.xidx[xe * 6 + i] + lv.src_x0) * C;
-        wx[i] = tab.xw[xe * 6 + i];
-        yi[i] = tab.yidx[ye * 6 + i] + lv.src_y0;
-        wy[i] = tab.yw[ye * 6 + i];
-    }
-    float acc[C];
-#pragma unroll
-    for (int ch = 0; ch < C; ++ch) acc[ch] = 0.0f;
-#pragma unroll
-    for (int j = 0; j < 6; ++j) {
-        const float* __restrict__ row = src + (long long)yi[j] * tab.W * C;
-#pragma unroll
-        for (int ch = 0; ch < C; ++ch) {
-            float h = 0.0f;
-#pragma unroll
-            for (int i = 0; i < 6; ++i) h = __builtin_fmaf(wx[i], row[xi[i] + ch], h);
-            acc[ch] = __builtin_fmaf(wy[j], h, acc[ch]);
-        }
-    }
-    float* __restrict__ po = dst + ((long long)oy * lv.out_w + ox) * C;
-#pragma unroll
-    for (int ch = 0; ch < C; ++ch) po[ch] = live ? acc[ch] : 0.0f;
-}
-
-template <int C>
-__global__ __launch_bounds__(256) void pyramid_kernel(const float* __restrict__ frames,
-                                                      float* __restrict__ pyr, const PyrTab tab) {
-    __shared__ __attribute__((aligned(16))) float smem[pyr_lds_floats<C>()];
-
+// ------------------------------------------------------------------------------------------ ZERO FILL
+__global__ __launch_bounds__(256) void pyramid_zero_kernel(float* __restrict__ pyr, const PyrTab tab) {
     const unsigned bid = blockIdx.x;
-    const int frame = (int)(bid / (unsigned)tab.tiles_per_frame);
-    int rem = (int)(bid - (unsigned)frame * (unsigned)tab.tiles_per_frame);
+    const int frame = (int)(bid / (unsigned)tab.zero_chunks_per_frame);
+    int rem = (int)(bid - (unsigned)frame * (unsigned)tab.zero_chunks_per_frame);
     int l = 0;
 #pragma unroll
     for (int i = 1; i < kMaxLevels; ++i)
-        if (i < tab.n_levels && rem >= tab.tile_start[i]) l = i;
-    rem -= tab.tile_start[l];
+        if (i < tab.n_levels && rem >= tab.zero_chunk_start[i]) l = i;
+    rem -= tab.zero_chunk_start[l];
     const PyrLevelDev& lv = tab.lv[l];
-    const int ty = rem / tab.tiles_x[l];
-    const int tx = rem - ty * tab.tiles_x[l];
-    const float* __restrict__ src = frames + (long long)frame * tab.H * tab.W * C;
-    float* __restrict__ dst = pyr + ((long long)frame * tab.frame_px_out + tab.px_off[l]) * C;
-    if (lv.kind == kPyrUnit)
-        pyr_unit_tile<C>(src, dst, tab, lv, ty, tx, smem);
-    else if (lv.kind == kPyrDense)
-        pyr_dense_tile<C>(src, dst, tab, lv, ty, tx, smem);
-    else
-        pyr_sparse_tile<C>(src, dst, tab, lv, ty, tx);
+    float* __restrict__ dst = pyr + ((long long)frame * tab.frame_px_out + tab.px_off[l]) * tab.C;
+    const int npx = lv.out_h * lv.out_w;
+    for (int k = 0; k < 4; ++k) {
+        const int p = rem * 1024 + k * 256 + threadIdx.x;
+        if (p >= npx) break;
+        const int y = p / lv.out_w, x = p - y * lv.out_w;
+        if (y >= lv.zoom_h || x >= lv.zoom_w)
+            for (int ch = 0; ch < tab.C; ++ch) dst[(long long)p * tab.C + ch] = 0.0f;
+    }
 }
 
 }  // namespace silent
