@@ -1,0 +1,80 @@
+"""The N > 1 path on CPU: world_size 2, gloo.  One broadcast of the constants, frame sharding, MAX timing."""
+import os
+import socket
+import subprocess
+import sys
+import textwrap
+
+import numpy as np
+
+from conftest import ROOT
+
+WORKER = textwrap.dedent("""
+    import os, sys, json
+    sys.path.insert(0, %r)
+    import numpy as np
+    import torch.distributed as dist
+    from pysilent_amd import distributed as D
+    from pysilent_amd.pipeline import default_constants
+    rank, world, local = D.init(backend="gloo")
+    assert dist.get_world_size() == 2 and world == 2
+    if rank != 0:
+        # prove the receivers take rank 0's floats: poison the local generator
+        import pysilent_amd.pipeline as P
+        real = P.default_constants
+        D.default_constants = lambda mode, n=4: {k: v * 0 - 1 for k, v in real(mode, n).items()}
+    consts = D.broadcast_constants("gray", 4)
+    want = default_constants("gray", 4)
+    ok = all(np.array_equal(consts[k], want[k]) for k in want)
+    rgb = D.broadcast_constants("rgb")
+    ok = ok and all(np.array_equal(rgb[k], default_constants("rgb")[k]) for k in rgb)
+    frames = D.shard_frame_indices(10, rank, world)
+    slow = D.max_over_ranks(1.0 + rank)
+    D.barrier()
+    print(json.dumps({"rank": rank, "ok": bool(ok), "frames": frames, "slow": slow}))
+    dist.destroy_process_group()
+""") % ROOT
+
+
+def free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def test_two_rank_gloo_broadcast_and_sharding(tmp_path):
+    script = tmp_path / "worker.py"
+    script.write_text(WORKER)
+    port = str(free_port())
+    procs = []
+    for rank in range(2):
+        env = dict(os.environ, RANK=str(rank), WORLD_SIZE="2", LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1",
+                   MASTER_PORT=port, HSA_ENABLE_IPC_MODE_LEGACY="0")
+        procs.append(subprocess.Popen([sys.executable, str(script)], env=env, stdout=subprocess.PIPE,
+                                      stderr=subprocess.PIPE, text=True))
+    import json
+    outs = []
+    for p in procs:
+        out, err = p.communicate(timeout=240)
+        assert p.returncode == 0, err[-2000:]
+        outs.append(json.loads(out.strip().splitlines()[-1]))
+    outs.sort(key=lambda d: d["rank"])
+    assert all(o["ok"] for o in outs)
+    assert outs[0]["frames"] == [0, 2, 4, 6, 8] and outs[1]["frames"] == [1, 3, 5, 7, 9]
+    assert outs[0]["slow"] == 2.0 and outs[1]["slow"] == 2.0
+
+
+def test_single_process_world_is_trivial():
+    from pysilent_amd import distributed as D
+    env_backup = {k: os.environ.pop(k, None) for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK")}
+    try:
+        assert D.world() == (0, 1, 0)
+        c = D.broadcast_constants("gray", 4)
+        assert c["end"].shape == (3, 3, 1, 4) and c["cs"].dtype == np.float32
+        assert D.max_over_ranks(3.5) == 3.5
+    finally:
+        for k, v in env_backup.items():
+            if v is not None:
+                os.environ[k] = v

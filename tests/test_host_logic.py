@@ -1,0 +1,100 @@
+"""Host-side logic of the product (no GPU): level geometry, packed pyramids, constant packing."""
+import math
+
+import numpy as np
+import numpy.testing as npt
+import pytest
+
+import silent_oracle as so
+
+
+def test_reference_levels_match_oracle_geometry():
+    from pysilent_amd.util.zoom.from_image import reference_levels
+    for hw, center, scale in [((480, 640), (288, 192), math.e ** .5), ((480, 640), (160, 120), math.e ** .5),
+                              ((1080, 1920), (192, 108), math.e ** .5), ((1080, 1920), (120, 68), math.e ** .5),
+                              ((97, 131), (32, 24), 1.7)]:
+        lv = reference_levels(hw, center, scale)
+        center_hw = list(reversed(center))
+        assert len(lv) == so.ref_num_scales(hw, center_hw, scale)
+        for s, l in enumerate(lv):
+            y0, x0, ch, cw, zh, zw, _ = so.ref_level_geometry(hw, center_hw, scale, s)
+            assert l == (y0, x0, ch, cw, zh, zw, center_hw[0], center_hw[1])
+    # level counts obtainable by choosing center_dimensions
+    assert len(reference_levels((480, 640), (160, 120), math.e ** .5)) == 3
+    assert len(reference_levels((1080, 1920), (192, 108), math.e ** .5)) == 5
+    assert len(reference_levels((1080, 1920), (120, 68), math.e ** .5)) == 6
+
+
+def test_classic_levels_match_oracle_extents():
+    from pysilent_amd.util.zoom.from_image import classic_levels
+    for hw, scale, n in [((1080, 1920), 2.0, 5), ((2160, 3840), 2.0, 8), ((480, 640), 2.0, 3), ((270, 480), math.e ** .5, 6)]:
+        lv = classic_levels(hw, scale, n)
+        assert [(l[6], l[7]) for l in lv] == so.classic_extents(hw[0], hw[1], scale, n)
+        assert all(l[:4] == (0, 0, hw[0], hw[1]) for l in lv)
+    with pytest.raises(ValueError):
+        classic_levels((4, 4), 2.0, 6)
+
+
+def test_from_image_argument_checks_mirror_reference_asserts():
+    from pysilent_amd.util import zoom
+    img = np.zeros((8, 8, 3), np.float32)
+    with pytest.raises(AssertionError, match="Scale must be greater than one"):
+        zoom.from_image(img, 3, (4, 4), 1.0)
+    with pytest.raises(AssertionError, match="colors"):
+        zoom.from_image(img, 0, (4, 4), 2.0)
+    with pytest.raises(AssertionError, match="dimension"):
+        zoom.from_image(img, 3, (0, 4), 2.0)
+    with pytest.raises(TypeError):
+        zoom.from_image([[1, 2]], 3, (4, 4), 2.0)
+
+
+def test_packed_pyramid_roundtrip():
+    from pysilent_amd import PackedPyramid
+    rng = np.random.default_rng(0)
+    levels = [rng.standard_normal((3, h, w, 2)).astype(np.float32) for h, w in [(5, 7), (3, 4), (1, 1)]]
+    p = PackedPyramid.from_levels(levels)
+    assert p.n_frames == 3 and p.channels == 2 and p.frame_px == 35 + 12 + 1 and not p.on_device
+    for l, lev in enumerate(levels):
+        npt.assert_array_equal(p.level(l), lev)
+    # layout: frames outermost, then levels (what the C ABI documents)
+    npt.assert_array_equal(p.data[:70], levels[0][0].reshape(-1))
+    npt.assert_array_equal(p.data[70:94], levels[1][0].reshape(-1))
+    q = p.like(4)
+    assert q.data.shape[0] == 3 * 48 * 4 and q.extents == p.extents
+    with pytest.raises(ValueError):
+        PackedPyramid(np.zeros(5, np.float32), [(2, 2)], 1, 1)
+
+
+def test_constants_pack_unpack_roundtrip():
+    from pysilent_amd.pipeline import default_constants, pack_constants, unpack_constants
+    for mode in ("gray", "rgb"):
+        c = default_constants(mode, 8)
+        blob, layout = pack_constants(c)
+        assert blob.dtype == np.float32 and blob.nbytes < 8192          # "< 8 KB" 
+        back = unpack_constants(blob, layout)
+        assert sorted(back) == sorted(c)
+        for k in c:
+            npt.assert_array_equal(back[k], c[k].astype(np.float32))
+    with pytest.raises(ValueError):
+        default_constants("bogus")
+
+
+def test_frame_sharding_is_a_partition():
+    from pysilent_amd.distributed import shard_frame_indices
+    for total, world in [(512, 8), (10, 4), (3, 8), (64, 1)]:
+        shards = [shard_frame_indices(total, r, world) for r in range(world)]
+        flat = sorted(i for s in shards for i in s)
+        assert flat == list(range(total))
+        assert all(i % world == r for r, s in enumerate(shards) for i in s)
+
+
+def test_get_dimensions_and_selection_argument_checks():
+    from pysilent_amd.util.get_dimensions import get_dimensions
+    from pysilent_amd.util.selection import pad_inwards, _regions_for
+    assert get_dimensions(np.zeros((1, 4, 4, 3))) == 2 and get_dimensions(np.zeros((1, 4, 4, 4, 1))) == 3
+    with pytest.raises(TypeError, match="must either be tensor or numpy array"):
+        get_dimensions(3.0)
+    with pytest.raises(ValueError):
+        pad_inwards(np.zeros((1, 4, 4, 3), np.float32), [[1, 0], [2, 2], [2, 2], [0, 0]])
+    assert _regions_for([(192, 288)], [1, 96.0, 144.0, 3]) == [(96, 144)]      # the reference passes floats
+    assert _regions_for([(8, 8), (4, 4)], [(4, 4), (2, 2)]) == [(4, 4), (2, 2)]

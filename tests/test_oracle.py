@@ -1,0 +1,170 @@
+"""The oracle itself: pinned against the reference-generated golden kernels, analytic known answers,
+an independent convolution (torch), scipy.ndimage.zoom, and its own C port.  CPU only."""
+import math
+
+import numpy as np
+import numpy.testing as npt
+import pytest
+
+import silent_oracle as so
+import c_oracle as co
+from conftest import noise_frame, structured_frame
+
+
+def test_conv_impulse_returns_flipped_kernel(golden):
+    k = golden["rgb_2d_end_tensors"]
+    x = np.zeros((1, 7, 7, 3), np.float32)
+    x[0, 3, 3, 2] = 1.0
+    out = so.conv2d_same(x, k)
+    k32 = k.astype(np.float32)
+    for dy in range(3):
+        for dx in range(3):
+            npt.assert_array_equal(out[0, 3 - (dy - 1), 3 - (dx - 1)], k32[dy, dx, 2])
+
+
+def test_conv_constant_image_known_answers(golden):
+    # midget_rgc sums to 4/3 - 2/3 = 2/3 per diagonal channel; centre 1.33333, edge -0.0976311
+    rgc = golden["midget_rgc_2"]
+    npt.assert_allclose(rgc[1, 1, 0, 0], 4.0 / 3.0, rtol=1e-12)
+    npt.assert_allclose(rgc[0, 1, 0, 0], -0.0976311, atol=1e-7)
+    npt.assert_allclose(rgc[0, 0, 0, 0], -0.0690356, atol=1e-7)
+    x = np.full((1, 6, 6, 3), 90.0, np.float32)
+    out = so.conv2d_same(x, rgc)
+    npt.assert_allclose(out[0, 1:-1, 1:-1], 60.0, rtol=1e-6)
+    npt.assert_allclose(out[0, 0, 0, 0], 90.0 * rgc[1:, 1:, 0, 0].sum(), rtol=1e-6)     # SAME zero padding
+
+
+@pytest.mark.parametrize("ks,ci,co_", [(3, 3, 3), (7, 3, 3), (3, 1, 8), (2, 3, 2), (5, 2, 1)])
+def test_conv_against_torch(ks, ci, co_):
+    torch = pytest.importorskip("torch")
+    F = torch.nn.functional
+    rng = np.random.default_rng(5)
+    x = (rng.standard_normal((2, 19, 23, ci)) * 50).astype(np.float32)
+    k = rng.standard_normal((ks, ks, ci, co_))
+    got = so.conv2d_same(x, k)
+    kt = torch.from_numpy(k.astype(np.float32)).permute(3, 2, 0, 1).double()
+    xt = torch.from_numpy(x).permute(0, 3, 1, 2).double()
+    pb = (ks - 1) // 2
+    want = F.conv2d(F.pad(xt, (pb, ks - 1 - pb, pb, ks - 1 - pb)), kt).permute(0, 2, 3, 1).float().numpy()
+    npt.assert_array_equal(got, want)
+
+
+def test_relu_and_clip_keep_nan():
+    x = np.array([np.nan, -1.0, 2.0, 300.0], np.float32)
+    r = so.relu_tf(x)
+    assert np.isnan(r[0]) and r[1] == 0 and r[2] == 2
+    c = so.clip_tf(x, 0, 255)
+    assert np.isnan(c[0]) and c[3] == 255
+
+
+def test_regulate_flat_region_policies(golden):
+    x = np.zeros((1, 12, 12, 3), np.float32)
+    x[0, 6, 6] = 4.0
+    blur = golden["blur_tensor_2_7"]
+    y = so.regulate(x, blur, 1.0, 0.1, "ieee")
+    assert np.isnan(y[0, 0, 0, 0])                 # 0 * (1 / pow(0, .1)) = 0 * inf
+    assert y[0, 6, 6, 0] == 4.0                    # blur >= 1 -> clamp to 1 -> x * 1
+    z = so.regulate(x, blur, 1.0, 0.1, "zero")
+    assert not np.isnan(z).any() and z[0, 6, 6, 0] == 4.0 and z[0, 0, 0, 0] == 0.0
+    small = (x * np.float32(0.01)).astype(np.float32)
+    got = so.regulate(small, blur, 2.0, 0.5, "zero")[0, 6, 6, 0]
+    b = np.float32(0.04 * 3)                       # centre weight 1 over 3 input channels
+    npt.assert_allclose(got, np.float32(0.04) * (np.float32(2.0) / np.float32(np.sqrt(np.float64(b)))), rtol=1e-6)
+
+
+def test_pad_value_nms_known_answers():
+    x = np.arange(1 * 5 * 6 * 3, dtype=np.float32).reshape(1, 5, 6, 3)
+    p = so.pad_inwards(x, [[0, 0], [2, 2], [2, 2], [0, 0]])
+    assert p[0, 2, 2:4].tolist() == x[0, 2, 2:4].tolist() and p.sum() == x[0, 2, 2:4].sum()
+    v = so.value_from_color(x)
+    npt.assert_array_equal(v[..., 0], ((x[..., 0] + x[..., 1]) + x[..., 2]) * (np.float32(1) / np.float32(3)))
+    m = np.zeros((1, 4, 4, 1), np.float32)
+    m[0, 1, 1, 0] = 3.0
+    m[0, 3, 3, 0] = 2.0
+    out = so.nms3x3(m, "product")
+    assert out[0, 1, 1, 0] == 9.0 and out[0, 3, 3, 0] == 4.0 and out.sum() == 13.0      # x^2 at maxima
+    fired = so.nms3x3(m, "fired")
+    assert fired[0, 1, 1, 0] == 1 and fired[0, 0, 0, 0] == 0 and fired[0, 0, 3, 0] == 1  # zero plateau corner fires
+
+
+def test_top_value_points_threshold():
+    v = np.arange(20, dtype=np.float32).reshape(1, 4, 5, 1)
+    c = np.repeat(v, 3, axis=3)
+    out = so.top_value_points(c, 0.1, v)            # thr = 0.9 * 19 + 0.1 * 0 = 17.1
+    assert (out[..., 0] > 0).sum() == 2 and out[0, 3, 4, 0] == 19 and out[0, 3, 3, 0] == 18
+
+
+def test_region_geometry_matches_survey_example():
+    # region_shape [1,96,144,3] on 192 x 288: 2x2 overlapping windows rows [0,144), [48,192);
+    # cols [0,216), [72,288), mapped back to quadrants
+    out, wins, src = so._region_pool_geometry(192, 96)
+    assert out == 2 and wins == [(0, 144), (48, 192)]
+    assert src[:96].tolist() == [0] * 96 and src[96:].tolist() == [1] * 96
+    out, wins, src = so._region_pool_geometry(288, 144)
+    assert wins == [(0, 216), (72, 288)]
+    v = np.zeros((1, 192, 288, 1), np.float32)
+    v[0, 10, 10, 0] = 5.0       # only inside window (0,0)
+    v[0, 150, 250, 0] = 7.0     # only inside window (1,1)
+    idx = so.max_value_indices_region(None, (1, 96, 144, 3), v)
+    # quadrant (0,0) compares against 5, quadrant (1,1) against 7; the mixed quadrants see max = 0 -> every pixel
+    assert [10, 10] in idx[:, 1:3].tolist() and [150, 250] in idx[:, 1:3].tolist()
+    assert len(idx) == 2 + 2 * 96 * 144
+    assert (np.diff(idx[:, 1] * 288 + idx[:, 2]) > 0).all()          # row-major sorted
+
+
+def test_spline_restatement_is_scipy(golden):
+    from scipy import ndimage
+    rng = np.random.default_rng(3)
+    for h, w, z in [(48, 64, 1.0), (48, 64, 0.5), (67, 33, 1 / math.e ** 0.5), (108, 192, 0.25), (9, 9, 2 / 9.0),
+                    (31, 57, 0.77)]:
+        p = rng.integers(0, 256, (h, w)).astype(np.float32)
+        ref = ndimage.zoom(p, z, prefilter=False, order=5)
+        assert ref.shape == (so.zoom_out_size(h, z), so.zoom_out_size(w, z))
+        npt.assert_array_equal(so.spline5_zoom(p, *ref.shape), ref)
+    p = np.zeros((11, 11), np.float32)
+    p[5, 5] = 120.0
+    npt.assert_allclose(so.spline5_zoom(p, 11, 11)[5, 3:8] * 120, [66, 1716, 4356, 1716, 66], rtol=1e-6)
+
+
+def test_zoom_from_image_matches_reference_geometry():
+    # reference default: 480x640x3 -> [2,192,288,3]; SURVEY 8a-1 level counts
+    img = noise_frame(0, 480, 640, 3)
+    z = so.zoom_from_image(img, 3, (288, 192), math.e ** .5)
+    assert z.shape == (2, 192, 288, 3) and z.dtype == np.float32
+    npt.assert_array_equal(z, so.zoom_from_image(img, 3, (288, 192), math.e ** .5, use_scipy=False))
+    assert so.ref_num_scales((1080, 1920), (192, 288), math.e ** .5) == 4
+    assert so.ref_num_scales((2160, 3840), (192, 288), math.e ** .5) == 6
+    assert so.classic_extents(1080, 1920, 2.0, 5) == [(1080, 1920), (540, 960), (270, 480), (135, 240), (68, 120)]
+    assert sum(h * w for h, w in so.classic_extents(1080, 1920, 2.0, 5)) == 2762160       # P
+    assert sum(h * w for h, w in so.classic_extents(2160, 3840, 2.0, 8)) == 11059110
+
+
+def test_c_port_equals_numpy_oracle(golden, kernels):
+    x = structured_frame(1, 41, 57, 3, 25)[None] + noise_frame(1, 41, 57, 3)[None] * np.float32(0.1)
+    for name in ("rgc", "rgby", "stripe", "end", "blur"):
+        npt.assert_array_equal(co.conv2d_same(x, kernels[name], relu=True), so.conv2d_same(x, kernels[name], relu=True))
+    s = so.conv2d_same(x, kernels["stripe"], relu=True)
+    for pol in ("ieee", "zero"):
+        npt.assert_array_equal(co.regulate(s, kernels["blur"], 1.0, 0.1, pol), so.regulate(s, kernels["blur"], 1.0, 0.1, pol))
+    pads = [[0, 0], [2, 2], [2, 2], [0, 0]]
+    npt.assert_array_equal(co.pad_inwards(x, pads), so.pad_inwards(x, pads))
+    npt.assert_array_equal(co.value_from_color(x), so.value_from_color(x))
+    npt.assert_array_equal(co.nms3x3(x), so.nms3x3(x))
+    npt.assert_array_equal(co.top_value_points(x, 0.37), so.top_value_points(x, 0.37))
+    npt.assert_array_equal(co.max_value_indices_region(x, (1, 20, 28, 3)), so.max_value_indices_region(x, (1, 20, 28, 3)))
+    img = noise_frame(2, 97, 131, 1)
+    ext = so.classic_extents(97, 131, 1.7, 4)
+    for a, b in zip(co.classic_pyramid(img, ext), so.classic_pyramid(img, 1.7, 4)):
+        npt.assert_array_equal(a, b)
+    cs, end = co.gray_line_end_level(img[None], kernels["cs_gray"], kernels["end4"])
+    (wcs, wend), = so.gray_line_end_pass([img[None]], kernels["cs_gray"], kernels["end4"])
+    npt.assert_array_equal(cs, wcs)
+    npt.assert_array_equal(end, wend)
+
+
+def test_chain_on_noise_has_no_nan(kernels):
+    # SURVEY hard part 3: parity fixtures on noise frames must keep the NaN set empty
+    out = so.rgb_line_end_chain(noise_frame(0, 48, 64, 3)[None], kernels)
+    for k, v in out.items():
+        assert not np.isnan(v).any(), k
+    assert out["padded"][0, :2].sum() == 0 and out["value"].shape == (1, 48, 64, 1)
