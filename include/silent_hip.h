@@ -191,7 +191,9 @@ int silent_max_value_indices_region_dev(silent_ctx* ctx, const float* value, con
                                         size_t cap_per_frame, int64_t* counts, silent_stream stream);
 
 /* ---------------------------------------------------------------------------- fused RGB chain
- * The reference graph recognition_testing.py:69-77 on 3-channel levels, in two launches:
+ * The reference graph recognition_testing.py:69-77 on 3-channel levels.  With a channel-uniform blur (what
+ * blur_tensor generates) this is ONE fused launch that reads the pyramid once; any other blur runs the
+ * stages as separate launches through workspace temporaries:
  *   orient   = regulate(relu(conv(relu(conv(relu(conv(x, rgc)), rgby)), stripe)), blur, rv, root)   (:69-71)
  *   line_end = pad_inwards(clip(relu(conv(orient, end)), 0, clip_hi), pad)                          (:73-75)
  *   value    = get_value_from_color(line_end)                                                        (:77)

@@ -11,7 +11,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 PKG = os.path.dirname(HERE)
 OUT = os.path.join(PKG, "lib", "libsilent_hip.so")
 SOURCES = ["silent_api.hip"]
-DEPS = SOURCES + ["silent_common.h", "silent_conv.h", "silent_peaks.h", "silent_pyramid.h",
+DEPS = SOURCES + ["silent_common.h", "silent_conv.h", "silent_peaks.h", "silent_pyramid.h", "silent_rgb.h",
                   os.path.join("..", "..", "include", "silent_hip.h")]
 
 
@@ -34,7 +34,7 @@ def build(force=False, verbose=False):
         return OUT
     os.makedirs(os.path.dirname(OUT), exist_ok=True)
     cmd = [hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-fvisibility=hidden",
-           "-ffp-contract=off", "-Wall", "-Wextra", "-Wno-unused-parameter",
+           "-ffp-contract=off", "-fno-slp-vectorize", "-Wall", "-Wextra", "-Wno-unused-parameter",
            "-o", OUT] + [os.path.join(HERE, s) for s in SOURCES]
     if verbose:
         cmd.insert(1, "-Rpass-analysis=kernel-resource-usage")

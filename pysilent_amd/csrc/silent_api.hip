@@ -14,6 +14,7 @@
 #include "silent_conv.h"
 #include "silent_peaks.h"
 #include "silent_pyramid.h"
+#include "silent_rgb.h"
 
 using namespace silent;
 
@@ -524,14 +525,47 @@ SILENT_EXPORT int silent_rgb_line_end_dev(silent_ctx* ctx, const float* pyr, con
         return fail(ctx, SILENT_E_INVALID, std::string(who) + ": bad levels / n_frames");
     for (int l = 0; l < n_levels; ++l)
         if (levels[l].h < 1 || levels[l].w < 1) return fail(ctx, SILENT_E_INVALID, std::string(who) + ": bad level extent");
-    // Stage-per-launch composition (round 1): two ping-pong temporaries in the context workspace.
+    hipStream_t s = (hipStream_t)stream;
+    // Fused single-launch path: needs a channel-uniform blur (what blur_tensor generates), so that the 7x7x3x3
+    // blur is a 49-tap filter of the channel sum.
+    bool uniform_blur = true;
+    for (int t = 0; t < 49 && uniform_blur; ++t)
+        for (int io = 1; io < 9; ++io)
+            if (p->blur[t * 9 + io] != p->blur[t * 9]) uniform_blur = false;
+    if (uniform_blur) {
+        LevelTab tab;
+        long long blocks;
+        TRY(build_level_tab(ctx, who, levels, n_levels, n_frames, kRgbTW, kRgbTH, &tab, &blocks));
+        if (p->flat_policy != SILENT_FLAT_IEEE && p->flat_policy != SILENT_FLAT_ZERO)
+            return fail(ctx, SILENT_E_INVALID, std::string(who) + ": flat_policy must be SILENT_FLAT_IEEE or SILENT_FLAT_ZERO");
+        RgbArgs a;
+        a.pyr = pyr;
+        a.orient_out = orient_out;
+        a.line_out = line_end_out;
+        a.value_out = value_out;
+        a.tab = tab;
+        auto repack = [](const float* hwio, float* dst) {  // HWIO [dy][dx][i][o] -> [o][dy][dx][i]
+            for (int o = 0; o < 3; ++o)
+                for (int dy = 0; dy < 3; ++dy)
+                    for (int dx = 0; dx < 3; ++dx)
+                        for (int i = 0; i < 3; ++i) dst[((o * 3 + dy) * 3 + dx) * 3 + i] = hwio[((dy * 3 + dx) * 3 + i) * 3 + o];
+        };
+        repack(p->rgc, a.w.rgc);
+        repack(p->rgby, a.w.rgby);
+        repack(p->stripe, a.w.stripe);
+        repack(p->end, a.w.end);
+        for (int t = 0; t < 49; ++t) a.w.blur[t] = p->blur[t * 9];
+        a.prm = RgbP{p->regulation_value, p->regulation_root, p->flat_policy, p->clip_hi, p->pad};
+        hipLaunchKernelGGL(rgb_line_end_kernel, dim3((unsigned)blocks), dim3(256), 0, s, a);
+        return check_launch(ctx, who);
+    }
+    // General blur: stage-per-launch composition through ping-pong temporaries in the context workspace.
     const size_t n = (size_t)pyramid_px(levels, n_levels) * n_frames * 3;
     const size_t bytes = align_up(n * sizeof(float));
     TRY(grow(ctx, ctx->ws, 3 * bytes));
     float* t0 = (float*)ctx->ws.p;
     float* t1 = (float*)((char*)ctx->ws.p + bytes);
     float* t2 = (float*)((char*)ctx->ws.p + 2 * bytes);
-    hipStream_t s = (hipStream_t)stream;
     const Epilogue relu{SILENT_RELU, 0.f, 0.f, 0.f, 0};
     TRY(conv_dispatch(ctx, who, pyr, levels, n_levels, n_frames, 3, p->rgc, 3, 3, 3, false, relu, t0, s));
     TRY(conv_dispatch(ctx, who, t0, levels, n_levels, n_frames, 3, p->rgby, 3, 3, 3, false, relu, t1, s));

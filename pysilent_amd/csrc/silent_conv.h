@@ -54,16 +54,29 @@ __global__ __launch_bounds__(256) void conv2d_same_kernel(const float* __restric
     const int x0 = tc.tx * TW, y0 = tc.ty * TH;
     const int tid = threadIdx.x;
 
-    // stage the (TH+KH-1) x (TW+KW-1) x CIN halo tile; consecutive threads read consecutive floats
-    for (int p = tid; p < IH * ROWF; p += 256) {
-        const int r = p / ROWF;
-        const int rem = p - r * ROWF;
-        const int c = rem / CIN;
-        const int ch = rem - c * CIN;
-        const int y = y0 + r - PH, x = x0 + c - PW;
-        float v = 0.0f;
-        if (y >= 0 && y < H && x >= 0 && x < W) v = src[((long long)y * W + x) * CIN + ch];
-        s_in[p] = v;
+    // stage the (TH+KH-1) x (TW+KW-1) x CIN halo tile; consecutive threads read consecutive floats.
+    // Predicated batch (clamped address + select, no branch around a load): every thread has all its
+    // requests in flight before the first wait.
+    {
+        constexpr int NB = (IH * ROWF + 255) / 256;
+        float v[NB];
+#pragma unroll
+        for (int k = 0; k < NB; ++k) {
+            const int p = min(tid + 256 * k, IH * ROWF - 1);
+            const int r = p / ROWF;
+            const int rem = p - r * ROWF;
+            const int c = rem / CIN;
+            const int ch = rem - c * CIN;
+            const int y = y0 + r - PH, x = x0 + c - PW;
+            const bool ok = y >= 0 && y < H && x >= 0 && x < W;
+            const float t = src[((long long)min(max(y, 0), H - 1) * W + min(max(x, 0), W - 1)) * CIN + ch];
+            v[k] = ok ? t : 0.0f;
+        }
+#pragma unroll
+        for (int k = 0; k < NB; ++k) {
+            const int p = tid + 256 * k;
+            if (p < IH * ROWF) s_in[p] = v[k];
+        }
     }
     __syncthreads();
 

@@ -1,0 +1,299 @@
+// Fused RGB chain (BASELINE config 3; reference graph recognition_testing.py:69-77):
+//   rgc -> ReLU -> rgby -> ReLU -> stripe -> ReLU -> regulate(blur 7x7) -> end -> ReLU -> clip -> pad_inwards -> value
+// in ONE launch: the pyramid is read once and only the returned maps (orient, line_end, value) are written.
+//
+// Wave-autonomous streaming, no barrier in the row loop (same idea as gray_line_end_kernel).  A wave owns 64
+// columns and walks down R + 14 input rows; lane = column.  Every convolution keeps ROLLING ROW ACCUMULATORS
+// instead of a window: an arriving row adds its dy = 2 terms to the oldest pending output row (which
+// completes), its dy = 1 terms to the next, and opens a new one with its dy = 0 terms -- the fma chain of an
+// output is still (dy, dx, i) ordered, bit-identical to conv2d_same_kernel.  Left / right neighbours come from
+// DPP wave shifts.  Each 3x3 stage costs one lane per side, the 7x7 blur three: lanes 7..56 (50 columns)
+// produce outputs.  The blur must be channel-uniform (blur_tensor writes one profile into every (in, out)
+// pair, gaussian_blur.py:51-52), so it acts on the channel SUM: 49 taps instead of 441.  The host checks
+// this and falls back to the stage-per-launch path otherwise.
+//
+// Weights: 373 floats do not fit the ~100 SGPRs of a wave.  Left to itself hipcc hoists every (loop
+// invariant) kernarg load out of the row loop and then spills SGPRs into VGPR lanes (v_writelane /
+// v_readlane + hazard nops), 9x below the VALU estimate.  What works: every fma chain re-reads its 7..9
+// weights from the kernarg segment (scalar cache) through a pointer laundered by an empty asm -- not
+// hoistable, not mergeable -- AND the chain's result is laundered too: SelectionDAG emits side-effecting
+// nodes in program order but lets pure fmas float, so without the second fence all weight loads of a row
+// step are emitted first and spilled.  ~20 weight SGPRs live, 90-140 VGPRs, no LDS.
+// (An LDS-resident weight table read by broadcast ds_read_b128 measured the same time: LDS issue and VALU
+// were co-limiting there.)
+#pragma once
+
+#include <cstddef>
+
+#include "silent_common.h"
+
+namespace silent {
+
+struct RgbW {
+    float rgc[81], rgby[81], stripe[81], end[81];  // [o][dy][dx][i] (repacked from HWIO by the host)
+    float blur[49];                                // profile [dy][dx]
+};
+
+struct RgbP {
+    float rv, root;
+    int flat_policy;
+    float clip_hi;
+    int pad;
+};
+
+constexpr int kRgbHalo = 7;
+constexpr int kRgbCols = 64 - 2 * kRgbHalo;  // 50 output columns per wave
+constexpr int kRgbTW = 4 * kRgbCols;         // 4 waves side by side
+constexpr int kRgbTH = 50;                   // output rows per tile
+constexpr int kRgbChunk = 2;                 // input rows per prefetch chunk; (TH + 14) % chunk == 0
+static_assert((kRgbTH + 2 * kRgbHalo) % kRgbChunk == 0, "row pipeline works in whole chunks");
+
+
+// Weights stay in the kernarg segment and are re-read per fma chain with scalar loads (scalar cache) through
+// a laundered pointer; the next chain is requested before the current chain's fmas.
+typedef const __attribute__((address_space(4))) float* kfloat_p;
+struct Chain3 {
+    float k[9];
+};
+__device__ __forceinline__ Chain3 load_chain3(kfloat_p wp, int off) {
+    __builtin_amdgcn_sched_barrier(0);
+    asm volatile("" : "+s"(wp));
+    Chain3 c;
+#pragma unroll
+    for (int j = 0; j < 9; ++j) c.k[j] = wp[off + j];
+    return c;
+}
+
+// One arriving row of a 3x3 x 3->3 convolution.  v[dx][i]: the row's values at x-1, x, x+1.
+// pa: output row with dy = 0,1 already in; pb: output row with dy = 0 in.  Returns the completed row in done.
+__device__ __forceinline__ void conv3_roll(const float (&v)[3][3], kfloat_p wstage, float (&pa)[3], float (&pb)[3],
+                                           float (&done)[3]) {
+    float acc[3][3];  // [o][dy]
+#pragma unroll
+    for (int o = 0; o < 3; ++o) {
+        acc[o][0] = 0.0f;   // chain dy continues the row that already holds dy' < dy
+        acc[o][1] = pb[o];
+        acc[o][2] = pa[o];
+    }
+    // chain order: c = o * 3 + (2 - dy); host layout [o][dy][dx][i] -> chain (o, dy) at (o * 3 + dy) * 9
+    Chain3 w0 = load_chain3(wstage, (0 * 3 + 2) * 9);
+#pragma unroll
+    for (int c = 0; c < 9; ++c) {
+        const int o = c / 3, dy = 2 - c % 3;
+        Chain3 w1 = w0;
+        if (c + 1 < 9) {
+            const int o1 = (c + 1) / 3, dy1 = 2 - (c + 1) % 3;
+            w1 = load_chain3(wstage, (o1 * 3 + dy1) * 9);
+        }
+        float t = acc[o][dy];
+#pragma unroll
+        for (int dx = 0; dx < 3; ++dx)
+#pragma unroll
+            for (int i = 0; i < 3; ++i) t = __builtin_fmaf(v[dx][i], w0.k[dx * 3 + i], t);
+        asm volatile("" : "+v"(t));  // pins the chain's fmas between the loads around it
+        acc[o][dy] = t;
+        w0 = w1;
+    }
+#pragma unroll
+    for (int o = 0; o < 3; ++o) {
+        done[o] = acc[o][2];
+        pa[o] = acc[o][1];
+        pb[o] = acc[o][0];
+    }
+}
+
+__device__ __forceinline__ void with_neighbours(const float (&c)[3], float (&v)[3][3]) {
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        v[0][i] = from_lane_below(c[i]);
+        v[1][i] = c[i];
+        v[2][i] = from_lane_above(c[i]);
+    }
+}
+
+// The kernel takes ONE by-value struct so that the offset of the weights inside the kernarg segment is
+// offsetof(RgbArgs, w) by construction.
+struct RgbArgs {
+    const float* pyr;
+    float* orient_out;
+    float* line_out;
+    float* value_out;
+    LevelTab tab;
+    RgbW w;
+    RgbP prm;
+};
+
+__global__ __launch_bounds__(256) void rgb_line_end_kernel(const RgbArgs args) {
+    constexpr int R = kRgbTH, D = kRgbChunk, NCH = (R + 2 * kRgbHalo) / D;
+    const float* __restrict__ pyr = args.pyr;
+    float* __restrict__ orient_out = args.orient_out;
+    float* __restrict__ line_out = args.line_out;
+    float* __restrict__ value_out = args.value_out;
+    const LevelTab& tab = args.tab;
+    const RgbP& prm = args.prm;
+
+    typedef const __attribute__((address_space(4))) char* kchar_p;
+    const kfloat_p wp = (kfloat_p)((kchar_p)__builtin_amdgcn_kernarg_segment_ptr() + offsetof(RgbArgs, w));
+
+    const TileCoord tc = locate_tile(tab, blockIdx.x);
+    const int H = tab.h[tc.level], W = tab.w[tc.level];
+    const long long base_px = (long long)tc.frame * tab.frame_px + tab.px_off[tc.level];
+    const float* __restrict__ src = pyr + base_px * 3;
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int xw0 = tc.tx * kRgbTW + wave * kRgbCols;
+    if (xw0 >= W) return;  // wave-uniform
+    const int y0 = tc.ty * R;
+    const int x = xw0 + lane - kRgbHalo;
+    const bool col_ok = x >= 0 && x < W;
+    const long long xoff = (long long)min(max(x, 0), W - 1) * 3;
+    const bool out_lane = lane >= kRgbHalo && lane < kRgbHalo + kRgbCols && x < W;
+    const bool pad_col = x >= prm.pad && x < W - prm.pad;
+    const float inv3 = 1.0f / 3.0f;
+
+    // rolling state
+    float a1[3] = {0, 0, 0}, b1[3] = {0, 0, 0};  // rgc
+    float a2[3] = {0, 0, 0}, b2[3] = {0, 0, 0};  // rgby
+    float a3[3] = {0, 0, 0}, b3[3] = {0, 0, 0};  // stripe
+    float a5[3] = {0, 0, 0}, b5[3] = {0, 0, 0};  // end
+    float pb[7] = {0, 0, 0, 0, 0, 0, 0};         // blur: pb[k] = pending output row (newest stripe row) - 3 + k
+    float hist[4][3];                            // stripe rows q, q-1, q-2, q-3 (own column)
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+#pragma unroll
+        for (int c = 0; c < 3; ++c) hist[k][c] = 0.0f;
+
+    float cur[D][3], nxt[D][3];
+    auto fetch = [&](float (&buf)[D][3], int chunk) {
+#pragma unroll
+        for (int d = 0; d < D; ++d) {
+            const int y = y0 - kRgbHalo + chunk * D + d;
+            const bool ok = y >= 0 && y < H && col_ok;
+            const float* __restrict__ p = src + (long long)min(max(y, 0), H - 1) * W * 3 + xoff;
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+                const float t = p[c];
+                buf[d][c] = ok ? t : 0.0f;
+            }
+        }
+    };
+    fetch(cur, 0);
+
+#pragma unroll 1
+    for (int chunk = 0; chunk < NCH; ++chunk) {
+        if (chunk + 1 < NCH) fetch(nxt, chunk + 1);
+#pragma unroll
+        for (int d = 0; d < D; ++d) {
+            const int yin = y0 - kRgbHalo + chunk * D + d;  // input row of this step
+            float v[3][3], g[3];
+            // ---- rgc: completes row yin - 1
+            with_neighbours(cur[d], v);
+            conv3_roll(v, wp + 0 * 81, a1, b1, g);
+            {
+                const bool ok = yin - 1 >= 0 && yin - 1 < H && col_ok;
+#pragma unroll
+                for (int c = 0; c < 3; ++c) g[c] = ok ? relu_tf(g[c]) : 0.0f;
+            }
+            // ---- rgby: completes row yin - 2
+            with_neighbours(g, v);
+            conv3_roll(v, wp + 1 * 81, a2, b2, g);
+            {
+                const bool ok = yin - 2 >= 0 && yin - 2 < H && col_ok;
+#pragma unroll
+                for (int c = 0; c < 3; ++c) g[c] = ok ? relu_tf(g[c]) : 0.0f;
+            }
+            // ---- stripe: completes row q = yin - 3
+            with_neighbours(g, v);
+            conv3_roll(v, wp + 2 * 81, a3, b3, g);
+            {
+                const bool ok = yin - 3 >= 0 && yin - 3 < H && col_ok;
+#pragma unroll
+                for (int c = 0; c < 3; ++c) g[c] = ok ? relu_tf(g[c]) : 0.0f;
+            }
+#pragma unroll
+            for (int k = 3; k > 0; --k)
+#pragma unroll
+                for (int c = 0; c < 3; ++c) hist[k][c] = hist[k - 1][c];
+#pragma unroll
+            for (int c = 0; c < 3; ++c) hist[0][c] = g[c];
+            // ---- blur of the channel sum: stripe row q feeds blur rows q-3 .. q+3; row t = q - 3 completes
+            float s7[7];
+            s7[3] = (g[0] + g[1]) + g[2];
+            s7[2] = from_lane_below(s7[3]);
+            s7[1] = from_lane_below(s7[2]);
+            s7[0] = from_lane_below(s7[1]);
+            s7[4] = from_lane_above(s7[3]);
+            s7[5] = from_lane_above(s7[4]);
+            s7[6] = from_lane_above(s7[5]);
+            float bdone;
+            {
+                // output row q-3+k takes kernel row dy = 6 - k from this stripe row
+                float nb[7];
+#pragma unroll
+                for (int k = 0; k < 7; ++k) {
+                    kfloat_p kb = wp + 4 * 81 + (6 - k) * 7;
+                    __builtin_amdgcn_sched_barrier(0);
+                    asm volatile("" : "+s"(kb));
+                    float kw[7];
+#pragma unroll
+                    for (int dx = 0; dx < 7; ++dx) kw[dx] = kb[dx];
+                    float acc = pb[k];
+#pragma unroll
+                    for (int dx = 0; dx < 7; ++dx) acc = __builtin_fmaf(s7[dx], kw[dx], acc);
+                    asm volatile("" : "+v"(acc));
+                    nb[k] = acc;
+                }
+                bdone = nb[0];
+#pragma unroll
+                for (int k = 0; k < 6; ++k) pb[k] = nb[k + 1];
+                pb[6] = 0.0f;
+            }
+            // ---- regulate row t = yin - 6 with the stripe row kept 3 steps back
+            const int t = yin - 6;
+            float o3[3];
+            {
+                const float m = bdone > 1.0f ? 1.0f : bdone;
+                const float r = prm.rv / powf(m, prm.root);
+                const bool ok = t >= 0 && t < H && col_ok;
+#pragma unroll
+                for (int c = 0; c < 3; ++c) {
+                    const float xs = hist[3][c];
+                    float y = xs * r;
+                    if (prm.flat_policy == SILENT_FLAT_ZERO && xs == 0.0f) y = 0.0f;
+                    o3[c] = ok ? y : 0.0f;
+                }
+            }
+            if (orient_out && t >= y0 && t < y0 + R && t < H && out_lane) {
+                float* __restrict__ po = orient_out + (base_px + (long long)t * W + x) * 3;
+                po[0] = o3[0];
+                po[1] = o3[1];
+                po[2] = o3[2];
+            }
+            // ---- end bank: completes row yout = yin - 7
+            with_neighbours(o3, v);
+            conv3_roll(v, wp + 3 * 81, a5, b5, g);
+            const int yout = yin - 7;
+            if (yout >= y0 && yout < H && out_lane) {
+                const float mk = (pad_col && yout >= prm.pad && yout < H - prm.pad) ? 1.0f : 0.0f;
+                float le[3];
+#pragma unroll
+                for (int c = 0; c < 3; ++c) le[c] = mk * clip_hi_tf(relu_tf(g[c]), prm.clip_hi);
+                const long long px = base_px + (long long)yout * W + x;
+                if (line_out) {
+                    line_out[px * 3 + 0] = le[0];
+                    line_out[px * 3 + 1] = le[1];
+                    line_out[px * 3 + 2] = le[2];
+                }
+                if (value_out) value_out[px] = __fmul_rn(__fadd_rn(__fadd_rn(le[0], le[1]), le[2]), inv3);
+            }
+        }
+        if (chunk + 1 < NCH) {
+#pragma unroll
+            for (int d = 0; d < D; ++d)
+#pragma unroll
+                for (int c = 0; c < 3; ++c) cur[d][c] = nxt[d][c];
+        }
+    }
+}
+
+}  // namespace silent
