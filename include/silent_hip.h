@@ -135,6 +135,28 @@ int silent_gray_line_end_dev(silent_ctx* ctx, const float* pyr, const silent_ext
                              int n_frames, const float* cs_kernel, const float* end_bank, int n_orient,
                              float clip_hi, float* cs_out, float* end_out, silent_stream stream);
 
+/* ---------------------------------------------------------------------------- whole grayscale hot path
+ * frames -> zoom pyramid -> CS -> ReLU -> K-orientation end bank -> ReLU -> clip in ONE call: the op order of
+ * LineEndDisplayer.callback + compile (recognition_testing.py:136-144, :69-74) restricted to one channel.
+ * Results are identical to silent_pyramid_dev followed by silent_gray_line_end_dev; the difference is traffic:
+ * levels whose zoom factor is exactly 1 (level 0, 75 % of the pixels) are smoothed, center-surround filtered
+ * and line-end filtered in one kernel, so that level is written once and never re-read.
+ * pyr / cs_out / end_out: packed pyramid batches with the plan's extents (1, 1 and K channels); pyr is
+ * always written (it is an output of the reference's from_image); cs_out or end_out may be NULL. */
+int silent_gray_pass(silent_ctx* ctx, const silent_pyramid_plan* plan, const float* frames, int n_frames,
+                     const float* cs_kernel, const float* end_bank, int n_orient, float clip_hi, float* pyr,
+                     float* cs_out, float* end_out);
+int silent_gray_pass_dev(silent_ctx* ctx, const silent_pyramid_plan* plan, const float* frames, int n_frames,
+                         const float* cs_kernel, const float* end_bank, int n_orient, float clip_hi, float* pyr,
+                         float* cs_out, float* end_out, silent_stream stream);
+
+/* Optional HIP-event timing of the DOMINANT kernel of the last silent_gray_pass_dev call (the fused
+ * unit-level kernel): enable with silent_set_profiling(ctx, 1); the events are recorded on the stream the
+ * kernel runs on.  silent_profile_elapsed_ms synchronises on the second event and returns the elapsed time
+ * and the number of level-0-class pixels the kernel processed. */
+int silent_set_profiling(silent_ctx* ctx, int enable);
+int silent_profile_elapsed_ms(silent_ctx* ctx, float* ms, int64_t* pixels);
+
 /* ---------------------------------------------------------------------------- a-6 regulator
  * Replaces regulate_tensor, slam_recognition/util/regulator/gaussian_regulator_tensor.py:10-36:
  *   y = x * (rv / pow(min(conv(x, blur), 1), root)); blur is HWIO [kh, kw, C, C]. */

@@ -76,6 +76,10 @@ _SIGNATURES = {
     "silent_conv2d_same_dev": [_vp, _fp, _ep, _i, _i, _i, _fp, _i, _i, _i, _u, _f, _fp, _vp],
     "silent_gray_line_end": [_vp, _fp, _ep, _i, _i, _fp, _fp, _i, _f, _fp, _fp],
     "silent_gray_line_end_dev": [_vp, _fp, _ep, _i, _i, _fp, _fp, _i, _f, _fp, _fp, _vp],
+    "silent_gray_pass": [_vp, _vp, _fp, _i, _fp, _fp, _i, _f, _fp, _fp, _fp],
+    "silent_gray_pass_dev": [_vp, _vp, _fp, _i, _fp, _fp, _i, _f, _fp, _fp, _fp, _vp],
+    "silent_set_profiling": [_vp, _i],
+    "silent_profile_elapsed_ms": [_vp, C.POINTER(_f), C.POINTER(C.c_int64)],
     "silent_regulate": [_vp, _fp, _ep, _i, _i, _i, _fp, _i, _i, _f, _f, _i, _fp],
     "silent_regulate_dev": [_vp, _fp, _ep, _i, _i, _i, _fp, _i, _i, _f, _f, _i, _fp, _vp],
     "silent_pad_inwards": [_vp, _fp, _ep, _i, _i, _i, _i, _i, _i, _i, _fp],

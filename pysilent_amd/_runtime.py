@@ -404,6 +404,47 @@ class PyramidPlan(object):
                                           C.c_void_p(out.ctypes.data)))
         return PackedPyramid(out, self.extents, c, n)
 
+    def gray_pass(self, frames, cs_kernel, end_bank, clip_hi=255.0):
+        """Whole grayscale hot path (silent_gray_pass): frames [n,H,W,1] -> (pyramid, cs, end) PackedPyramids.
+        Same results as run() + gray_line_end(), one pass less over level 0."""
+        h, w, c = self.frame_shape
+        if c != 1:
+            raise ValueError("gray_pass needs a single-channel plan")
+        cs = _kernel_arg(cs_kernel, 1)
+        eb = _kernel_arg(end_bank, 1)
+        if cs.shape != (3, 3, 1, 1) or eb.shape[:3] != (3, 3, 1):
+            raise ValueError("gray_pass needs a [3,3,1,1] CS kernel and a [3,3,1,K] end bank")
+        K = eb.shape[3]
+        lib = _lib.load()
+        if is_torch_tensor(frames):
+            import torch
+            if tuple(frames.shape[1:]) != (h, w, c):
+                raise ValueError("frames must be [n, %d, %d, 1]" % (h, w))
+            f = frames.to(torch.float32).contiguous()
+            n = int(f.shape[0])
+            mk = lambda ch: torch.empty(n * self.frame_px * ch, dtype=torch.float32, device=f.device)
+            pyr, cso, endo = mk(1), mk(1), mk(K)
+            stream = C.c_void_p(torch.cuda.current_stream(f.device).cuda_stream)
+            self.ctx.check(lib.silent_gray_pass_dev(self.ctx.handle, self.handle, C.c_void_p(f.data_ptr()), n,
+                                                    C.c_void_p(cs.ctypes.data), C.c_void_p(eb.ctypes.data), K,
+                                                    float(clip_hi), C.c_void_p(pyr.data_ptr()),
+                                                    C.c_void_p(cso.data_ptr()), C.c_void_p(endo.data_ptr()), stream))
+        else:
+            if not isinstance(frames, np.ndarray):
+                raise TypeError(TYPE_ERROR_MESSAGE)
+            if tuple(frames.shape[1:]) != (h, w, c):
+                raise ValueError("frames must be [n, %d, %d, 1], got %s" % (h, w, frames.shape))
+            f = np.ascontiguousarray(frames, dtype=np.float32)
+            n = f.shape[0]
+            mk = lambda ch: np.empty(n * self.frame_px * ch, dtype=np.float32)
+            pyr, cso, endo = mk(1), mk(1), mk(K)
+            self.ctx.check(lib.silent_gray_pass(self.ctx.handle, self.handle, C.c_void_p(f.ctypes.data), n,
+                                                C.c_void_p(cs.ctypes.data), C.c_void_p(eb.ctypes.data), K,
+                                                float(clip_hi), C.c_void_p(pyr.ctypes.data),
+                                                C.c_void_p(cso.ctypes.data), C.c_void_p(endo.ctypes.data)))
+        P = PackedPyramid
+        return P(pyr, self.extents, 1, n), P(cso, self.extents, 1, n), P(endo, self.extents, K, n)
+
     def close(self):
         if self.handle:
             _lib.load().silent_pyramid_plan_destroy(self.handle)

@@ -5,6 +5,7 @@
 #include <algorithm>
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <new>
 #include <string>
@@ -33,6 +34,10 @@ struct silent_ctx {
     std::string name;
     DevBuf arena;  // staging for the host-pointer entry points
     DevBuf ws;     // scratch for reductions / compaction / the RGB chain temporaries
+    bool profiling = false;
+    bool prof_valid = false;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    long long prof_pixels = 0;
 };
 
 struct silent_pyramid_plan {
@@ -40,6 +45,7 @@ struct silent_pyramid_plan {
     PyrTab tab{};
     std::vector<silent_extent> extents;
     void* tables = nullptr;
+    float unit_w[5] = {0, 0, 0, 0, 0};  // taps of a unit-zoom level ([1,26,66,26,1]/120 as float32)
 };
 
 static thread_local std::string g_create_err;
@@ -128,6 +134,8 @@ SILENT_EXPORT void silent_destroy(silent_ctx* ctx) {
     (void)hipSetDevice(ctx->device);
     if (ctx->arena.p) (void)hipFree(ctx->arena.p);
     if (ctx->ws.p) (void)hipFree(ctx->ws.p);
+    if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
+    if (ctx->ev1) (void)hipEventDestroy(ctx->ev1);
     delete ctx;
 }
 
@@ -185,7 +193,8 @@ SILENT_EXPORT int silent_synchronize(silent_ctx* ctx, silent_stream stream) {
 
 // tile_h == 0 selects the 1-D "chunk" decomposition (kChunk flattened pixels per block).
 static int build_level_tab(silent_ctx* ctx, const char* who, const silent_extent* levels, int n_levels, int n_frames,
-                           int tile_w, int tile_h, LevelTab* tab, long long* n_blocks) {
+                           int tile_w, int tile_h, LevelTab* tab, long long* n_blocks,
+                           const bool* skip = nullptr) {
     if (!levels) return fail(ctx, SILENT_E_INVALID, std::string(who) + ": levels is NULL");
     if (n_levels < 1 || n_levels > kMaxLevels)
         return fail(ctx, SILENT_E_INVALID, std::string(who) + ": n_levels must be in [1, " + std::to_string(kMaxLevels) + "]");
@@ -211,7 +220,7 @@ static int build_level_tab(silent_ctx* ctx, const char* who, const silent_extent
             ty = (h + tile_h - 1) / tile_h;
         }
         tab->tiles_x[l] = (int)tx;
-        tiles += tx * ty;
+        if (!(skip && skip[l])) tiles += tx * ty;  // a skipped level keeps its place in the layout, gets no tiles
         px += h * w;
     }
     tab->tile_start[n_levels] = (int)tiles;
@@ -319,37 +328,49 @@ SILENT_EXPORT int silent_regulate_dev(silent_ctx* ctx, const float* in, const si
 
 // ------------------------------------------------------------------------------------------ fused gray pass
 
-SILENT_EXPORT int silent_gray_line_end_dev(silent_ctx* ctx, const float* pyr, const silent_extent* levels,
-                                           int n_levels, int n_frames, const float* cs_kernel, const float* end_bank,
-                                           int n_orient, float clip_hi, float* cs_out, float* end_out,
-                                           silent_stream stream) {
-    NEED_CTX(ctx);
-    const char* who = "silent_gray_line_end";
+static int launch_gray(silent_ctx* ctx, const char* who, const float* pyr, const silent_extent* levels, int n_levels,
+                       int n_frames, const float* cs_kernel, const float* end_bank, int n_orient, float clip_hi,
+                       float* cs_out, float* end_out, hipStream_t s, const bool* skip) {
     if (!pyr || !cs_kernel) return fail(ctx, SILENT_E_INVALID, std::string(who) + ": NULL pointer");
     if (!cs_out && !end_out) return fail(ctx, SILENT_E_INVALID, std::string(who) + ": both outputs are NULL");
     if (end_out && !end_bank) return fail(ctx, SILENT_E_INVALID, std::string(who) + ": end_bank is NULL");
     if (n_orient != 3 && n_orient != 4 && n_orient != 8)
         return fail(ctx, SILENT_E_UNSUPPORTED, std::string(who) + ": n_orient must be 3, 4 or 8");
+    // development knob for interleaved A/B timing (scripts/ab_gray.py): bit0 XCD-aware tile order (measured
+    // 7 % slower, off), bit1 32-row tiles (3 % slower, off), bit2 non-temporal stores (no effect, off)
+    const char* knob = std::getenv("SILENT_GRAY_OPTS");
+    const unsigned opts = knob ? (unsigned)std::atoi(knob) : 0u;
+    const int th = (opts & 2u) ? 32 : kGrayTH;
     LevelTab tab;
     long long blocks;
-    TRY(build_level_tab(ctx, who, levels, n_levels, n_frames, kGrayTW, kGrayTH, &tab, &blocks));
+    TRY(build_level_tab(ctx, who, levels, n_levels, n_frames, kGrayTW, th, &tab, &blocks, skip));
+    if (blocks == 0) return SILENT_OK;
     GrayW w;
     std::memset(&w, 0, sizeof(w));
     std::memcpy(w.cs, cs_kernel, sizeof(float) * 9);
     if (end_bank) std::memcpy(w.end, end_bank, sizeof(float) * 9 * n_orient);
-    hipStream_t s = (hipStream_t)stream;
-    switch (n_orient) {
-        case 3:
-            hipLaunchKernelGGL(gray_line_end_kernel<3>, dim3((unsigned)blocks), dim3(256), 0, s, pyr, cs_out, end_out, tab, w, clip_hi);
-            break;
-        case 4:
-            hipLaunchKernelGGL(gray_line_end_kernel<4>, dim3((unsigned)blocks), dim3(256), 0, s, pyr, cs_out, end_out, tab, w, clip_hi);
-            break;
-        default:
-            hipLaunchKernelGGL(gray_line_end_kernel<8>, dim3((unsigned)blocks), dim3(256), 0, s, pyr, cs_out, end_out, tab, w, clip_hi);
-            break;
+#define GRAY_LAUNCH(K_, R_) \
+    hipLaunchKernelGGL((gray_line_end_kernel<K_, R_>), dim3((unsigned)blocks), dim3(256), 0, s, pyr, cs_out, end_out, tab, w, clip_hi, opts)
+    if (th == 32) {
+        if (n_orient == 3) GRAY_LAUNCH(3, 32);
+        else if (n_orient == 4) GRAY_LAUNCH(4, 32);
+        else GRAY_LAUNCH(8, 32);
+    } else {
+        if (n_orient == 3) GRAY_LAUNCH(3, kGrayTH);
+        else if (n_orient == 4) GRAY_LAUNCH(4, kGrayTH);
+        else GRAY_LAUNCH(8, kGrayTH);
     }
+#undef GRAY_LAUNCH
     return check_launch(ctx, who);
+}
+
+SILENT_EXPORT int silent_gray_line_end_dev(silent_ctx* ctx, const float* pyr, const silent_extent* levels,
+                                           int n_levels, int n_frames, const float* cs_kernel, const float* end_bank,
+                                           int n_orient, float clip_hi, float* cs_out, float* end_out,
+                                           silent_stream stream) {
+    NEED_CTX(ctx);
+    return launch_gray(ctx, "silent_gray_line_end", pyr, levels, n_levels, n_frames, cs_kernel, end_bank, n_orient,
+                       clip_hi, cs_out, end_out, (hipStream_t)stream, nullptr);
 }
 
 // ------------------------------------------------------------------------------------------ pointwise / nms
@@ -704,6 +725,7 @@ SILENT_EXPORT int silent_pyramid_plan_create(silent_ctx* ctx, int frame_h, int f
         d.yreg_off = (int)yreg.size();
         if (unit) {
             unit_tiles += (long long)tab.unit_tiles_x[l] * ((d.out_h + kUnitTH - 1) / kUnitTH);
+            for (int j = 0; j < 5; ++j) plan->unit_w[j] = xwl[j];
             continue;
         }
         ++tab.n_general;
@@ -789,20 +811,17 @@ SILENT_EXPORT void silent_pyramid_plan_destroy(silent_pyramid_plan* plan) {
     delete plan;
 }
 
-SILENT_EXPORT int silent_pyramid_dev(silent_ctx* ctx, const silent_pyramid_plan* plan, const float* frames,
-                                     int n_frames, float* pyr, silent_stream stream) {
-    NEED_CTX(ctx);
-    const char* who = "silent_pyramid";
+static int launch_pyramid(silent_ctx* ctx, const char* who, const silent_pyramid_plan* plan, const float* frames,
+                          int n_frames, float* pyr, hipStream_t s, bool with_unit) {
     if (!plan || !frames || !pyr) return fail(ctx, SILENT_E_INVALID, std::string(who) + ": NULL pointer");
     if (plan->ctx != ctx) return fail(ctx, SILENT_E_INVALID, std::string(who) + ": plan belongs to another context");
     if (n_frames < 1) return fail(ctx, SILENT_E_INVALID, std::string(who) + ": n_frames must be >= 1");
     const PyrTab& tab = plan->tab;
-    const long long b_unit = (long long)tab.unit_tiles_per_frame * n_frames;
+    const long long b_unit = with_unit ? (long long)tab.unit_tiles_per_frame * n_frames : 0;
     const long long b_region = tab.n_general ? (long long)tab.regions_x * tab.regions_y * n_frames : 0;
     const long long b_zero = (long long)tab.zero_chunks_per_frame * n_frames;
     if (b_unit > 0x7fffffffll || b_region > 0x7fffffffll || b_zero > 0x7fffffffll)
         return fail(ctx, SILENT_E_INVALID, std::string(who) + ": too many tiles for one launch");
-    hipStream_t s = (hipStream_t)stream;
     if (tab.C == 1) {
         if (b_unit) hipLaunchKernelGGL(pyramid_unit_kernel<1>, dim3((unsigned)b_unit), dim3(256), 0, s, frames, pyr, tab);
         if (b_region) hipLaunchKernelGGL(pyramid_region_kernel<1>, dim3((unsigned)b_region), dim3(256), 0, s, frames, pyr, tab);
@@ -812,6 +831,116 @@ SILENT_EXPORT int silent_pyramid_dev(silent_ctx* ctx, const silent_pyramid_plan*
     }
     if (b_zero) hipLaunchKernelGGL(pyramid_zero_kernel, dim3((unsigned)b_zero), dim3(256), 0, s, pyr, tab);
     return check_launch(ctx, who);
+}
+
+SILENT_EXPORT int silent_pyramid_dev(silent_ctx* ctx, const silent_pyramid_plan* plan, const float* frames,
+                                     int n_frames, float* pyr, silent_stream stream) {
+    NEED_CTX(ctx);
+    return launch_pyramid(ctx, "silent_pyramid", plan, frames, n_frames, pyr, (hipStream_t)stream, true);
+}
+
+// ------------------------------------------------------------------------------------------ whole gray pass
+
+SILENT_EXPORT int silent_set_profiling(silent_ctx* ctx, int enable) {
+    NEED_CTX(ctx);
+    if (enable && !ctx->ev0) {
+        HIP_TRY(ctx, hipEventCreate(&ctx->ev0));
+        HIP_TRY(ctx, hipEventCreate(&ctx->ev1));
+    }
+    ctx->profiling = enable != 0;
+    ctx->prof_valid = false;
+    return SILENT_OK;
+}
+
+SILENT_EXPORT int silent_profile_elapsed_ms(silent_ctx* ctx, float* ms, int64_t* pixels) {
+    NEED_CTX(ctx);
+    if (!ms) return fail(ctx, SILENT_E_INVALID, "silent_profile_elapsed_ms: ms is NULL");
+    if (!ctx->prof_valid) return fail(ctx, SILENT_E_INVALID, "silent_profile_elapsed_ms: no profiled launch recorded");
+    HIP_TRY(ctx, hipEventSynchronize(ctx->ev1));
+    HIP_TRY(ctx, hipEventElapsedTime(ms, ctx->ev0, ctx->ev1));
+    if (pixels) *pixels = ctx->prof_pixels;
+    return SILENT_OK;
+}
+
+SILENT_EXPORT int silent_gray_pass_dev(silent_ctx* ctx, const silent_pyramid_plan* plan, const float* frames,
+                                       int n_frames, const float* cs_kernel, const float* end_bank, int n_orient,
+                                       float clip_hi, float* pyr, float* cs_out, float* end_out,
+                                       silent_stream stream) {
+    NEED_CTX(ctx);
+    const char* who = "silent_gray_pass";
+    if (!plan || !frames || !pyr || !cs_kernel) return fail(ctx, SILENT_E_INVALID, std::string(who) + ": NULL pointer");
+    if (plan->ctx != ctx) return fail(ctx, SILENT_E_INVALID, std::string(who) + ": plan belongs to another context");
+    if (plan->tab.C != 1) return fail(ctx, SILENT_E_INVALID, std::string(who) + ": the plan must be single-channel");
+    if (!cs_out && !end_out) return fail(ctx, SILENT_E_INVALID, std::string(who) + ": both outputs are NULL");
+    if (end_out && !end_bank) return fail(ctx, SILENT_E_INVALID, std::string(who) + ": end_bank is NULL");
+    if (n_orient != 3 && n_orient != 4 && n_orient != 8)
+        return fail(ctx, SILENT_E_UNSUPPORTED, std::string(who) + ": n_orient must be 3, 4 or 8");
+    if (n_frames < 1) return fail(ctx, SILENT_E_INVALID, std::string(who) + ": n_frames must be >= 1");
+    hipStream_t s = (hipStream_t)stream;
+    const PyrTab& pt = plan->tab;
+    // 1. every non-unit level of the pyramid (region kernel), and the zero fill
+    TRY(launch_pyramid(ctx, who, plan, frames, n_frames, pyr, s, false));
+    // 2. unit levels: pyramid + CS + end in one kernel
+    const char* knob = std::getenv("SILENT_GRAY_OPTS");  // bit3: 32-row tiles in the fused kernel (A/B knob)
+    const int fth = (knob && (std::atoi(knob) & 8)) ? 32 : kFusedTH;
+    FusedTab ft;
+    std::memset(&ft, 0, sizeof(ft));
+    bool is_unit[kMaxLevels] = {false};
+    long long tiles = 0, unit_px = 0;
+    for (int l = 0; l < pt.n_levels; ++l) {
+        const PyrLevelDev& d = pt.lv[l];
+        if (d.kind != kPyrUnit) continue;
+        is_unit[l] = true;
+        if (ft.n == 0)
+            for (int j = 0; j < 5; ++j) {  // every unit level has the same [1,26,66,26,1]/120 taps
+                ft.wx[j] = plan->unit_w[j];
+                ft.wy[j] = plan->unit_w[j];
+            }
+        FusedLevel& f = ft.lv[ft.n++];
+        f.src_y0 = d.src_y0; f.src_x0 = d.src_x0; f.src_h = d.src_h; f.src_w = d.src_w;
+        f.zoom_h = d.zoom_h; f.zoom_w = d.zoom_w; f.out_h = d.out_h; f.out_w = d.out_w;
+        f.tiles_x = (d.out_w + kFusedTW - 1) / kFusedTW;
+        f.tile_start = (int)tiles;
+        f.px_off = pt.px_off[l];
+        tiles += (long long)f.tiles_x * ((d.out_h + fth - 1) / fth);
+        unit_px += (long long)d.out_h * d.out_w;
+    }
+    ft.tiles_per_frame = (int)tiles;
+    ft.H = pt.H;
+    ft.W = pt.W;
+    ft.frame_px = pt.frame_px_out;
+    const long long blocks = tiles * n_frames;
+    if (blocks > 0x7fffffffll) return fail(ctx, SILENT_E_INVALID, std::string(who) + ": too many tiles for one launch");
+    if (blocks) {
+        GrayW w;
+        std::memset(&w, 0, sizeof(w));
+        std::memcpy(w.cs, cs_kernel, sizeof(float) * 9);
+        if (end_bank) std::memcpy(w.end, end_bank, sizeof(float) * 9 * n_orient);
+        if (ctx->profiling) HIP_TRY(ctx, hipEventRecord(ctx->ev0, s));
+#define FUSED_LAUNCH(K_, R_) \
+    hipLaunchKernelGGL((gray_unit_fused_kernel<K_, R_>), dim3((unsigned)blocks), dim3(256), 0, s, frames, pyr, cs_out, end_out, ft, w, clip_hi)
+        if (fth == 32) {
+            if (n_orient == 3) FUSED_LAUNCH(3, 32);
+            else if (n_orient == 4) FUSED_LAUNCH(4, 32);
+            else FUSED_LAUNCH(8, 32);
+        } else {
+            if (n_orient == 3) FUSED_LAUNCH(3, kFusedTH);
+            else if (n_orient == 4) FUSED_LAUNCH(4, kFusedTH);
+            else FUSED_LAUNCH(8, kFusedTH);
+        }
+#undef FUSED_LAUNCH
+        if (ctx->profiling) {
+            HIP_TRY(ctx, hipEventRecord(ctx->ev1, s));
+            ctx->prof_valid = true;
+            ctx->prof_pixels = unit_px * n_frames;
+        }
+        TRY(check_launch(ctx, who));
+    }
+    // 3. CS + end on the remaining levels (they read the pyramid written in step 1)
+    if (pt.n_general)
+        TRY(launch_gray(ctx, who, pyr, plan->extents.data(), pt.n_levels, n_frames, cs_kernel, end_bank, n_orient,
+                        clip_hi, cs_out, end_out, s, is_unit));
+    return SILENT_OK;
 }
 
 // ------------------------------------------------------------------------------------------ host-pointer twins
@@ -1051,4 +1180,28 @@ SILENT_EXPORT int silent_pyramid(silent_ctx* ctx, const silent_pyramid_plan* pla
     TRY(silent_pyramid_dev(ctx, plan, st.ptr<float>(i_in), n_frames, st.ptr<float>(i_out), nullptr));
     TRY(sync0(ctx));
     return d2h(ctx, pyr, st.ptr<float>(i_out), bo);
+}
+
+SILENT_EXPORT int silent_gray_pass(silent_ctx* ctx, const silent_pyramid_plan* plan, const float* frames, int n_frames,
+                                   const float* cs_kernel, const float* end_bank, int n_orient, float clip_hi,
+                                   float* pyr, float* cs_out, float* end_out) {
+    NEED_CTX(ctx);
+    if (!plan || !frames || !pyr) return fail(ctx, SILENT_E_INVALID, "silent_gray_pass: NULL pointer");
+    if (n_frames < 1) return fail(ctx, SILENT_E_INVALID, "silent_gray_pass: n_frames must be >= 1");
+    if (n_orient < 1 || n_orient > 8) return fail(ctx, SILENT_E_UNSUPPORTED, "silent_gray_pass: n_orient must be 3, 4 or 8");
+    Stage st(ctx);
+    const size_t px = (size_t)plan->tab.frame_px_out * n_frames;
+    const size_t bi = (size_t)plan->tab.H * plan->tab.W * plan->tab.C * 4 * n_frames;
+    const size_t b1 = px * 4, bk = px * n_orient * 4;
+    const size_t i_in = st.add(bi), i_p = st.add(b1), i_cs = st.add(b1), i_end = st.add(bk);
+    TRY(st.commit());
+    TRY(h2d(ctx, st.ptr<float>(i_in), frames, bi));
+    TRY(silent_gray_pass_dev(ctx, plan, st.ptr<float>(i_in), n_frames, cs_kernel, end_bank, n_orient, clip_hi,
+                             st.ptr<float>(i_p), cs_out ? st.ptr<float>(i_cs) : nullptr,
+                             end_out ? st.ptr<float>(i_end) : nullptr, nullptr));
+    TRY(sync0(ctx));
+    TRY(d2h(ctx, pyr, st.ptr<float>(i_p), b1));
+    if (cs_out) TRY(d2h(ctx, cs_out, st.ptr<float>(i_cs), b1));
+    if (end_out) TRY(d2h(ctx, end_out, st.ptr<float>(i_end), bk));
+    return SILENT_OK;
 }

@@ -28,6 +28,17 @@ struct TileCoord {
     int frame, level, ty, tx;
 };
 
+// XCD-aware block order.  Workgroups are dealt round-robin over the 8 XCDs (each with its own 4 MiB L2), so
+// with the identity order two tiles that share halo rows land on different L2s.  Remap so that every XCD walks
+// a contiguous run of tiles: vertical neighbours are then a few blocks apart on the SAME L2.  Bijective for any
+// grid size; placement is a speed hint only, never a correctness assumption.
+__device__ __forceinline__ unsigned xcd_swizzle(unsigned bid, unsigned n) {
+    constexpr unsigned kXcd = 8;
+    const unsigned per = n / kXcd, rem = n % kXcd;   // XCD x owns per (+1 if x < rem) consecutive tiles
+    const unsigned x = bid % kXcd, k = bid / kXcd;
+    return x * per + (x < rem ? x : rem) + k;
+}
+
 __device__ __forceinline__ TileCoord locate_tile(const LevelTab& tab, unsigned bid) {
     TileCoord t;
     t.frame = (int)(bid / (unsigned)tab.tiles_per_frame);

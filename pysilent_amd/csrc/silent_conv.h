@@ -205,13 +205,12 @@ constexpr int kGrayCols = 60;            // output columns per wave
 constexpr int kGrayTW = 4 * kGrayCols;   // 4 waves side by side
 constexpr int kGrayTH = 16;              // rows per tile (R)
 
-template <int K>
+template <int K, int R>
 __global__ __launch_bounds__(256) void gray_line_end_kernel(const float* __restrict__ pyr,
                                                             float* __restrict__ cs_out,
                                                             float* __restrict__ end_out, const LevelTab tab,
-                                                            const GrayW wts, float clip_hi) {
-    constexpr int R = kGrayTH;
-    const TileCoord tc = locate_tile(tab, blockIdx.x);
+                                                            const GrayW wts, float clip_hi, unsigned opts) {
+    const TileCoord tc = locate_tile(tab, (opts & 1u) ? xcd_swizzle(blockIdx.x, gridDim.x) : blockIdx.x);
     const int H = tab.h[tc.level], W = tab.w[tc.level];
     const long long base_px = (long long)tc.frame * tab.frame_px + tab.px_off[tc.level];
     const float* __restrict__ src = pyr + base_px;
@@ -279,6 +278,178 @@ __global__ __launch_bounds__(256) void gray_line_end_kernel(const float* __restr
             const int y = y0 + i - 4;  // output row
             if (y < H && out_lane) {
                 const long long px = base_px + (long long)y * W + x;
+                if (cs_out) {
+                    if (opts & 4u) __builtin_nontemporal_store(cw[1][1], cs_out + px);
+                    else cs_out[px] = cw[1][1];
+                }
+                if (end_out) {
+                    float acc[K];
+#pragma unroll
+                    for (int k = 0; k < K; ++k) acc[k] = 0.0f;
+#pragma unroll
+                    for (int dy = 0; dy < 3; ++dy)
+#pragma unroll
+                        for (int dx = 0; dx < 3; ++dx)
+#pragma unroll
+                            for (int k = 0; k < K; ++k)
+                                acc[k] = __builtin_fmaf(cw[dy][dx], wts.end[(dy * 3 + dx) * K + k], acc[k]);
+#pragma unroll
+                    for (int k = 0; k < K; ++k) acc[k] = clip_hi_tf(relu_tf(acc[k]), clip_hi);
+                    float* __restrict__ po = end_out + px * K;
+                    if constexpr (K == 4) {
+                        typedef float nf4 __attribute__((ext_vector_type(4)));
+                        const nf4 v4 = {acc[0], acc[1], acc[2], acc[3]};
+                        if (opts & 4u) __builtin_nontemporal_store(v4, reinterpret_cast<nf4*>(po));
+                        else *reinterpret_cast<nf4*>(po) = v4;
+                    } else if constexpr (K == 8) {
+                        reinterpret_cast<float4*>(po)[0] = make_float4(acc[0], acc[1], acc[2], acc[3]);
+                        reinterpret_cast<float4*>(po)[1] = make_float4(acc[4], acc[5], acc[6], acc[7]);
+                    } else {
+#pragma unroll
+                        for (int k = 0; k < K; ++k) po[k] = acc[k];
+                    }
+                }
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Unit-zoom level, pyramid AND filters in one pass (the whole hot path for level 0, 75 % of all pixels):
+//     p   = smooth5x5(frame)               -> pyramid level   (scipy zoom factor 1 = [1,26,66,26,1]/120 per axis)
+//     cs  = relu(conv3x3(p, cs_k))         -> CS map
+//     end = clip(relu(conv3x3(cs, bank)))  -> K-orientation line-end maps
+// Same wave-autonomous streaming structure as gray_line_end_kernel, with the 5-tap smoother in front: the
+// level is never re-read from HBM by the filter pass.  Each stage costs halo lanes (2 + 1 + 1 per side):
+// 56 of the 64 lanes produce outputs; a tile is 224 columns x 16 rows and streams 24 source rows.
+constexpr int kFusedCols = 56;
+constexpr int kFusedTW = 4 * kFusedCols;
+constexpr int kFusedTH = 16;
+
+struct FusedLevel {  // the unit levels of a pyramid plan, as the kernel needs them
+    int src_y0, src_x0, src_h, src_w;  // crop of the frame (mirror extension happens inside the crop)
+    int zoom_h, zoom_w, out_h, out_w;  // resampler extents (== crop) and canvas extents
+    int tiles_x, tile_start;
+    long long px_off;                  // pixel offset of the level inside one pyramid
+};
+
+struct FusedTab {
+    int n, tiles_per_frame, H, W;
+    long long frame_px;                // pixels of one whole pyramid (all levels)
+    float wx[5], wy[5];
+    FusedLevel lv[kMaxLevels];
+};
+
+template <int K, int R>
+__global__ __launch_bounds__(256) void gray_unit_fused_kernel(const float* __restrict__ frames,
+                                                              float* __restrict__ pyr, float* __restrict__ cs_out,
+                                                              float* __restrict__ end_out, const FusedTab tab,
+                                                              const GrayW wts, float clip_hi) {
+    const unsigned bid = blockIdx.x;
+    const int frame = (int)(bid / (unsigned)tab.tiles_per_frame);
+    int rem = (int)(bid - (unsigned)frame * (unsigned)tab.tiles_per_frame);
+    int li = 0;
+#pragma unroll
+    for (int i = 1; i < kMaxLevels; ++i)
+        if (i < tab.n && rem >= tab.lv[i].tile_start) li = i;
+    const FusedLevel& lv = tab.lv[li];
+    rem -= lv.tile_start;
+    const int ty = rem / lv.tiles_x, tx = rem - ty * lv.tiles_x;
+
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int xw0 = tx * kFusedTW + wave * kFusedCols;
+    if (xw0 >= lv.out_w) return;  // wave-uniform
+    const int y0 = ty * R;
+    const int ox = xw0 + lane - 4;
+    const int W = tab.W;
+    const float* __restrict__ src = frames + (long long)frame * tab.H * W;
+    const long long base_px = (long long)frame * tab.frame_px + lv.px_off;
+
+    // scipy 'mirror' inside the crop, then the crop's offset in the frame
+    auto mirror = [](int i, int n) {
+        if ((unsigned)i < (unsigned)n) return i;
+        if (n == 1) return 0;
+        const int period = 2 * (n - 1);
+        if (i < 0) i = -i;
+        i %= period;
+        return i >= n ? period - i : i;
+    };
+    const long long sx = mirror(ox, lv.src_w) + lv.src_x0;
+    float in[R + 8];
+#pragma unroll
+    for (int i = 0; i < R + 8; ++i)
+        in[i] = src[(long long)(mirror(y0 - 4 + i, lv.src_h) + lv.src_y0) * W + sx];
+#pragma unroll
+    for (int i = 0; i < R + 8; ++i) asm volatile("" ::"v"(in[i]));  // retire loads before the first store
+
+    const bool col_in = ox >= 0 && ox < lv.out_w;                  // inside the level (SAME padding is 0 outside)
+    const bool out_lane = lane >= 4 && lane < 4 + kFusedCols && ox < lv.out_w;
+    float hw[5] = {0, 0, 0, 0, 0};
+    float iw[3][3], cw[3][3];
+#pragma unroll
+    for (int a = 0; a < 3; ++a)
+#pragma unroll
+        for (int b = 0; b < 3; ++b) iw[a][b] = cw[a][b] = 0.0f;
+
+#pragma unroll
+    for (int i = 0; i < R + 8; ++i) {
+        // ---- horizontal 5 taps of source row y0 - 4 + i
+        {
+            const float c0 = in[i];
+            const float l1 = from_lane_below(c0), l2 = from_lane_below(l1);
+            const float r1 = from_lane_above(c0), r2 = from_lane_above(r1);
+            float h = tab.wx[0] * l2;
+            h = __builtin_fmaf(tab.wx[1], l1, h);
+            h = __builtin_fmaf(tab.wx[2], c0, h);
+            h = __builtin_fmaf(tab.wx[3], r1, h);
+            h = __builtin_fmaf(tab.wx[4], r2, h);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) hw[j] = hw[j + 1];
+            hw[4] = h;
+        }
+        if (i >= 4) {
+            // ---- pyramid row p = y0 + i - 6 (vertical 5 taps)
+            const int p = y0 + i - 6;
+            float v = tab.wy[0] * hw[0];
+#pragma unroll
+            for (int j = 1; j < 5; ++j) v = __builtin_fmaf(tab.wy[j], hw[j], v);
+            v = (p < lv.zoom_h && ox < lv.zoom_w) ? v : 0.0f;                 // canvas beyond the zoomed crop
+            if (p >= y0 && p < y0 + R && p < lv.out_h && out_lane) pyr[base_px + (long long)p * lv.out_w + ox] = v;
+            v = (p >= 0 && p < lv.out_h && col_in) ? v : 0.0f;                // SAME zero padding of the first conv
+#pragma unroll
+            for (int b = 0; b < 3; ++b) {
+                iw[0][b] = iw[1][b];
+                iw[1][b] = iw[2][b];
+            }
+            iw[2][1] = v;
+            iw[2][0] = from_lane_below(v);
+            iw[2][2] = from_lane_above(v);
+        }
+        if (i >= 6) {
+            // ---- CS row c = y0 + i - 7
+            const int c = y0 + i - 7;
+            float acc = 0.0f;
+#pragma unroll
+            for (int dy = 0; dy < 3; ++dy)
+#pragma unroll
+                for (int dx = 0; dx < 3; ++dx) acc = __builtin_fmaf(iw[dy][dx], wts.cs[dy * 3 + dx], acc);
+            float cs = relu_tf(acc);
+            cs = (c >= 0 && c < lv.out_h && col_in) ? cs : 0.0f;
+#pragma unroll
+            for (int b = 0; b < 3; ++b) {
+                cw[0][b] = cw[1][b];
+                cw[1][b] = cw[2][b];
+            }
+            cw[2][1] = cs;
+            cw[2][0] = from_lane_below(cs);
+            cw[2][2] = from_lane_above(cs);
+        }
+        if (i >= 8) {
+            // ---- output row y = y0 + i - 8
+            const int y = y0 + i - 8;
+            if (y < lv.out_h && out_lane) {
+                const long long px = base_px + (long long)y * lv.out_w + ox;
                 if (cs_out) cs_out[px] = cw[1][1];
                 if (end_out) {
                     float acc[K];

@@ -151,13 +151,34 @@ class LineEndPipeline(object):
             C.c_void_p(self.kp_idx.data_ptr()), self.kp_cap, C.c_void_p(self.kp_counts.data_ptr()),
             stream or self._stream()))
 
+    def run_gray_pass(self, frames, stream=None):
+        """Whole grayscale hot path in one C-ABI call (silent_gray_pass_dev): region kernel for the non-unit
+        levels, fused pyramid + CS + end kernel for the unit levels, filter kernel for the rest."""
+        self._check_frames(frames)
+        self.ctx.check(self._lib.silent_gray_pass_dev(
+            self.ctx.handle, self.plan.handle, C.c_void_p(frames.data_ptr()), self.batch,
+            C.c_void_p(self.consts["cs"].ctypes.data), C.c_void_p(self.consts["end"].ctypes.data), self.n_orient,
+            self.clip_hi, C.c_void_p(self.pyr.data_ptr()), C.c_void_p(self.cs.data_ptr()),
+            C.c_void_p(self.end.data_ptr()), stream or self._stream()))
+
+    def set_profiling(self, enable=True):
+        self.ctx.check(self._lib.silent_set_profiling(self.ctx.handle, 1 if enable else 0))
+
+    def profiled_kernel(self):
+        """(milliseconds, pixels) of the dominant kernel of the last run_gray_pass (HIP events on its stream)."""
+        ms, px = C.c_float(0), C.c_int64(0)
+        self.ctx.check(self._lib.silent_profile_elapsed_ms(self.ctx.handle, C.byref(ms), C.byref(px)))
+        return ms.value, px.value
+
     def step(self, frames):
         """One pass of the hot path over one batch of frames (asynchronous)."""
         s = self._stream()
+        if self.mode == "gray":
+            self.run_gray_pass(frames, s)
+            return
         self.run_pyramid(frames, s)
         self.run_filters(s)
-        if self.mode == "rgb":
-            self.run_keypoints(s)
+        self.run_keypoints(s)
 
     # -- results as PackedPyramids over the pipeline's buffers ---------------------------------------
     def outputs(self):

@@ -332,6 +332,52 @@ def test_torch_device_path_is_bit_identical(rt, kernels):
     np.testing.assert_array_equal(y.cpu().numpy(), filters.rgc_filter(x.cpu().numpy()))
 
 
+# ----------------------------------------------------------------------------- whole gray pass (fused level 0)
+
+@pytest.mark.parametrize("shape,scale,n,K", [((135, 240, 1), 2.0, 5, 4), ((97, 131, 1), 1.7, 4, 8), ((64, 300, 1), 2.0, 3, 3),
+                                             ((33, 57, 1), 2.0, 1, 4)])
+def test_gray_pass_equals_pyramid_then_filters(rt, kernels, shape, scale, n, K):
+    """silent_gray_pass (level 0 smoothed + filtered in one kernel) is bit-identical to the two-step path,
+    and both match the oracle."""
+    from pysilent_amd.util.zoom.from_image import classic_levels
+    frames = np.stack([noise_frame(s, *shape) for s in range(2)])
+    plan = rt.PyramidPlan(shape[0], shape[1], 1, classic_levels(shape[:2], scale, n))
+    bank = kernels["end%d" % K]
+    pyr, cs, end = plan.gray_pass(frames, kernels["cs_gray"], bank)
+    pyr2 = plan.run(frames)
+    cs2, end2 = rt.gray_line_end(pyr2, kernels["cs_gray"], bank)
+    np.testing.assert_array_equal(pyr.data, pyr2.data)
+    np.testing.assert_array_equal(cs.data, cs2.data)
+    np.testing.assert_array_equal(end.data, end2.data)
+    want = so.classic_pyramid(frames[1], scale, n)
+    for l, (wcs, wend) in enumerate(so.gray_line_end_pass(want, kernels["cs_gray"], bank)):
+        assert_close(pyr.level(l)[1:2], want[l], RTOL, scale=255.0, what="pyr %d" % l)
+        assert_close(cs.level(l)[1:2], wcs, RTOL, scale=255.0, what="cs %d" % l)
+        assert_close(end.level(l)[1:2], wend, RTOL, scale=255.0, what="end %d" % l)
+
+
+def test_gray_pass_reference_layout_and_device_path(rt, kernels):
+    """Reference layout (level 0 = centred crop at zoom 1, other levels crops at e^-s/2) through the fused pass,
+    host and torch-device paths."""
+    torch = pytest.importorskip("torch")
+    from pysilent_amd.util.zoom.from_image import reference_levels
+    img = noise_frame(5, 240, 320, 1)
+    levels = reference_levels((240, 320), (80, 60), math.e ** .5)
+    plan = rt.PyramidPlan(240, 320, 1, levels)
+    pyr, cs, end = plan.gray_pass(img[None], kernels["cs_gray"], kernels["end4"])
+    want = so.zoom_from_image(img, 1, (80, 60), math.e ** .5)
+    got = pyr.data.reshape(want.shape)
+    assert_close(got, want, RTOL, scale=255.0, what="pyramid")
+    wcs = so.conv2d_same(want, kernels["cs_gray"], relu=True)
+    assert_close(cs.data.reshape(wcs.shape), wcs, RTOL, scale=255.0, what="cs")
+    wend = so.conv2d_same(wcs, kernels["end4"], relu=True, clip_hi=255.0)
+    assert_close(end.data.reshape(wend.shape), wend, RTOL, scale=255.0, what="end")
+    dp, dc, de = plan.gray_pass(torch.from_numpy(img[None]).cuda(), kernels["cs_gray"], kernels["end4"])
+    np.testing.assert_array_equal(dp.data.cpu().numpy(), pyr.data)
+    np.testing.assert_array_equal(dc.data.cpu().numpy(), cs.data)
+    np.testing.assert_array_equal(de.data.cpu().numpy(), end.data)
+
+
 # ----------------------------------------------------------------------------- full size (BASELINE config 2)
 
 def test_config2_1080p_full_size_against_c_oracle(rt, kernels):
@@ -342,6 +388,11 @@ def test_config2_1080p_full_size_against_c_oracle(rt, kernels):
     assert pyr.extents == [(1080, 1920), (540, 960), (270, 480), (135, 240), (68, 120)]
     assert pyr.frame_px == 2762160
     cs, end = rt.gray_line_end(pyr, kernels["cs_gray"], kernels["end4"])
+    from pysilent_amd.util.zoom.from_image import classic_levels
+    fused = rt.PyramidPlan(1080, 1920, 1, classic_levels((1080, 1920), 2.0, 5)).gray_pass(
+        frame[None], kernels["cs_gray"], kernels["end4"])
+    for a, b in zip(fused, (pyr, cs, end)):
+        np.testing.assert_array_equal(a.data, b.data)          # the bench path (silent_gray_pass) == two-step path
     want_pyr = co.classic_pyramid(frame, pyr.extents)
     for l in range(5):
         assert_close(pyr.level(l), want_pyr[l], RTOL, scale=255.0, what="pyramid %d" % l)
