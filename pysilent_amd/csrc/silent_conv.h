@@ -205,11 +205,34 @@ constexpr int kGrayCols = 60;            // output columns per wave
 constexpr int kGrayTW = 4 * kGrayCols;   // 4 waves side by side
 constexpr int kGrayTH = 16;              // rows per tile (R)
 
+// K = 8: a pixel's 8 floats are 32 bytes, so "one float4 pair per lane" makes every store instruction write
+// 16-byte pieces at a 32-byte stride (measured 3.1 TB/s vs 5.2 for K = 4).  Instead the wave transposes the
+// row through a wave-private LDS slab: lane l then stores the l-th 16-byte piece of the row, so that each of
+// the two store instructions covers 1 KiB of contiguous memory.  first / count: the lanes (= pixels of the
+// wave's 64 columns) that may be written.  Every lane of the wave must call this (LDS exchange).
+__device__ __forceinline__ void store_row_k8(float* __restrict__ row_base /* address of pixel of lane 0 */,
+                                             const float (&acc)[8], float* s_slab /* 512 floats, wave private */,
+                                             int lane, int first, int count) {
+    typedef float nf4 __attribute__((ext_vector_type(4)));
+    nf4* slab4 = reinterpret_cast<nf4*>(s_slab);
+    slab4[lane * 2 + 0] = nf4{acc[0], acc[1], acc[2], acc[3]};
+    slab4[lane * 2 + 1] = nf4{acc[4], acc[5], acc[6], acc[7]};
+    __builtin_amdgcn_wave_barrier();
+    const nf4 a = slab4[lane], b = slab4[64 + lane];
+    __builtin_amdgcn_wave_barrier();
+    // piece q (16 bytes) belongs to pixel q / 2
+    const int pa = lane >> 1, pb = 32 + (lane >> 1);
+    nf4* out4 = reinterpret_cast<nf4*>(row_base);
+    if (pa >= first && pa < first + count) out4[lane] = a;
+    if (pb >= first && pb < first + count) out4[64 + lane] = b;
+}
+
 template <int K, int R>
 __global__ __launch_bounds__(256) void gray_line_end_kernel(const float* __restrict__ pyr,
                                                             float* __restrict__ cs_out,
                                                             float* __restrict__ end_out, const LevelTab tab,
                                                             const GrayW wts, float clip_hi, unsigned opts) {
+    __shared__ __attribute__((aligned(16))) float s_slab[K == 8 ? 4 * 512 : 4];  // K = 8 store transpose, per wave
     const TileCoord tc = locate_tile(tab, (opts & 1u) ? xcd_swizzle(blockIdx.x, gridDim.x) : blockIdx.x);
     const int H = tab.h[tc.level], W = tab.w[tc.level];
     const long long base_px = (long long)tc.frame * tab.frame_px + tab.px_off[tc.level];
@@ -276,9 +299,9 @@ __global__ __launch_bounds__(256) void gray_line_end_kernel(const float* __restr
         }
         if (i >= 4) {
             const int y = y0 + i - 4;  // output row
-            if (y < H && out_lane) {
+            if (y < H) {               // wave-uniform
                 const long long px = base_px + (long long)y * W + x;
-                if (cs_out) {
+                if (cs_out && out_lane) {
                     if (opts & 4u) __builtin_nontemporal_store(cw[1][1], cs_out + px);
                     else cs_out[px] = cw[1][1];
                 }
@@ -295,18 +318,22 @@ __global__ __launch_bounds__(256) void gray_line_end_kernel(const float* __restr
                                 acc[k] = __builtin_fmaf(cw[dy][dx], wts.end[(dy * 3 + dx) * K + k], acc[k]);
 #pragma unroll
                     for (int k = 0; k < K; ++k) acc[k] = clip_hi_tf(relu_tf(acc[k]), clip_hi);
-                    float* __restrict__ po = end_out + px * K;
-                    if constexpr (K == 4) {
-                        typedef float nf4 __attribute__((ext_vector_type(4)));
-                        const nf4 v4 = {acc[0], acc[1], acc[2], acc[3]};
-                        if (opts & 4u) __builtin_nontemporal_store(v4, reinterpret_cast<nf4*>(po));
-                        else *reinterpret_cast<nf4*>(po) = v4;
-                    } else if constexpr (K == 8) {
-                        reinterpret_cast<float4*>(po)[0] = make_float4(acc[0], acc[1], acc[2], acc[3]);
-                        reinterpret_cast<float4*>(po)[1] = make_float4(acc[4], acc[5], acc[6], acc[7]);
-                    } else {
+                    if constexpr (K == 8) {
+                        // lane 0's pixel is column xw0 - 2; valid pixels are lanes 2 .. 2 + ncols
+                        const int ncols = min(kGrayCols, W - xw0);
+                        store_row_k8(end_out + (base_px + (long long)y * W + (xw0 - 2)) * 8, acc, s_slab + wave * 512, lane,
+                                     2, ncols);
+                    } else if (out_lane) {
+                        float* __restrict__ po = end_out + px * K;
+                        if constexpr (K == 4) {
+                            typedef float nf4 __attribute__((ext_vector_type(4)));
+                            const nf4 v4 = {acc[0], acc[1], acc[2], acc[3]};
+                            if (opts & 4u) __builtin_nontemporal_store(v4, reinterpret_cast<nf4*>(po));
+                            else *reinterpret_cast<nf4*>(po) = v4;
+                        } else {
 #pragma unroll
-                        for (int k = 0; k < K; ++k) po[k] = acc[k];
+                            for (int k = 0; k < K; ++k) po[k] = acc[k];
+                        }
                     }
                 }
             }
@@ -345,6 +372,7 @@ __global__ __launch_bounds__(256) void gray_unit_fused_kernel(const float* __res
                                                               float* __restrict__ pyr, float* __restrict__ cs_out,
                                                               float* __restrict__ end_out, const FusedTab tab,
                                                               const GrayW wts, float clip_hi) {
+    __shared__ __attribute__((aligned(16))) float s_slab[K == 8 ? 4 * 512 : 4];  // K = 8 store transpose, per wave
     const unsigned bid = blockIdx.x;
     const int frame = (int)(bid / (unsigned)tab.tiles_per_frame);
     int rem = (int)(bid - (unsigned)frame * (unsigned)tab.tiles_per_frame);
@@ -448,9 +476,9 @@ __global__ __launch_bounds__(256) void gray_unit_fused_kernel(const float* __res
         if (i >= 8) {
             // ---- output row y = y0 + i - 8
             const int y = y0 + i - 8;
-            if (y < lv.out_h && out_lane) {
+            if (y < lv.out_h) {  // wave-uniform
                 const long long px = base_px + (long long)y * lv.out_w + ox;
-                if (cs_out) cs_out[px] = cw[1][1];
+                if (cs_out && out_lane) cs_out[px] = cw[1][1];
                 if (end_out) {
                     float acc[K];
 #pragma unroll
@@ -464,15 +492,18 @@ __global__ __launch_bounds__(256) void gray_unit_fused_kernel(const float* __res
                                 acc[k] = __builtin_fmaf(cw[dy][dx], wts.end[(dy * 3 + dx) * K + k], acc[k]);
 #pragma unroll
                     for (int k = 0; k < K; ++k) acc[k] = clip_hi_tf(relu_tf(acc[k]), clip_hi);
-                    float* __restrict__ po = end_out + px * K;
-                    if constexpr (K == 4) {
-                        *reinterpret_cast<float4*>(po) = make_float4(acc[0], acc[1], acc[2], acc[3]);
-                    } else if constexpr (K == 8) {
-                        reinterpret_cast<float4*>(po)[0] = make_float4(acc[0], acc[1], acc[2], acc[3]);
-                        reinterpret_cast<float4*>(po)[1] = make_float4(acc[4], acc[5], acc[6], acc[7]);
-                    } else {
+                    if constexpr (K == 8) {
+                        const int ncols = min(kFusedCols, lv.out_w - xw0);
+                        store_row_k8(end_out + (base_px + (long long)y * lv.out_w + (xw0 - 4)) * 8, acc,
+                                     s_slab + wave * 512, lane, 4, ncols);
+                    } else if (out_lane) {
+                        float* __restrict__ po = end_out + px * K;
+                        if constexpr (K == 4) {
+                            *reinterpret_cast<float4*>(po) = make_float4(acc[0], acc[1], acc[2], acc[3]);
+                        } else {
 #pragma unroll
-                        for (int k = 0; k < K; ++k) po[k] = acc[k];
+                            for (int k = 0; k < K; ++k) po[k] = acc[k];
+                        }
                     }
                 }
             }
