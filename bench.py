@@ -77,7 +77,7 @@ def cpu_baseline(wl, consts, budget_s=12.0):
 
     one(0)                       # warm (page faults, OpenMP team start)
     n, total = 0, 0.0
-    while (total < budget_s and n < 512) or n < 4:      # bounded sample: ~12 s of CPU work
+    while (total < budget_s and n < 4096) or n < 4:     # bounded sample: ~12 s of CPU work
         total += one(1 + n)
         n += 1
     return {"value": round(n * h * w / total / 1e6, 3), "unit": "Mpx/s", "cores": co.num_threads(), "kind": "port",
@@ -102,7 +102,14 @@ def main():
     from pysilent_amd import distributed as D
     from pysilent_amd.pipeline import LineEndPipeline
 
-    rank, world, local = D.init()
+    # rehearsal knobs (one-GPU box): SILENT_BENCH_SHARE_GPU=1 puts every rank on GPU 0, SILENT_DIST_BACKEND=gloo
+    # moves the (init-only) collectives to the CPU; the driver's real multi-GPU runs use neither
+    share = os.environ.get("SILENT_BENCH_SHARE_GPU") == "1"
+    if share:
+        os.environ["SILENT_DEVICE"] = "0"
+    rank, world, local = D.init(backend=os.environ.get("SILENT_DIST_BACKEND"), device=0 if share else None)
+    if share:
+        local = 0
     if world != args.gpus:
         raise SystemExit("--gpus %d but WORLD_SIZE is %d: launch with torch.distributed.run --nproc-per-node %d"
                          % (args.gpus, world, args.gpus))
@@ -169,6 +176,7 @@ def main():
         filt_ms = float(np.mean([b.elapsed_time(e) for _, b, e in ev]))
 
     if rank != 0:
+        D.finalize()
         return
     total_frames = B * world * args.steps
     mpx_in = total_frames * h * w / elapsed / 1e6
@@ -220,6 +228,7 @@ def main():
     else:
         out["cpu_baseline"] = None
     print(json.dumps(out))
+    D.finalize()
 
 
 if __name__ == "__main__":

@@ -18,9 +18,12 @@ def world():
             int(os.environ.get("LOCAL_RANK", "0")))
 
 
-def init(backend=None):
-    """Initialise torch.distributed when launched with more than one rank.  Returns (rank, world_size, local_rank)."""
+def init(backend=None, device=None):
+    """Initialise torch.distributed when launched with more than one rank.  Returns (rank, world_size, local_rank).
+    ``device``: GPU index of this rank (default: LOCAL_RANK)."""
     rank, size, local = world()
+    if device is not None:
+        local = int(device)
     if size > 1:
         import torch
         import torch.distributed as dist
@@ -67,7 +70,7 @@ def max_over_ranks(value):
         return float(value)
     on_gpu = dist.get_backend() == "nccl"
     t = torch.tensor([float(value)], dtype=torch.float64,
-                     device=torch.device("cuda", int(os.environ.get("LOCAL_RANK", "0"))) if on_gpu else "cpu")
+                     device=torch.device("cuda", torch.cuda.current_device()) if on_gpu else "cpu")
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
     return float(t.item())
 
@@ -76,6 +79,12 @@ def barrier():
     import torch.distributed as dist
     if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
         dist.barrier()
+
+
+def finalize():
+    import torch.distributed as dist
+    if dist.is_available() and dist.is_initialized():
+        dist.destroy_process_group()
 
 
 def synthetic_frame(index, h, w, c):
