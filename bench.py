@@ -182,14 +182,17 @@ def main():
     mpx_in = total_frames * h * w / elapsed / 1e6
     mpx_pyr = total_frames * pipe.frame_px / elapsed / 1e6
     if gray:
-        # fused unit-level kernel: per level-0 pixel it reads the frame (4 B) and writes pyramid (4), CS (4), K end maps
-        dom_bytes = dom_px * (4 + 4 + 4 + 4 * wl["n_orient"])
-        roof = {"bound": "hbm", "kernel": "gray_unit_fused_kernel<%d>" % wl["n_orient"],
+        # dominant kernel = gray_stream_kernel: per level-0 pixel it reads the frame (4 B) and writes pyramid (4), CS (4)
+        # and K end maps (4K); it also writes the pyramid of every other level (4 B per pixel of those levels)
+        other_px = (pipe.frame_px * B) - dom_px
+        dom_bytes = dom_px * (4 + 4 + 4 + 4 * wl["n_orient"]) + other_px * 4
+        kname = "gray_stream_kernel<%d," % wl["n_orient"]
+        roof = {"bound": "hbm", "kernel": "gray_stream_kernel<%d>" % wl["n_orient"],
                 "achieved": round(dom_bytes / (dom_ms * 1e-3) / 1e9, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": round(dom_bytes / (dom_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
-                "traffic": pmc_traffic_per_launch("gray_unit_fused_kernel<%d," % wl["n_orient"], B),
+                "traffic": pmc_traffic_per_launch(kname, B),
                 "algorithmic_bytes_per_launch": int(dom_bytes), "avg_launch_ms": round(dom_ms, 4),
-                "pixels_per_launch": int(dom_px)}
+                "unit_level_pixels_per_launch": int(dom_px)}
     else:
         filt_bytes = pipe.filter_bytes_per_frame() * B
         roof = {"bound": "hbm", "kernel": "rgb_line_end_kernel", "achieved": round(filt_bytes / (filt_ms * 1e-3) / 1e9, 1),
@@ -216,7 +219,8 @@ def main():
                                                                / elapsed / 1e9, 1),
                    "whole_pass_frac_of_hbm_peak": round(pipe.algorithmic_bytes_per_frame() * B * args.steps
                                                         / elapsed / 1e9 / HBM_PEAK_GBS, 4),
-                   "launches_per_step": "region pyramid (levels>=1) + fused unit-level kernel + filter (levels>=1)"
+                   "launches_per_step": "gray_stream_kernel (whole pyramid + level-0 CS/line-end, frame read once) + "
+                                        "gray_line_end_kernel (levels >= 1)"
                    if gray else "unit + region pyramid, fused RGB chain, 5 keypoint kernels",
                    "pyramid_kernels_ms": None if pyr_ms is None else round(pyr_ms, 4),
                    "filter_kernel_ms": None if filt_ms is None else round(filt_ms, 4),

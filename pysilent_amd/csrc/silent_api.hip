@@ -46,6 +46,11 @@ struct silent_pyramid_plan {
     std::vector<silent_extent> extents;
     void* tables = nullptr;
     float unit_w[5] = {0, 0, 0, 0, 0};  // taps of a unit-zoom level ([1,26,66,26,1]/120 as float32)
+    // single-read "stream" path (gray_stream_kernel): row programs + column records, when the plan is eligible
+    bool stream_ok = false;
+    void* stream_tables = nullptr;
+    StreamTab stream{};
+    int stream_unit_level = -1;
 };
 
 static thread_local std::string g_create_err;
@@ -800,6 +805,102 @@ SILENT_EXPORT int silent_pyramid_plan_create(silent_ctx* ctx, int frame_h, int f
     tab.yw = (const float*)dptr[3];
     tab.xreg = (const int*)dptr[4];
     tab.yreg = (const int*)dptr[5];
+    // ---- single-read stream path (see gray_stream_kernel): eligible when there is exactly one unit level and
+    // every other level resamples the same crop with a step large enough for 4 vertical slots
+    {
+        int unit = -1, n_unit = 0;
+        for (int l = 0; l < n_levels; ++l)
+            if (tab.lv[l].kind == kPyrUnit) { unit = l; ++n_unit; }
+        bool ok = channels == 1 && n_unit == 1 && tab.n_general >= 1 && tab.n_general <= 7;
+        if (ok) {
+            const PyrLevelDev& u = tab.lv[unit];
+            ok = u.out_h >= u.src_h && u.out_w >= u.src_w;
+            for (int l = 0; l < n_levels && ok; ++l) {
+                const PyrLevelDev& d = tab.lv[l];
+                if (d.kind != kPyrGeneral) continue;
+                ok = d.src_y0 == u.src_y0 && d.src_x0 == u.src_x0 && d.src_h == u.src_h && d.src_w == u.src_w;
+            }
+        }
+        if (ok) {
+            const PyrLevelDev& u = tab.lv[unit];
+            const int G = tab.n_general;
+            const int tiles_y = (u.out_h + kFusedTH - 1) / kFusedTH;
+            const int waves_x = ((u.out_w + kFusedTW - 1) / kFusedTW) * 4;
+            const size_t prog_dw = (size_t)tiles_y * kStreamRows * G * kStreamProgDw;
+            std::vector<int> prog(prog_dw, 0), hdr((size_t)G * waves_x * 2, 0), rec((size_t)G * waves_x * 64 * 8, 0);
+            for (size_t e = 0; e < prog_dw / kStreamProgDw; ++e) prog[e * kStreamProgDw + 4] = 7 << 4;  // no slot completes
+            std::vector<char> used(prog_dw / kStreamProgDw * kStreamSlots, 0);
+            int g = 0;
+            for (int l = 0; l < n_levels && ok; ++l) {
+                const PyrLevelDev& d = tab.lv[l];
+                if (d.kind != kPyrGeneral) continue;
+                const int zc = std::min(d.zoom_w, d.out_w), zr = std::min(d.zoom_h, d.out_h);
+                const int* yb = ybase.data() + d.ytab_off;
+                const int* xb = xbase.data() + d.xtab_off;
+                for (int oy = 0; oy < zr && ok; ++oy) {
+                    const int t = yb[oy] / kFusedTH;
+                    if (yb[oy] < 0 || t >= tiles_y) { ok = false; break; }
+                    const int slot = oy % stream_slots(g);
+                    for (int j = 0; j < 6; ++j) {
+                        const int i = yb[oy] - t * kFusedTH + 2 + j;  // stream row of tap j (a tile streams rows y0-4 ..)
+                        if (i < 0 || i >= kStreamRows) { ok = false; break; }
+                        const size_t e = ((size_t)t * kStreamRows + i) * G + g;
+                        if (used[e * kStreamSlots + slot]) { ok = false; break; }  // two live rows in one slot: step too small
+                        used[e * kStreamSlots + slot] = 1;
+                        int* pe = prog.data() + e * kStreamProgDw;
+                        std::memcpy(pe + slot, &yw[(size_t)(d.ytab_off + oy) * 6 + j], 4);
+                        pe[4] |= 128;  // this stream row feeds level g
+                        if (j == 0) pe[4] |= 1 << slot;
+                        if (j == 5) {
+                            if (((pe[4] >> 4) & 7) != 7) { ok = false; break; }  // two rows completing together
+                            pe[4] = (pe[4] & 0x8f) | (slot << 4) | (oy << 8);
+                        }
+                    }
+                }
+                int ox = 0;
+                for (int wx = 0; wx < waves_x && ok; ++wx) {
+                    const int xw0 = wx * kFusedCols;
+                    while (ox < zc && xb[ox] < xw0) ++ox;
+                    int n = 0;
+                    while (ox + n < zc && xb[ox + n] < xw0 + kFusedCols) ++n;
+                    if (n > 64) { ok = false; break; }
+                    hdr[((size_t)g * waves_x + wx) * 2] = ox;
+                    hdr[((size_t)g * waves_x + wx) * 2 + 1] = n;
+                    for (int j = 0; j < n; ++j) {
+                        int* r = rec.data() + (((size_t)g * waves_x + wx) * 64 + j) * 8;
+                        r[0] = xb[ox + j] - xw0 + 2;  // lane holding tap 0 (lane 0 <-> column xw0 - 4)
+                        if (r[0] < 0 || r[0] + 5 > 63) { ok = false; break; }
+                        std::memcpy(r + 1, &xw[(size_t)(d.xtab_off + ox + j) * 6], 24);
+                    }
+                    ox += n;
+                }
+                plan->stream.px_off[g] = tab.px_off[l];
+                plan->stream.out_w[g] = d.out_w;
+                ++g;
+            }
+            if (ok) {
+                const size_t b0 = align_up(prog.size() * 4), b1 = align_up(hdr.size() * 4), b2 = align_up(rec.size() * 4);
+                hipError_t se = hipMalloc(&plan->stream_tables, b0 + b1 + b2);
+                if (se == hipSuccess) se = hipMemcpy(plan->stream_tables, prog.data(), prog.size() * 4, hipMemcpyHostToDevice);
+                if (se == hipSuccess) se = hipMemcpy((char*)plan->stream_tables + b0, hdr.data(), hdr.size() * 4, hipMemcpyHostToDevice);
+                if (se == hipSuccess) se = hipMemcpy((char*)plan->stream_tables + b0 + b1, rec.data(), rec.size() * 4, hipMemcpyHostToDevice);
+                if (se != hipSuccess) {
+                    (void)hipGetLastError();
+                    if (plan->stream_tables) (void)hipFree(plan->stream_tables);
+                    plan->stream_tables = nullptr;
+                } else {
+                    plan->stream.G = G;
+                    plan->stream.tiles_y = tiles_y;
+                    plan->stream.waves_x = waves_x;
+                    plan->stream.row_prog = (const int*)plan->stream_tables;
+                    plan->stream.col_hdr = (const int*)((char*)plan->stream_tables + b0);
+                    plan->stream.col_rec = (const int*)((char*)plan->stream_tables + b0 + b1);
+                    plan->stream_unit_level = unit;
+                    plan->stream_ok = true;
+                }
+            }
+        }
+    }
     *out = plan;
     return SILENT_OK;
 }
@@ -808,17 +909,18 @@ SILENT_EXPORT void silent_pyramid_plan_destroy(silent_pyramid_plan* plan) {
     if (!plan) return;
     if (plan->ctx) (void)hipSetDevice(plan->ctx->device);
     if (plan->tables) (void)hipFree(plan->tables);
+    if (plan->stream_tables) (void)hipFree(plan->stream_tables);
     delete plan;
 }
 
 static int launch_pyramid(silent_ctx* ctx, const char* who, const silent_pyramid_plan* plan, const float* frames,
-                          int n_frames, float* pyr, hipStream_t s, bool with_unit) {
+                          int n_frames, float* pyr, hipStream_t s, bool with_unit, bool with_region = true) {
     if (!plan || !frames || !pyr) return fail(ctx, SILENT_E_INVALID, std::string(who) + ": NULL pointer");
     if (plan->ctx != ctx) return fail(ctx, SILENT_E_INVALID, std::string(who) + ": plan belongs to another context");
     if (n_frames < 1) return fail(ctx, SILENT_E_INVALID, std::string(who) + ": n_frames must be >= 1");
     const PyrTab& tab = plan->tab;
     const long long b_unit = with_unit ? (long long)tab.unit_tiles_per_frame * n_frames : 0;
-    const long long b_region = tab.n_general ? (long long)tab.regions_x * tab.regions_y * n_frames : 0;
+    const long long b_region = (with_region && tab.n_general) ? (long long)tab.regions_x * tab.regions_y * n_frames : 0;
     const long long b_zero = (long long)tab.zero_chunks_per_frame * n_frames;
     if (b_unit > 0x7fffffffll || b_region > 0x7fffffffll || b_zero > 0x7fffffffll)
         return fail(ctx, SILENT_E_INVALID, std::string(who) + ": too many tiles for one launch");
@@ -878,11 +980,14 @@ SILENT_EXPORT int silent_gray_pass_dev(silent_ctx* ctx, const silent_pyramid_pla
     if (n_frames < 1) return fail(ctx, SILENT_E_INVALID, std::string(who) + ": n_frames must be >= 1");
     hipStream_t s = (hipStream_t)stream;
     const PyrTab& pt = plan->tab;
-    // 1. every non-unit level of the pyramid (region kernel), and the zero fill
-    TRY(launch_pyramid(ctx, who, plan, frames, n_frames, pyr, s, false));
+    const char* knob = std::getenv("SILENT_GRAY_OPTS");  // A/B knobs: bit3 32-row fused tiles, bit4 disable the stream path
+    const int kopts = knob ? std::atoi(knob) : 0;
+    const bool stream_path = plan->stream_ok && !(kopts & 16);
+    // 1. non-unit levels of the pyramid: by the region kernel, unless the stream kernel of step 2 produces them
+    //    from the same single read of the frame; plus the zero fill of canvases larger than their zoomed crop
+    TRY(launch_pyramid(ctx, who, plan, frames, n_frames, pyr, s, false, !stream_path));
     // 2. unit levels: pyramid + CS + end in one kernel
-    const char* knob = std::getenv("SILENT_GRAY_OPTS");  // bit3: 32-row tiles in the fused kernel (A/B knob)
-    const int fth = (knob && (std::atoi(knob) & 8)) ? 32 : kFusedTH;
+    const int fth = (!stream_path && (kopts & 8)) ? 32 : kFusedTH;
     FusedTab ft;
     std::memset(&ft, 0, sizeof(ft));
     bool is_unit[kMaxLevels] = {false};
@@ -917,18 +1022,34 @@ SILENT_EXPORT int silent_gray_pass_dev(silent_ctx* ctx, const silent_pyramid_pla
         std::memcpy(w.cs, cs_kernel, sizeof(float) * 9);
         if (end_bank) std::memcpy(w.end, end_bank, sizeof(float) * 9 * n_orient);
         if (ctx->profiling) HIP_TRY(ctx, hipEventRecord(ctx->ev0, s));
+        if (stream_path) {
+            const StreamTab& st = plan->stream;
+#define STREAM_LAUNCH(K_, G_) \
+    hipLaunchKernelGGL((gray_stream_kernel<K_, G_>), dim3((unsigned)blocks), dim3(256), 0, s, frames, pyr, cs_out, end_out, ft, st, w, clip_hi)
+            if (st.G <= 4) {
+                if (n_orient == 3) STREAM_LAUNCH(3, 4);
+                else if (n_orient == 4) STREAM_LAUNCH(4, 4);
+                else STREAM_LAUNCH(8, 4);
+            } else {
+                if (n_orient == 3) STREAM_LAUNCH(3, 7);
+                else if (n_orient == 4) STREAM_LAUNCH(4, 7);
+                else STREAM_LAUNCH(8, 7);
+            }
+#undef STREAM_LAUNCH
+        } else {
 #define FUSED_LAUNCH(K_, R_) \
     hipLaunchKernelGGL((gray_unit_fused_kernel<K_, R_>), dim3((unsigned)blocks), dim3(256), 0, s, frames, pyr, cs_out, end_out, ft, w, clip_hi)
-        if (fth == 32) {
-            if (n_orient == 3) FUSED_LAUNCH(3, 32);
-            else if (n_orient == 4) FUSED_LAUNCH(4, 32);
-            else FUSED_LAUNCH(8, 32);
-        } else {
-            if (n_orient == 3) FUSED_LAUNCH(3, kFusedTH);
-            else if (n_orient == 4) FUSED_LAUNCH(4, kFusedTH);
-            else FUSED_LAUNCH(8, kFusedTH);
-        }
+            if (fth == 32) {
+                if (n_orient == 3) FUSED_LAUNCH(3, 32);
+                else if (n_orient == 4) FUSED_LAUNCH(4, 32);
+                else FUSED_LAUNCH(8, 32);
+            } else {
+                if (n_orient == 3) FUSED_LAUNCH(3, kFusedTH);
+                else if (n_orient == 4) FUSED_LAUNCH(4, kFusedTH);
+                else FUSED_LAUNCH(8, kFusedTH);
+            }
 #undef FUSED_LAUNCH
+        }
         if (ctx->profiling) {
             HIP_TRY(ctx, hipEventRecord(ctx->ev1, s));
             ctx->prof_valid = true;

@@ -511,4 +511,256 @@ __global__ __launch_bounds__(256) void gray_unit_fused_kernel(const float* __res
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// gray_stream_kernel: the fused unit-level kernel above, PLUS the pyramid of every other level, from the
+// same single stream of frame rows (the frame is read once for the whole pyramid).
+//
+// Eligible plans (host-checked): one unit level, and every other level resamples the SAME crop with a
+// step > 1.25 source pixels per output pixel (classic whole-frame pyramids; the reference layout, whose
+// levels are different crops, keeps the region kernel).
+//
+// Pass 1 (registers, fully unrolled) is exactly gray_unit_fused_kernel; on the way the wave also drops its
+// 24 streamed rows into a wave-private LDS slab.  Pass 2 is a compact ROLLED loop over those rows for the
+// other levels.  Vertical pass of level g: the lane holds its own column, so it keeps up to 4 output rows of
+// level g in flight (slot = output row mod 4) and adds w * value per row.  Which slot gets which weight at
+// which stream row, which slot restarts and which one completes is a tiny per-tile ROW PROGRAM built by the
+// host from the same float64 tap tables (8 dwords per level and stream row), staged into LDS once per block.
+// Horizontal pass of a completed row: the outputs anchored in the wave's 56 columns gather their 6 taps from
+// the other lanes with ds_bpermute (lane = tap position - first column of the wave) and store one coalesced
+// run.  Arithmetic order = region kernel's (vertical then horizontal, taps ascending): bit-identical output.
+constexpr int kStreamSlots = 4;
+// output rows of general level number g that can be in flight at once (their vertical taps overlap):
+// 4 for the first one (step > 1.25), 2 for the next two (step > 2.5), 1 beyond (step > 5); host-checked
+__host__ __device__ constexpr int stream_slots(int g) { return g == 0 ? 4 : (g <= 2 ? 2 : 1); }
+constexpr int kStreamRows = kFusedTH + 8;
+constexpr int kStreamProgDw = 8;  // per (stream row, level): 4 weights, meta, 3 pad
+// meta: bits 0-3 "slot restarts", bits 4-6 completing slot (7 = none), bit 7 "row feeds this level", bits 8.. output row
+
+struct StreamTab {
+    int G;                        // general levels handled here (<= template G; extra ones are inert)
+    int tiles_y, waves_x;         // tile rows of the unit level, 56-column wave tiles per row
+    const int* row_prog;          // [tiles_y][kStreamRows][G][kStreamProgDw]
+    const int* col_hdr;           // [G][waves_x][2]: first output column, number of outputs
+    const int* col_rec;           // [G][waves_x][64][8]: lane of tap 0, 6 weight bits, pad
+    long long px_off[8];          // pixel offset of level g inside one pyramid
+    int out_w[8];
+};
+
+template <int K, int G>
+__global__ __launch_bounds__(256) void gray_stream_kernel(const float* __restrict__ frames, float* __restrict__ pyr,
+                                                          float* __restrict__ cs_out, float* __restrict__ end_out,
+                                                          const FusedTab tab, const StreamTab st, const GrayW wts,
+                                                          float clip_hi) {
+    constexpr int R = kFusedTH, NR = kStreamRows;
+    __shared__ __attribute__((aligned(16))) float s_slab[K == 8 ? 4 * 512 : 4];
+    __shared__ __attribute__((aligned(16))) int s_prog[NR * G * kStreamProgDw];
+    __shared__ float s_rows[4][NR][64];  // the streamed rows of each wave (wave private)
+    const unsigned bid = blockIdx.x;
+    const int frame = (int)(bid / (unsigned)tab.tiles_per_frame);
+    const int rem = (int)(bid - (unsigned)frame * (unsigned)tab.tiles_per_frame);
+    const FusedLevel& lv = tab.lv[0];  // the one unit level
+    const int ty = rem / lv.tiles_x, tx = rem - ty * lv.tiles_x;
+
+    // row program of this tile row -> LDS (st.G <= G levels are live; the rest stays inert)
+    {
+        const int* __restrict__ src_prog = st.row_prog + (long long)ty * (NR * st.G * kStreamProgDw);
+        for (int j = threadIdx.x; j < NR * G * kStreamProgDw; j += 256) {
+            const int r = j / (G * kStreamProgDw), q = j - r * (G * kStreamProgDw);
+            const int g = q / kStreamProgDw, e = q - g * kStreamProgDw;
+            s_prog[j] = g < st.G ? src_prog[(r * st.G + g) * kStreamProgDw + e] : (e == 4 ? (7 << 4) : 0);
+        }
+    }
+    __syncthreads();
+
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int xw0 = tx * kFusedTW + wave * kFusedCols;
+    if (xw0 >= lv.out_w) return;  // wave-uniform
+    const int wx_tile = tx * 4 + wave;
+    const int y0 = ty * R;
+    const int ox = xw0 + lane - 4;
+    const int W = tab.W;
+    const float* __restrict__ src = frames + (long long)frame * tab.H * W;
+    const long long frame_px0 = (long long)frame * tab.frame_px;
+    const long long base_px = frame_px0 + lv.px_off;
+
+    auto mirror = [](int i, int n) {
+        if ((unsigned)i < (unsigned)n) return i;
+        if (n == 1) return 0;
+        const int period = 2 * (n - 1);
+        if (i < 0) i = -i;
+        i %= period;
+        return i >= n ? period - i : i;
+    };
+    const long long sx = mirror(ox, lv.src_w) + lv.src_x0;
+    float in[R + 8];
+#pragma unroll
+    for (int i = 0; i < R + 8; ++i)
+        in[i] = src[(long long)(mirror(y0 - 4 + i, lv.src_h) + lv.src_y0) * W + sx];
+    // per-level column records of this lane (output j of the wave's run = lane j), requested with the rows
+    int gx0[G], gn[G], glane[G];
+    float gw[G][6];
+#pragma unroll
+    for (int g = 0; g < G; ++g) {
+        const int gg = min(g, st.G - 1);
+        const int* __restrict__ h = st.col_hdr + ((long long)gg * st.waves_x + wx_tile) * 2;
+        gx0[g] = h[0];
+        gn[g] = g < st.G ? h[1] : 0;
+        const int4* __restrict__ rec = reinterpret_cast<const int4*>(st.col_rec + (((long long)gg * st.waves_x + wx_tile) * 64 + lane) * 8);
+        const int4 a = rec[0], b = rec[1];
+        glane[g] = a.x * 4;  // byte index for ds_bpermute
+        gw[g][0] = __int_as_float(a.y);
+        gw[g][1] = __int_as_float(a.z);
+        gw[g][2] = __int_as_float(a.w);
+        gw[g][3] = __int_as_float(b.x);
+        gw[g][4] = __int_as_float(b.y);
+        gw[g][5] = __int_as_float(b.z);
+    }
+#pragma unroll
+    for (int i = 0; i < R + 8; ++i) asm volatile("" ::"v"(in[i]));  // retire loads before the first store
+#pragma unroll
+    for (int g = 0; g < G; ++g) {
+        asm volatile("" ::"v"(glane[g]));
+#pragma unroll
+        for (int j = 0; j < 6; ++j) asm volatile("" ::"v"(gw[g][j]));
+    }
+#pragma unroll
+    for (int i = 0; i < R + 8; ++i) s_rows[wave][i][lane] = in[i];
+
+    // ================= pass 1: unit level (pyramid + CS + end), registers only =================
+    const bool col_in = ox >= 0 && ox < lv.out_w;
+    const bool out_lane = lane >= 4 && lane < 4 + kFusedCols && ox < lv.out_w;
+    {
+        float hw[5] = {0, 0, 0, 0, 0};
+        float iw[3][3], cw[3][3];
+#pragma unroll
+        for (int a = 0; a < 3; ++a)
+#pragma unroll
+            for (int b = 0; b < 3; ++b) iw[a][b] = cw[a][b] = 0.0f;
+#pragma unroll
+        for (int i = 0; i < R + 8; ++i) {
+            {
+                const float c0 = in[i];
+                const float l1 = from_lane_below(c0), l2 = from_lane_below(l1);
+                const float r1 = from_lane_above(c0), r2 = from_lane_above(r1);
+                float h = tab.wx[0] * l2;
+                h = __builtin_fmaf(tab.wx[1], l1, h);
+                h = __builtin_fmaf(tab.wx[2], c0, h);
+                h = __builtin_fmaf(tab.wx[3], r1, h);
+                h = __builtin_fmaf(tab.wx[4], r2, h);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) hw[j] = hw[j + 1];
+                hw[4] = h;
+            }
+            if (i >= 4) {
+                const int p = y0 + i - 6;
+                float v = tab.wy[0] * hw[0];
+#pragma unroll
+                for (int j = 1; j < 5; ++j) v = __builtin_fmaf(tab.wy[j], hw[j], v);
+                v = (p < lv.zoom_h && ox < lv.zoom_w) ? v : 0.0f;
+                if (p >= y0 && p < y0 + R && p < lv.out_h && out_lane) pyr[base_px + (long long)p * lv.out_w + ox] = v;
+                v = (p >= 0 && p < lv.out_h && col_in) ? v : 0.0f;
+#pragma unroll
+                for (int b = 0; b < 3; ++b) {
+                    iw[0][b] = iw[1][b];
+                    iw[1][b] = iw[2][b];
+                }
+                iw[2][1] = v;
+                iw[2][0] = from_lane_below(v);
+                iw[2][2] = from_lane_above(v);
+            }
+            if (i >= 6) {
+                const int c = y0 + i - 7;
+                float acc = 0.0f;
+#pragma unroll
+                for (int dy = 0; dy < 3; ++dy)
+#pragma unroll
+                    for (int dx = 0; dx < 3; ++dx) acc = __builtin_fmaf(iw[dy][dx], wts.cs[dy * 3 + dx], acc);
+                float cs = relu_tf(acc);
+                cs = (c >= 0 && c < lv.out_h && col_in) ? cs : 0.0f;
+#pragma unroll
+                for (int b = 0; b < 3; ++b) {
+                    cw[0][b] = cw[1][b];
+                    cw[1][b] = cw[2][b];
+                }
+                cw[2][1] = cs;
+                cw[2][0] = from_lane_below(cs);
+                cw[2][2] = from_lane_above(cs);
+            }
+            if (i >= 8) {
+                const int y = y0 + i - 8;
+                if (y < lv.out_h) {  // wave-uniform
+                    const long long px = base_px + (long long)y * lv.out_w + ox;
+                    if (cs_out && out_lane) cs_out[px] = cw[1][1];
+                    if (end_out) {
+                        float acc[K];
+#pragma unroll
+                        for (int k = 0; k < K; ++k) acc[k] = 0.0f;
+#pragma unroll
+                        for (int dy = 0; dy < 3; ++dy)
+#pragma unroll
+                            for (int dx = 0; dx < 3; ++dx)
+#pragma unroll
+                                for (int k = 0; k < K; ++k)
+                                    acc[k] = __builtin_fmaf(cw[dy][dx], wts.end[(dy * 3 + dx) * K + k], acc[k]);
+#pragma unroll
+                        for (int k = 0; k < K; ++k) acc[k] = clip_hi_tf(relu_tf(acc[k]), clip_hi);
+                        if constexpr (K == 8) {
+                            const int ncols = min(kFusedCols, lv.out_w - xw0);
+                            store_row_k8(end_out + (base_px + (long long)y * lv.out_w + (xw0 - 4)) * 8, acc,
+                                         s_slab + wave * 512, lane, 4, ncols);
+                        } else if (out_lane) {
+                            float* __restrict__ po = end_out + px * K;
+                            if constexpr (K == 4) {
+                                *reinterpret_cast<float4*>(po) = make_float4(acc[0], acc[1], acc[2], acc[3]);
+                            } else {
+#pragma unroll
+                                for (int k = 0; k < K; ++k) po[k] = acc[k];
+                            }
+                        }
+                    }
+                }
+            }
+        }
+    }
+
+    // ================= pass 2: every other level of the pyramid, rolled loop over the same rows =================
+    float vacc[G][kStreamSlots];
+#pragma unroll
+    for (int g = 0; g < G; ++g)
+#pragma unroll
+        for (int k = 0; k < kStreamSlots; ++k) vacc[g][k] = 0.0f;
+#pragma unroll 1
+    for (int i = 0; i < NR; ++i) {
+        const float c0 = s_rows[wave][i][lane];
+#pragma unroll
+        for (int g = 0; g < G; ++g) {
+            const int4* __restrict__ pr = reinterpret_cast<const int4*>(s_prog + (i * G + g) * kStreamProgDw);
+            const int meta = __builtin_amdgcn_readfirstlane(pr[1].x);
+            if (!(meta & 128)) continue;  // wave-uniform: this stream row carries no tap of level g
+            const int4 pw = pr[0];
+            const int wbits[4] = {pw.x, pw.y, pw.z, pw.w};
+#pragma unroll
+            for (int k = 0; k < stream_slots(g); ++k) {
+                const float w = __int_as_float(wbits[k]);
+                const float prev = (meta >> k) & 1 ? 0.0f : vacc[g][k];
+                vacc[g][k] = __builtin_fmaf(w, c0, prev);
+            }
+            const int done = (meta >> 4) & 7;
+            if (done < kStreamSlots) {  // wave-uniform: slot `done` holds a finished output row of level g
+                const int oy = meta >> 8;
+                float v = vacc[g][0];
+#pragma unroll
+                for (int k = 1; k < stream_slots(g); ++k) v = done == k ? vacc[g][k] : v;
+                const int vbits = __float_as_int(v);
+                float acc = gw[g][0] * __int_as_float(__builtin_amdgcn_ds_bpermute(glane[g], vbits));
+#pragma unroll
+                for (int t = 1; t < 6; ++t)
+                    acc = __builtin_fmaf(gw[g][t], __int_as_float(__builtin_amdgcn_ds_bpermute(glane[g] + 4 * t, vbits)), acc);
+                if (lane < gn[g]) pyr[frame_px0 + st.px_off[g] + (long long)oy * st.out_w[g] + gx0[g] + lane] = acc;
+            }
+        }
+    }
+}
+
 }  // namespace silent
