@@ -150,6 +150,11 @@ int silent_gray_pass_dev(silent_ctx* ctx, const silent_pyramid_plan* plan, const
                          const float* cs_kernel, const float* end_bank, int n_orient, float clip_hi, float* pyr,
                          float* cs_out, float* end_out, silent_stream stream);
 
+/* 1 when silent_gray_pass runs this plan through the single-read stream kernel (one unit-zoom level and every
+ * other level resampling the same crop with a step > 1.25: classic whole-frame pyramids), 0 when it falls
+ * back to region + unit-fused + filter kernels (e.g. the reference's centred-crop layout). */
+int silent_pyramid_plan_is_streamable(const silent_pyramid_plan* plan);
+
 /* Optional HIP-event timing of the DOMINANT kernel of the last silent_gray_pass_dev call (the fused
  * unit-level kernel): enable with silent_set_profiling(ctx, 1); the events are recorded on the stream the
  * kernel runs on.  silent_profile_elapsed_ms synchronises on the second event and returns the elapsed time

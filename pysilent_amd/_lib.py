@@ -78,6 +78,7 @@ _SIGNATURES = {
     "silent_gray_line_end_dev": [_vp, _fp, _ep, _i, _i, _fp, _fp, _i, _f, _fp, _fp, _vp],
     "silent_gray_pass": [_vp, _vp, _fp, _i, _fp, _fp, _i, _f, _fp, _fp, _fp],
     "silent_gray_pass_dev": [_vp, _vp, _fp, _i, _fp, _fp, _i, _f, _fp, _fp, _fp, _vp],
+    "silent_pyramid_plan_is_streamable": [_vp],
     "silent_set_profiling": [_vp, _i],
     "silent_profile_elapsed_ms": [_vp, C.POINTER(_f), C.POINTER(C.c_int64)],
     "silent_regulate": [_vp, _fp, _ep, _i, _i, _i, _fp, _i, _i, _f, _f, _i, _fp],

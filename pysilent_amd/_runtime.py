@@ -404,6 +404,11 @@ class PyramidPlan(object):
                                           C.c_void_p(out.ctypes.data)))
         return PackedPyramid(out, self.extents, c, n)
 
+    @property
+    def streamable(self):
+        """True when silent_gray_pass takes the single-read stream kernel for this plan."""
+        return bool(_lib.load().silent_pyramid_plan_is_streamable(self.handle))
+
     def gray_pass(self, frames, cs_kernel, end_bank, clip_hi=255.0):
         """Whole grayscale hot path (silent_gray_pass): frames [n,H,W,1] -> (pyramid, cs, end) PackedPyramids.
         Same results as run() + gray_line_end(), one pass less over level 0."""

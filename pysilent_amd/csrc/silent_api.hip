@@ -943,6 +943,10 @@ SILENT_EXPORT int silent_pyramid_dev(silent_ctx* ctx, const silent_pyramid_plan*
 
 // ------------------------------------------------------------------------------------------ whole gray pass
 
+SILENT_EXPORT int silent_pyramid_plan_is_streamable(const silent_pyramid_plan* plan) {
+    return plan && plan->stream_ok ? 1 : 0;
+}
+
 SILENT_EXPORT int silent_set_profiling(silent_ctx* ctx, int enable) {
     NEED_CTX(ctx);
     if (enable && !ctx->ev0) {

@@ -529,9 +529,9 @@ __global__ __launch_bounds__(256) void gray_unit_fused_kernel(const float* __res
 // the other lanes with ds_bpermute (lane = tap position - first column of the wave) and store one coalesced
 // run.  Arithmetic order = region kernel's (vertical then horizontal, taps ascending): bit-identical output.
 constexpr int kStreamSlots = 4;
-// output rows of general level number g that can be in flight at once (their vertical taps overlap):
-// 4 for the first one (step > 1.25), 2 for the next two (step > 2.5), 1 beyond (step > 5); host-checked
-__host__ __device__ constexpr int stream_slots(int g) { return g == 0 ? 4 : (g <= 2 ? 2 : 1); }
+// output rows of general level number g that can be in flight at once (their vertical taps overlap): 4, 3, 2, 2,
+// then 1 -- enough for zoom ladders of ratio >= e^0.5 (the reference's default) and 2; host-checked per plan
+__host__ __device__ constexpr int stream_slots(int g) { return g == 0 ? 4 : (g == 1 ? 3 : (g <= 3 ? 2 : 1)); }
 constexpr int kStreamRows = kFusedTH + 8;
 constexpr int kStreamProgDw = 8;  // per (stream row, level): 4 weights, meta, 3 pad
 // meta: bits 0-3 "slot restarts", bits 4-6 completing slot (7 = none), bit 7 "row feeds this level", bits 8.. output row

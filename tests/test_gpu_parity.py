@@ -335,13 +335,17 @@ def test_torch_device_path_is_bit_identical(rt, kernels):
 # ----------------------------------------------------------------------------- whole gray pass (fused level 0)
 
 @pytest.mark.parametrize("shape,scale,n,K", [((135, 240, 1), 2.0, 5, 4), ((97, 131, 1), 1.7, 4, 8), ((64, 300, 1), 2.0, 3, 3),
-                                             ((33, 57, 1), 2.0, 1, 4)])
+                                             ((33, 57, 1), 2.0, 1, 4),
+                                             ((270, 480, 1), 2.0, 8, 4),            # 7 general levels: stream kernel <K, 7>
+                                             ((270, 480, 1), math.e ** .5, 6, 8),   # the reference's zoom ratio
+                                             ((100, 260, 1), 1.2, 3, 4)])           # step 1.2: not stream-eligible -> region path
 def test_gray_pass_equals_pyramid_then_filters(rt, kernels, shape, scale, n, K):
     """silent_gray_pass (level 0 smoothed + filtered in one kernel) is bit-identical to the two-step path,
     and both match the oracle."""
     from pysilent_amd.util.zoom.from_image import classic_levels
     frames = np.stack([noise_frame(s, *shape) for s in range(2)])
     plan = rt.PyramidPlan(shape[0], shape[1], 1, classic_levels(shape[:2], scale, n))
+    assert plan.streamable == (n > 1 and scale > 1.25)      # which path silent_gray_pass takes for this plan
     bank = kernels["end%d" % K]
     pyr, cs, end = plan.gray_pass(frames, kernels["cs_gray"], bank)
     pyr2 = plan.run(frames)
@@ -364,6 +368,7 @@ def test_gray_pass_reference_layout_and_device_path(rt, kernels):
     img = noise_frame(5, 240, 320, 1)
     levels = reference_levels((240, 320), (80, 60), math.e ** .5)
     plan = rt.PyramidPlan(240, 320, 1, levels)
+    assert not plan.streamable                     # levels are different crops: region + unit-fused + filter kernels
     pyr, cs, end = plan.gray_pass(img[None], kernels["cs_gray"], kernels["end4"])
     want = so.zoom_from_image(img, 1, (80, 60), math.e ** .5)
     got = pyr.data.reshape(want.shape)
