@@ -217,6 +217,19 @@ int silent_max_value_indices_region_dev(silent_ctx* ctx, const float* value, con
                                         int n_levels, int n_frames, const silent_extent* regions, int64_t* idx,
                                         size_t cap_per_frame, int64_t* counts, silent_stream stream);
 
+/* ---------------------------------------------------------------------------- centroids
+ * Replaces get_centroids, slam_recognition/util/centroids.py:21-46 (with index_tensor.from_shape,
+ * util/index_tensor.py:7-20, dimensions reversed: channel 0 = x, channel 1 = y): per cell of region_h x
+ * region_w pixels (window = stride, TF SAME geometry) the value-weighted centroid; every pixel gets the L1
+ * distance to the centroid of its (nearest-neighbour) cell.  Empty cells give 0/0 = NaN like the reference.
+ * value: packed 1-channel maps.  dist_out: same geometry.  total_out: packed cell maps, level l has
+ * ceil(h_l / region_h) x ceil(w_l / region_w) cells (the reference's total_pool). */
+int silent_centroids(silent_ctx* ctx, const float* value, const silent_extent* levels, int n_levels, int n_frames,
+                     int region_h, int region_w, float* dist_out, float* total_out);
+int silent_centroids_dev(silent_ctx* ctx, const float* value, const silent_extent* levels, int n_levels,
+                         int n_frames, int region_h, int region_w, float* dist_out, float* total_out,
+                         silent_stream stream);
+
 /* ---------------------------------------------------------------------------- fused RGB chain
  * The reference graph recognition_testing.py:69-77 on 3-channel levels.  With a channel-uniform blur (what
  * blur_tensor generates) this is ONE fused launch that reads the pyramid once; any other blur runs the

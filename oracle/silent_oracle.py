@@ -211,6 +211,63 @@ def max_value_indices_region(color, region_shape, value=None):
     return np.argwhere(value >= thr).astype(np.int64)
 
 
+# ----------------------------------------------------------------------------- centroids
+
+def index_tensor_from_shape(shape):
+    """slam_recognition/util/index_tensor.py:7-20 with are_dimensions_reversed = True: [h, w, 2] holding (x, y).
+    Pinned by the reference's tests/test_index_tensor.py:10-11 ([[[0,0],[1,0]],[[0,1],[1,1]]] for 2 x 2)."""
+    h, w = int(shape[1]), int(shape[2])
+    idx = np.empty((h, w, 2), dtype=np.int32)
+    idx[..., 0] = np.arange(w)[None, :]
+    idx[..., 1] = np.arange(h)[:, None]
+    return idx
+
+
+def _strided_same_geometry(size, k):
+    """tf.nn.convolution(strides = k, window = k, SAME): (n_out, first input index of window 0)."""
+    out = -(-size // k)
+    pad_total = max((out - 1) * k + k - size, 0)
+    return out, -(pad_total // 2)
+
+
+def get_centroids(value, region_shape):
+    """slam_recognition/util/centroids.py:21-46.  value: [N, h, w, 1]; region_shape = [1, rh, rw].
+    Returns (value_centroids [N, h, w, 1], total_pool [N, ceil(h/rh), ceil(w/rw), 1]):
+      centroid_pool = box sums (stride = window = region, SAME) of (x * v, y * v); total_pool = box sums of v
+      (the filter ones/num_channels applied to v tiled to 2 channels); corrected = centroid / total (0/0 = NaN);
+      nearest-neighbour resize back; value_centroids = |cx - x| + |cy - y|."""
+    value = np.asarray(value, dtype=F32)
+    n, h, w, c = value.shape
+    assert c == 1
+    rh, rw = int(region_shape[1]), int(region_shape[2])
+    oh, y_first = _strided_same_geometry(h, rh)
+    ow, x_first = _strided_same_geometry(w, rw)
+    idx = index_tensor_from_shape((n, h, w, 1)).astype(F32)
+    v = value[..., 0]
+    bx = (idx[None, :, :, 0] * v).astype(F32)          # ind_tens * full_channel_values, float32
+    by = (idx[None, :, :, 1] * v).astype(F32)
+    half = (v * F32(0.5)).astype(F32)                  # each of the 2 tiled channels times the 1/2 filter tap
+    cx = np.zeros((n, oh, ow), np.float64)
+    cy = np.zeros((n, oh, ow), np.float64)
+    tot = np.zeros((n, oh, ow), np.float64)
+    for j in range(oh):
+        y0, y1 = max(y_first + j * rh, 0), min(y_first + j * rh + rh, h)
+        for i in range(ow):
+            x0, x1 = max(x_first + i * rw, 0), min(x_first + i * rw + rw, w)
+            cx[:, j, i] = bx[:, y0:y1, x0:x1].astype(np.float64).sum(axis=(1, 2))
+            cy[:, j, i] = by[:, y0:y1, x0:x1].astype(np.float64).sum(axis=(1, 2))
+            tot[:, j, i] = 2.0 * half[:, y0:y1, x0:x1].astype(np.float64).sum(axis=(1, 2))
+    cx, cy, tot = cx.astype(F32), cy.astype(F32), tot.astype(F32)
+    with np.errstate(divide="ignore", invalid="ignore"):
+        ccx, ccy = (cx / tot).astype(F32), (cy / tot).astype(F32)
+    sy = np.minimum(np.floor((np.arange(h, dtype=F32) * (F32(oh) / F32(h))).astype(F32)).astype(np.int64), oh - 1)
+    sx = np.minimum(np.floor((np.arange(w, dtype=F32) * (F32(ow) / F32(w))).astype(F32)).astype(np.int64), ow - 1)
+    rx, ry = ccx[:, sy][:, :, sx], ccy[:, sy][:, :, sx]
+    with np.errstate(invalid="ignore"):
+        dist = (np.abs(rx - idx[None, :, :, 0]).astype(F32) + np.abs(ry - idx[None, :, :, 1]).astype(F32)).astype(F32)
+    return dist[..., None], tot[..., None]
+
+
 # ----------------------------------------------------------------------------- pyramid
 
 def _spline5_weights(t):

@@ -93,6 +93,8 @@ _SIGNATURES = {
     "silent_top_value_points_dev": [_vp, _fp, _fp, _ep, _i, _i, _i, _d, _fp, _vp],
     "silent_max_value_indices_region": [_vp, _fp, _ep, _i, _i, _ep, _vp, _sz, _vp],
     "silent_max_value_indices_region_dev": [_vp, _fp, _ep, _i, _i, _ep, _vp, _sz, _vp, _vp],
+    "silent_centroids": [_vp, _fp, _ep, _i, _i, _i, _i, _fp, _fp],
+    "silent_centroids_dev": [_vp, _fp, _ep, _i, _i, _i, _i, _fp, _fp, _vp],
     "silent_rgb_line_end": [_vp, _fp, _ep, _i, _i, C.POINTER(RgbChainParams), _fp, _fp, _fp],
     "silent_rgb_line_end_dev": [_vp, _fp, _ep, _i, _i, C.POINTER(RgbChainParams), _fp, _fp, _fp, _vp],
 }

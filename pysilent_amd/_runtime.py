@@ -332,6 +332,30 @@ def max_value_indices_region(value, regions, cap_per_frame=None):
     return idx, counts
 
 
+def centroids(value, region_h, region_w):
+    """silent_centroids: (L1 distance map like ``value``, total_pool as a tensor of cells)."""
+    op = _Operand(value, channels=1)
+    rh, rw = int(region_h), int(region_w)
+    if rh < 1 or rw < 1:
+        raise ValueError("region extents must be >= 1")
+    cell_ext = [(-(-h // rh), -(-w // rw)) for h, w in op.extents]
+    n_cells = op.n_frames * sum(a * b for a, b in cell_ext)
+    dist, dptr = op.alloc(1)
+    lib, ctx = _lib.load(), op.ctx
+    if op.dev:
+        import torch
+        tot = torch.empty(n_cells, dtype=torch.float32, device=op._torch_device)
+        tptr = C.c_void_p(tot.data_ptr())
+    else:
+        tot = np.empty(n_cells, dtype=np.float32)
+        tptr = C.c_void_p(tot.ctypes.data)
+    args = (ctx.handle, op.ptr) + op.geom() + (rh, rw, dptr, tptr)
+    ctx.check(lib.silent_centroids_dev(*(args + (op.stream,))) if op.dev else lib.silent_centroids(*args))
+    if op.packed:
+        return op.wrap(dist, 1), PackedPyramid(tot, cell_ext, 1, op.n_frames)
+    return op.wrap(dist, 1), tot.reshape(op.n_frames, cell_ext[0][0], cell_ext[0][1], 1)
+
+
 def rgb_line_end(x, kernels, regulation_value=1.0, regulation_root=0.1, flat_policy="ieee", clip_hi=255.0, pad=2,
                  want=("orient", "line_end", "value")):
     """The reference graph recognition_testing.py:69-77 on 3-channel levels.  ``kernels``: dict with

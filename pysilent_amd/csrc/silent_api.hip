@@ -535,6 +535,52 @@ SILENT_EXPORT int silent_max_value_indices_region_dev(silent_ctx* ctx, const flo
     return check_launch(ctx, who);
 }
 
+// ------------------------------------------------------------------------------------------ centroids
+
+static int build_cell_tab(silent_ctx* ctx, const char* who, const silent_extent* levels, int n_levels, int rh, int rw,
+                          CellTab* ct) {
+    if (rh < 1 || rw < 1) return fail(ctx, SILENT_E_INVALID, std::string(who) + ": region extents must be >= 1");
+    std::memset(ct, 0, sizeof(*ct));
+    ct->rh = rh;
+    ct->rw = rw;
+    long long cells = 0;
+    for (int l = 0; l < n_levels; ++l) {
+        const int h = levels[l].h, w = levels[l].w;
+        ct->oh[l] = (h + rh - 1) / rh;
+        ct->ow[l] = (w + rw - 1) / rw;
+        ct->y_first[l] = -(std::max((ct->oh[l] - 1) * rh + rh - h, 0) / 2);
+        ct->x_first[l] = -(std::max((ct->ow[l] - 1) * rw + rw - w, 0) / 2);
+        ct->yscale[l] = (float)ct->oh[l] / (float)h;
+        ct->xscale[l] = (float)ct->ow[l] / (float)w;
+        ct->cell_off[l] = cells;
+        cells += (long long)ct->oh[l] * ct->ow[l];
+    }
+    ct->frame_cells = cells;
+    return SILENT_OK;
+}
+
+SILENT_EXPORT int silent_centroids_dev(silent_ctx* ctx, const float* value, const silent_extent* levels, int n_levels,
+                                       int n_frames, int region_h, int region_w, float* dist_out, float* total_out,
+                                       silent_stream stream) {
+    NEED_CTX(ctx);
+    const char* who = "silent_centroids";
+    if (!value || !dist_out || !total_out) return fail(ctx, SILENT_E_INVALID, std::string(who) + ": NULL pointer");
+    LevelTab tab;
+    long long blocks;
+    TRY(build_level_tab(ctx, who, levels, n_levels, n_frames, 0, 0, &tab, &blocks));
+    CellTab ct;
+    TRY(build_cell_tab(ctx, who, levels, n_levels, region_h, region_w, &ct));
+    const long long cells = ct.frame_cells * n_frames;
+    if ((cells + 255) / 256 > 0x7fffffffll) return fail(ctx, SILENT_E_INVALID, std::string(who) + ": too many cells");
+    TRY(grow(ctx, ctx->ws, (size_t)cells * 2 * sizeof(float)));
+    float* cxy = (float*)ctx->ws.p;
+    hipStream_t s = (hipStream_t)stream;
+    hipLaunchKernelGGL(centroid_cells_kernel, dim3((unsigned)((cells + 255) / 256), (unsigned)n_frames), dim3(256), 0, s,
+                       value, tab, ct, total_out, cxy);
+    hipLaunchKernelGGL(centroid_dist_kernel, dim3((unsigned)blocks), dim3(256), 0, s, tab, ct, cxy, dist_out);
+    return check_launch(ctx, who);
+}
+
 // ------------------------------------------------------------------------------------------ RGB chain
 
 SILENT_EXPORT int silent_rgb_line_end_dev(silent_ctx* ctx, const float* pyr, const silent_extent* levels, int n_levels,
@@ -1029,7 +1075,7 @@ SILENT_EXPORT int silent_gray_pass_dev(silent_ctx* ctx, const silent_pyramid_pla
         if (stream_path) {
             const StreamTab& st = plan->stream;
 #define STREAM_LAUNCH(K_, G_) \
-    hipLaunchKernelGGL((gray_stream_kernel<K_, G_>), dim3((unsigned)blocks), dim3(256), 0, s, frames, pyr, cs_out, end_out, ft, st, w, clip_hi)
+    hipLaunchKernelGGL((gray_stream_kernel<K_, G_>), dim3((unsigned)blocks), dim3(256), 0, s, frames, pyr, cs_out, end_out, ft, st, w, clip_hi, (unsigned)((kopts >> 5) & 1))
             if (st.G <= 4) {
                 if (n_orient == 3) STREAM_LAUNCH(3, 4);
                 else if (n_orient == 4) STREAM_LAUNCH(4, 4);
@@ -1329,4 +1375,24 @@ SILENT_EXPORT int silent_gray_pass(silent_ctx* ctx, const silent_pyramid_plan* p
     if (cs_out) TRY(d2h(ctx, cs_out, st.ptr<float>(i_cs), b1));
     if (end_out) TRY(d2h(ctx, end_out, st.ptr<float>(i_end), bk));
     return SILENT_OK;
+}
+
+SILENT_EXPORT int silent_centroids(silent_ctx* ctx, const float* value, const silent_extent* levels, int n_levels,
+                                   int n_frames, int region_h, int region_w, float* dist_out, float* total_out) {
+    NEED_CTX(ctx);
+    if (!value || !dist_out || !total_out) return fail(ctx, SILENT_E_INVALID, "silent_centroids: NULL pointer");
+    long long px;
+    TRY(check_levels(ctx, "silent_centroids", levels, n_levels, n_frames, &px));
+    CellTab ct;
+    TRY(build_cell_tab(ctx, "silent_centroids", levels, n_levels, region_h, region_w, &ct));
+    Stage st(ctx);
+    const size_t bv = (size_t)px * 4, bt = (size_t)ct.frame_cells * n_frames * 4;
+    const size_t i_v = st.add(bv), i_d = st.add(bv), i_t = st.add(bt);
+    TRY(st.commit());
+    TRY(h2d(ctx, st.ptr<float>(i_v), value, bv));
+    TRY(silent_centroids_dev(ctx, st.ptr<float>(i_v), levels, n_levels, n_frames, region_h, region_w,
+                             st.ptr<float>(i_d), st.ptr<float>(i_t), nullptr));
+    TRY(sync0(ctx));
+    TRY(d2h(ctx, dist_out, st.ptr<float>(i_d), bv));
+    return d2h(ctx, total_out, st.ptr<float>(i_t), bt);
 }

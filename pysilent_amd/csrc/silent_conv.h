@@ -550,12 +550,12 @@ template <int K, int G>
 __global__ __launch_bounds__(256) void gray_stream_kernel(const float* __restrict__ frames, float* __restrict__ pyr,
                                                           float* __restrict__ cs_out, float* __restrict__ end_out,
                                                           const FusedTab tab, const StreamTab st, const GrayW wts,
-                                                          float clip_hi) {
+                                                          float clip_hi, unsigned opts) {
     constexpr int R = kFusedTH, NR = kStreamRows;
     __shared__ __attribute__((aligned(16))) float s_slab[K == 8 ? 4 * 512 : 4];
     __shared__ __attribute__((aligned(16))) int s_prog[NR * G * kStreamProgDw];
     __shared__ float s_rows[4][NR][64];  // the streamed rows of each wave (wave private)
-    const unsigned bid = blockIdx.x;
+    const unsigned bid = (opts & 1u) ? xcd_swizzle(blockIdx.x, gridDim.x) : blockIdx.x;
     const int frame = (int)(bid / (unsigned)tab.tiles_per_frame);
     const int rem = (int)(bid - (unsigned)frame * (unsigned)tab.tiles_per_frame);
     const FusedLevel& lv = tab.lv[0];  // the one unit level

@@ -374,4 +374,69 @@ __global__ __launch_bounds__(256) void region_write_kernel(const float* __restri
     }
 }
 
+// ---- centroids (reference slam_recognition/util/centroids.py:21-46)
+// cells: box sums (window = stride = region, TF SAME geometry) of v, x*v, y*v per cell; the corrected centroid
+// (sum / total, 0/0 = NaN like the reference) goes to a workspace, total_pool to the caller.
+struct CellTab {
+    int rh, rw;
+    int oh[kMaxLevels], ow[kMaxLevels];          // cells per level
+    int y_first[kMaxLevels], x_first[kMaxLevels];  // first input index of cell 0 (<= 0: SAME padding)
+    long long cell_off[kMaxLevels];              // cell offset of level l inside one frame
+    long long frame_cells;
+    float yscale[kMaxLevels], xscale[kMaxLevels];  // float32 cells / extent: nearest-neighbour resize back
+};
+
+__global__ __launch_bounds__(256) void centroid_cells_kernel(const float* __restrict__ value, const LevelTab tab,
+                                                             const CellTab ct, float* __restrict__ total_out,
+                                                             float* __restrict__ cxy) {
+    const long long gid = (long long)blockIdx.x * 256 + threadIdx.x;
+    const int frame = (int)(gid / ct.frame_cells);
+    if (frame >= (int)gridDim.y) return;
+    long long rem = gid - (long long)frame * ct.frame_cells;
+    int l = 0;
+#pragma unroll
+    for (int i = 1; i < kMaxLevels; ++i)
+        if (i < tab.n_levels && rem >= ct.cell_off[i]) l = i;
+    rem -= ct.cell_off[l];
+    const int H = tab.h[l], W = tab.w[l];
+    const int j = (int)(rem / ct.ow[l]), i = (int)(rem - (long long)j * ct.ow[l]);
+    const float* __restrict__ v = value + (long long)frame * tab.frame_px + tab.px_off[l];
+    const int y0 = max(ct.y_first[l] + j * ct.rh, 0), y1 = min(ct.y_first[l] + j * ct.rh + ct.rh, H);
+    const int x0 = max(ct.x_first[l] + i * ct.rw, 0), x1 = min(ct.x_first[l] + i * ct.rw + ct.rw, W);
+    float tot = 0.0f, sx = 0.0f, sy = 0.0f;
+    for (int y = y0; y < y1; ++y)
+        for (int x = x0; x < x1; ++x) {
+            const float val = v[(long long)y * W + x];
+            sx = __fadd_rn(sx, __fmul_rn((float)x, val));   // ind_tens * value, then the box sum (float32)
+            sy = __fadd_rn(sy, __fmul_rn((float)y, val));
+            const float half = __fmul_rn(val, 0.5f);        // value tiled to 2 channels times the 1/2 tap
+            tot = __fadd_rn(__fadd_rn(tot, half), half);
+        }
+    const long long cell = (long long)frame * ct.frame_cells + ct.cell_off[l] + rem;
+    total_out[cell] = tot;
+    cxy[cell * 2 + 0] = sx / tot;
+    cxy[cell * 2 + 1] = sy / tot;
+}
+
+// per pixel: |cx(cell) - x| + |cy(cell) - y| with the TF1 nearest-neighbour cell lookup
+__global__ __launch_bounds__(256) void centroid_dist_kernel(const LevelTab tab, const CellTab ct,
+                                                            const float* __restrict__ cxy, float* __restrict__ out) {
+    const TileCoord tc = locate_tile(tab, blockIdx.x);
+    const int l = tc.level, W = tab.w[l];
+    const int npx = tab.h[l] * W;
+    const long long base_px = (long long)tc.frame * tab.frame_px + tab.px_off[l];
+    const float* __restrict__ c = cxy + ((long long)tc.frame * ct.frame_cells + ct.cell_off[l]) * 2;
+    for (int k = 0; k < 4; ++k) {
+        const int p = tc.tx * kChunk + k * 256 + threadIdx.x;
+        if (p >= npx) break;
+        const int y = p / W, x = p - y * W;
+        int sy = (int)floorf(__fmul_rn((float)y, ct.yscale[l]));
+        int sx = (int)floorf(__fmul_rn((float)x, ct.xscale[l]));
+        sy = min(sy, ct.oh[l] - 1);
+        sx = min(sx, ct.ow[l] - 1);
+        const float cx = c[((long long)sy * ct.ow[l] + sx) * 2], cy = c[((long long)sy * ct.ow[l] + sx) * 2 + 1];
+        out[base_px + p] = __fadd_rn(fabsf(cx - (float)x), fabsf(cy - (float)y));
+    }
+}
+
 }  // namespace silent

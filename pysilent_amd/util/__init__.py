@@ -1,4 +1,5 @@
 """Utility layer; same sub-module names as slam_recognition/util/__init__.py:1-2 (minus the out-of-scope
-math / relativity / index_tensor / centroids, SURVEY.md sections 2 and 8f)."""
+math / relativity)."""
 from . import attractor, color, energy, normalize, orientation, regulator, selection, zoom
-from . import apply_filter, get_dimensions
+from . import apply_filter, get_dimensions, index_tensor
+from .centroids import get_centroids

@@ -10,7 +10,8 @@ pipe = LineEndPipeline((1080, 1920), mode="gray", n_levels=5, n_orient=4, batch=
 frames = torch.randint(0, 256, (B, 1080, 1920, 1), device="cuda").float()
 def two_step():
     pipe.run_pyramid(frames); pipe.run_filters()
-variants = {"two-step": ("0", two_step), "fused R16": ("0", lambda: pipe.step(frames)), "fused R32": ("8", lambda: pipe.step(frames))}
+variants = {"two-step": ("0", two_step), "stream": ("0", lambda: pipe.step(frames)),
+            "stream+xcd": ("32", lambda: pipe.step(frames)), "no-stream": ("16", lambda: pipe.step(frames))}
 times = {k: [] for k in variants}
 for rnd in range(12):
     for k, (opt, fn) in variants.items():

@@ -269,6 +269,40 @@ def test_max_value_indices_capacity_error(rt):
         rt.max_value_indices_region(v, [(8, 8)], cap_per_frame=10)
 
 
+# ----------------------------------------------------------------------------- centroids
+
+@pytest.mark.parametrize("shape,region", [((2, 192, 288, 1), [1, 3, 3]), ((1, 37, 53, 1), [1, 3, 3]),
+                                          ((3, 20, 31, 1), [1, 4, 5]), ((1, 7, 7, 1), [1, 2, 2])])
+def test_get_centroids(rt, shape, region):
+    from pysilent_amd.util import get_centroids
+    rng = np.random.default_rng(12)
+    v = (rng.random(shape) * (rng.random(shape) > 0.6)).astype(np.float32)      # sparse: some cells are empty -> NaN
+    v[0, :6, :9] = 0
+    dist, total = get_centroids(v, region)
+    wd, wt = so.get_centroids(v, region)
+    assert np.isnan(wd).any()
+    assert dist.shape == wd.shape and total.shape == wt.shape
+    assert_close(total, wt, RTOL, what="total_pool")
+    assert_close(dist, wd, RTOL, scale=float(max(shape[1], shape[2])), what="value_centroids")
+
+
+def test_get_centroids_known_answer_and_packed(rt):
+    from pysilent_amd.util import get_centroids
+    v = np.zeros((1, 6, 9, 1), np.float32)
+    v[0, 1, 4, 0] = 2.0
+    v[0, 2, 5, 0] = 2.0                                   # cell (0,1): centroid (x, y) = (4.5, 1.5), total 4
+    dist, total = get_centroids(v, [1, 3, 3])
+    assert total[0, 0, 1, 0] == 4.0 and total.sum() == 4.0
+    np.testing.assert_array_equal(dist[0, :3, 3:6, 0], [[3, 2, 2], [2, 1, 1], [2, 1, 1]])
+    assert np.isnan(dist[0, 0, 0, 0])                     # empty cell: 0/0 like the reference
+    packed, levels = ragged_pyramid(rt, 5, [(12, 20), (7, 9)], c=1, n_frames=2)
+    d, t = get_centroids(packed, [1, 3, 3])
+    for l, lev in enumerate(levels):
+        wd, wt = so.get_centroids(lev, [1, 3, 3])
+        assert_close(d.level(l), wd, RTOL, scale=20.0, what="packed dist %d" % l)
+        assert_close(t.level(l), wt, RTOL, what="packed total %d" % l)
+
+
 # ----------------------------------------------------------------------------- RGB chain
 
 @pytest.mark.parametrize("policy,frame", [("ieee", "noise"), ("zero", "structured"), ("ieee", "structured")])

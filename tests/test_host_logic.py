@@ -98,3 +98,11 @@ def test_get_dimensions_and_selection_argument_checks():
         pad_inwards(np.zeros((1, 4, 4, 3), np.float32), [[1, 0], [2, 2], [2, 2], [0, 0]])
     assert _regions_for([(192, 288)], [1, 96.0, 144.0, 3]) == [(96, 144)]      # the reference passes floats
     assert _regions_for([(8, 8), (4, 4)], [(4, 4), (2, 2)]) == [(4, 4), (2, 2)]
+
+
+def test_index_tensor_matches_reference_test_literal():
+    # reference tests/test_index_tensor.py:7-30: from_shape([4,2,2,3]) == [[[0,0],[1,0]],[[0,1],[1,1]]] (x, y order)
+    from pysilent_amd.util import index_tensor
+    assert index_tensor.from_shape([4, 2, 2, 3]).tolist() == [[[0, 0], [1, 0]], [[0, 1], [1, 1]]]
+    assert index_tensor.from_tensor(np.ones((4, 2, 2, 3))).tolist() == [[[0, 0], [1, 0]], [[0, 1], [1, 1]]]
+    npt.assert_array_equal(index_tensor.from_shape([1, 5, 7, 1]), so.index_tensor_from_shape([1, 5, 7, 1]))
