@@ -230,6 +230,38 @@ int silent_centroids_dev(silent_ctx* ctx, const float* value, const silent_exten
                          int n_frames, int region_h, int region_w, float* dist_out, float* total_out,
                          silent_stream stream);
 
+/* ---------------------------------------------------------------------------- boosting state
+ * Replaces get_boosting, slam_recognition/util/energy/boosting.py:10-42 with generate_recovery,
+ * util/energy/recovery.py:4-22.  The state ("exhaustion_tensor", a tf.Variable in the reference,
+ * recognition_testing.py:56) is a caller-owned float buffer with the geometry of the input, updated IN PLACE:
+ *     m      = input ** energy                      (float64 pow rounded to float32)
+ *     fired  = (m == maxpool3x3 SAME (m)) ? 1 : 0
+ *     energy = clip((energy*255 - fired*255 + recovery) / 255, -exhaustion_max, +excitation_max)
+ * Saving / restoring a stream is a copy of that buffer (initial value: 8 everywhere, boosting.py:6-7).  Each frame
+ * slot of the batch is its own stream; successive calls advance every stream by one step, so the frames of one
+ * stream must come to the same slot, in order.
+ * visualize = 0: fired_out and energy_out (may be NULL) have 1 channel (has_fired, new energy).
+ * visualize = 1 (for_visualizing, boosting.py:35-40): both have 3 identical channels, fired * input and
+ *                energy * 255/(exhaustion_max+excitation_max) + 255*excitation_max/(exhaustion_max+excitation_max). */
+#define SILENT_RECOVERY_CONSTANT 1u
+#define SILENT_RECOVERY_INPUT 2u
+
+typedef struct silent_boosting_params {
+    float exhaustion_max;      /* 1 */
+    float excitation_max;      /* 1 */
+    unsigned recovery_mode;    /* SILENT_RECOVERY_CONSTANT (reference default) | SILENT_RECOVERY_INPUT */
+    float recovery_amount;     /* 10   (recovery.py:4) */
+    float recovery_percentage; /* 0.8  (recovery.py:8) */
+    int32_t visualize;
+} silent_boosting_params;
+
+int silent_boosting_step(silent_ctx* ctx, const float* input, const silent_extent* levels, int n_levels,
+                         int n_frames, const silent_boosting_params* params, float* energy, float* fired_out,
+                         float* energy_out);
+int silent_boosting_step_dev(silent_ctx* ctx, const float* input, const silent_extent* levels, int n_levels,
+                             int n_frames, const silent_boosting_params* params, float* energy, float* fired_out,
+                             float* energy_out, silent_stream stream);
+
 /* ---------------------------------------------------------------------------- fused RGB chain
  * The reference graph recognition_testing.py:69-77 on 3-channel levels.  With a channel-uniform blur (what
  * blur_tensor generates) this is ONE fused launch that reads the pyramid once; any other blur runs the

@@ -445,3 +445,58 @@ def rgb_line_end_chain(x, kernels, flat_policy="ieee", blur_root=0.1, blur_rv=1.
     padded = pad_inwards(line_end, [[0, 0], [pad, pad], [pad, pad], [0, 0]])
     value = value_from_color(padded)
     return dict(rgc=rgc, rgby=rgby, stripe=stripe, orient=orient, line_end=line_end, padded=padded, value=value)
+
+
+# ----------------------------------------------------------------------------- boosting state
+
+def generate_recovery(fire_strength, is_input_based=False, is_constant=True, recovery_amount=10.0,
+                      recovery_percentage=0.8):
+    """slam_recognition/util/energy/recovery.py:4-22 (float32)."""
+    fire_strength = np.asarray(fire_strength, np.float32)
+    const = np.full_like(fire_strength, np.float32(recovery_amount))            # ones_like * amount
+    inp = fire_strength * np.float32(recovery_percentage)
+    if is_input_based and not is_constant:
+        return inp
+    if is_constant and not is_input_based:
+        return const
+    if is_input_based and is_constant:
+        return np.where(inp < const, const, inp).astype(np.float32)              # tf.maximum, Eigen (a < b) ? b : a
+    raise ValueError("You must choose a type of recovery")
+
+
+def boosting_power(x, energy):
+    """``input_tensor ** exhaustion_tensor`` (boosting.py:17).  TF evaluates float32 pow with the device's libm
+    (glibc powf on CPU, CUDA powf on GPU: not bit-reproducible across devices); the oracle and the HIP kernel
+    both use the correctly rounded form: pow in float64, rounded once to float32."""
+    with np.errstate(all="ignore"):
+        return np.power(np.asarray(x, np.float64), np.asarray(energy, np.float64)).astype(np.float32)
+
+
+def get_boosting(x, energy, exhaustion_max=1, excitation_max=1, input_based_recovery=False, constant_recovery=True,
+                 for_visualizing=False):
+    """slam_recognition/util/energy/boosting.py:10-42.  x, energy: [N,h,w,1] float32.
+    Returns (has_fired, new_energy) -- the caller stores new_energy as the next state (the reference's
+    ``exhaustion_tensor.assign``); with for_visualizing the two maps are the 3-channel display forms."""
+    x = np.asarray(x, np.float32)
+    energy = np.asarray(energy, np.float32)
+    m = boosting_power(x, energy)
+    pooled = maxpool3x3_same(m)
+    fired = np.where(m == pooled, np.float32(1), np.float32(0)).astype(np.float32)
+    fire_strength = fired * x
+    exhaustion = fired * np.float32(255.0)
+    recovery = generate_recovery(fire_strength, input_based_recovery, constant_recovery)
+    with np.errstate(all="ignore"):
+        upd = (energy * np.float32(255.0) - exhaustion + recovery) / np.float32(255.0)
+    new_energy = clip_tf(upd, np.float32(-exhaustion_max), np.float32(excitation_max))
+    if not for_visualizing:
+        return fired, new_energy
+    normer = np.float32(255.0 / (exhaustion_max + excitation_max))
+    centerer = np.float32((float(excitation_max) / (exhaustion_max + excitation_max)) * 255.0)
+    fired2 = np.repeat(fired, 3, axis=-1) * x
+    vis = np.repeat(new_energy * normer + centerer, 3, axis=-1)
+    return fired2.astype(np.float32), vis.astype(np.float32), new_energy
+
+
+def initialize_boosting(x, initial_multiplier=8):
+    """boosting.py:6-7."""
+    return np.full(np.shape(x), np.float32(initial_multiplier), np.float32)

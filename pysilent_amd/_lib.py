@@ -24,6 +24,8 @@ FLAT_IEEE = 0
 FLAT_ZERO = 1
 NMS_PRODUCT = 0
 NMS_FIRED = 1
+RECOVERY_CONSTANT = 1
+RECOVERY_INPUT = 2
 MAX_LEVELS = 16
 ABI_VERSION = 1
 
@@ -42,6 +44,11 @@ class RgbChainParams(C.Structure):
                 ("blur", C.POINTER(C.c_float)), ("end", C.POINTER(C.c_float)),
                 ("regulation_value", C.c_float), ("regulation_root", C.c_float), ("flat_policy", C.c_int32),
                 ("clip_hi", C.c_float), ("pad", C.c_int32)]
+
+
+class BoostingParams(C.Structure):
+    _fields_ = [("exhaustion_max", C.c_float), ("excitation_max", C.c_float), ("recovery_mode", C.c_uint),
+                ("recovery_amount", C.c_float), ("recovery_percentage", C.c_float), ("visualize", C.c_int32)]
 
 
 class SilentLibraryError(RuntimeError):
@@ -95,6 +102,8 @@ _SIGNATURES = {
     "silent_max_value_indices_region_dev": [_vp, _fp, _ep, _i, _i, _ep, _vp, _sz, _vp, _vp],
     "silent_centroids": [_vp, _fp, _ep, _i, _i, _i, _i, _fp, _fp],
     "silent_centroids_dev": [_vp, _fp, _ep, _i, _i, _i, _i, _fp, _fp, _vp],
+    "silent_boosting_step": [_vp, _fp, _ep, _i, _i, C.POINTER(BoostingParams), _fp, _fp, _fp],
+    "silent_boosting_step_dev": [_vp, _fp, _ep, _i, _i, C.POINTER(BoostingParams), _fp, _fp, _fp, _vp],
     "silent_rgb_line_end": [_vp, _fp, _ep, _i, _i, C.POINTER(RgbChainParams), _fp, _fp, _fp],
     "silent_rgb_line_end_dev": [_vp, _fp, _ep, _i, _i, C.POINTER(RgbChainParams), _fp, _fp, _fp, _vp],
 }

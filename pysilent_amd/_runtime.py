@@ -356,6 +356,38 @@ def centroids(value, region_h, region_w):
     return op.wrap(dist, 1), tot.reshape(op.n_frames, cell_ext[0][0], cell_ext[0][1], 1)
 
 
+def _require_inplace(state):
+    """The boosting state is updated in place: it has to be float32 and contiguous already (no hidden copy)."""
+    data = state.data if isinstance(state, PackedPyramid) else state
+    if isinstance(data, np.ndarray):
+        ok = data.dtype == np.float32 and data.flags["C_CONTIGUOUS"] and data.flags["WRITEABLE"]
+    elif is_torch_tensor(data):
+        import torch
+        ok = data.dtype == torch.float32 and data.is_contiguous()
+    else:
+        raise TypeError(TYPE_ERROR_MESSAGE)
+    if not ok:
+        raise ValueError("the boosting state must be a writable, contiguous float32 tensor (it is updated in place)")
+
+
+def boosting_step(x, energy, exhaustion_max=1.0, excitation_max=1.0, recovery_mode=_lib.RECOVERY_CONSTANT,
+                  visualize=False, recovery_amount=10.0, recovery_percentage=0.8):
+    """silent_boosting_step: advances ``energy`` in place, returns (fired map, energy map) -- 3 channels each when
+    ``visualize``."""
+    _require_inplace(energy)
+    op, st = _Operand(x, channels=1), _Operand(energy, channels=1)
+    _same_geometry(op, st, "boosting_step")
+    c = 3 if visualize else 1
+    fired, fptr = op.alloc(c)
+    eout, eptr = op.alloc(c)
+    params = _lib.BoostingParams(float(exhaustion_max), float(excitation_max), int(recovery_mode),
+                                 float(recovery_amount), float(recovery_percentage), 1 if visualize else 0)
+    lib, ctx = _lib.load(), op.ctx
+    args = (ctx.handle, op.ptr) + op.geom() + (C.byref(params), st.ptr, fptr, eptr)
+    ctx.check(lib.silent_boosting_step_dev(*(args + (op.stream,))) if op.dev else lib.silent_boosting_step(*args))
+    return op.wrap(fired, c), op.wrap(eout, c)
+
+
 def rgb_line_end(x, kernels, regulation_value=1.0, regulation_root=0.1, flat_policy="ieee", clip_hi=255.0, pad=2,
                  want=("orient", "line_end", "value")):
     """The reference graph recognition_testing.py:69-77 on 3-channel levels.  ``kernels``: dict with

@@ -581,6 +581,46 @@ SILENT_EXPORT int silent_centroids_dev(silent_ctx* ctx, const float* value, cons
     return check_launch(ctx, who);
 }
 
+// ------------------------------------------------------------------------------------------ boosting state
+
+static int check_boost_params(silent_ctx* ctx, const silent_boosting_params* p, BoostP* bp) {
+    if (!p) return fail(ctx, SILENT_E_INVALID, "silent_boosting_step: NULL params");
+    if (p->recovery_mode < 1 || p->recovery_mode > 3)
+        return fail(ctx, SILENT_E_INVALID, "silent_boosting_step: You must choose a type of recovery");
+    bp->lo = -p->exhaustion_max;
+    bp->hi = p->excitation_max;
+    bp->recovery_mode = (int)p->recovery_mode;
+    bp->recovery_amount = p->recovery_amount;
+    bp->recovery_percentage = p->recovery_percentage;
+    bp->visualize = p->visualize ? 1 : 0;
+    const double span = (double)p->exhaustion_max + (double)p->excitation_max;
+    bp->normer = (float)(255.0 / span);
+    bp->centerer = (float)(((double)p->excitation_max / span) * 255.0);
+    return SILENT_OK;
+}
+
+SILENT_EXPORT int silent_boosting_step_dev(silent_ctx* ctx, const float* input, const silent_extent* levels,
+                                           int n_levels, int n_frames, const silent_boosting_params* params,
+                                           float* energy, float* fired_out, float* energy_out, silent_stream stream) {
+    NEED_CTX(ctx);
+    const char* who = "silent_boosting_step";
+    if (!input || !energy || !fired_out) return fail(ctx, SILENT_E_INVALID, std::string(who) + ": NULL pointer");
+    BoostP bp;
+    TRY(check_boost_params(ctx, params, &bp));
+    LevelTab tab;
+    long long blocks;
+    TRY(build_level_tab(ctx, who, levels, n_levels, n_frames, 0, 0, &tab, &blocks));
+    const long long n = tab.frame_px * n_frames;
+    if ((n + 255) / 256 > 0x7fffffffll) return fail(ctx, SILENT_E_INVALID, std::string(who) + ": too many pixels");
+    TRY(grow(ctx, ctx->ws, (size_t)n * sizeof(float)));
+    float* m = (float*)ctx->ws.p;
+    hipStream_t s = (hipStream_t)stream;
+    hipLaunchKernelGGL(boost_power_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, input, energy, m, n);
+    hipLaunchKernelGGL(boost_update_kernel, dim3((unsigned)blocks), dim3(256), 0, s, input, m, energy, fired_out,
+                       energy_out, tab, bp);
+    return check_launch(ctx, who);
+}
+
 // ------------------------------------------------------------------------------------------ RGB chain
 
 SILENT_EXPORT int silent_rgb_line_end_dev(silent_ctx* ctx, const float* pyr, const silent_extent* levels, int n_levels,
@@ -1395,4 +1435,27 @@ SILENT_EXPORT int silent_centroids(silent_ctx* ctx, const float* value, const si
     TRY(sync0(ctx));
     TRY(d2h(ctx, dist_out, st.ptr<float>(i_d), bv));
     return d2h(ctx, total_out, st.ptr<float>(i_t), bt);
+}
+
+SILENT_EXPORT int silent_boosting_step(silent_ctx* ctx, const float* input, const silent_extent* levels, int n_levels,
+                                       int n_frames, const silent_boosting_params* params, float* energy,
+                                       float* fired_out, float* energy_out) {
+    NEED_CTX(ctx);
+    if (!input || !energy || !fired_out) return fail(ctx, SILENT_E_INVALID, "silent_boosting_step: NULL pointer");
+    BoostP bp;
+    TRY(check_boost_params(ctx, params, &bp));
+    long long px;
+    TRY(check_levels(ctx, "silent_boosting_step", levels, n_levels, n_frames, &px));
+    Stage st(ctx);
+    const size_t b1 = (size_t)px * 4, bc = b1 * (bp.visualize ? 3 : 1);
+    const size_t i_x = st.add(b1), i_e = st.add(b1), i_f = st.add(bc), i_o = st.add(bc);
+    TRY(st.commit());
+    TRY(h2d(ctx, st.ptr<float>(i_x), input, b1));
+    TRY(h2d(ctx, st.ptr<float>(i_e), energy, b1));
+    TRY(silent_boosting_step_dev(ctx, st.ptr<float>(i_x), levels, n_levels, n_frames, params, st.ptr<float>(i_e),
+                                 st.ptr<float>(i_f), energy_out ? st.ptr<float>(i_o) : nullptr, nullptr));
+    TRY(sync0(ctx));
+    TRY(d2h(ctx, energy, st.ptr<float>(i_e), b1));
+    TRY(d2h(ctx, fired_out, st.ptr<float>(i_f), bc));
+    return energy_out ? d2h(ctx, energy_out, st.ptr<float>(i_o), bc) : SILENT_OK;
 }

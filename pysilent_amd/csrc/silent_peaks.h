@@ -439,4 +439,69 @@ __global__ __launch_bounds__(256) void centroid_dist_kernel(const LevelTab tab, 
     }
 }
 
+// ---- boosting state (reference slam_recognition/util/energy/boosting.py:10-42)
+// step 1: memory_biased_values = input ** energy.  pow in float64 rounded once to float32 (the reference's float32
+// pow is libm dependent; this is the correctly rounded value, see oracle/silent_oracle.py boosting_power).
+__global__ __launch_bounds__(256) void boost_power_kernel(const float* __restrict__ x, const float* __restrict__ energy,
+                                                          float* __restrict__ m, long long n) {
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i < n) m[i] = (float)pow((double)x[i], (double)energy[i]);
+}
+
+struct BoostP {
+    float lo, hi;             // clip range of the state: [-exhaustion_max, +excitation_max]
+    int recovery_mode;        // bit 0 constant, bit 1 input based
+    float recovery_amount, recovery_percentage;
+    int visualize;            // outputs carry 3 identical channels: fired * x, energy * normer + centerer
+    float normer, centerer;
+};
+
+// step 2: has_fired = (m == maxpool3x3 SAME(m)); energy <- clip((energy*255 - fired*255 + recovery) / 255, lo, hi)
+// in place (a pixel's update reads only its own energy; the neighbours enter through m, which is a separate buffer).
+__global__ __launch_bounds__(256) void boost_update_kernel(const float* __restrict__ x, const float* __restrict__ m,
+                                                           float* __restrict__ energy, float* __restrict__ fired_out,
+                                                           float* __restrict__ energy_out, const LevelTab tab,
+                                                           const BoostP bp) {
+    const TileCoord tc = locate_tile(tab, blockIdx.x);
+    const int H = tab.h[tc.level], W = tab.w[tc.level];
+    const long long base_px = (long long)tc.frame * tab.frame_px + tab.px_off[tc.level];
+    const float* __restrict__ src = m + base_px;
+    const int npx = H * W;
+    const int C = bp.visualize ? 3 : 1;
+    for (int k = 0; k < 4; ++k) {
+        const int p = tc.tx * kChunk + k * 256 + threadIdx.x;
+        if (p >= npx) break;
+        const int y = p / W, xx0 = p - y * W;
+        float mx = -INFINITY;
+        for (int dy = -1; dy <= 1; ++dy) {
+            const int yy = y + dy;
+            if (yy < 0 || yy >= H) continue;
+            for (int dx = -1; dx <= 1; ++dx) {
+                const int xx = xx0 + dx;
+                if (xx < 0 || xx >= W) continue;
+                const float v = src[(long long)yy * W + xx];
+                mx = mx < v ? v : mx;
+            }
+        }
+        const float fired = src[p] == mx ? 1.0f : 0.0f;
+        const float xin = x[base_px + p];
+        const float strength = __fmul_rn(fired, xin);
+        const float r_in = __fmul_rn(strength, bp.recovery_percentage);
+        float rec = bp.recovery_amount;
+        if (bp.recovery_mode == 2) rec = r_in;
+        else if (bp.recovery_mode == 3) rec = r_in < bp.recovery_amount ? bp.recovery_amount : r_in;
+        const float e = energy[base_px + p];
+        float u = __fadd_rn(__fsub_rn(__fmul_rn(e, 255.0f), __fmul_rn(fired, 255.0f)), rec) / 255.0f;
+        u = u < bp.lo ? bp.lo : u;
+        u = u > bp.hi ? bp.hi : u;
+        energy[base_px + p] = u;
+        const float f_out = bp.visualize ? strength : fired;
+        const float e_out = bp.visualize ? __fadd_rn(__fmul_rn(u, bp.normer), bp.centerer) : u;
+        for (int c = 0; c < C; ++c) {
+            fired_out[(base_px + p) * C + c] = f_out;
+            if (energy_out) energy_out[(base_px + p) * C + c] = e_out;
+        }
+    }
+}
+
 }  // namespace silent

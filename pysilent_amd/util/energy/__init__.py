@@ -2,7 +2,7 @@
 
 ``local_maxima``  x * where(x == maxpool3x3(x), x, 0)   slam_recognition/_experimental/vision_filter.py:88-89
 ``has_fired``     where(x == maxpool3x3(x), 1, 0)        slam_recognition/util/energy/boosting.py:18-22
-The stateful exhaustion update of get_boosting (boosting.py:24-33) is SURVEY.md section 8f "next".
+The stateful exhaustion update is in .boosting (get_boosting / initialize_boosting) and .recovery.
 """
 from ... import _runtime
 from ..get_dimensions import get_dimensions
@@ -16,3 +16,6 @@ def local_maxima(tensor):
 def has_fired(tensor):
     get_dimensions(tensor)
     return _runtime.nms3x3(tensor, "fired")
+
+
+from .boosting import get_boosting, initialize_boosting  # noqa: E402

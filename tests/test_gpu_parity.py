@@ -303,6 +303,53 @@ def test_get_centroids_known_answer_and_packed(rt):
         assert_close(t.level(l), wt, RTOL, what="packed total %d" % l)
 
 
+# ----------------------------------------------------------------------------- boosting state
+
+@pytest.mark.parametrize("inp,const", [(False, True), (True, False), (True, True)])
+@pytest.mark.parametrize("vis", [False, True])
+def test_get_boosting_sequence(rt, inp, const, vis):
+    """Five successive frames of one stream: fired masks bit-exact, state within tolerance at every step."""
+    from pysilent_amd.util.energy import get_boosting, initialize_boosting
+    rng = np.random.default_rng(31)
+    shape = (3, 41, 67, 1)
+    state = initialize_boosting(np.empty(shape, np.float32))
+    assert state.dtype == np.float32 and (state == 8).all()
+    want_state = so.initialize_boosting(np.empty(shape))
+    for step in range(5):
+        x = np.floor(rng.random(shape) * 256).astype(np.float32) * (rng.random(shape) > 0.3)
+        got = get_boosting(x, state, 1, 1, inp, const, for_visualizing=vis)
+        want = so.get_boosting(x, want_state, 1, 1, inp, const, for_visualizing=vis)
+        want_state = want[-1] if vis else want[1]
+        np.testing.assert_array_equal(got[0], want[0], err_msg="fired, step %d" % step)
+        assert_close(got[1], want[1], RTOL, what="energy map, step %d" % step)
+        assert_close(state, want_state, RTOL, what="state, step %d" % step)
+    assert state.min() >= -1 and state.max() <= 1
+
+
+def test_get_boosting_first_step_from_initial_state_and_packed(rt):
+    """From the initial state 8 (boosting.py:6-7), packed ragged levels, wider clip range, device-resident state."""
+    import torch
+    from pysilent_amd.util.energy import get_boosting, initialize_boosting
+    packed, levels = ragged_pyramid(rt, 9, [(24, 40), (11, 13), (5, 3)], c=1, n_frames=2)
+    state = initialize_boosting(packed)
+    fired, energy = get_boosting(packed, state, exhaustion_max=2, excitation_max=8)
+    for l, lev in enumerate(levels):
+        wf, we = so.get_boosting(lev, so.initialize_boosting(lev), 2, 8)
+        np.testing.assert_array_equal(fired.level(l), wf)
+        assert_close(energy.level(l), we, RTOL, what="energy %d" % l)
+        assert_close(state.level(l), we, RTOL, what="state %d" % l)
+    x = torch.rand((1, 16, 16, 1), device="cuda") * 255
+    st = initialize_boosting(x)
+    f, e = get_boosting(x, st)
+    wf, we = so.get_boosting(x.cpu().numpy(), so.initialize_boosting(np.empty((1, 16, 16, 1))))
+    np.testing.assert_array_equal(f.cpu().numpy(), wf)
+    assert_close(st.cpu().numpy(), we, RTOL, what="device state")
+    with pytest.raises(ValueError, match="type of recovery"):
+        get_boosting(x, st, input_based_recovery=False, constant_recovery=False)
+    with pytest.raises(ValueError, match="in place"):
+        get_boosting(np.ones((1, 4, 4, 1), np.float32), np.ones((1, 4, 4, 1), np.float64))
+
+
 # ----------------------------------------------------------------------------- RGB chain
 
 @pytest.mark.parametrize("policy,frame", [("ieee", "noise"), ("zero", "structured"), ("ieee", "structured")])

@@ -168,3 +168,44 @@ def test_chain_on_noise_has_no_nan(kernels):
     for k, v in out.items():
         assert not np.isnan(v).any(), k
     assert out["padded"][0, :2].sum() == 0 and out["value"].shape == (1, 48, 64, 1)
+
+
+# ----------------------------------------------------------------------------- 8f: centroids, boosting (hand-worked)
+
+def test_centroids_known_answer():
+    v = np.zeros((1, 6, 9, 1), np.float32)
+    v[0, 1, 4, 0] = 2.0
+    v[0, 2, 5, 0] = 2.0
+    dist, total = so.get_centroids(v, [1, 3, 3])
+    assert total.shape == (1, 2, 3, 1) and dist.shape == v.shape
+    npt.assert_array_equal(total[0, :, :, 0], [[0, 4, 0], [0, 0, 0]])
+    npt.assert_array_equal(dist[0, :3, 3:6, 0], [[3, 2, 2], [2, 1, 1], [2, 1, 1]])   # centroid (x, y) = (4.5, 1.5)
+    assert np.isnan(dist[0, :, :3, 0]).all() and np.isnan(dist[0, 3:, :, 0]).all()    # empty cells: 0/0
+
+
+def test_centroids_same_padding_geometry():
+    # 7 px, window 3, stride 3, SAME: 3 cells, pad_total 2 -> the first cell starts at -1 (covers px 0..1)
+    assert so._strided_same_geometry(7, 3) == (3, -1)
+    assert so._strided_same_geometry(6, 3) == (2, 0)
+    assert so._strided_same_geometry(8, 3) == (3, 0)
+    v = np.ones((1, 7, 7, 1), np.float32)
+    _, total = so.get_centroids(v, [1, 3, 3])
+    npt.assert_array_equal(total[0, :, :, 0], [[4, 6, 4], [6, 9, 6], [4, 6, 4]])
+
+
+def test_boosting_known_answer():
+    x = np.array([[0, 2], [3, 2]], np.float32).reshape(1, 2, 2, 1)
+    e = np.ones_like(x)
+    fired, new_e = so.get_boosting(x, e)
+    npt.assert_array_equal(fired[0, :, :, 0], [[0, 0], [1, 0]])
+    # not fired: clip((255 + 10)/255, -1, 1) = 1; fired: (255 - 255 + 10)/255
+    npt.assert_allclose(new_e[0, :, :, 0], [[1, 1], [np.float32(10) / np.float32(255), 1]], rtol=0, atol=0)
+    f3, vis, st = so.get_boosting(x, e, for_visualizing=True)
+    npt.assert_array_equal(st, new_e)
+    npt.assert_array_equal(f3[0, 1, 0], [3, 3, 3])
+    npt.assert_allclose(vis[0, 0, 0], [255, 255, 255])                                # 1 * 127.5 + 127.5
+    both = so.generate_recovery(np.array([0, 20], np.float32), True, True)
+    npt.assert_array_equal(both, [10, 16])
+    with pytest.raises(ValueError):
+        so.generate_recovery(x, False, False)
+    assert (so.initialize_boosting(x) == 8).all()
