@@ -262,6 +262,29 @@ int silent_boosting_step_dev(silent_ctx* ctx, const float* input, const silent_e
                              int n_frames, const silent_boosting_params* params, float* energy, float* fired_out,
                              float* energy_out, silent_stream stream);
 
+/* ---------------------------------------------------------------------------- display-graph glue
+ * The scalar ops between the kernels of LineEndDisplayer.compile, recognition_testing.py:79-81 and :99
+ * (``t / 255.0``, ``clip_by_value(t * (255 / 4.0), 1, 256) - 1``, ``255 - t * 255``, ``t * 255``):
+ *     out[i] = clip(in[i] * mul / div + add, lo, hi) + post_add        (float32, one rounding per operation;
+ * mul = div = 1, add = post_add = 0, lo = -INFINITY, hi = +INFINITY are the neutral values).  in == out is allowed. */
+typedef struct silent_affine_params {
+    float mul, div, add, lo, hi, post_add;
+} silent_affine_params;
+
+int silent_affine_clip(silent_ctx* ctx, const float* in, size_t n_values, const silent_affine_params* params,
+                       float* out);
+int silent_affine_clip_dev(silent_ctx* ctx, const float* in, size_t n_values, const silent_affine_params* params,
+                           float* out, silent_stream stream);
+
+/* tf.image.resize_nearest_neighbor with the TF1 defaults (align_corners = False), recognition_testing.py:82-83
+ * and util/centroids.py:41: out(y, x) = in(min(floor(y * float32(in_h / out_h)), in_h - 1), ...).
+ * in: packed maps with extents in_levels; out: packed maps with extents out_levels (same level count). */
+int silent_resize_nearest(silent_ctx* ctx, const float* in, const silent_extent* in_levels, int n_levels,
+                          int n_frames, int channels, const silent_extent* out_levels, float* out);
+int silent_resize_nearest_dev(silent_ctx* ctx, const float* in, const silent_extent* in_levels, int n_levels,
+                              int n_frames, int channels, const silent_extent* out_levels, float* out,
+                              silent_stream stream);
+
 /* ---------------------------------------------------------------------------- fused RGB chain
  * The reference graph recognition_testing.py:69-77 on 3-channel levels.  With a channel-uniform blur (what
  * blur_tensor generates) this is ONE fused launch that reads the pyramid once; any other blur runs the

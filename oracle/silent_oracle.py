@@ -500,3 +500,52 @@ def get_boosting(x, energy, exhaustion_max=1, excitation_max=1, input_based_reco
 def initialize_boosting(x, initial_multiplier=8):
     """boosting.py:6-7."""
     return np.full(np.shape(x), np.float32(initial_multiplier), np.float32)
+
+
+# ----------------------------------------------------------------------------- display graph (SURVEY 8f rank 3)
+
+def resize_nearest_tf1(x, out_h, out_w):
+    """tf.image.resize_nearest_neighbor, TF1 default (align_corners=False): src = min(floor(dst * float32(in/out)),
+    in - 1).  x: [N, h, w, C]."""
+    x = np.asarray(x)
+    n, h, w, c = x.shape
+    sy = np.minimum(np.floor((np.arange(out_h, dtype=F32) * (F32(h) / F32(out_h))).astype(F32)).astype(np.int64), h - 1)
+    sx = np.minimum(np.floor((np.arange(out_w, dtype=F32) * (F32(w) / F32(out_w))).astype(F32)).astype(np.int64), w - 1)
+    return x[:, sy][:, :, sx]
+
+
+def affine_clip(x, mul=1.0, add=0.0, lo=-np.inf, hi=np.inf, post_add=0.0, div=1.0):
+    """clip(x * mul / div + add, lo, hi) + post_add in float32, one rounding per operation (the scalar glue ops
+    of recognition_testing.py:79-81, :99: ``t / 255.0``, ``clip(t * (255 / 4.0), 1, 256) - 1``, ``255 - t * 255``)."""
+    with np.errstate(all="ignore"):
+        y = ((np.asarray(x, F32) * F32(mul)).astype(F32) / F32(div)).astype(F32) + F32(add)
+        return (clip_tf(y.astype(F32), lo, hi) + F32(post_add)).astype(F32)
+
+
+def displayer_half_shape(h, w):
+    """recognition_testing.py:82: int32(float32(shape) / float32(e ** .5))."""
+    root_e = F32(np.e ** .5)
+    return int(F32(h) / root_e), int(F32(w) / root_e)
+
+
+def line_end_displayer_tail(padded, energy, centroid_region=(1, 3, 3)):
+    """The part of LineEndDisplayer.compile after pad_inwards, recognition_testing.py:77-87: value -> centroids,
+    importances, half-size centroids, boosting.  Returns ([255 - centroids * 255, 255 - centroids2 * 255,
+    fired * 255, update_importances], new_energy)."""
+    gray = value_from_color(padded)
+    centroids, imp = get_centroids(affine_clip(gray, div=255.0), centroid_region)
+    imp = affine_clip(imp, 255 / 4.0, 0.0, 1.0, 256.0, -1.0)
+    hh, hw = displayer_half_shape(gray.shape[1], gray.shape[2])
+    im2 = resize_nearest_tf1(gray, hh, hw)
+    centroids2, _ = get_centroids(affine_clip(im2, div=255.0), centroid_region)
+    fired3, vis, new_energy = get_boosting(imp, energy, for_visualizing=True)
+    return [affine_clip(centroids, -255.0, 255.0), affine_clip(centroids2, -255.0, 255.0),
+            affine_clip(fired3, 255.0), vis], new_energy
+
+
+def line_end_displayer_run(pyramid, energy, kernels, centroid_region=(1, 3, 3)):
+    """LineEndDisplayer.compile + run, recognition_testing.py:60-100, :132: the six fetched tensors and the
+    new boosting state.  pyramid: [L, h, w, 3]; energy: [L, ceil(h/3), ceil(w/3), 1]."""
+    ch = rgb_line_end_chain(pyramid, kernels)
+    tail, new_energy = line_end_displayer_tail(ch["padded"], energy, centroid_region)
+    return [ch["orient"]] + tail + [ch["padded"]], new_energy

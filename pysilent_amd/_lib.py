@@ -51,6 +51,11 @@ class BoostingParams(C.Structure):
                 ("recovery_amount", C.c_float), ("recovery_percentage", C.c_float), ("visualize", C.c_int32)]
 
 
+class AffineParams(C.Structure):
+    _fields_ = [("mul", C.c_float), ("div", C.c_float), ("add", C.c_float), ("lo", C.c_float), ("hi", C.c_float),
+                ("post_add", C.c_float)]
+
+
 class SilentLibraryError(RuntimeError):
     """libsilent_hip.so is missing or cannot be loaded."""
 
@@ -104,6 +109,10 @@ _SIGNATURES = {
     "silent_centroids_dev": [_vp, _fp, _ep, _i, _i, _i, _i, _fp, _fp, _vp],
     "silent_boosting_step": [_vp, _fp, _ep, _i, _i, C.POINTER(BoostingParams), _fp, _fp, _fp],
     "silent_boosting_step_dev": [_vp, _fp, _ep, _i, _i, C.POINTER(BoostingParams), _fp, _fp, _fp, _vp],
+    "silent_affine_clip": [_vp, _fp, _sz, C.POINTER(AffineParams), _fp],
+    "silent_affine_clip_dev": [_vp, _fp, _sz, C.POINTER(AffineParams), _fp, _vp],
+    "silent_resize_nearest": [_vp, _fp, _ep, _i, _i, _i, _ep, _fp],
+    "silent_resize_nearest_dev": [_vp, _fp, _ep, _i, _i, _i, _ep, _fp, _vp],
     "silent_rgb_line_end": [_vp, _fp, _ep, _i, _i, C.POINTER(RgbChainParams), _fp, _fp, _fp],
     "silent_rgb_line_end_dev": [_vp, _fp, _ep, _i, _i, C.POINTER(RgbChainParams), _fp, _fp, _fp, _vp],
 }

@@ -388,6 +388,43 @@ def boosting_step(x, energy, exhaustion_max=1.0, excitation_max=1.0, recovery_mo
     return op.wrap(fired, c), op.wrap(eout, c)
 
 
+def affine_clip(x, mul=1.0, add=0.0, lo=-float("inf"), hi=float("inf"), post_add=0.0, div=1.0):
+    """silent_affine_clip: clip(x * mul / div + add, lo, hi) + post_add, any channel count."""
+    op = _Operand(x)
+    out, optr = op.alloc(op.c)
+    params = _lib.AffineParams(float(mul), float(div), float(add), float(lo), float(hi), float(post_add))
+    lib, ctx = _lib.load(), op.ctx
+    n = op.n_frames * op.frame_px * op.c
+    args = (ctx.handle, op.ptr, n, C.byref(params), optr)
+    ctx.check(lib.silent_affine_clip_dev(*(args + (op.stream,))) if op.dev else lib.silent_affine_clip(*args))
+    return op.wrap(out, op.c)
+
+
+def resize_nearest(x, out_extents):
+    """silent_resize_nearest.  ``out_extents``: one (h, w) for an NHWC tensor, one per level for a PackedPyramid."""
+    op = _Operand(x)
+    if not op.packed:
+        out_extents = [tuple(out_extents)] if np.ndim(out_extents[0]) == 0 else list(out_extents)
+    out_extents = [(int(h), int(w)) for h, w in out_extents]
+    if len(out_extents) != op.n_levels or min(min(e) for e in out_extents) < 1:
+        raise ValueError("resize_nearest: need one positive (h, w) per level")
+    out_levels = (_lib.Extent * op.n_levels)(*[_lib.Extent(h, w) for h, w in out_extents])
+    n = op.n_frames * sum(h * w for h, w in out_extents) * op.c
+    lib, ctx = _lib.load(), op.ctx
+    if op.dev:
+        import torch
+        out = torch.empty(n, dtype=torch.float32, device=op._torch_device)
+        optr = C.c_void_p(out.data_ptr())
+    else:
+        out = np.empty(n, dtype=np.float32)
+        optr = C.c_void_p(out.ctypes.data)
+    args = (ctx.handle, op.ptr) + op.geom() + (op.c, out_levels, optr)
+    ctx.check(lib.silent_resize_nearest_dev(*(args + (op.stream,))) if op.dev else lib.silent_resize_nearest(*args))
+    if op.packed:
+        return PackedPyramid(out, out_extents, op.c, op.n_frames)
+    return out.reshape(op.n_frames, out_extents[0][0], out_extents[0][1], op.c)
+
+
 def rgb_line_end(x, kernels, regulation_value=1.0, regulation_root=0.1, flat_policy="ieee", clip_hi=255.0, pad=2,
                  want=("orient", "line_end", "value")):
     """The reference graph recognition_testing.py:69-77 on 3-channel levels.  ``kernels``: dict with

@@ -621,6 +621,49 @@ SILENT_EXPORT int silent_boosting_step_dev(silent_ctx* ctx, const float* input, 
     return check_launch(ctx, who);
 }
 
+// ------------------------------------------------------------------------------------------ display-graph glue
+
+SILENT_EXPORT int silent_affine_clip_dev(silent_ctx* ctx, const float* in, size_t n_values,
+                                         const silent_affine_params* params, float* out, silent_stream stream) {
+    NEED_CTX(ctx);
+    const char* who = "silent_affine_clip";
+    if (!in || !out || !params) return fail(ctx, SILENT_E_INVALID, std::string(who) + ": NULL pointer");
+    if (n_values == 0) return fail(ctx, SILENT_E_INVALID, std::string(who) + ": empty tensor");
+    if ((n_values + 255) / 256 > 0x7fffffffull) return fail(ctx, SILENT_E_INVALID, std::string(who) + ": too many values");
+    const AffineP ap = {params->mul, params->div, params->add, params->lo, params->hi, params->post_add};
+    hipLaunchKernelGGL(affine_clip_kernel, dim3((unsigned)((n_values + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+                       in, out, (long long)n_values, ap);
+    return check_launch(ctx, who);
+}
+
+SILENT_EXPORT int silent_resize_nearest_dev(silent_ctx* ctx, const float* in, const silent_extent* in_levels,
+                                            int n_levels, int n_frames, int channels, const silent_extent* out_levels,
+                                            float* out, silent_stream stream) {
+    NEED_CTX(ctx);
+    const char* who = "silent_resize_nearest";
+    if (!in || !out) return fail(ctx, SILENT_E_INVALID, std::string(who) + ": NULL pointer");
+    if (channels < 1) return fail(ctx, SILENT_E_INVALID, std::string(who) + ": channels must be >= 1");
+    LevelTab tab;
+    long long blocks;
+    TRY(build_level_tab(ctx, who, in_levels, n_levels, n_frames, 0, 0, &tab, &blocks));   // validates the input side
+    TRY(build_level_tab(ctx, who, out_levels, n_levels, n_frames, 0, 0, &tab, &blocks));
+    ResizeTab rt;
+    std::memset(&rt, 0, sizeof(rt));
+    long long off = 0;
+    for (int l = 0; l < n_levels; ++l) {
+        rt.ih[l] = in_levels[l].h;
+        rt.iw[l] = in_levels[l].w;
+        rt.in_off[l] = off;
+        off += (long long)in_levels[l].h * in_levels[l].w;
+        rt.yscale[l] = (float)in_levels[l].h / (float)out_levels[l].h;
+        rt.xscale[l] = (float)in_levels[l].w / (float)out_levels[l].w;
+    }
+    rt.in_px = off;
+    hipLaunchKernelGGL(resize_nearest_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, in, out, tab, rt,
+                       channels);
+    return check_launch(ctx, who);
+}
+
 // ------------------------------------------------------------------------------------------ RGB chain
 
 SILENT_EXPORT int silent_rgb_line_end_dev(silent_ctx* ctx, const float* pyr, const silent_extent* levels, int n_levels,
@@ -1458,4 +1501,38 @@ SILENT_EXPORT int silent_boosting_step(silent_ctx* ctx, const float* input, cons
     TRY(d2h(ctx, energy, st.ptr<float>(i_e), b1));
     TRY(d2h(ctx, fired_out, st.ptr<float>(i_f), bc));
     return energy_out ? d2h(ctx, energy_out, st.ptr<float>(i_o), bc) : SILENT_OK;
+}
+
+SILENT_EXPORT int silent_affine_clip(silent_ctx* ctx, const float* in, size_t n_values,
+                                     const silent_affine_params* params, float* out) {
+    NEED_CTX(ctx);
+    if (!in || !out || !params) return fail(ctx, SILENT_E_INVALID, "silent_affine_clip: NULL pointer");
+    if (n_values == 0) return fail(ctx, SILENT_E_INVALID, "silent_affine_clip: empty tensor");
+    Stage st(ctx);
+    const size_t b = n_values * 4;
+    const size_t i_x = st.add(b);
+    TRY(st.commit());
+    TRY(h2d(ctx, st.ptr<float>(i_x), in, b));
+    TRY(silent_affine_clip_dev(ctx, st.ptr<float>(i_x), n_values, params, st.ptr<float>(i_x), nullptr));
+    TRY(sync0(ctx));
+    return d2h(ctx, out, st.ptr<float>(i_x), b);
+}
+
+SILENT_EXPORT int silent_resize_nearest(silent_ctx* ctx, const float* in, const silent_extent* in_levels, int n_levels,
+                                        int n_frames, int channels, const silent_extent* out_levels, float* out) {
+    NEED_CTX(ctx);
+    if (!in || !out) return fail(ctx, SILENT_E_INVALID, "silent_resize_nearest: NULL pointer");
+    if (channels < 1) return fail(ctx, SILENT_E_INVALID, "silent_resize_nearest: channels must be >= 1");
+    long long ipx, opx;
+    TRY(check_levels(ctx, "silent_resize_nearest", in_levels, n_levels, n_frames, &ipx));
+    TRY(check_levels(ctx, "silent_resize_nearest", out_levels, n_levels, n_frames, &opx));
+    Stage st(ctx);
+    const size_t bi = (size_t)ipx * channels * 4, bo = (size_t)opx * channels * 4;
+    const size_t i_x = st.add(bi), i_o = st.add(bo);
+    TRY(st.commit());
+    TRY(h2d(ctx, st.ptr<float>(i_x), in, bi));
+    TRY(silent_resize_nearest_dev(ctx, st.ptr<float>(i_x), in_levels, n_levels, n_frames, channels, out_levels,
+                                  st.ptr<float>(i_o), nullptr));
+    TRY(sync0(ctx));
+    return d2h(ctx, out, st.ptr<float>(i_o), bo);
 }

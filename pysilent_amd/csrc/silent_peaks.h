@@ -504,4 +504,46 @@ __global__ __launch_bounds__(256) void boost_update_kernel(const float* __restri
     }
 }
 
+// ---- display-graph glue (reference recognition_testing.py:79-83, :99)
+// out = clip(in * mul / div + add, lo, hi) + post_add, each operation rounded to float32 like the TF scalar ops.
+struct AffineP {
+    float mul, div, add, lo, hi, post_add;
+};
+
+__global__ __launch_bounds__(256) void affine_clip_kernel(const float* __restrict__ in, float* __restrict__ out,
+                                                          long long n, const AffineP ap) {
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    float y = __fadd_rn(__fdiv_rn(__fmul_rn(in[i], ap.mul), ap.div), ap.add);
+    y = y < ap.lo ? ap.lo : y;
+    y = y > ap.hi ? ap.hi : y;
+    out[i] = __fadd_rn(y, ap.post_add);
+}
+
+// tf.image.resize_nearest_neighbor (TF1, align_corners = False): src = min(floor(dst * float32(in / out)), in - 1).
+// ``tab`` describes the OUTPUT maps; the input level l has extents (ih[l], iw[l]) at in_off[l] of a frame of in_px.
+struct ResizeTab {
+    int ih[kMaxLevels], iw[kMaxLevels];
+    long long in_off[kMaxLevels];
+    long long in_px;
+    float yscale[kMaxLevels], xscale[kMaxLevels];
+};
+
+__global__ __launch_bounds__(256) void resize_nearest_kernel(const float* __restrict__ in, float* __restrict__ out,
+                                                             const LevelTab tab, const ResizeTab rt, int C) {
+    const TileCoord tc = locate_tile(tab, blockIdx.x);
+    const int l = tc.level, W = tab.w[l];
+    const int npx = tab.h[l] * W;
+    const float* __restrict__ src = in + ((long long)tc.frame * rt.in_px + rt.in_off[l]) * C;
+    float* __restrict__ dst = out + ((long long)tc.frame * tab.frame_px + tab.px_off[l]) * C;
+    for (int k = 0; k < 4; ++k) {
+        const int p = tc.tx * kChunk + k * 256 + threadIdx.x;
+        if (p >= npx) break;
+        const int y = p / W, x = p - y * W;
+        const int sy = min((int)floorf(__fmul_rn((float)y, rt.yscale[l])), rt.ih[l] - 1);
+        const int sx = min((int)floorf(__fmul_rn((float)x, rt.xscale[l])), rt.iw[l] - 1);
+        for (int c = 0; c < C; ++c) dst[(long long)p * C + c] = src[((long long)sy * rt.iw[l] + sx) * C + c];
+    }
+}
+
 }  // namespace silent

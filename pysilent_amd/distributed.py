@@ -42,6 +42,12 @@ def shard_frame_indices(n_frames_total, rank, world_size):
     return list(range(rank, n_frames_total, world_size))
 
 
+def shard_stream_indices(n_streams, rank, world_size):
+    """Stateful mode (boosting): a camera stream carries per-pixel state from frame to
+    frame, so whole streams are sharded -- stream s lives on rank s mod G for all of its frames, in order."""
+    return list(range(rank, n_streams, world_size))
+
+
 def broadcast_constants(mode, n_orient=4, device=None):
     """Rank 0 generates the constant kernels; everyone receives one flat float32 blob (< 8 KB).
 

@@ -1,0 +1,95 @@
+"""``LineEndDisplayer``: the reference's end-to-end application graph on the GPU.
+
+Mirror of slam_recognition/recognition_testing.py:21-144: ``callback(frame)`` builds
+the zoom pyramid (zoom.from_image, :141-142) and ``run`` evaluates what the reference fetches from its TF graph
+(:99-100, :132):
+
+    [orient_tensor, 255 - centroids * 255, 255 - centroids2 * 255, fired_importants * 255, update_importances,
+     padded_line_end_tensor]
+
+every one as a float32 [levels, ...] array; ``callback`` returns ``[frame] + 6 lists of per-level images`` (:144).
+The boosting state (``energy_values``, a tf.Variable in the reference, :56) is ``self.energy_values``, a GPU tensor
+that every ``run`` advances; like the reference (:108-117) it is re-initialised to 8 when the pyramid shape changes.
+All intermediate maps stay on the GPU; only the six results are copied back.
+"""
+import math as m
+
+import numpy as np
+
+from . import _runtime
+from .pipeline import default_constants
+from .pyramid_displayer import PyramidDisplayer
+from .util import zoom
+from .util.energy.recovery import recovery_mode
+
+
+class LineEndDisplayer(PyramidDisplayer):
+    def __init__(self, n_dimensions=2, **argv):
+        super(LineEndDisplayer, self).__init__(**argv)
+        if n_dimensions != 2:
+            raise ValueError("only 2-D images are supported")
+        self.kernels = default_constants("rgb")
+        self.simplex_end_stop = self.kernels["end"]
+        self.constant_recovery = True
+        self.input_based_recovery = False
+        self.centroid_region_shape = [1, 3, 3]
+        self.pyramid_tensor_shape = None
+        self.energy_values = None
+        self.device_index = _runtime.default_device()
+
+    # -- state -------------------------------------------------------------------------------------------
+    def pre_compile(self, pyramid_tensor):
+        """Initial boosting state: 8 in every centroid cell (recognition_testing.py:45-58)."""
+        import torch
+        n, h, w = (int(s) for s in pyramid_tensor.shape[:3])
+        rh, rw = self.centroid_region_shape[1], self.centroid_region_shape[2]
+        self.energy_values = torch.full((n, -(-h // rh), -(-w // rw), 1), 8.0, dtype=torch.float32,
+                                        device=torch.device("cuda", self.device_index))
+        self.pyramid_tensor_shape = tuple(pyramid_tensor.shape)
+
+    def get_state(self):
+        """Host copy of the boosting state (checkpoint); None before the first run."""
+        return None if self.energy_values is None else self.energy_values.cpu().numpy()
+
+    def set_state(self, state):
+        import torch
+        state = np.ascontiguousarray(state, np.float32)
+        if self.energy_values is None or tuple(state.shape) != tuple(self.energy_values.shape):
+            raise ValueError("state shape %s does not match the compiled pyramid" % (state.shape,))
+        self.energy_values.copy_(torch.from_numpy(state))
+
+    # -- the graph -----------------------------------------------------------------------------------------
+    def run_device(self, pyramid_tensor):
+        """The six fetched tensors as GPU tensors."""
+        import torch
+        rt = _runtime
+        if _runtime.is_torch_tensor(pyramid_tensor):
+            x = pyramid_tensor.to(torch.float32)
+        else:
+            x = torch.from_numpy(np.ascontiguousarray(pyramid_tensor, np.float32)).to(
+                torch.device("cuda", self.device_index))
+        if x.ndim != 4 or x.shape[3] != 3:
+            raise ValueError("pyramid tensor must be [levels, h, w, 3]")
+        if self.pyramid_tensor_shape != tuple(x.shape):
+            self.pre_compile(x)
+        ch = rt.rgb_line_end(x, self.kernels)
+        gray = ch["value"]
+        centroids, importances = rt.centroids(rt.affine_clip(gray, div=255.0), *self.centroid_region_shape[1:])
+        importances = rt.affine_clip(importances, 255 / 4.0, 0.0, 1.0, 256.0, -1.0)
+        root_e = np.float32(m.e ** .5)
+        half = (int(np.float32(x.shape[1]) / root_e), int(np.float32(x.shape[2]) / root_e))
+        im2 = rt.resize_nearest(gray, half)
+        centroids2, _ = rt.centroids(rt.affine_clip(im2, div=255.0), *self.centroid_region_shape[1:])
+        fired, update = rt.boosting_step(importances, self.energy_values, 1.0, 1.0,
+                                         recovery_mode(self.input_based_recovery, self.constant_recovery), True)
+        return [ch["orient"], rt.affine_clip(centroids, -255.0, 255.0), rt.affine_clip(centroids2, -255.0, 255.0),
+                rt.affine_clip(fired, 255.0), update, ch["line_end"]]
+
+    def run(self, pyramid_tensor):
+        return [t.cpu().numpy() for t in self.run_device(pyramid_tensor)]
+
+    def callback(self, frame, cam_id=None, depth=2):
+        z_tensor = np.asarray(frame, dtype=np.float32)
+        z_tensor = zoom.from_image(z_tensor, self.output_colors, self.output_size, self.zoom_ratio)
+        tensors = self.run(z_tensor)
+        return [frame] + [[tensors[x][y] for y in range(len(tensors[x]))] for x in range(6)]

@@ -350,6 +350,63 @@ def test_get_boosting_first_step_from_initial_state_and_packed(rt):
         get_boosting(np.ones((1, 4, 4, 1), np.float32), np.ones((1, 4, 4, 1), np.float64))
 
 
+# ----------------------------------------------------------------------------- display graph
+
+def test_affine_clip_and_resize_nearest(rt):
+    rng = np.random.default_rng(77)
+    x = (rng.standard_normal((2, 13, 17, 3)) * 100).astype(np.float32)
+    x[0, 0, 0, 0] = np.nan
+    for kw in (dict(div=255.0), dict(mul=255 / 4.0, lo=1.0, hi=256.0, post_add=-1.0), dict(mul=-255.0, add=255.0)):
+        got = rt.affine_clip(x, **kw)
+        np.testing.assert_array_equal(got, so.affine_clip(x, **kw))
+    for out in ((7, 10), (13, 17), (30, 19), (1, 1)):
+        np.testing.assert_array_equal(rt.resize_nearest(x, out), so.resize_nearest_tf1(x, *out))
+    packed, levels = ragged_pyramid(rt, 3, [(12, 20), (7, 9)], c=1, n_frames=2)
+    got = rt.resize_nearest(packed, [(7, 12), (9, 4)])
+    np.testing.assert_array_equal(got.level(0), so.resize_nearest_tf1(levels[0], 7, 12))
+    np.testing.assert_array_equal(got.level(1), so.resize_nearest_tf1(levels[1], 9, 4))
+
+
+def test_line_end_displayer_three_frames(rt, kernels):
+    """The reference application graph (recognition_testing.py:60-144) over three successive frames of one
+    stream: all six fetched tensors and the boosting state against the oracle."""
+    from pysilent_amd.recognition_testing import LineEndDisplayer
+    from pysilent_amd.util import zoom
+    disp = LineEndDisplayer(output_size=(96, 64))
+    ks = {k: kernels[k] for k in ("rgc", "rgby", "stripe", "blur", "end")}
+    want_state = None
+    names = ["orient", "255 - centroids * 255", "255 - centroids2 * 255", "fired * 255", "update", "padded"]
+    for step in range(3):
+        frame = structured_frame(40 + step, 150, 230, 3)
+        res = disp.callback(frame)
+        assert len(res) == 7 and res[0] is frame
+        pyr = zoom.from_image(frame.astype(np.float32), 3, (96, 64), disp.zoom_ratio)
+        assert pyr.shape[1:] == (64, 96, 3) and len(res[1]) == pyr.shape[0]
+        if want_state is None:
+            want_state = np.full((pyr.shape[0], 22, 32, 1), 8, np.float32)
+        # the filter chain against the oracle chain; everything after pad_inwards against the oracle applied to the
+        # GPU's own padded map (a centroid is a ratio of sums: where a cell holds only rounding residue the ratio
+        # is ill-conditioned, so stage-wise comparison is the meaningful one -- same idea as "end|gpu-cs" above)
+        full, _ = so.line_end_displayer_run(pyr, want_state, ks)
+        got = [np.stack(r) for r in res[1:]]
+        assert_close(got[0], full[0], RTOL, what="orient, frame %d" % step)
+        assert_close(got[5], full[5], RTOL, scale=255.0, what="padded, frame %d" % step)
+        tail, want_state = so.line_end_displayer_tail(got[5], want_state)
+        for i, name in enumerate(names[1:5]):
+            assert got[1 + i].shape == tail[i].shape, name
+            # 255 - |c - x| * 255: the terms are pixel coordinates (< h + w) times 255
+            scale = 255.0 * (64 + 96) if i < 2 else 255.0
+            assert_close(got[1 + i], tail[i], RTOL, scale=scale, what="%s, frame %d" % (name, step))
+        assert_close(disp.get_state(), want_state, RTOL, what="state, frame %d" % step)
+    saved = disp.get_state()
+    disp.set_state(saved * 0 + 8)
+    assert (disp.get_state() == 8).all()
+    shown = disp.display(structured_frame(1, 150, 230, 3))
+    assert len(shown) == 7 and float(np.nanmax(shown[6])) <= 1.0
+    with pytest.raises(NotImplementedError):
+        disp.run_camera()
+
+
 # ----------------------------------------------------------------------------- RGB chain
 
 @pytest.mark.parametrize("policy,frame", [("ieee", "noise"), ("zero", "structured"), ("ieee", "structured")])

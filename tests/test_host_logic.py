@@ -106,3 +106,20 @@ def test_index_tensor_matches_reference_test_literal():
     assert index_tensor.from_shape([4, 2, 2, 3]).tolist() == [[[0, 0], [1, 0]], [[0, 1], [1, 1]]]
     assert index_tensor.from_tensor(np.ones((4, 2, 2, 3))).tolist() == [[[0, 0], [1, 0]], [[0, 1], [1, 1]]]
     npt.assert_array_equal(index_tensor.from_shape([1, 5, 7, 1]), so.index_tensor_from_shape([1, 5, 7, 1]))
+
+
+def test_stream_sharding_keeps_streams_whole():
+    from pysilent_amd import distributed as d
+    owners = {}
+    for rank in range(3):
+        for s_ in d.shard_stream_indices(8, rank, 3):
+            assert s_ not in owners
+            owners[s_] = rank
+    assert sorted(owners) == list(range(8)) and all(owners[s_] == s_ % 3 for s_ in owners)
+
+
+def test_recovery_mode_mirrors_reference_errors():
+    from pysilent_amd.util.energy.recovery import recovery_mode
+    assert recovery_mode(False, True) == 1 and recovery_mode(True, False) == 2 and recovery_mode(True, True) == 3
+    with pytest.raises(ValueError, match="You must choose a type of recovery"):
+        recovery_mode(False, False)
