@@ -3,15 +3,14 @@
 Behavioural mirror of ``stripe_tensor`` / ``simplex_stripe_tensors`` /
 ``rgb_2d_stripe_tensors`` in
 slam_recognition/constant_convolutions/edge_orientation_detector/stripe_tensor.py:21-108.
-The 7x7 ``edge_tensor`` family of the same reference directory is out of scope
-(not used by any filter or pipeline).
+The 7x7 ``edge_tensor`` family of the same reference directory is in ``.edge_tensor``.
 """
 import numpy as np
 
-from ..util.attractor import euclidian_attractor_function_generator
-from ..util.normalize import normalize_tensor_positive_negative
-from ..util.orientation import above_axis_simplex_coordinates
-from ._oriented import expand_profile
+from ...util.attractor import euclidian_attractor_function_generator
+from ...util.normalize import normalize_tensor_positive_negative
+from ...util.orientation import above_axis_simplex_coordinates
+from .._oriented import expand_profile
 
 __all__ = ["stripe_tensor", "simplex_stripe_tensors", "rgb_2d_stripe_tensors"]
 

@@ -56,6 +56,8 @@ def main():
         center_surround_tensor, midget_rgc, rgby, rgby_3)
     from slam_recognition.constant_convolutions.edge_orientation_detector.stripe_tensor import (
         rgb_2d_stripe_tensors, stripe_tensor)
+    import importlib
+    ref_edge = importlib.import_module("slam_recognition.constant_convolutions.edge_orientation_detector.edge_tensor")
     from slam_recognition.constant_convolutions.oriented_end_detector import (
         end_tensor, rgb_2d_end_tensors, simplex_end_tensors)
     from slam_recognition.constant_convolutions.gaussian_blur.gaussian_blur import blur_tensor
@@ -108,6 +110,17 @@ def main():
     out["stripe_tensor_diag_rgb"] = stripe_tensor([0.5, 0.8660254037844386], [1, 1, 1], [4, -1, -1],
                                                   [1, 1, 1], [-4, 1, 1])
 
+    # 7x7 thick-edge family
+    out["edge_tensor_x_gray"] = ref_edge.edge_tensor([1.0, 0.0], [1], [1], [1], [-1])
+    out["edge_tensor_diag_rgb"] = ref_edge.edge_tensor([-0.5, 0.8660254037844386], [1, 1, 1], [4, -1, -1],
+                                                       [1, 1, 1], [-4, 1, 1])
+    out["rgb_2d_edge_tensors"] = ref_edge.rgb_2d_edge_tensors()
+    out["rgb_2d_edge_tensors_time_diff"] = ref_edge.rgb_2d_edge_tensors_time_diff()
+    out["rgb_2d_end_tensors_7x7"] = ref_edge.rgb_2d_end_tensors()
+    out["simplex_edge_tensors_flip0"] = np.stack(ref_edge.simplex_edge_tensors(
+        2, [[1, 0, 0]] * 3, [[1, 0, 0], [0, 1, 0], [0, 0, 1]], [[0, 1, 0]] * 3, [[0, 0, 1]] * 3, flip=0), 0)
+    f2n = euclidian_attractor_function_generator(2, max_positive=0.0, max_negative=-1.0)
+
     xs = np.array([-2.5, -1.0, -0.25, 0.0, 0.25, 0.5, 1.0, 1.4142135623730951, 2.0, 3.0])
     f2 = euclidian_attractor_function_generator(2)
     f2b = euclidian_attractor_function_generator(2, max_negative=0)
@@ -118,6 +131,7 @@ def main():
     out["attractor_euclid_n2"] = np.array([f2(x) for x in xs])
     out["attractor_euclid_n2_neg0"] = np.array([f2b(x) for x in xs])
     out["attractor_euclid_n3_p2_n05"] = np.array([f3(x) for x in xs])
+    out["attractor_euclid_n2_p0_nm1"] = np.array([f2n(x) for x in xs])
     out["attractor_linear"] = np.array([fl(x) for x in xs])
     out["attractor_linear_p2_n05"] = np.array([fl2(x) for x in xs])
 

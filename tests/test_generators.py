@@ -99,6 +99,17 @@ CASES = {
     "stripe_tensor_x_gray": lambda g: cc.stripe_tensor([1., 0.], [1], [1], [1], [-1]),
     "stripe_tensor_diag_rgb": lambda g: cc.stripe_tensor([0.5, 0.8660254037844386], [1, 1, 1], [4, -1, -1],
                                                          [1, 1, 1], [-4, 1, 1]),
+    # 7x7 thick-edge family
+    "edge_tensor_x_gray": lambda g: cc.edge_tensor([1., 0.], [1], [1], [1], [-1]),
+    "edge_tensor_diag_rgb": lambda g: cc.edge_tensor([-0.5, 0.8660254037844386], [1, 1, 1], [4, -1, -1],
+                                                     [1, 1, 1], [-4, 1, 1]),
+    "rgb_2d_edge_tensors": lambda g: cc.rgb_2d_edge_tensors(),
+    "rgb_2d_edge_tensors_time_diff": lambda g: cc.rgb_2d_edge_tensors_time_diff(),
+    "rgb_2d_end_tensors_7x7": lambda g: cc.edge_orientation_detector.rgb_2d_end_tensors(),
+    "simplex_edge_tensors_flip0": lambda g: np.stack(cc.simplex_edge_tensors(
+        2, [[1, 0, 0]] * 3, [[1, 0, 0], [0, 1, 0], [0, 0, 1]], [[0, 1, 0]] * 3, [[0, 0, 1]] * 3, flip=0), 0),
+    "attractor_euclid_n2_p0_nm1": lambda g: euclidian_attractor_function_generator(
+        2, max_positive=0.0, max_negative=-1.0)(g["attractor_x"]),
     "attractor_euclid_n2": lambda g: euclidian_attractor_function_generator(2)(g["attractor_x"]),
     "attractor_euclid_n2_neg0": lambda g: euclidian_attractor_function_generator(2, max_negative=0)(g["attractor_x"]),
     "attractor_euclid_n3_p2_n05": lambda g: euclidian_attractor_function_generator(3, 2.0, 0.5)(g["attractor_x"]),
@@ -139,3 +150,13 @@ def test_kernel_structure_facts(golden):
     assert (blur == blur[:, :, :1, :1]).all() and blur[3, 3, 0, 0] == 1.0 and blur[3, 0, 0, 0] == 1.0 / 7
     with pytest.raises(ValueError):
         cc.stripe_tensor([1., 0.], [1, 1, 1], [1, 0], [1, 1, 1], [1, 0])   # non-square channel lists
+
+
+def test_edge_tensor_facet_passes_through_tap_1_not_the_centre():
+    # reference behaviour kept on purpose (edge_tensor.py:56): distance is measured from tap (1, 1) of the 7-grid
+    z = cc.edge_tensor([1., 0.], [1], [1], [1], [-1])[:, :, 0, 0]
+    assert (z[1] == 0).all() and (z[0] < 0).all() and (z[2:] > 0).all()
+    npt.assert_allclose(z[0].sum(), -1.0, atol=1e-12)          # normalised: sum- = -1, sum+ = +1
+    npt.assert_allclose(z[2:].sum(), 1.0, atol=1e-12)
+    with pytest.raises(ValueError):
+        cc.edge_tensor([1., 0.], [1, 1], [1], [1, 1], [1])      # non-square channel lists, like the reference

@@ -38,6 +38,19 @@ def test_conv2d_reference_kernels(rt, kernels, name, shape):
     assert_close(got, so.conv2d_same(x, kernels[name], relu=True), RTOL, what=name)
 
 
+@pytest.mark.parametrize("gen", ["rgb_2d_edge_tensors", "rgb_2d_edge_tensors_time_diff", "rgb_2d_end_tensors"])
+def test_conv2d_7x7_thick_edge_banks(rt, gen):
+    """the 7x7x3x3 edge_tensor banks through the 7x7 stencil (the blur's kernel shape)."""
+    from pysilent_amd.constant_convolutions import edge_orientation_detector as eod
+    from pysilent_amd.util.apply_filter import apply_filter
+    k = getattr(eod, gen)()
+    assert k.shape == (7, 7, 3, 3)
+    x = structured_frame(5, 61, 83, 3)[None]
+    assert_close(apply_filter(x, k), so.conv2d_same(x, k), RTOL, what=gen)
+    assert_close(rt.conv2d_same(x, k, relu=True, clip_hi=255.0), so.conv2d_same(x, k, relu=True, clip_hi=255.0), RTOL,
+                 what=gen + " relu clip")
+
+
 @pytest.mark.parametrize("kshape", [(3, 3, 1, 1), (3, 3, 1, 3), (3, 3, 1, 4), (3, 3, 1, 8), (3, 3, 3, 1), (3, 3, 3, 4),
                                     (7, 7, 1, 1), (5, 5, 3, 2), (2, 2, 3, 3), (1, 3, 3, 3), (4, 6, 2, 5)])
 def test_conv2d_shapes_including_generic_path(rt, kshape):
