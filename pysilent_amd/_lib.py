@@ -9,7 +9,8 @@ import importlib.util
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libsilent_hip.so")
+# SILENT_LIB_PATH: load another build of the same library (kernel experiments, scripts/experiment_builds.sh)
+LIB_PATH = os.environ.get("SILENT_LIB_PATH") or os.path.join(_HERE, "lib", "libsilent_hip.so")
 
 SILENT_OK = 0
 SILENT_E_INVALID = -1

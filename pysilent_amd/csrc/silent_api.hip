@@ -849,8 +849,9 @@ SILENT_EXPORT int silent_pyramid_plan_create(silent_ctx* ctx, int frame_h, int f
         axis_table(d.src_w, d.zoom_w, xb, xidx.data() + (size_t)d.xtab_off * 6, xwl);
         axis_table(d.src_h, d.zoom_h, yb, yidx.data() + (size_t)d.ytab_off * 6, ywl);
         // zoom factor exactly 1 <=> every output samples an integer coordinate: weights [1,26,66,26,1,~0]/120
+        // (the streaming unit kernels mirror with one reflection: needs at least kMirrorNearMin source pixels per axis)
         const bool unit = d.zoom_h == d.src_h && d.zoom_w == d.src_w && std::fabs(xwl[5]) < 1e-12f &&
-                          std::fabs(ywl[5]) < 1e-12f;
+                          std::fabs(ywl[5]) < 1e-12f && d.src_h >= kMirrorNearMin && d.src_w >= kMirrorNearMin;
         d.kind = unit ? kPyrUnit : kPyrGeneral;
         tab.unit_tile_start[l] = (int)unit_tiles;
         tab.zero_chunk_start[l] = (int)zero_chunks;
@@ -955,10 +956,12 @@ SILENT_EXPORT int silent_pyramid_plan_create(silent_ctx* ctx, int frame_h, int f
             const int G = tab.n_general;
             const int tiles_y = (u.out_h + kFusedTH - 1) / kFusedTH;
             const int waves_x = ((u.out_w + kFusedTW - 1) / kFusedTW) * 4;
-            const size_t prog_dw = (size_t)tiles_y * kStreamRows * G * kStreamProgDw;
-            std::vector<int> prog(prog_dw, 0), hdr((size_t)G * waves_x * 2, 0), rec((size_t)G * waves_x * 64 * 8, 0);
-            for (size_t e = 0; e < prog_dw / kStreamProgDw; ++e) prog[e * kStreamProgDw + 4] = 7 << 4;  // no slot completes
-            std::vector<char> used(prog_dw / kStreamProgDw * kStreamSlots, 0);
+            const int Gp = stream_pad_levels(G), PR = kStreamProgRow(Gp);
+            const size_t n_rec = (size_t)tiles_y * kStreamRows;
+            std::vector<int> prog(n_rec * PR, 0), hdr((size_t)G * waves_x * 2, 0), rec((size_t)G * waves_x * 64 * 8, 0);
+            for (size_t r = 0; r < n_rec; ++r)
+                for (int gg = 0; gg < Gp; ++gg) prog[r * PR + gg] = 7 << 4;  // inert: feeds nothing, no slot completes
+            std::vector<char> used(n_rec * G * kStreamSlots, 0);
             int g = 0;
             for (int l = 0; l < n_levels && ok; ++l) {
                 const PyrLevelDev& d = tab.lv[l];
@@ -973,16 +976,18 @@ SILENT_EXPORT int silent_pyramid_plan_create(silent_ctx* ctx, int frame_h, int f
                     for (int j = 0; j < 6; ++j) {
                         const int i = yb[oy] - t * kFusedTH + 2 + j;  // stream row of tap j (a tile streams rows y0-4 ..)
                         if (i < 0 || i >= kStreamRows) { ok = false; break; }
-                        const size_t e = ((size_t)t * kStreamRows + i) * G + g;
+                        const size_t r = (size_t)t * kStreamRows + i;
+                        const size_t e = r * G + g;
                         if (used[e * kStreamSlots + slot]) { ok = false; break; }  // two live rows in one slot: step too small
                         used[e * kStreamSlots + slot] = 1;
-                        int* pe = prog.data() + e * kStreamProgDw;
-                        std::memcpy(pe + slot, &yw[(size_t)(d.ytab_off + oy) * 6 + j], 4);
-                        pe[4] |= 128;  // this stream row feeds level g
-                        if (j == 0) pe[4] |= 1 << slot;
+                        int* pr = prog.data() + r * PR;
+                        int& meta = pr[g];
+                        std::memcpy(pr + stream_w_off(Gp, g) + slot, &yw[(size_t)(d.ytab_off + oy) * 6 + j], 4);
+                        meta |= 128;  // this stream row feeds level g
+                        if (j == 0) meta |= 1 << slot;
                         if (j == 5) {
-                            if (((pe[4] >> 4) & 7) != 7) { ok = false; break; }  // two rows completing together
-                            pe[4] = (pe[4] & 0x8f) | (slot << 4) | (oy << 8);
+                            if (((meta >> 4) & 7) != 7) { ok = false; break; }  // two rows completing together
+                            meta = (meta & 0x8f) | (slot << 4) | (oy << 8);
                         }
                     }
                 }
@@ -1157,8 +1162,20 @@ SILENT_EXPORT int silent_gray_pass_dev(silent_ctx* ctx, const silent_pyramid_pla
         if (ctx->profiling) HIP_TRY(ctx, hipEventRecord(ctx->ev0, s));
         if (stream_path) {
             const StreamTab& st = plan->stream;
-#define STREAM_LAUNCH(K_, G_) \
-    hipLaunchKernelGGL((gray_stream_kernel<K_, G_>), dim3((unsigned)blocks), dim3(256), 0, s, frames, pyr, cs_out, end_out, ft, st, w, clip_hi, (unsigned)((kopts >> 5) & 1))
+            // 16-byte stores of the unit level's 1-channel maps need every row start on a 4-pixel boundary
+            const FusedLevel& u0 = ft.lv[0];
+            const bool vec = !(kopts & 64u) && ft.frame_px % 4 == 0 && u0.px_off % 4 == 0 && u0.out_w % 4 == 0 &&
+                             (reinterpret_cast<uintptr_t>(pyr) & 15) == 0 &&
+                             (!cs_out || (reinterpret_cast<uintptr_t>(cs_out) & 15) == 0);
+#define STREAM_LAUNCH(K_, G_)                                                                                          \
+    do {                                                                                                               \
+        if (vec)                                                                                                       \
+            hipLaunchKernelGGL((gray_stream_kernel<K_, G_, true>), dim3((unsigned)blocks), dim3(256), 0, s, frames,    \
+                               pyr, cs_out, end_out, ft, st, w, clip_hi, (unsigned)((kopts >> 5) & 1));                \
+        else                                                                                                           \
+            hipLaunchKernelGGL((gray_stream_kernel<K_, G_, false>), dim3((unsigned)blocks), dim3(256), 0, s, frames,   \
+                               pyr, cs_out, end_out, ft, st, w, clip_hi, (unsigned)((kopts >> 5) & 1));                \
+    } while (0)
             if (st.G <= 4) {
                 if (n_orient == 3) STREAM_LAUNCH(3, 4);
                 else if (n_orient == 4) STREAM_LAUNCH(4, 4);

@@ -55,14 +55,24 @@ __device__ __forceinline__ TileCoord locate_tile(const LevelTab& tab, unsigned b
 }
 
 // Neighbour exchange inside a wave by DPP wavefront shifts (VALU, no LDS round trip).
-// lane i receives lane i-1 (lane 0 keeps its own value) / lane i+1 (lane 63 keeps its own value).
+// lane i receives lane i-1 (lane 0 gets 0) / lane i+1 (lane 63 gets 0): bound_ctrl with a zero "old" value is a
+// single v_mov_b32_dpp; keeping the lane's own value instead costs an extra v_mov per shift.  The edge lanes of a
+// wave are halo lanes in every kernel that uses these.
 __device__ __forceinline__ float from_lane_below(float v) {
-    const int i = __float_as_int(v);
-    return __int_as_float(__builtin_amdgcn_update_dpp(i, i, 0x138 /* wave_shr:1 */, 0xf, 0xf, false));
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x138 /* wave_shr:1 */, 0xf, 0xf, true));
 }
 __device__ __forceinline__ float from_lane_above(float v) {
-    const int i = __float_as_int(v);
-    return __int_as_float(__builtin_amdgcn_update_dpp(i, i, 0x130 /* wave_shl:1 */, 0xf, 0xf, false));
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x130 /* wave_shl:1 */, 0xf, 0xf, true));
+}
+
+// scipy 'mirror' extension (d c b | a b c d | c b a) for an index within ONE reflection of [0, n): exact for
+// -(n-1) <= i <= 2(n-1); anything further out is clamped into range (such taps only feed outputs that are
+// never stored).  The streaming kernels reach at most 4 pixels outside, hence kMirrorNearMin.
+constexpr int kMirrorNearMin = 5;
+__device__ __forceinline__ int mirror_near(int i, int n) {
+    i = i < 0 ? -i : i;
+    i = i >= n ? 2 * (n - 1) - i : i;
+    return min(max(i, 0), n - 1);
 }
 
 // tf.maximum(x, [0]) with Eigen's CPU functor: a NaN stays a NaN (oracle: relu_tf).

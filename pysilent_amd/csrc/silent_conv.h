@@ -395,19 +395,11 @@ __global__ __launch_bounds__(256) void gray_unit_fused_kernel(const float* __res
     const long long base_px = (long long)frame * tab.frame_px + lv.px_off;
 
     // scipy 'mirror' inside the crop, then the crop's offset in the frame
-    auto mirror = [](int i, int n) {
-        if ((unsigned)i < (unsigned)n) return i;
-        if (n == 1) return 0;
-        const int period = 2 * (n - 1);
-        if (i < 0) i = -i;
-        i %= period;
-        return i >= n ? period - i : i;
-    };
-    const long long sx = mirror(ox, lv.src_w) + lv.src_x0;
+    const long long sx = mirror_near(ox, lv.src_w) + lv.src_x0;
     float in[R + 8];
 #pragma unroll
     for (int i = 0; i < R + 8; ++i)
-        in[i] = src[(long long)(mirror(y0 - 4 + i, lv.src_h) + lv.src_y0) * W + sx];
+        in[i] = src[(long long)(mirror_near(y0 - 4 + i, lv.src_h) + lv.src_y0) * W + sx];
 #pragma unroll
     for (int i = 0; i < R + 8; ++i) asm volatile("" ::"v"(in[i]));  // retire loads before the first store
 
@@ -533,49 +525,46 @@ constexpr int kStreamSlots = 4;
 // then 1 -- enough for zoom ladders of ratio >= e^0.5 (the reference's default) and 2; host-checked per plan
 __host__ __device__ constexpr int stream_slots(int g) { return g == 0 ? 4 : (g == 1 ? 3 : (g <= 3 ? 2 : 1)); }
 constexpr int kStreamRows = kFusedTH + 8;
-constexpr int kStreamProgDw = 8;  // per (stream row, level): 4 weights, meta, 3 pad
+// Row program, one record per stream row of a tile row, padded to the kernel's template G (4 or 7 levels):
+//   [meta(0) .. meta(Gp-1)] [weights of level 0 (4)] [level 1 (3)] [level 2 (2)] ... ; kStreamProgRow(Gp) dwords.
+// It is wave-uniform data: the kernel reads it with scalar loads, one record ahead of the row it is working on.
+__host__ __device__ constexpr int stream_pad_levels(int g) { return g <= 4 ? 4 : 7; }
+__host__ __device__ constexpr int stream_w_off(int gp, int g) {
+    int o = gp;
+    for (int h = 0; h < g; ++h) o += (h == 0 ? 4 : (h == 1 ? 3 : (h <= 3 ? 2 : 1)));
+    return o;
+}
+__host__ __device__ constexpr int kStreamProgRow(int gp) { return gp <= 4 ? 16 : 24; }  // >= stream_w_off(gp, gp)
 // meta: bits 0-3 "slot restarts", bits 4-6 completing slot (7 = none), bit 7 "row feeds this level", bits 8.. output row
 
 struct StreamTab {
     int G;                        // general levels handled here (<= template G; extra ones are inert)
     int tiles_y, waves_x;         // tile rows of the unit level, 56-column wave tiles per row
-    const int* row_prog;          // [tiles_y][kStreamRows][G][kStreamProgDw]
+    const int* row_prog;          // [tiles_y][kStreamRows][kStreamProgRow(Gp)], Gp = stream_pad_levels(G)
     const int* col_hdr;           // [G][waves_x][2]: first output column, number of outputs
     const int* col_rec;           // [G][waves_x][64][8]: lane of tap 0, 6 weight bits, pad
     long long px_off[8];          // pixel offset of level g inside one pyramid
     int out_w[8];
 };
 
-template <int K, int G>
+template <int K, int G, bool VEC>
 __global__ __launch_bounds__(256) void gray_stream_kernel(const float* __restrict__ frames, float* __restrict__ pyr,
                                                           float* __restrict__ cs_out, float* __restrict__ end_out,
                                                           const FusedTab tab, const StreamTab st, const GrayW wts,
                                                           float clip_hi, unsigned opts) {
     constexpr int R = kFusedTH, NR = kStreamRows;
     __shared__ __attribute__((aligned(16))) float s_slab[K == 8 ? 4 * 512 : 4];
-    __shared__ __attribute__((aligned(16))) int s_prog[NR * G * kStreamProgDw];
-    __shared__ float s_rows[4][NR][64];  // the streamed rows of each wave (wave private)
+    __shared__ __attribute__((aligned(16))) float s_rows[4][NR][64];  // the streamed rows of each wave (wave private)
     const unsigned bid = (opts & 1u) ? xcd_swizzle(blockIdx.x, gridDim.x) : blockIdx.x;
     const int frame = (int)(bid / (unsigned)tab.tiles_per_frame);
     const int rem = (int)(bid - (unsigned)frame * (unsigned)tab.tiles_per_frame);
     const FusedLevel& lv = tab.lv[0];  // the one unit level
     const int ty = rem / lv.tiles_x, tx = rem - ty * lv.tiles_x;
 
-    // row program of this tile row -> LDS (st.G <= G levels are live; the rest stays inert)
-    {
-        const int* __restrict__ src_prog = st.row_prog + (long long)ty * (NR * st.G * kStreamProgDw);
-        for (int j = threadIdx.x; j < NR * G * kStreamProgDw; j += 256) {
-            const int r = j / (G * kStreamProgDw), q = j - r * (G * kStreamProgDw);
-            const int g = q / kStreamProgDw, e = q - g * kStreamProgDw;
-            s_prog[j] = g < st.G ? src_prog[(r * st.G + g) * kStreamProgDw + e] : (e == 4 ? (7 << 4) : 0);
-        }
-    }
-    __syncthreads();
-
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int xw0 = tx * kFusedTW + wave * kFusedCols;
-    if (xw0 >= lv.out_w) return;  // wave-uniform
+    const bool live = xw0 < lv.out_w;  // wave-uniform: this wave has columns of the level
     const int wx_tile = tx * 4 + wave;
     const int y0 = ty * R;
     const int ox = xw0 + lane - 4;
@@ -584,38 +573,46 @@ __global__ __launch_bounds__(256) void gray_stream_kernel(const float* __restric
     const long long frame_px0 = (long long)frame * tab.frame_px;
     const long long base_px = frame_px0 + lv.px_off;
 
-    auto mirror = [](int i, int n) {
-        if ((unsigned)i < (unsigned)n) return i;
-        if (n == 1) return 0;
-        const int period = 2 * (n - 1);
-        if (i < 0) i = -i;
-        i %= period;
-        return i >= n ? period - i : i;
-    };
-    const long long sx = mirror(ox, lv.src_w) + lv.src_x0;
+    // request the 24 frame rows and the per-level column records of this lane (output j of the wave's run = lane j)
+    const long long sx = mirror_near(ox, lv.src_w) + lv.src_x0;
     float in[R + 8];
-#pragma unroll
-    for (int i = 0; i < R + 8; ++i)
-        in[i] = src[(long long)(mirror(y0 - 4 + i, lv.src_h) + lv.src_y0) * W + sx];
-    // per-level column records of this lane (output j of the wave's run = lane j), requested with the rows
     int gx0[G], gn[G], glane[G];
     float gw[G][6];
 #pragma unroll
+    for (int i = 0; i < R + 8; ++i) in[i] = 0.0f;
+#pragma unroll
     for (int g = 0; g < G; ++g) {
-        const int gg = min(g, st.G - 1);
-        const int* __restrict__ h = st.col_hdr + ((long long)gg * st.waves_x + wx_tile) * 2;
-        gx0[g] = h[0];
-        gn[g] = g < st.G ? h[1] : 0;
-        const int4* __restrict__ rec = reinterpret_cast<const int4*>(st.col_rec + (((long long)gg * st.waves_x + wx_tile) * 64 + lane) * 8);
-        const int4 a = rec[0], b = rec[1];
-        glane[g] = a.x * 4;  // byte index for ds_bpermute
-        gw[g][0] = __int_as_float(a.y);
-        gw[g][1] = __int_as_float(a.z);
-        gw[g][2] = __int_as_float(a.w);
-        gw[g][3] = __int_as_float(b.x);
-        gw[g][4] = __int_as_float(b.y);
-        gw[g][5] = __int_as_float(b.z);
+        gx0[g] = gn[g] = glane[g] = 0;
+#pragma unroll
+        for (int j = 0; j < 6; ++j) gw[g][j] = 0.0f;
     }
+    if (live) {
+#if defined(SILENT_EXPERIMENT) && (SILENT_EXPERIMENT >= 3 && SILENT_EXPERIMENT != 8)   // no frame loads at all
+#pragma unroll
+        for (int i = 0; i < R + 8; ++i) in[i] = (float)(i + lane) + clip_hi;
+#else
+#pragma unroll
+        for (int i = 0; i < R + 8; ++i)
+            in[i] = src[(long long)(mirror_near(y0 - 4 + i, lv.src_h) + lv.src_y0) * W + sx];
+#endif
+#pragma unroll
+        for (int g = 0; g < G; ++g) {
+            const int gg = min(g, st.G - 1);
+            const int* __restrict__ h = st.col_hdr + ((long long)gg * st.waves_x + wx_tile) * 2;
+            gx0[g] = h[0];
+            gn[g] = g < st.G ? h[1] : 0;
+            const int4* __restrict__ rec = reinterpret_cast<const int4*>(st.col_rec + (((long long)gg * st.waves_x + wx_tile) * 64 + lane) * 8);
+            const int4 a = rec[0], b = rec[1];
+            glane[g] = a.x * 4;  // byte index for ds_bpermute
+            gw[g][0] = __int_as_float(a.y);
+            gw[g][1] = __int_as_float(a.z);
+            gw[g][2] = __int_as_float(a.w);
+            gw[g][3] = __int_as_float(b.x);
+            gw[g][4] = __int_as_float(b.y);
+            gw[g][5] = __int_as_float(b.z);
+        }
+    }
+    if (!live) return;
 #pragma unroll
     for (int i = 0; i < R + 8; ++i) asm volatile("" ::"v"(in[i]));  // retire loads before the first store
 #pragma unroll
@@ -627,122 +624,41 @@ __global__ __launch_bounds__(256) void gray_stream_kernel(const float* __restric
 #pragma unroll
     for (int i = 0; i < R + 8; ++i) s_rows[wave][i][lane] = in[i];
 
-    // ================= pass 1: unit level (pyramid + CS + end), registers only =================
-    const bool col_in = ox >= 0 && ox < lv.out_w;
-    const bool out_lane = lane >= 4 && lane < 4 + kFusedCols && ox < lv.out_w;
-    {
-        float hw[5] = {0, 0, 0, 0, 0};
-        float iw[3][3], cw[3][3];
-#pragma unroll
-        for (int a = 0; a < 3; ++a)
-#pragma unroll
-            for (int b = 0; b < 3; ++b) iw[a][b] = cw[a][b] = 0.0f;
-#pragma unroll
-        for (int i = 0; i < R + 8; ++i) {
-            {
-                const float c0 = in[i];
-                const float l1 = from_lane_below(c0), l2 = from_lane_below(l1);
-                const float r1 = from_lane_above(c0), r2 = from_lane_above(r1);
-                float h = tab.wx[0] * l2;
-                h = __builtin_fmaf(tab.wx[1], l1, h);
-                h = __builtin_fmaf(tab.wx[2], c0, h);
-                h = __builtin_fmaf(tab.wx[3], r1, h);
-                h = __builtin_fmaf(tab.wx[4], r2, h);
-#pragma unroll
-                for (int j = 0; j < 4; ++j) hw[j] = hw[j + 1];
-                hw[4] = h;
-            }
-            if (i >= 4) {
-                const int p = y0 + i - 6;
-                float v = tab.wy[0] * hw[0];
-#pragma unroll
-                for (int j = 1; j < 5; ++j) v = __builtin_fmaf(tab.wy[j], hw[j], v);
-                v = (p < lv.zoom_h && ox < lv.zoom_w) ? v : 0.0f;
-                if (p >= y0 && p < y0 + R && p < lv.out_h && out_lane) pyr[base_px + (long long)p * lv.out_w + ox] = v;
-                v = (p >= 0 && p < lv.out_h && col_in) ? v : 0.0f;
-#pragma unroll
-                for (int b = 0; b < 3; ++b) {
-                    iw[0][b] = iw[1][b];
-                    iw[1][b] = iw[2][b];
-                }
-                iw[2][1] = v;
-                iw[2][0] = from_lane_below(v);
-                iw[2][2] = from_lane_above(v);
-            }
-            if (i >= 6) {
-                const int c = y0 + i - 7;
-                float acc = 0.0f;
-#pragma unroll
-                for (int dy = 0; dy < 3; ++dy)
-#pragma unroll
-                    for (int dx = 0; dx < 3; ++dx) acc = __builtin_fmaf(iw[dy][dx], wts.cs[dy * 3 + dx], acc);
-                float cs = relu_tf(acc);
-                cs = (c >= 0 && c < lv.out_h && col_in) ? cs : 0.0f;
-#pragma unroll
-                for (int b = 0; b < 3; ++b) {
-                    cw[0][b] = cw[1][b];
-                    cw[1][b] = cw[2][b];
-                }
-                cw[2][1] = cs;
-                cw[2][0] = from_lane_below(cs);
-                cw[2][2] = from_lane_above(cs);
-            }
-            if (i >= 8) {
-                const int y = y0 + i - 8;
-                if (y < lv.out_h) {  // wave-uniform
-                    const long long px = base_px + (long long)y * lv.out_w + ox;
-                    if (cs_out && out_lane) cs_out[px] = cw[1][1];
-                    if (end_out) {
-                        float acc[K];
-#pragma unroll
-                        for (int k = 0; k < K; ++k) acc[k] = 0.0f;
-#pragma unroll
-                        for (int dy = 0; dy < 3; ++dy)
-#pragma unroll
-                            for (int dx = 0; dx < 3; ++dx)
-#pragma unroll
-                                for (int k = 0; k < K; ++k)
-                                    acc[k] = __builtin_fmaf(cw[dy][dx], wts.end[(dy * 3 + dx) * K + k], acc[k]);
-#pragma unroll
-                        for (int k = 0; k < K; ++k) acc[k] = clip_hi_tf(relu_tf(acc[k]), clip_hi);
-                        if constexpr (K == 8) {
-                            const int ncols = min(kFusedCols, lv.out_w - xw0);
-                            store_row_k8(end_out + (base_px + (long long)y * lv.out_w + (xw0 - 4)) * 8, acc,
-                                         s_slab + wave * 512, lane, 4, ncols);
-                        } else if (out_lane) {
-                            float* __restrict__ po = end_out + px * K;
-                            if constexpr (K == 4) {
-                                *reinterpret_cast<float4*>(po) = make_float4(acc[0], acc[1], acc[2], acc[3]);
-                            } else {
-#pragma unroll
-                                for (int k = 0; k < K; ++k) po[k] = acc[k];
-                            }
-                        }
-                    }
-                }
-            }
-        }
-    }
-
-    // ================= pass 2: every other level of the pyramid, rolled loop over the same rows =================
+    // ================= pass 2 (runs first: its registers die before pass 1): every other level of the pyramid,
+    // rolled loop over the rows in LDS =================
     float vacc[G][kStreamSlots];
 #pragma unroll
     for (int g = 0; g < G; ++g)
 #pragma unroll
         for (int k = 0; k < kStreamSlots; ++k) vacc[g][k] = 0.0f;
+    static_assert(G == stream_pad_levels(G), "row programs are padded to 4 or 7 levels");
+    constexpr int PR = kStreamProgRow(G);
+    // constant address space: with a wave-uniform address these are s_load_dwordx16 (no VGPR, no readfirstlane)
+    typedef const __attribute__((address_space(4))) int* const_int_ptr;
+    const_int_ptr prog = (const_int_ptr)(st.row_prog + (long long)ty * (NR * PR));
+    int cur[PR], nxt[PR];
+#pragma unroll
+    for (int e = 0; e < PR; ++e) cur[e] = prog[e];
+    float c0 = s_rows[wave][0][lane];
+#if defined(SILENT_EXPERIMENT) && (SILENT_EXPERIMENT == 7 || SILENT_EXPERIMENT == 8)
+    const int nr_run = clip_hi == -12345.0f ? NR : 0;
+#else
+    const int nr_run = NR;
+#endif
 #pragma unroll 1
-    for (int i = 0; i < NR; ++i) {
-        const float c0 = s_rows[wave][i][lane];
+    for (int i = 0; i < nr_run; ++i) {
+        // record and row of the NEXT step are requested before this step's work
+        const int in = min(i + 1, NR - 1);
+#pragma unroll
+        for (int e = 0; e < PR; ++e) nxt[e] = prog[in * PR + e];
+        const float c_next = s_rows[wave][in][lane];
 #pragma unroll
         for (int g = 0; g < G; ++g) {
-            const int4* __restrict__ pr = reinterpret_cast<const int4*>(s_prog + (i * G + g) * kStreamProgDw);
-            const int meta = __builtin_amdgcn_readfirstlane(pr[1].x);
+            const int meta = cur[g];
             if (!(meta & 128)) continue;  // wave-uniform: this stream row carries no tap of level g
-            const int4 pw = pr[0];
-            const int wbits[4] = {pw.x, pw.y, pw.z, pw.w};
 #pragma unroll
             for (int k = 0; k < stream_slots(g); ++k) {
-                const float w = __int_as_float(wbits[k]);
+                const float w = __int_as_float(cur[stream_w_off(G, g) + k]);
                 const float prev = (meta >> k) & 1 ? 0.0f : vacc[g][k];
                 vacc[g][k] = __builtin_fmaf(w, c0, prev);
             }
@@ -758,6 +674,206 @@ __global__ __launch_bounds__(256) void gray_stream_kernel(const float* __restric
                 for (int t = 1; t < 6; ++t)
                     acc = __builtin_fmaf(gw[g][t], __int_as_float(__builtin_amdgcn_ds_bpermute(glane[g] + 4 * t, vbits)), acc);
                 if (lane < gn[g]) pyr[frame_px0 + st.px_off[g] + (long long)oy * st.out_w[g] + gx0[g] + lane] = acc;
+            }
+        }
+#pragma unroll
+        for (int e = 0; e < PR; ++e) cur[e] = nxt[e];
+        c0 = c_next;
+    }
+
+    // ================= pass 1: unit level (pyramid + CS + end), rows back from LDS =================
+    // The conv weights live in VGPRs here (K <= 4): a VALU fma whose sources are all VGPRs issues at about twice
+    // the rate of one that reads an SGPR once two waves per SIMD are ready (2.7 vs 4.2 cycles per wave
+    // instruction, scripts/ubench/valu_rate.hip), and the ~50 SGPRs they would take no longer force reloads of
+    // the weights from the kernarg segment in every row.
+    constexpr bool VW = K <= 4;
+    float wv[5], csw[9], endw[VW ? 9 * K : 1];
+#pragma unroll
+    for (int j = 0; j < 5; ++j) {
+        wv[j] = tab.wx[j];  // the unit level's taps are the same on both axes ([1,26,66,26,1]/120)
+        if constexpr (VW) asm volatile("" : "+v"(wv[j]));
+    }
+#pragma unroll
+    for (int j = 0; j < 9; ++j) {
+        csw[j] = wts.cs[j];
+        if constexpr (VW) asm volatile("" : "+v"(csw[j]));
+    }
+    if constexpr (VW) {
+#pragma unroll
+        for (int j = 0; j < 9 * K; ++j) {
+            endw[j] = wts.end[j];
+            asm volatile("" : "+v"(endw[j]));
+        }
+    }
+    const int eff_h = min(lv.zoom_h, lv.out_h), eff_w = min(lv.zoom_w, lv.out_w);
+    const bool col_eff = ox >= 0 && ox < eff_w;       // inside the zoomed crop (zero outside it)
+    const bool col_in = ox >= 0 && ox < lv.out_w;     // inside the level (zero padding of the convolutions)
+#if defined(SILENT_EXPERIMENT) && (SILENT_EXPERIMENT == 1 || SILENT_EXPERIMENT == 6 || SILENT_EXPERIMENT == 7)   // no stores from pass 1
+    const bool out_lane = lane >= 4 && lane < 4 + kFusedCols && ox < lv.out_w && clip_hi == -12345.0f;
+#else
+    const bool out_lane = lane >= 4 && lane < 4 + kFusedCols && ox < lv.out_w;
+#endif
+    const long long wave_px = base_px + (xw0 - 4);    // + row * out_w + lane: wave-uniform part of every address
+    // VEC: the two 1-channel maps of the unit level leave in groups of 4 rows.  A global store costs about the same
+    // issue time whatever its width (measured: the 4-byte-per-lane stores of pyr + cs took as long as the 16-byte
+    // stores of the end maps carrying 4x the bytes), so each finished row is parked in an LDS row this pass has
+    // already consumed (slots 0-3 for the pyramid, 4-7 for CS), and every fourth row one ds_read_b128 + one
+    // global_store_dwordx4 writes 4 rows x 64 columns: lane l -> row l/16, columns 4*(l%16) .. +3.  The 4-column
+    // halo on either side is exactly one 16-byte chunk, so the lane mask is (l % 16) in [1, 14].
+    const int vec_off = (lane >> 4) * lv.out_w + (lane & 15) * 4;
+    const bool vec_lane = (lane & 15) >= 1 && (lane & 15) <= 14 && xw0 - 4 + (lane & 15) * 4 < lv.out_w;
+    auto store_group = [&](float* __restrict__ map, int slot0, int row0) {
+        if (row0 >= lv.out_h) return;  // wave-uniform
+#if defined(SILENT_EXPERIMENT) && (SILENT_EXPERIMENT == 4 || SILENT_EXPERIMENT == 6 || SILENT_EXPERIMENT == 7)
+        if (clip_hi != -12345.0f) return;
+#endif
+        const float* __restrict__ ring = &s_rows[wave][slot0][0];
+        const float4 t = make_float4(ring[lane * 4 + 0], ring[lane * 4 + 1], ring[lane * 4 + 2], ring[lane * 4 + 3]);
+        float* __restrict__ g0 = map + (wave_px + (long long)row0 * lv.out_w);
+        if (vec_lane && row0 + (lane >> 4) < lv.out_h) *reinterpret_cast<float4*>(g0 + vec_off) = t;
+    };
+    {
+        float hw[5] = {0, 0, 0, 0, 0};
+        float iw[3][3], cw[3][3];
+#pragma unroll
+        for (int a = 0; a < 3; ++a)
+#pragma unroll
+            for (int b = 0; b < 3; ++b) iw[a][b] = cw[a][b] = 0.0f;
+#pragma unroll
+        for (int i = 0; i < R + 8; ++i) {
+            {
+                const float c0 = s_rows[wave][i][lane];
+#if defined(SILENT_EXPERIMENT) && (SILENT_EXPERIMENT >= 2 && SILENT_EXPERIMENT < 8)   // no arithmetic (loads + stores only)
+                float h = c0;
+#else
+                const float l1 = from_lane_below(c0), l2 = from_lane_below(l1);
+                const float r1 = from_lane_above(c0), r2 = from_lane_above(r1);
+                float h = wv[0] * l2;
+                h = __builtin_fmaf(wv[1], l1, h);
+                h = __builtin_fmaf(wv[2], c0, h);
+                h = __builtin_fmaf(wv[3], r1, h);
+                h = __builtin_fmaf(wv[4], r2, h);
+#endif
+#pragma unroll
+                for (int j = 0; j < 4; ++j) hw[j] = hw[j + 1];
+                hw[4] = h;
+            }
+            if (i >= 4) {
+                const int p = y0 + i - 6;
+#if defined(SILENT_EXPERIMENT) && (SILENT_EXPERIMENT >= 2 && SILENT_EXPERIMENT < 8)
+                float v = hw[2];
+#else
+                float v = wv[0] * hw[0];
+#pragma unroll
+                for (int j = 1; j < 5; ++j) v = __builtin_fmaf(wv[j], hw[j], v);
+                v = (p >= 0 && p < eff_h && col_eff) ? v : 0.0f;
+#endif
+                if constexpr (VEC) {
+                    if (i >= 6 && i < R + 6) {
+                        s_rows[wave][(i - 6) & 3][lane] = v;
+                        if (((i - 6) & 3) == 3) store_group(pyr, 0, p - 3);
+                    }
+                } else if (p >= y0 && p < y0 + R && p < lv.out_h) {  // wave-uniform
+                    float* __restrict__ prow = pyr + (wave_px + (long long)p * lv.out_w);
+#if defined(SILENT_EXPERIMENT) && SILENT_EXPERIMENT == 4   // stores only, and only the end maps
+                    if (out_lane && clip_hi == -12345.0f) prow[lane] = v;
+#else
+                    if (out_lane) prow[lane] = v;
+#endif
+                }
+#pragma unroll
+                for (int b = 0; b < 3; ++b) {
+                    iw[0][b] = iw[1][b];
+                    iw[1][b] = iw[2][b];
+                }
+                iw[2][1] = v;
+#if !(defined(SILENT_EXPERIMENT) && (SILENT_EXPERIMENT >= 2 && SILENT_EXPERIMENT < 8))
+                iw[2][0] = from_lane_below(v);
+                iw[2][2] = from_lane_above(v);
+#endif
+            }
+            if (i >= 6) {
+                const int c = y0 + i - 7;
+#if defined(SILENT_EXPERIMENT) && (SILENT_EXPERIMENT >= 2 && SILENT_EXPERIMENT < 8)
+                const float cs = iw[1][1];
+#else
+                float acc = 0.0f;
+#pragma unroll
+                for (int dy = 0; dy < 3; ++dy)
+#pragma unroll
+                    for (int dx = 0; dx < 3; ++dx) acc = __builtin_fmaf(iw[dy][dx], csw[dy * 3 + dx], acc);
+                // relu (a NaN stays a NaN) and the zero padding of the end convolution in one select
+                const float cs = (c >= 0 && c < lv.out_h && col_in && !(acc < 0.0f)) ? acc : 0.0f;
+#endif
+#pragma unroll
+                for (int b = 0; b < 3; ++b) {
+                    cw[0][b] = cw[1][b];
+                    cw[1][b] = cw[2][b];
+                }
+                cw[2][1] = cs;
+#if !(defined(SILENT_EXPERIMENT) && (SILENT_EXPERIMENT >= 2 && SILENT_EXPERIMENT < 8))
+                cw[2][0] = from_lane_below(cs);
+                cw[2][2] = from_lane_above(cs);
+#endif
+            }
+            if (i >= 8) {
+                const int y = y0 + i - 8;
+                if constexpr (VEC) {
+                    if (cs_out) {
+                        s_rows[wave][4 + ((i - 8) & 3)][lane] = cw[1][1];
+                        if (((i - 8) & 3) == 3) store_group(cs_out, 4, y - 3);
+                    }
+                }
+                if (y < lv.out_h) {  // wave-uniform
+                    const long long row_px = wave_px + (long long)y * lv.out_w;
+                    if (cs_out && !VEC) {
+                        float* __restrict__ crow = cs_out + row_px;
+#if defined(SILENT_EXPERIMENT) && SILENT_EXPERIMENT == 4
+                        if (out_lane && clip_hi == -12345.0f) crow[lane] = cw[1][1];
+#else
+                        if (out_lane) crow[lane] = cw[1][1];
+#endif
+                    }
+                    if (end_out) {
+                        float acc[K];
+#pragma unroll
+                        for (int k = 0; k < K; ++k) acc[k] = 0.0f;
+#if defined(SILENT_EXPERIMENT) && (SILENT_EXPERIMENT >= 2 && SILENT_EXPERIMENT < 8)
+#pragma unroll
+                        for (int k = 0; k < K; ++k) acc[k] = cw[1][1];
+#else
+#pragma unroll
+                        for (int dy = 0; dy < 3; ++dy)
+#pragma unroll
+                            for (int dx = 0; dx < 3; ++dx)
+#pragma unroll
+                                for (int k = 0; k < K; ++k) {
+                                    const int wi = (dy * 3 + dx) * K + k;
+                                    if constexpr (VW) acc[k] = __builtin_fmaf(cw[dy][dx], endw[wi], acc[k]);
+                                    else acc[k] = __builtin_fmaf(cw[dy][dx], wts.end[wi], acc[k]);
+                                }
+#pragma unroll
+                        for (int k = 0; k < K; ++k) acc[k] = clip_hi_tf(relu_tf(acc[k]), clip_hi);
+#endif
+                        if constexpr (K == 8) {
+                            const int ncols = min(kFusedCols, lv.out_w - xw0);
+                            store_row_k8(end_out + row_px * 8, acc, s_slab + wave * 512, lane, 4, ncols);
+                        } else if constexpr (K == 4) {
+                            float4* __restrict__ erow = reinterpret_cast<float4*>(end_out + row_px * 4);
+#if defined(SILENT_EXPERIMENT) && SILENT_EXPERIMENT == 5   // stores only, and only the 1-channel maps
+                            if (out_lane && clip_hi == -12345.0f) erow[lane] = make_float4(acc[0], acc[1], acc[2], acc[3]);
+#else
+                            if (out_lane) erow[lane] = make_float4(acc[0], acc[1], acc[2], acc[3]);
+#endif
+                        } else {
+                            float* __restrict__ po = end_out + row_px * K;
+                            if (out_lane) {
+#pragma unroll
+                                for (int k = 0; k < K; ++k) po[lane * K + k] = acc[k];
+                            }
+                        }
+                    }
+                }
             }
         }
     }

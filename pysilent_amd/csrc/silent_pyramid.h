@@ -114,11 +114,11 @@ __global__ __launch_bounds__(256) void pyramid_unit_kernel(const float* __restri
         wx[i] = tab.xw[(long long)lv.xtab_off * 6 + i];
         wy[i] = tab.yw[(long long)lv.ytab_off * 6 + i];
     }
-    const long long sx = (long long)(mirror_index(ox, lv.src_w) + lv.src_x0) * C;
+    const long long sx = (long long)(mirror_near(ox, lv.src_w) + lv.src_x0) * C;
     float in[R + 4][C];
 #pragma unroll
     for (int i = 0; i < R + 4; ++i) {
-        const long long sy = mirror_index(y0 - 2 + i, lv.src_h) + lv.src_y0;
+        const long long sy = mirror_near(y0 - 2 + i, lv.src_h) + lv.src_y0;
 #pragma unroll
         for (int ch = 0; ch < C; ++ch) in[i][ch] = src[sy * W * C + sx + ch];
     }

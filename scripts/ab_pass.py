@@ -28,3 +28,24 @@ byt = pipe.algorithmic_bytes_per_frame() * B
 for k in variants:
     t = np.array(times[k])
     print("%-10s median %.4f ms  min %.4f  max %.4f   %.0f GB/s algorithmic = %.1f %% of 8 TB/s" % (k, np.median(t), t.min(), t.max(), byt / np.median(t) / 1e6, byt / np.median(t) / 1e6 / 80))
+
+# dominant kernel alone (HIP events recorded by the library around its launch) + a device copy for calibration
+os.environ["SILENT_GRAY_OPTS"] = "0"
+pipe.set_profiling(True)
+ks = []
+for _ in range(30):
+    pipe.step(frames)
+    torch.cuda.synchronize()
+    ks.append(pipe.profiled_kernel()[0])
+pipe.set_profiling(False)
+ks = np.array(ks[5:])
+a = torch.empty(1 << 28, dtype=torch.float32, device="cuda")
+b_ = torch.empty_like(a)
+cs = []
+for _ in range(8):
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record(); b_.copy_(a); e1.record(); torch.cuda.synchronize()
+    cs.append(e0.elapsed_time(e1))
+copy_gbs = 2 * a.numel() * 4 / (np.median(cs[2:]) * 1e6)
+print("stream kernel alone: median %.4f ms  min %.4f   | 1 GiB device copy: %.0f GB/s (read+write)  | kernel_ms x copy_TB/s = %.3f"
+      % (np.median(ks), ks.min(), copy_gbs, np.median(ks) * copy_gbs / 1000))
