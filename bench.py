@@ -39,10 +39,14 @@ HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s 
 
 def pmc_traffic_per_launch(kernel_substr, frames_in_launch):
     """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes
-    (profiles/r01/pmc_hbm_bytes.json: separate --pmc FETCH_SIZE / WRITE_SIZE runs of this same bench at 64
+    (profiles/<latest>/pmc_hbm_bytes.json: separate --pmc FETCH_SIZE / WRITE_SIZE runs of this same bench at 64
     frames per launch), corrected as MI355X_MICROARCH.md prescribes for gfx950: FETCH_SIZE counts 64 B per
     128-B request -> x2; WRITE_SIZE exact; both in KiB.  Scaled linearly to this run's frames per launch."""
-    path = os.path.join(ROOT, "profiles", "r01", "pmc_hbm_bytes.json")
+    import glob
+    cands = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*", "pmc_hbm_bytes.json")))
+    if not cands:
+        return None
+    path = cands[-1]
     try:
         prof = json.load(open(path))
     except (OSError, ValueError):

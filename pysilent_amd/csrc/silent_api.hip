@@ -1162,20 +1162,8 @@ SILENT_EXPORT int silent_gray_pass_dev(silent_ctx* ctx, const silent_pyramid_pla
         if (ctx->profiling) HIP_TRY(ctx, hipEventRecord(ctx->ev0, s));
         if (stream_path) {
             const StreamTab& st = plan->stream;
-            // 16-byte stores of the unit level's 1-channel maps need every row start on a 4-pixel boundary
-            const FusedLevel& u0 = ft.lv[0];
-            const bool vec = !(kopts & 64u) && ft.frame_px % 4 == 0 && u0.px_off % 4 == 0 && u0.out_w % 4 == 0 &&
-                             (reinterpret_cast<uintptr_t>(pyr) & 15) == 0 &&
-                             (!cs_out || (reinterpret_cast<uintptr_t>(cs_out) & 15) == 0);
-#define STREAM_LAUNCH(K_, G_)                                                                                          \
-    do {                                                                                                               \
-        if (vec)                                                                                                       \
-            hipLaunchKernelGGL((gray_stream_kernel<K_, G_, true>), dim3((unsigned)blocks), dim3(256), 0, s, frames,    \
-                               pyr, cs_out, end_out, ft, st, w, clip_hi, (unsigned)((kopts >> 5) & 1));                \
-        else                                                                                                           \
-            hipLaunchKernelGGL((gray_stream_kernel<K_, G_, false>), dim3((unsigned)blocks), dim3(256), 0, s, frames,   \
-                               pyr, cs_out, end_out, ft, st, w, clip_hi, (unsigned)((kopts >> 5) & 1));                \
-    } while (0)
+#define STREAM_LAUNCH(K_, G_) \
+    hipLaunchKernelGGL((gray_stream_kernel<K_, G_>), dim3((unsigned)blocks), dim3(256), 0, s, frames, pyr, cs_out, end_out, ft, st, w, clip_hi, (unsigned)((kopts >> 5) & 1))
             if (st.G <= 4) {
                 if (n_orient == 3) STREAM_LAUNCH(3, 4);
                 else if (n_orient == 4) STREAM_LAUNCH(4, 4);

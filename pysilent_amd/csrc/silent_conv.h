@@ -547,7 +547,7 @@ struct StreamTab {
     int out_w[8];
 };
 
-template <int K, int G, bool VEC>
+template <int K, int G>
 __global__ __launch_bounds__(256) void gray_stream_kernel(const float* __restrict__ frames, float* __restrict__ pyr,
                                                           float* __restrict__ cs_out, float* __restrict__ end_out,
                                                           const FusedTab tab, const StreamTab st, const GrayW wts,
@@ -714,24 +714,9 @@ __global__ __launch_bounds__(256) void gray_stream_kernel(const float* __restric
     const bool out_lane = lane >= 4 && lane < 4 + kFusedCols && ox < lv.out_w;
 #endif
     const long long wave_px = base_px + (xw0 - 4);    // + row * out_w + lane: wave-uniform part of every address
-    // VEC: the two 1-channel maps of the unit level leave in groups of 4 rows.  A global store costs about the same
-    // issue time whatever its width (measured: the 4-byte-per-lane stores of pyr + cs took as long as the 16-byte
-    // stores of the end maps carrying 4x the bytes), so each finished row is parked in an LDS row this pass has
-    // already consumed (slots 0-3 for the pyramid, 4-7 for CS), and every fourth row one ds_read_b128 + one
-    // global_store_dwordx4 writes 4 rows x 64 columns: lane l -> row l/16, columns 4*(l%16) .. +3.  The 4-column
-    // halo on either side is exactly one 16-byte chunk, so the lane mask is (l % 16) in [1, 14].
-    const int vec_off = (lane >> 4) * lv.out_w + (lane & 15) * 4;
-    const bool vec_lane = (lane & 15) >= 1 && (lane & 15) <= 14 && xw0 - 4 + (lane & 15) * 4 < lv.out_w;
-    auto store_group = [&](float* __restrict__ map, int slot0, int row0) {
-        if (row0 >= lv.out_h) return;  // wave-uniform
-#if defined(SILENT_EXPERIMENT) && (SILENT_EXPERIMENT == 4 || SILENT_EXPERIMENT == 6 || SILENT_EXPERIMENT == 7)
-        if (clip_hi != -12345.0f) return;
-#endif
-        const float* __restrict__ ring = &s_rows[wave][slot0][0];
-        const float4 t = make_float4(ring[lane * 4 + 0], ring[lane * 4 + 1], ring[lane * 4 + 2], ring[lane * 4 + 3]);
-        float* __restrict__ g0 = map + (wave_px + (long long)row0 * lv.out_w);
-        if (vec_lane && row0 + (lane >> 4) < lv.out_h) *reinterpret_cast<float4*>(g0 + vec_off) = t;
-    };
+    // (Tried and dropped: a 3-instruction relu+clip (v_med3 + NaN select) instead of 4: no measurable change, the kernel
+    // is not VALU-bound any more.  Parking 4 finished rows of the 1-channel maps in consumed LDS rows and writing them with one
+    // global_store_dwordx4 per 4 rows -- 24 instead of 48 stores per tile -- was 3.5 % slower in an alternating A/B.)
     {
         float hw[5] = {0, 0, 0, 0, 0};
         float iw[3][3], cw[3][3];
@@ -768,12 +753,7 @@ __global__ __launch_bounds__(256) void gray_stream_kernel(const float* __restric
                 for (int j = 1; j < 5; ++j) v = __builtin_fmaf(wv[j], hw[j], v);
                 v = (p >= 0 && p < eff_h && col_eff) ? v : 0.0f;
 #endif
-                if constexpr (VEC) {
-                    if (i >= 6 && i < R + 6) {
-                        s_rows[wave][(i - 6) & 3][lane] = v;
-                        if (((i - 6) & 3) == 3) store_group(pyr, 0, p - 3);
-                    }
-                } else if (p >= y0 && p < y0 + R && p < lv.out_h) {  // wave-uniform
+                if (p >= y0 && p < y0 + R && p < lv.out_h) {  // wave-uniform
                     float* __restrict__ prow = pyr + (wave_px + (long long)p * lv.out_w);
 #if defined(SILENT_EXPERIMENT) && SILENT_EXPERIMENT == 4   // stores only, and only the end maps
                     if (out_lane && clip_hi == -12345.0f) prow[lane] = v;
@@ -818,15 +798,9 @@ __global__ __launch_bounds__(256) void gray_stream_kernel(const float* __restric
             }
             if (i >= 8) {
                 const int y = y0 + i - 8;
-                if constexpr (VEC) {
-                    if (cs_out) {
-                        s_rows[wave][4 + ((i - 8) & 3)][lane] = cw[1][1];
-                        if (((i - 8) & 3) == 3) store_group(cs_out, 4, y - 3);
-                    }
-                }
                 if (y < lv.out_h) {  // wave-uniform
                     const long long row_px = wave_px + (long long)y * lv.out_w;
-                    if (cs_out && !VEC) {
+                    if (cs_out) {
                         float* __restrict__ crow = cs_out + row_px;
 #if defined(SILENT_EXPERIMENT) && SILENT_EXPERIMENT == 4
                         if (out_lane && clip_hi == -12345.0f) crow[lane] = cw[1][1];

@@ -12,6 +12,8 @@ def two_step():
     pipe.run_pyramid(frames); pipe.run_filters()
 variants = {"two-step": ("0", two_step), "stream": ("0", lambda: pipe.step(frames)),
             "stream+xcd": ("32", lambda: pipe.step(frames)), "no-stream": ("16", lambda: pipe.step(frames))}
+if os.environ.get("AB_QUICK"):
+    variants = {"stream": variants["stream"]}
 times = {k: [] for k in variants}
 for rnd in range(12):
     for k, (opt, fn) in variants.items():
@@ -30,7 +32,7 @@ for k in variants:
     print("%-10s median %.4f ms  min %.4f  max %.4f   %.0f GB/s algorithmic = %.1f %% of 8 TB/s" % (k, np.median(t), t.min(), t.max(), byt / np.median(t) / 1e6, byt / np.median(t) / 1e6 / 80))
 
 # dominant kernel alone (HIP events recorded by the library around its launch) + a device copy for calibration
-os.environ["SILENT_GRAY_OPTS"] = "0"
+os.environ["SILENT_GRAY_OPTS"] = os.environ.get("AB_BASE_OPTS", "0")
 pipe.set_profiling(True)
 ks = []
 for _ in range(30):
