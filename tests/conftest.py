@@ -66,7 +66,9 @@ def assert_close(got, want, rtol=1e-5, scale=None, what=""):
     assert got.shape == want.shape, (what, got.shape, want.shape)
     nan_g, nan_w = np.isnan(got), np.isnan(want)
     assert np.array_equal(nan_g, nan_w), "%s: NaN pattern differs (%d vs %d)" % (what, nan_g.sum(), nan_w.sum())
-    fin = ~nan_w
+    inf = np.isinf(got) | np.isinf(want)
+    assert np.array_equal(got[inf], want[inf]), "%s: infinities differ" % what
+    fin = ~nan_w & ~inf
     if scale is None:
         scale = float(np.max(np.abs(want[fin]))) if fin.any() else 1.0
     err = np.abs(got[fin].astype(np.float64) - want[fin].astype(np.float64))

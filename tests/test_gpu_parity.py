@@ -534,6 +534,85 @@ def test_gray_pass_reference_layout_and_device_path(rt, kernels):
     np.testing.assert_array_equal(de.data.cpu().numpy(), end.data)
 
 
+@pytest.mark.parametrize("shape,n", [((1, 1, 1), 1), ((4, 9, 1), 2), ((5, 5, 1), 2), ((6, 70, 1), 3), ((16, 56, 1), 2),
+                                     ((17, 57, 1), 3), ((24, 224, 1), 2), ((25, 225, 1), 2)])
+def test_gray_pass_tiny_and_tile_boundary_frames(rt, kernels, shape, n):
+    """Frames smaller than the stencil reach (levels with < 5 source pixels per axis leave the streaming kernels),
+    and extents exactly at / one past the 16 x 56 tile of a wave and the 224-column tile of a block."""
+    from pysilent_amd.util.zoom.from_image import classic_levels
+    frames = np.stack([noise_frame(40 + s_, *shape) for s_ in range(3)])
+    plan = rt.PyramidPlan(shape[0], shape[1], 1, classic_levels(shape[:2], 2.0, n))
+    pyr, cs, end = plan.gray_pass(frames, kernels["cs_gray"], kernels["end4"])
+    pyr2 = plan.run(frames)
+    cs2, end2 = rt.gray_line_end(pyr2, kernels["cs_gray"], kernels["end4"])
+    for a, b in ((pyr, pyr2), (cs, cs2), (end, end2)):
+        np.testing.assert_array_equal(a.data, b.data)
+    want = so.classic_pyramid(frames[2], 2.0, n)
+    for l, (wcs, wend) in enumerate(so.gray_line_end_pass(want, kernels["cs_gray"], kernels["end4"])):
+        assert_close(pyr.level(l)[2:3], want[l], RTOL, scale=255.0, what="pyr %d" % l)
+        assert_close(cs.level(l)[2:3], wcs, RTOL, scale=255.0, what="cs %d" % l)
+        assert_close(end.level(l)[2:3], wend, RTOL, scale=255.0, what="end %d" % l)
+
+
+def test_gray_pass_nan_and_inf_propagate_like_the_oracle(rt, kernels):
+    """Non-finite values: a NaN stays a NaN through relu / clip (Eigen's (x < 0) ? 0 : x), +inf clips to 255, and the
+    single-read kernel agrees with the two-step path bit for bit (NaN payloads aside).
+    Documented deviation: at zoom 1 scipy still multiplies the exactly-zero 6th spline tap, so a
+    non-finite FRAME pixel poisons a 6 x 6 neighbourhood there and 5 x 5 here."""
+    from pysilent_amd.util.zoom.from_image import classic_levels
+    frame = noise_frame(3, 96, 160, 1)
+    bad = frame.copy()
+    bad[10, 20, 0] = np.nan
+    bad[50, 100, 0] = np.inf
+    bad[70, 5, 0] = -np.inf
+    plan = rt.PyramidPlan(96, 160, 1, classic_levels((96, 160), 2.0, 3))
+    assert plan.streamable
+    got = plan.gray_pass(bad[None], kernels["cs_gray"], kernels["end4"])
+    pyr2 = plan.run(bad[None])
+    two = (pyr2,) + tuple(rt.gray_line_end(pyr2, kernels["cs_gray"], kernels["end4"]))
+    for a, b in zip(got, two):
+        np.testing.assert_array_equal(np.isnan(a.data), np.isnan(b.data))
+        np.testing.assert_array_equal(np.nan_to_num(a.data, nan=-1.0), np.nan_to_num(b.data, nan=-1.0))
+    want = so.classic_pyramid(bad, 2.0, 3)
+    far = np.ones((96, 160), bool)                 # outside scipy's 6 x 6 footprint (outputs p-3 .. p+2) of each bad pixel
+    for y, x in ((10, 20), (50, 100), (70, 5)):
+        far[max(y - 3, 0):y + 3, max(x - 3, 0):x + 3] = False
+    g0, w0 = got[0].level(0)[0, :, :, 0], want[0][0, :, :, 0]
+    assert np.isfinite(g0[far]).all() and np.isfinite(w0[far]).all()
+    assert_close(g0[far], w0[far], RTOL, scale=255.0, what="level 0 away from the bad pixels")
+    assert np.isnan(g0[8:13, 18:23]).all() and np.isnan(w0[7:13, 17:23]).all()   # 5 x 5 here, 6 x 6 in scipy
+    assert np.isposinf(g0[48:53, 98:103]).all()
+    # the filters themselves: non-finite values injected into a finite pyramid, every level, against the oracle
+    pyr = plan.run(frame[None])
+    levels = [np.array(pyr.level(l)) for l in range(3)]
+    levels[0][0, 30, 40, 0] = np.nan
+    levels[1][0, 5, 7, 0] = np.inf
+    levels[2][0, 20, 3, 0] = -np.inf
+    packed = rt.PackedPyramid.from_levels(levels)
+    cs, end = rt.gray_line_end(packed, kernels["cs_gray"], kernels["end4"])
+    for l, lev in enumerate(levels):
+        wcs = so.conv2d_same(lev, kernels["cs_gray"], relu=True)
+        wend = so.conv2d_same(wcs, kernels["end4"], relu=True, clip_hi=255.0)
+        assert_close(cs.level(l), wcs, RTOL, scale=255.0, what="cs %d" % l)          # NaN pattern checked inside
+        assert_close(end.level(l), wend, RTOL, scale=255.0, what="end %d" % l)
+    assert np.isnan(end.level(0)).any() and np.nanmax(end.level(1)) <= 255.0
+
+
+def test_config5_4k_8_levels_8_orientations_against_c_oracle(rt, kernels):
+    """BASELINE config 5 (the largest): one 3840 x 2160 frame, 8-level pyramid, K = 8 -- stream kernel <8, 7>."""
+    from pysilent_amd.util.zoom.from_image import classic_levels
+    frame = structured_frame(9, 2160, 3840, 1, n_lines=2000)
+    plan = rt.PyramidPlan(2160, 3840, 1, classic_levels((2160, 3840), 2.0, 8))
+    assert plan.streamable and len(plan.extents) == 8
+    pyr, cs, end = plan.gray_pass(frame[None], kernels["cs_gray"], kernels["end8"])
+    want_pyr = co.classic_pyramid(frame, plan.extents)
+    for l in range(8):
+        assert_close(pyr.level(l), want_pyr[l], RTOL, scale=255.0, what="pyramid %d" % l)
+        wcs, wend = co.gray_line_end_level(want_pyr[l], kernels["cs_gray"], kernels["end8"])
+        assert_close(cs.level(l), wcs, RTOL, scale=255.0, what="cs %d" % l)
+        assert_close(end.level(l), wend, RTOL, scale=255.0, what="end %d" % l)
+
+
 # ----------------------------------------------------------------------------- full size (BASELINE config 2)
 
 def test_config2_1080p_full_size_against_c_oracle(rt, kernels):
