@@ -29,7 +29,7 @@ WORKLOADS = {
                     name="1080p gray, 5-level pyramid (scale 2), CS + 4-orientation line-end"),
     # configs[2]: 1080p RGB, 6-level pyramid, normalize + peak extraction
     "config3": dict(hw=(1080, 1920), mode="rgb", n_levels=6, n_orient=3,
-                    name="1080p RGB, 6-level pyramid (scale 2), rgc>rgby>stripe>regulate>end + keypoints"),
+                    name="1080p RGB, 6-level pyramid (scale 2), rgc>rgby>stripe>regulate>end>pad>value, top 10 %, NMS, keypoints"),
     # configs[4]: 4K, 8-level pyramid, 8-orientation bank
     "config5": dict(hw=(2160, 3840), mode="gray", n_levels=8, n_orient=8,
                     name="4K gray, 8-level pyramid (scale 2), CS + 8-orientation line-end"),
@@ -128,7 +128,8 @@ def main():
     # working set per rank well beyond the 256 MiB Infinity Cache (hard part 6)
     B = args.frames or {"config2": 64, "config3": 32, "config5": 16}[args.workload]
     pipe = LineEndPipeline((h, w), mode=wl["mode"], n_levels=wl["n_levels"], n_orient=wl["n_orient"], batch=B,
-                           device=local, constants=consts, max_keypoints_per_frame=1 << 16)
+                           device=local, constants=consts, max_keypoints_per_frame=1 << 16,
+                           **({"selection": True} if wl["mode"] == "rgb" else {}))
     frames = torch.empty((B, h, w, c), dtype=torch.float32, device=dev)
     for j, gi in enumerate(D.shard_frame_indices(B * world, rank, world)):
         frames[j] = torch.from_numpy(D.synthetic_frame(gi, h, w, c)).to(dev)

@@ -711,7 +711,21 @@ SILENT_EXPORT int silent_rgb_line_end_dev(silent_ctx* ctx, const float* pyr, con
         repack(p->end, a.w.end);
         for (int t = 0; t < 49; ++t) a.w.blur[t] = p->blur[t * 9];
         a.prm = RgbP{p->regulation_value, p->regulation_root, p->flat_policy, p->clip_hi, p->pad};
-        hipLaunchKernelGGL(rgb_line_end_kernel, dim3((unsigned)blocks), dim3(256), 0, s, a);
+        // structure of the actual weights (what the reference's generators produce, but checked, not assumed):
+        // rgc channel-diagonal -> 27 instead of 81 fmas; stripe independent of the input channel -> a filter of the sum
+        bool rgc_diag = true, stripe_sum = true;
+        for (int t = 0; t < 9; ++t)
+            for (int i = 0; i < 3; ++i)
+                for (int o = 0; o < 3; ++o) {
+                    if (i != o && p->rgc[(t * 3 + i) * 3 + o] != 0.0f) rgc_diag = false;
+                    if (p->stripe[(t * 3 + i) * 3 + o] != p->stripe[(t * 3 + 0) * 3 + o]) stripe_sum = false;
+                }
+        unsigned kopts = 0;
+        if (const char* e = std::getenv("SILENT_RGB_OPTS")) kopts = (unsigned)std::strtoul(e, nullptr, 0);  // 1: generic
+        if (rgc_diag && stripe_sum && !(kopts & 1u))
+            hipLaunchKernelGGL((rgb_line_end_kernel<0x111u, true>), dim3((unsigned)blocks), dim3(256), 0, s, a);
+        else
+            hipLaunchKernelGGL((rgb_line_end_kernel<0x1ffu, false>), dim3((unsigned)blocks), dim3(256), 0, s, a);
         return check_launch(ctx, who);
     }
     // General blur: stage-per-launch composition through ping-pong temporaries in the context workspace.

@@ -66,6 +66,10 @@ __device__ __forceinline__ Chain3 load_chain3(kfloat_p wp, int off) {
 
 // One arriving row of a 3x3 x 3->3 convolution.  v[dx][i]: the row's values at x-1, x, x+1.
 // pa: output row with dy = 0,1 already in; pb: output row with dy = 0 in.  Returns the completed row in done.
+// PAIRS: bit (o * 3 + i) set = output o reads input i.  The host clears a bit only when all 9 taps of that pair
+// are exactly 0 (midget_rgc is channel-diagonal: 27 of its 81 weights are non-zero), so for finite inputs the
+// skipped fmas would have added exactly 0.
+template <unsigned PAIRS>
 __device__ __forceinline__ void conv3_roll(const float (&v)[3][3], kfloat_p wstage, float (&pa)[3], float (&pb)[3],
                                            float (&done)[3]) {
     float acc[3][3];  // [o][dy]
@@ -89,10 +93,45 @@ __device__ __forceinline__ void conv3_roll(const float (&v)[3][3], kfloat_p wsta
 #pragma unroll
         for (int dx = 0; dx < 3; ++dx)
 #pragma unroll
-            for (int i = 0; i < 3; ++i) t = __builtin_fmaf(v[dx][i], w0.k[dx * 3 + i], t);
+            for (int i = 0; i < 3; ++i)
+                if ((PAIRS >> (o * 3 + i)) & 1u) t = __builtin_fmaf(v[dx][i], w0.k[dx * 3 + i], t);
         asm volatile("" : "+v"(t));  // pins the chain's fmas between the loads around it
         acc[o][dy] = t;
         w0 = w1;
+    }
+#pragma unroll
+    for (int o = 0; o < 3; ++o) {
+        done[o] = acc[o][2];
+        pa[o] = acc[o][1];
+        pb[o] = acc[o][0];
+    }
+}
+
+// The same for a kernel that does not depend on the input channel (rgb_2d_stripe_tensors with its default
+// in_channel = (1, 1, 1): every orientation reads the channel SUM): 27 fmas on the sum instead of 81.
+// s[dx]: channel sum at x-1, x, x+1.  Rounding differs from the 81-term chain like the blur's does.
+__device__ __forceinline__ void conv3_roll_sum(const float (&s)[3], kfloat_p wstage, float (&pa)[3], float (&pb)[3],
+                                               float (&done)[3]) {
+    float acc[3][3];  // [o][dy]
+#pragma unroll
+    for (int o = 0; o < 3; ++o) {
+        acc[o][0] = 0.0f;
+        acc[o][1] = pb[o];
+        acc[o][2] = pa[o];
+    }
+#pragma unroll
+    for (int o = 0; o < 3; ++o) {
+        Chain3 w[3];  // the three rows of output o: 3 x 9 weights of which every third (i = 0) is used
+#pragma unroll
+        for (int dy = 0; dy < 3; ++dy) w[dy] = load_chain3(wstage, (o * 3 + dy) * 9);
+#pragma unroll
+        for (int dy = 2; dy >= 0; --dy) {
+            float t = acc[o][dy];
+#pragma unroll
+            for (int dx = 0; dx < 3; ++dx) t = __builtin_fmaf(s[dx], w[dy].k[dx * 3], t);
+            acc[o][dy] = t;
+        }
+        asm volatile("" : "+v"(acc[o][0]), "+v"(acc[o][1]), "+v"(acc[o][2]));
     }
 #pragma unroll
     for (int o = 0; o < 3; ++o) {
@@ -123,6 +162,9 @@ struct RgbArgs {
     RgbP prm;
 };
 
+// RGC_PAIRS: (o, i) pairs of the rgc kernel that are not identically zero; STRIPE_SUM: the stripe kernel does not
+// depend on the input channel.  The host checks both on the actual weights and launches <0x1ff, false> otherwise.
+template <unsigned RGC_PAIRS, bool STRIPE_SUM>
 __global__ __launch_bounds__(256) void rgb_line_end_kernel(const RgbArgs args) {
     constexpr int R = kRgbTH, D = kRgbChunk, NCH = (R + 2 * kRgbHalo) / D;
     const float* __restrict__ pyr = args.pyr;
@@ -188,7 +230,7 @@ __global__ __launch_bounds__(256) void rgb_line_end_kernel(const RgbArgs args) {
             float v[3][3], g[3];
             // ---- rgc: completes row yin - 1
             with_neighbours(cur[d], v);
-            conv3_roll(v, wp + 0 * 81, a1, b1, g);
+            conv3_roll<RGC_PAIRS>(v, wp + 0 * 81, a1, b1, g);
             {
                 const bool ok = yin - 1 >= 0 && yin - 1 < H && col_ok;
 #pragma unroll
@@ -196,15 +238,23 @@ __global__ __launch_bounds__(256) void rgb_line_end_kernel(const RgbArgs args) {
             }
             // ---- rgby: completes row yin - 2
             with_neighbours(g, v);
-            conv3_roll(v, wp + 1 * 81, a2, b2, g);
+            conv3_roll<0x1ffu>(v, wp + 1 * 81, a2, b2, g);
             {
                 const bool ok = yin - 2 >= 0 && yin - 2 < H && col_ok;
 #pragma unroll
                 for (int c = 0; c < 3; ++c) g[c] = ok ? relu_tf(g[c]) : 0.0f;
             }
             // ---- stripe: completes row q = yin - 3
-            with_neighbours(g, v);
-            conv3_roll(v, wp + 2 * 81, a3, b3, g);
+            if constexpr (STRIPE_SUM) {
+                float s3[3];
+                s3[1] = (g[0] + g[1]) + g[2];
+                s3[0] = from_lane_below(s3[1]);
+                s3[2] = from_lane_above(s3[1]);
+                conv3_roll_sum(s3, wp + 2 * 81, a3, b3, g);
+            } else {
+                with_neighbours(g, v);
+                conv3_roll<0x1ffu>(v, wp + 2 * 81, a3, b3, g);
+            }
             {
                 const bool ok = yin - 3 >= 0 && yin - 3 < H && col_ok;
 #pragma unroll
@@ -271,7 +321,7 @@ __global__ __launch_bounds__(256) void rgb_line_end_kernel(const RgbArgs args) {
             }
             // ---- end bank: completes row yout = yin - 7
             with_neighbours(o3, v);
-            conv3_roll(v, wp + 3 * 81, a5, b5, g);
+            conv3_roll<0x1ffu>(v, wp + 3 * 81, a5, b5, g);
             const int yout = yin - 7;
             if (yout >= y0 && yout < H && out_lane) {
                 const float mk = (pad_col && yout >= prm.pad && yout < H - prm.pad) ? 1.0f : 0.0f;

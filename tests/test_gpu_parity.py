@@ -461,6 +461,33 @@ def test_rgb_chain_on_packed_levels_and_keypoints(rt, kernels):
         np.testing.assert_array_equal(kp[f], np.concatenate(rows))     # bit-exact, row-major, level-major
 
 
+def test_rgb_pipeline_with_selection_stage(rt, kernels):
+    """chain -> top-percent (a-10, p = 0.1) -> NMS (a-9) -> value -> keypoints (a-11); every stage
+    after the chain is index-like and compared bit for bit with the oracle applied to the GPU's own line-end map."""
+    import torch
+    from pysilent_amd.pipeline import LineEndPipeline
+    pipe = LineEndPipeline((96, 160), mode="rgb", n_levels=3, batch=2, selection=True, max_keypoints_per_frame=1 << 15)
+    frames = np.stack([noise_frame(70 + i, 96, 160, 3) for i in range(2)])      # noise frames stay finite (no 0 * inf)
+    pipe.step(torch.from_numpy(frames).cuda())
+    torch.cuda.synchronize()
+    out = pipe.outputs()
+    host = lambda name, l, f: np.ascontiguousarray(out[name].level(l)[f:f + 1].cpu().numpy())
+    for f in range(2):
+        rows = []
+        for l, (h, w) in enumerate(pipe.extents):
+            line, value = host("line_end", l, f), host("value", l, f)
+            top = so.top_value_points(line, 0.1, value)
+            peaks = so.nms3x3(top, "product")
+            pv = so.value_from_color(peaks)
+            np.testing.assert_array_equal(host("top", l, f), top)
+            np.testing.assert_array_equal(host("peaks", l, f), peaks)
+            np.testing.assert_array_equal(host("peak_value", l, f), pv)
+            r = so.max_value_indices_region(None, (1, max(h // 2, 1), max(w // 2, 1), 3), pv)
+            r[:, 0] = l
+            rows.append(r)
+        np.testing.assert_array_equal(out["keypoints"][f], np.concatenate(rows))
+
+
 # ----------------------------------------------------------------------------- device-resident (torch) path
 
 def test_torch_device_path_is_bit_identical(rt, kernels):
