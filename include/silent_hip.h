@@ -217,6 +217,19 @@ int silent_max_value_indices_region_dev(silent_ctx* ctx, const float* value, con
                                         int n_levels, int n_frames, const silent_extent* regions, int64_t* idx,
                                         size_t cap_per_frame, int64_t* counts, silent_stream stream);
 
+/* ---------------------------------------------------------------------------- fused selection
+ * top_value_points (util/selection/top_value_points.py:8-29) -> 3x3 NMS in product form
+ * (_experimental/vision_filter.py:88-89) -> get_value_from_color (util/color/get_value.py:6-12) in one streaming
+ * pass after the per-level max / min reduction: bit-identical to silent_top_value_points + silent_nms3x3 +
+ * silent_value_from_color, without the two intermediate colour maps in HBM.  value may be NULL (computed from color).
+ * Any of top_out [C ch], peaks_out [C ch], peak_value_out [1 ch] may be NULL, not all.  channels: 1 or 3. */
+int silent_select_peaks(silent_ctx* ctx, const float* color, const float* value, const silent_extent* levels,
+                        int n_levels, int n_frames, int channels, double top_percent, float* top_out,
+                        float* peaks_out, float* peak_value_out);
+int silent_select_peaks_dev(silent_ctx* ctx, const float* color, const float* value, const silent_extent* levels,
+                            int n_levels, int n_frames, int channels, double top_percent, float* top_out,
+                            float* peaks_out, float* peak_value_out, silent_stream stream);
+
 /* ---------------------------------------------------------------------------- centroids
  * Replaces get_centroids, slam_recognition/util/centroids.py:21-46 (with index_tensor.from_shape,
  * util/index_tensor.py:7-20, dimensions reversed: channel 0 = x, channel 1 = y): per cell of region_h x

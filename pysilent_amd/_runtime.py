@@ -332,6 +332,26 @@ def max_value_indices_region(value, regions, cap_per_frame=None):
     return idx, counts
 
 
+def select_peaks(color, top_percent=0.1, value=None, want=("top", "peaks", "peak_value")):
+    """silent_select_peaks: top_value_points -> nms3x3 (product) -> value in one pass.  Returns a dict."""
+    op = _Operand(color)
+    vptr = None
+    if value is not None:
+        vop = _Operand(value, channels=1)
+        _same_geometry(op, vop, "select_peaks")
+        vptr = vop.ptr
+    outs, ptrs = {}, {}
+    for name, ch in (("top", op.c), ("peaks", op.c), ("peak_value", 1)):
+        if name in want:
+            outs[name], ptrs[name] = op.alloc(ch)
+        else:
+            ptrs[name] = None
+    lib, ctx = _lib.load(), op.ctx
+    args = (ctx.handle, op.ptr, vptr) + op.geom() + (op.c, float(top_percent), ptrs["top"], ptrs["peaks"], ptrs["peak_value"])
+    ctx.check(lib.silent_select_peaks_dev(*(args + (op.stream,))) if op.dev else lib.silent_select_peaks(*args))
+    return {n: op.wrap(o, 1 if n == "peak_value" else op.c) for n, o in outs.items()}
+
+
 def centroids(value, region_h, region_w):
     """silent_centroids: (L1 distance map like ``value``, total_pool as a tensor of cells)."""
     op = _Operand(value, channels=1)

@@ -455,6 +455,36 @@ SILENT_EXPORT int silent_top_value_points_dev(silent_ctx* ctx, const float* colo
     return check_launch(ctx, who);
 }
 
+SILENT_EXPORT int silent_select_peaks_dev(silent_ctx* ctx, const float* color, const float* value,
+                                          const silent_extent* levels, int n_levels, int n_frames, int channels,
+                                          double top_percent, float* top_out, float* peaks_out, float* peak_value_out,
+                                          silent_stream stream) {
+    NEED_CTX(ctx);
+    const char* who = "silent_select_peaks";
+    if (!color) return fail(ctx, SILENT_E_INVALID, std::string(who) + ": NULL pointer");
+    if (!top_out && !peaks_out && !peak_value_out) return fail(ctx, SILENT_E_INVALID, std::string(who) + ": all outputs are NULL");
+    if (channels != 1 && channels != 3) return fail(ctx, SILENT_E_UNSUPPORTED, std::string(who) + ": channels must be 1 or 3");
+    LevelTab rtab, tab;
+    long long rblocks, blocks;
+    TRY(build_level_tab(ctx, who, levels, n_levels, n_frames, 0, 0, &rtab, &rblocks));
+    TRY(build_level_tab(ctx, who, levels, n_levels, n_frames, kSelTW, kSelTH, &tab, &blocks));
+    const int nmm = n_frames * n_levels;
+    TRY(grow(ctx, ctx->ws, sizeof(unsigned) * 2 * (size_t)nmm));
+    unsigned* mm = (unsigned*)ctx->ws.p;
+    hipStream_t s = (hipStream_t)stream;
+    hipLaunchKernelGGL(init_maxmin_kernel, dim3((nmm + 255) / 256), dim3(256), 0, s, mm, nmm);
+    hipLaunchKernelGGL(level_maxmin_kernel, dim3((unsigned)rblocks), dim3(256), 0, s, value, value ? nullptr : color,
+                       channels, rtab, mm);
+    const float a = (float)(1.0 - top_percent), b = (float)top_percent;
+    if (channels == 3)
+        hipLaunchKernelGGL(select_peaks_kernel<3>, dim3((unsigned)blocks), dim3(256), 0, s, color, value, top_out, peaks_out,
+                           peak_value_out, tab, a, b, mm);
+    else
+        hipLaunchKernelGGL(select_peaks_kernel<1>, dim3((unsigned)blocks), dim3(256), 0, s, color, value, top_out, peaks_out,
+                           peak_value_out, tab, a, b, mm);
+    return check_launch(ctx, who);
+}
+
 // ------------------------------------------------------------------------------------------ keypoint indices
 
 // TF1 max_pool SAME geometry with window == full extent
@@ -1554,4 +1584,30 @@ SILENT_EXPORT int silent_resize_nearest(silent_ctx* ctx, const float* in, const 
                                   st.ptr<float>(i_o), nullptr));
     TRY(sync0(ctx));
     return d2h(ctx, out, st.ptr<float>(i_o), bo);
+}
+
+SILENT_EXPORT int silent_select_peaks(silent_ctx* ctx, const float* color, const float* value, const silent_extent* levels,
+                                      int n_levels, int n_frames, int channels, double top_percent, float* top_out,
+                                      float* peaks_out, float* peak_value_out) {
+    NEED_CTX(ctx);
+    if (!color) return fail(ctx, SILENT_E_INVALID, "silent_select_peaks: NULL pointer");
+    if (!top_out && !peaks_out && !peak_value_out) return fail(ctx, SILENT_E_INVALID, "silent_select_peaks: all outputs are NULL");
+    if (channels != 1 && channels != 3) return fail(ctx, SILENT_E_UNSUPPORTED, "silent_select_peaks: channels must be 1 or 3");
+    long long px;
+    TRY(check_levels(ctx, "silent_select_peaks", levels, n_levels, n_frames, &px));
+    Stage st(ctx);
+    const size_t bc = (size_t)px * channels * 4, bv = (size_t)px * 4;
+    const size_t i_c = st.add(bc), i_v = st.add(bv), i_t = st.add(bc), i_p = st.add(bc), i_o = st.add(bv);
+    TRY(st.commit());
+    TRY(h2d(ctx, st.ptr<float>(i_c), color, bc));
+    if (value) TRY(h2d(ctx, st.ptr<float>(i_v), value, bv));
+    TRY(silent_select_peaks_dev(ctx, st.ptr<float>(i_c), value ? st.ptr<float>(i_v) : nullptr, levels, n_levels, n_frames,
+                                channels, top_percent, top_out ? st.ptr<float>(i_t) : nullptr,
+                                peaks_out ? st.ptr<float>(i_p) : nullptr, peak_value_out ? st.ptr<float>(i_o) : nullptr,
+                                nullptr));
+    TRY(sync0(ctx));
+    if (top_out) TRY(d2h(ctx, top_out, st.ptr<float>(i_t), bc));
+    if (peaks_out) TRY(d2h(ctx, peaks_out, st.ptr<float>(i_p), bc));
+    if (peak_value_out) TRY(d2h(ctx, peak_value_out, st.ptr<float>(i_o), bv));
+    return SILENT_OK;
 }

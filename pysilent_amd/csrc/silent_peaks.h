@@ -175,6 +175,115 @@ __global__ __launch_bounds__(256) void top_value_points_kernel(const float* __re
     }
 }
 
+// ---- a-10 -> a-9 -> a-8 in one streaming pass ("top 10 %, NMS" between the chain and the keypoints)
+//   top   = color * (value >= thr ? 1 : 0)                          top_value_points_kernel
+//   peaks = top * (top == maxpool3x3 SAME(top) ? top : 0)           nms3x3_kernel, SILENT_NMS_PRODUCT
+//   pv    = (sum_c peaks) * float32(1 / C)                          value_from_color_kernel
+// Same operations in the same order as the three separate kernels (bit-identical, tested), but the two
+// intermediate colour maps stay in registers unless the caller asks for them: 16 + 4 bytes per pixel instead of 72.
+// Wave-autonomous streaming like gray_line_end_kernel: lane = column (halo 2), rows walk down, the 3x3 maximum is a
+// row maximum by DPP followed by a 3-row window; out-of-image taps are -inf (max_pool ignores them).
+constexpr int kSelCols = 60, kSelTW = 4 * kSelCols, kSelTH = 32;
+
+template <int C>
+__global__ __launch_bounds__(256) void select_peaks_kernel(const float* __restrict__ color,
+                                                           const float* __restrict__ value,
+                                                           float* __restrict__ top_out, float* __restrict__ peaks_out,
+                                                           float* __restrict__ pv_out, const LevelTab tab,
+                                                           float one_minus_p, float p_f,
+                                                           const unsigned* __restrict__ mm) {
+    constexpr int R = kSelTH;
+    const TileCoord tc = locate_tile(tab, blockIdx.x);
+    const int H = tab.h[tc.level], W = tab.w[tc.level];
+    const long long base_px = (long long)tc.frame * tab.frame_px + tab.px_off[tc.level];
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int xw0 = tc.tx * kSelTW + wave * kSelCols;
+    if (xw0 >= W) return;  // wave-uniform
+    const int y0 = tc.ty * R;
+    const int x = xw0 + lane - 2;
+    const bool col_ok = x >= 0 && x < W;
+    const int xc = min(max(x, 0), W - 1);
+    const bool out_lane = lane >= 2 && lane < 2 + kSelCols && x < W;
+    const unsigned* slot = mm + ((long long)tc.frame * tab.n_levels + tc.level) * 2;
+    const float thr = __fadd_rn(__fmul_rn(one_minus_p, ord2f(slot[0])), __fmul_rn(p_f, ord2f(slot[1])));
+    const float inv = 1.0f / (float)C;
+
+    float hm[C][2], ctr[C];  // row maxima of rows y-2, y-1; centre values of row y-1
+#pragma unroll
+    for (int c = 0; c < C; ++c) {
+        hm[c][0] = hm[c][1] = -INFINITY;
+        ctr[c] = 0.0f;
+    }
+    constexpr int CH = 8;  // rows requested per batch
+    static_assert((R + 2) % 2 == 0, "");
+#pragma unroll 1
+    for (int i0 = 0; i0 < R + 2; i0 += CH) {
+        float col[CH][C], val[CH];
+#pragma unroll
+        for (int j = 0; j < CH; ++j) {
+            const int y = y0 - 1 + i0 + j;
+            const long long px = base_px + (long long)min(max(y, 0), H - 1) * W + xc;
+#pragma unroll
+            for (int c = 0; c < C; ++c) col[j][c] = color[px * C + c];
+            val[j] = value ? value[px] : 0.0f;
+        }
+#pragma unroll
+        for (int j = 0; j < CH; ++j) {
+            const int i = i0 + j;
+            if (i >= R + 2) break;  // wave-uniform
+            const int y = y0 - 1 + i;  // arriving row; row y - 1 completes
+            const bool in_img = y >= 0 && y < H && col_ok;
+            float v = val[j];
+            if (!value) {
+                v = col[j][0];
+#pragma unroll
+                for (int c = 1; c < C; ++c) v = __fadd_rn(v, col[j][c]);
+                v = __fmul_rn(v, inv);
+            }
+            const float m = v >= thr ? 1.0f : 0.0f;
+            float t[C], o[C];
+#pragma unroll
+            for (int c = 0; c < C; ++c) {
+                t[c] = __fmul_rn(col[j][c], m);
+                const float tp = in_img ? t[c] : -INFINITY;  // max_pool SAME ignores taps outside the image
+                const float l = from_lane_below(tp), r = from_lane_above(tp);
+                float h = -INFINITY;                          // same NaN-ignoring order as nms3x3_kernel
+                h = h < l ? l : h;
+                h = h < tp ? tp : h;
+                h = h < r ? r : h;
+                float mx = hm[c][0];
+                mx = mx < hm[c][1] ? hm[c][1] : mx;
+                mx = mx < h ? h : mx;
+                const float xv = ctr[c];
+                o[c] = __fmul_rn(xv, xv == mx ? xv : 0.0f);
+                hm[c][0] = hm[c][1];
+                hm[c][1] = h;
+            }
+            const int yo = y - 1;
+            if (i >= 2 && yo < H && out_lane) {  // rows y0 .. y0 + R - 1
+                const long long px = base_px + (long long)yo * W + x;
+                if (top_out) {
+#pragma unroll
+                    for (int c = 0; c < C; ++c) top_out[px * C + c] = ctr[c];
+                }
+                if (peaks_out) {
+#pragma unroll
+                    for (int c = 0; c < C; ++c) peaks_out[px * C + c] = o[c];
+                }
+                if (pv_out) {
+                    float pv = o[0];
+#pragma unroll
+                    for (int c = 1; c < C; ++c) pv = __fadd_rn(pv, o[c]);
+                    pv_out[px] = __fmul_rn(pv, inv);
+                }
+            }
+#pragma unroll
+            for (int c = 0; c < C; ++c) ctr[c] = t[c];
+        }
+    }
+}
+
 // ---- a-11 max_value_indices_region
 // The TF1 op is max_pool(k = full extent, stride = region, SAME): every window is the level clipped to
 // a shifted copy of itself, i.e. a PREFIX or a SUFFIX of rows (and of columns).  The distinct window

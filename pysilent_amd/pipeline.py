@@ -56,7 +56,7 @@ def unpack_constants(blob, layout):
 class LineEndPipeline(object):
     def __init__(self, frame_hw, mode="gray", n_levels=5, scale=2.0, n_orient=4, batch=1, device=None,
                  constants=None, center_dimensions=None, clip_hi=255.0, flat_policy="ieee", pad=2,
-                 max_keypoints_per_frame=None, selection=False, top_percent=0.1):
+                 max_keypoints_per_frame=None, selection=False, top_percent=0.1, keep_selection_maps=False):
         import torch
         self.torch = torch
         self.mode = mode
@@ -94,9 +94,11 @@ class LineEndPipeline(object):
             # then the per-region keypoint indices (a-11) of what survives; False: the reference graph
             # (recognition_testing.py:90), keypoints straight from the padded line-end map
             self.selection, self.top_percent = bool(selection), float(top_percent)
+            self.keep_selection_maps = bool(keep_selection_maps)
             if self.selection:
-                self.top = torch.empty(n * 3, **f32)
-                self.peaks = torch.empty(n * 3, **f32)
+                if self.keep_selection_maps:
+                    self.top = torch.empty(n * 3, **f32)
+                    self.peaks = torch.empty(n * 3, **f32)
                 self.peak_value = torch.empty(n, **f32)
             self.kp_cap = int(max_keypoints_per_frame or self.frame_px)
             self.kp_idx = torch.empty((self.batch, self.kp_cap, 4), dtype=torch.int64, device=self.tdev)
@@ -159,12 +161,11 @@ class LineEndPipeline(object):
         if self.selection:
             geom = (self.levels_c, self.n_levels, self.batch)
             p = lambda t: C.c_void_p(t.data_ptr())
-            self.ctx.check(self._lib.silent_top_value_points_dev(self.ctx.handle, p(self.line_end), p(self.value), *geom, 3,
-                                                                 self.top_percent, p(self.top), s))
-            self.ctx.check(self._lib.silent_nms3x3_dev(self.ctx.handle, p(self.top), *geom, 3, _lib.NMS_PRODUCT,
-                                                       p(self.peaks), s))
-            self.ctx.check(self._lib.silent_value_from_color_dev(self.ctx.handle, p(self.peaks), *geom, 3,
-                                                                 p(self.peak_value), s))
+            # a-10 -> a-9 -> a-8 in one streaming pass; the intermediate colour maps are only written when kept
+            self.ctx.check(self._lib.silent_select_peaks_dev(
+                self.ctx.handle, p(self.line_end), p(self.value), *geom, 3, self.top_percent,
+                p(self.top) if self.keep_selection_maps else None, p(self.peaks) if self.keep_selection_maps else None,
+                p(self.peak_value), s))
             value = self.peak_value
         self.ctx.check(self._lib.silent_max_value_indices_region_dev(
             self.ctx.handle, C.c_void_p(value.data_ptr()), self.levels_c, self.n_levels, self.batch, self.regions,
@@ -211,8 +212,9 @@ class LineEndPipeline(object):
             out["line_end"] = P(self.line_end, self.extents, 3, self.batch)
             out["value"] = P(self.value, self.extents, 1, self.batch)
             if self.selection:
-                out["top"] = P(self.top, self.extents, 3, self.batch)
-                out["peaks"] = P(self.peaks, self.extents, 3, self.batch)
+                if self.keep_selection_maps:
+                    out["top"] = P(self.top, self.extents, 3, self.batch)
+                    out["peaks"] = P(self.peaks, self.extents, 3, self.batch)
                 out["peak_value"] = P(self.peak_value, self.extents, 1, self.batch)
             counts = self.kp_counts.cpu().numpy()
             idx = self.kp_idx.cpu().numpy()

@@ -461,12 +461,39 @@ def test_rgb_chain_on_packed_levels_and_keypoints(rt, kernels):
         np.testing.assert_array_equal(kp[f], np.concatenate(rows))     # bit-exact, row-major, level-major
 
 
+@pytest.mark.parametrize("c", [1, 3])
+@pytest.mark.parametrize("with_value", [True, False])
+def test_select_peaks_equals_the_three_separate_ops(rt, c, with_value):
+    """silent_select_peaks == top_value_points -> nms3x3(product) -> value_from_color, bit for bit, ragged levels
+    (including 1 x 1 and extents around the 60-column wave tile), ties and zero plateaus included."""
+    from pysilent_amd.util.selection import top_value_points
+    from pysilent_amd.util.color import get_value_from_color
+    extents = [(37, 131), (70, 60), (33, 61), (1, 1), (2, 300), (64, 241)]
+    rng = np.random.default_rng(5 + c)
+    levels = [np.floor(rng.random((2, h, w, c)) * 8).astype(np.float32) * 32 for h, w in extents]      # many ties
+    packed = rt.PackedPyramid.from_levels(levels)
+    value = get_value_from_color(packed) if with_value else None
+    got = rt.select_peaks(packed, 0.1, value)
+    top = top_value_points(packed, 0.1, value)
+    peaks = rt.nms3x3(top, "product")
+    pv = get_value_from_color(peaks)
+    np.testing.assert_array_equal(got["top"].data, top.data)
+    np.testing.assert_array_equal(got["peaks"].data, peaks.data)
+    np.testing.assert_array_equal(got["peak_value"].data, pv.data)
+    only = rt.select_peaks(packed, 0.1, value, want=("peak_value",))
+    np.testing.assert_array_equal(only["peak_value"].data, pv.data)
+    for l, lev in enumerate(levels):                                     # and against the oracle
+        v = so.value_from_color(lev)
+        np.testing.assert_array_equal(got["peaks"].level(l), so.nms3x3(so.top_value_points(lev, 0.1, v), "product"))
+
+
 def test_rgb_pipeline_with_selection_stage(rt, kernels):
     """chain -> top-percent (a-10, p = 0.1) -> NMS (a-9) -> value -> keypoints (a-11); every stage
     after the chain is index-like and compared bit for bit with the oracle applied to the GPU's own line-end map."""
     import torch
     from pysilent_amd.pipeline import LineEndPipeline
-    pipe = LineEndPipeline((96, 160), mode="rgb", n_levels=3, batch=2, selection=True, max_keypoints_per_frame=1 << 15)
+    pipe = LineEndPipeline((96, 160), mode="rgb", n_levels=3, batch=2, selection=True, keep_selection_maps=True,
+                           max_keypoints_per_frame=1 << 15)
     frames = np.stack([noise_frame(70 + i, 96, 160, 3) for i in range(2)])      # noise frames stay finite (no 0 * inf)
     pipe.step(torch.from_numpy(frames).cuda())
     torch.cuda.synchronize()
