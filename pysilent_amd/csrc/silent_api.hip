@@ -196,7 +196,7 @@ SILENT_EXPORT int silent_synchronize(silent_ctx* ctx, silent_stream stream) {
 
 // ------------------------------------------------------------------------------------------ tile tables
 
-// tile_h == 0 selects the 1-D "chunk" decomposition (kChunk flattened pixels per block).
+// tile_h == 0 selects the 1-D "chunk" decomposition (kChunk flattened pixels per block; tile_w > 0: that many).
 static int build_level_tab(silent_ctx* ctx, const char* who, const silent_extent* levels, int n_levels, int n_frames,
                            int tile_w, int tile_h, LevelTab* tab, long long* n_blocks,
                            const bool* skip = nullptr) {
@@ -218,7 +218,8 @@ static int build_level_tab(silent_ctx* ctx, const char* who, const silent_extent
         tab->tile_start[l] = (int)tiles;
         long long tx, ty;
         if (tile_h == 0) {
-            tx = (h * w + kChunk - 1) / kChunk;
+            const long long chunk = tile_w > 0 ? tile_w : kChunk;
+            tx = (h * w + chunk - 1) / chunk;
             ty = 1;
         } else {
             tx = (w + tile_w - 1) / tile_w;
@@ -441,13 +442,16 @@ SILENT_EXPORT int silent_top_value_points_dev(silent_ctx* ctx, const float* colo
     LevelTab tab;
     long long blocks;
     TRY(build_level_tab(ctx, who, levels, n_levels, n_frames, 0, 0, &tab, &blocks));
+    LevelTab rtab;
+    long long rblocks;
+    TRY(build_level_tab(ctx, who, levels, n_levels, n_frames, kRedChunk, 0, &rtab, &rblocks));
     const int nmm = n_frames * n_levels;
     TRY(grow(ctx, ctx->ws, sizeof(unsigned) * 2 * (size_t)nmm));
     unsigned* mm = (unsigned*)ctx->ws.p;
     hipStream_t s = (hipStream_t)stream;
     hipLaunchKernelGGL(init_maxmin_kernel, dim3((nmm + 255) / 256), dim3(256), 0, s, mm, nmm);
-    hipLaunchKernelGGL(level_maxmin_kernel, dim3((unsigned)blocks), dim3(256), 0, s, value, value ? nullptr : color,
-                       channels, tab, mm);
+    hipLaunchKernelGGL(level_maxmin_kernel, dim3((unsigned)rblocks), dim3(256), 0, s, value, value ? nullptr : color,
+                       channels, rtab, mm);
     // python: (1.0 - top_percent) and top_percent are doubles that TF casts to float32 constants
     const float a = (float)(1.0 - top_percent), b = (float)top_percent;
     hipLaunchKernelGGL(top_value_points_kernel, dim3((unsigned)blocks), dim3(256), 0, s, color, value, out, tab,
@@ -466,7 +470,7 @@ SILENT_EXPORT int silent_select_peaks_dev(silent_ctx* ctx, const float* color, c
     if (channels != 1 && channels != 3) return fail(ctx, SILENT_E_UNSUPPORTED, std::string(who) + ": channels must be 1 or 3");
     LevelTab rtab, tab;
     long long rblocks, blocks;
-    TRY(build_level_tab(ctx, who, levels, n_levels, n_frames, 0, 0, &rtab, &rblocks));
+    TRY(build_level_tab(ctx, who, levels, n_levels, n_frames, kRedChunk, 0, &rtab, &rblocks));
     TRY(build_level_tab(ctx, who, levels, n_levels, n_frames, kSelTW, kSelTH, &tab, &blocks));
     const int nmm = n_frames * n_levels;
     TRY(grow(ctx, ctx->ws, sizeof(unsigned) * 2 * (size_t)nmm));
@@ -530,9 +534,10 @@ SILENT_EXPORT int silent_max_value_indices_region_dev(silent_ctx* ctx, const flo
     const char* who = "silent_max_value_indices_region";
     if (!value || !regions || !counts || (!idx && cap_per_frame))
         return fail(ctx, SILENT_E_INVALID, std::string(who) + ": NULL pointer");
-    LevelTab tab;
-    long long blocks;
-    TRY(build_level_tab(ctx, who, levels, n_levels, n_frames, 0, 0, &tab, &blocks));
+    LevelTab tab, ctab;
+    long long blocks, cblocks;
+    TRY(build_level_tab(ctx, who, levels, n_levels, n_frames, kKpChunk, 0, &tab, &blocks));   // count / write chunks
+    TRY(build_level_tab(ctx, who, levels, n_levels, n_frames, kRedChunk, 0, &ctab, &cblocks));  // cell maxima
     RegionTab rt;
     std::memset(&rt, 0, sizeof(rt));
     for (int l = 0; l < n_levels; ++l) {
@@ -555,7 +560,7 @@ SILENT_EXPORT int silent_max_value_indices_region_dev(silent_ctx* ctx, const flo
     long long* chunk_offsets = (long long*)((char*)ctx->ws.p + off_offsets);
     hipStream_t s = (hipStream_t)stream;
     hipLaunchKernelGGL(init_cells_kernel, dim3((unsigned)((n_cells + 255) / 256)), dim3(256), 0, s, cells, (long long)n_cells);
-    hipLaunchKernelGGL(region_cell_max_kernel, dim3((unsigned)blocks), dim3(256), 0, s, value, tab, rt, cells);
+    hipLaunchKernelGGL(region_cell_max_kernel, dim3((unsigned)cblocks), dim3(256), 0, s, value, ctab, rt, cells);
     hipLaunchKernelGGL(region_count_kernel, dim3((unsigned)blocks), dim3(256), 0, s, value, tab, rt, cells, chunk_counts);
     hipLaunchKernelGGL(region_scan_kernel, dim3((unsigned)n_frames), dim3(256), 0, s, chunk_counts, chunk_offsets,
                        tab.tiles_per_frame, counts);
