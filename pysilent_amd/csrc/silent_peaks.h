@@ -319,6 +319,16 @@ struct RegionTab {
 
 constexpr int kCells = kMaxSeg * kMaxSeg;
 
+// (y, x) of pixel p are carried by the caller: the kernels walk their pixels with a fixed stride, so one integer
+// division per thread replaces one per pixel
+__device__ __forceinline__ void advance_yx(int& y, int& x, int step, int W) {
+    x += step;
+    while (x >= W) {
+        x -= W;
+        ++y;
+    }
+}
+
 __global__ void init_cells_kernel(unsigned* cells, long long n) {
     const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
     if (i < n) cells[i] = 0u;
@@ -335,14 +345,14 @@ __global__ __launch_bounds__(256) void region_cell_max_kernel(const float* __res
     const long long base_px = (long long)tc.frame * tab.frame_px + tab.px_off[tc.level];
     for (int i = threadIdx.x; i < kCells; i += 256) s_cell[i] = 0u;
     __syncthreads();
-    for (int k = 0; k < kRedChunk / 256; ++k) {
+    int y = (tc.tx * kRedChunk + (int)threadIdx.x) / W, x = tc.tx * kRedChunk + (int)threadIdx.x - y * W;
+    for (int k = 0; k < kRedChunk / 256; ++k, advance_yx(y, x, 256, W)) {
         const int p = tc.tx * kRedChunk + k * 256 + threadIdx.x;
         if (tc.tx * kRedChunk + k * 256 >= npx) break;  // block-uniform
         const bool live = p < npx;
         int cell = -1;
         float v = -INFINITY;
         if (live) {
-            const int y = p / W, x = p - y * W;
             int rs = 0, cs = 0;
             for (int s = 1; s < rl.nrs; ++s) rs = y >= rl.rcut[s] ? s : rs;
             for (int s = 1; s < rl.ncs; ++s) cs = x >= rl.ccut[s] ? s : cs;
@@ -379,9 +389,8 @@ __device__ __forceinline__ void load_pooled(const unsigned* __restrict__ cells, 
     }
 }
 
-__device__ __forceinline__ bool region_pred(const float* __restrict__ value, long long base_px, int p, int W,
+__device__ __forceinline__ bool region_pred(const float* __restrict__ value, long long base_px, int p, int y, int x,
                                             const RegionLevel& rl, const float* s_pooled) {
-    const int y = p / W, x = p - y * W;
     // TF1 ResizeNearestNeighbor: min(floorf(dst * scale), in - 1), float32
     int sy = (int)floorf(__fmul_rn((float)y, rl.yscale));
     int sx = (int)floorf(__fmul_rn((float)x, rl.xscale));
@@ -409,10 +418,11 @@ __global__ __launch_bounds__(256) void region_count_kernel(const float* __restri
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int seg = tc.tx * kKpChunk + wave * (kKpChunk / 4);
     int n = 0;
+    int y = (seg + lane) / W, x = seg + lane - y * W;
 #pragma unroll 4
-    for (int k = 0; k < kKpPer; ++k) {
+    for (int k = 0; k < kKpPer; ++k, advance_yx(y, x, 64, W)) {
         const int p = seg + k * 64 + lane;
-        const bool hit = p < npx && region_pred(value, base_px, min(p, npx - 1), W, rl, s_pooled);
+        const bool hit = p < npx && region_pred(value, base_px, min(p, npx - 1), y, x, rl, s_pooled);
         n += __popcll(__ballot(hit));
     }
     if (lane == 0) s_cnt[wave] = n;
@@ -470,10 +480,12 @@ __global__ __launch_bounds__(256) void region_write_kernel(const float* __restri
     const int seg = tc.tx * kKpChunk + wave * (kKpChunk / 4);
     unsigned long long hits[kKpPer];
     int n = 0;
+    const int y0 = (seg + lane) / W, x0 = seg + lane - y0 * W;
+    int y = y0, x = x0;
 #pragma unroll
-    for (int k = 0; k < kKpPer; ++k) {
+    for (int k = 0; k < kKpPer; ++k, advance_yx(y, x, 64, W)) {
         const int p = seg + k * 64 + lane;
-        const bool hit = p < npx && region_pred(value, base_px, min(p, npx - 1), W, rl, s_pooled);
+        const bool hit = p < npx && region_pred(value, base_px, min(p, npx - 1), y, x, rl, s_pooled);
         hits[k] = __ballot(hit);
         n += __popcll(hits[k]);
     }
@@ -483,14 +495,14 @@ __global__ __launch_bounds__(256) void region_write_kernel(const float* __restri
     for (int i = 0; i < wave; ++i) pos += s_wave[i];
     int64_t* dst = idx + (long long)tc.frame * cap_per_frame * 4;
     const unsigned long long below = (1ull << lane) - 1ull;
+    y = y0;
+    x = x0;
 #pragma unroll
-    for (int k = 0; k < kKpPer; ++k) {
+    for (int k = 0; k < kKpPer; ++k, advance_yx(y, x, 64, W)) {
         const unsigned long long m = hits[k];
         if ((m >> lane) & 1ull) {
             const long long r = pos + __popcll(m & below);
             if (r < cap_per_frame) {
-                const int p = seg + k * 64 + lane;
-                const int y = p / W, x = p - y * W;
                 dst[r * 4 + 0] = tc.level;
                 dst[r * 4 + 1] = y;
                 dst[r * 4 + 2] = x;
