@@ -156,9 +156,11 @@ int silent_gray_pass_dev(silent_ctx* ctx, const silent_pyramid_plan* plan, const
 int silent_pyramid_plan_is_streamable(const silent_pyramid_plan* plan);
 
 /* Optional HIP-event timing of the DOMINANT kernel of the last silent_gray_pass_dev call (the fused
- * unit-level kernel): enable with silent_set_profiling(ctx, 1); the events are recorded on the stream the
- * kernel runs on.  silent_profile_elapsed_ms synchronises on the second event and returns the elapsed time
- * and the number of level-0-class pixels the kernel processed. */
+ * unit-level kernel): silent_set_profiling(ctx, n) with n >= 1 brackets that kernel with an event pair on every
+ * n-th call (n = 0: off), on the stream the kernel runs on -- an event is a packet in the queue, so bracketing every
+ * call costs a few per cent of a millisecond-long pass.  silent_profile_elapsed_ms synchronises and returns the MEAN
+ * over the (up to 8 most recent) recorded pairs since the last silent_set_profiling, and the number of
+ * level-0-class pixels the kernel processed per launch. */
 int silent_set_profiling(silent_ctx* ctx, int enable);
 int silent_profile_elapsed_ms(silent_ctx* ctx, float* ms, int64_t* pixels);
 

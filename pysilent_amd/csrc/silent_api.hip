@@ -35,8 +35,12 @@ struct silent_ctx {
     DevBuf arena;  // staging for the host-pointer entry points
     DevBuf ws;     // scratch for reductions / compaction / the RGB chain temporaries
     bool profiling = false;
-    bool prof_valid = false;
-    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    // HIP-event sampling of the dominant kernel of silent_gray_pass_dev: every prof_period-th call records a pair
+    // into a ring of kProfPairs, silent_profile_elapsed_ms averages the recorded ones
+    static constexpr int kProfPairs = 8;
+    hipEvent_t prof_ev[kProfPairs][2] = {};
+    int prof_period = 1, prof_calls = 0, prof_recorded = 0;
+    bool prof_sample = false;
     long long prof_pixels = 0;
 };
 
@@ -139,8 +143,9 @@ SILENT_EXPORT void silent_destroy(silent_ctx* ctx) {
     (void)hipSetDevice(ctx->device);
     if (ctx->arena.p) (void)hipFree(ctx->arena.p);
     if (ctx->ws.p) (void)hipFree(ctx->ws.p);
-    if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
-    if (ctx->ev1) (void)hipEventDestroy(ctx->ev1);
+    for (auto& pr : ctx->prof_ev)
+        for (hipEvent_t e : pr)
+            if (e) (void)hipEventDestroy(e);
     delete ctx;
 }
 
@@ -1132,21 +1137,29 @@ SILENT_EXPORT int silent_pyramid_plan_is_streamable(const silent_pyramid_plan* p
 
 SILENT_EXPORT int silent_set_profiling(silent_ctx* ctx, int enable) {
     NEED_CTX(ctx);
-    if (enable && !ctx->ev0) {
-        HIP_TRY(ctx, hipEventCreate(&ctx->ev0));
-        HIP_TRY(ctx, hipEventCreate(&ctx->ev1));
-    }
+    if (enable < 0) return fail(ctx, SILENT_E_INVALID, "silent_set_profiling: enable must be >= 0");
+    if (enable && !ctx->prof_ev[0][0])
+        for (auto& pr : ctx->prof_ev)
+            for (hipEvent_t& e : pr) HIP_TRY(ctx, hipEventCreate(&e));
     ctx->profiling = enable != 0;
-    ctx->prof_valid = false;
+    ctx->prof_period = enable > 0 ? enable : 1;
+    ctx->prof_calls = ctx->prof_recorded = 0;
     return SILENT_OK;
 }
 
 SILENT_EXPORT int silent_profile_elapsed_ms(silent_ctx* ctx, float* ms, int64_t* pixels) {
     NEED_CTX(ctx);
     if (!ms) return fail(ctx, SILENT_E_INVALID, "silent_profile_elapsed_ms: ms is NULL");
-    if (!ctx->prof_valid) return fail(ctx, SILENT_E_INVALID, "silent_profile_elapsed_ms: no profiled launch recorded");
-    HIP_TRY(ctx, hipEventSynchronize(ctx->ev1));
-    HIP_TRY(ctx, hipEventElapsedTime(ms, ctx->ev0, ctx->ev1));
+    if (!ctx->prof_recorded) return fail(ctx, SILENT_E_INVALID, "silent_profile_elapsed_ms: no profiled launch recorded");
+    const int n = std::min(ctx->prof_recorded, silent_ctx::kProfPairs);
+    double sum = 0.0;
+    for (int i = 0; i < n; ++i) {
+        float t = 0.f;
+        HIP_TRY(ctx, hipEventSynchronize(ctx->prof_ev[i][1]));
+        HIP_TRY(ctx, hipEventElapsedTime(&t, ctx->prof_ev[i][0], ctx->prof_ev[i][1]));
+        sum += t;
+    }
+    *ms = (float)(sum / n);
     if (pixels) *pixels = ctx->prof_pixels;
     return SILENT_OK;
 }
@@ -1208,7 +1221,9 @@ SILENT_EXPORT int silent_gray_pass_dev(silent_ctx* ctx, const silent_pyramid_pla
         std::memset(&w, 0, sizeof(w));
         std::memcpy(w.cs, cs_kernel, sizeof(float) * 9);
         if (end_bank) std::memcpy(w.end, end_bank, sizeof(float) * 9 * n_orient);
-        if (ctx->profiling) HIP_TRY(ctx, hipEventRecord(ctx->ev0, s));
+        ctx->prof_sample = ctx->profiling && (ctx->prof_calls++ % ctx->prof_period) == 0;
+        const int prof_slot = ctx->prof_recorded % silent_ctx::kProfPairs;
+        if (ctx->prof_sample) HIP_TRY(ctx, hipEventRecord(ctx->prof_ev[prof_slot][0], s));
         if (stream_path) {
             const StreamTab& st = plan->stream;
 #define STREAM_LAUNCH(K_, G_) \
@@ -1237,9 +1252,9 @@ SILENT_EXPORT int silent_gray_pass_dev(silent_ctx* ctx, const silent_pyramid_pla
             }
 #undef FUSED_LAUNCH
         }
-        if (ctx->profiling) {
-            HIP_TRY(ctx, hipEventRecord(ctx->ev1, s));
-            ctx->prof_valid = true;
+        if (ctx->prof_sample) {
+            HIP_TRY(ctx, hipEventRecord(ctx->prof_ev[prof_slot][1], s));
+            ++ctx->prof_recorded;
             ctx->prof_pixels = unit_px * n_frames;
         }
         TRY(check_launch(ctx, who));

@@ -302,8 +302,7 @@ __global__ __launch_bounds__(256) void gray_line_end_kernel(const float* __restr
             if (y < H) {               // wave-uniform
                 const long long px = base_px + (long long)y * W + x;
                 if (cs_out && out_lane) {
-                    if (opts & 4u) __builtin_nontemporal_store(cw[1][1], cs_out + px);
-                    else cs_out[px] = cw[1][1];
+                    cs_out[px] = cw[1][1];  // (non-temporal here: within noise, unlike in gray_stream_kernel)
                 }
                 if (end_out) {
                     float acc[K];
@@ -328,8 +327,7 @@ __global__ __launch_bounds__(256) void gray_line_end_kernel(const float* __restr
                         if constexpr (K == 4) {
                             typedef float nf4 __attribute__((ext_vector_type(4)));
                             const nf4 v4 = {acc[0], acc[1], acc[2], acc[3]};
-                            if (opts & 4u) __builtin_nontemporal_store(v4, reinterpret_cast<nf4*>(po));
-                            else *reinterpret_cast<nf4*>(po) = v4;
+                            *reinterpret_cast<nf4*>(po) = v4;
                         } else {
 #pragma unroll
                             for (int k = 0; k < K; ++k) po[k] = acc[k];
@@ -470,7 +468,7 @@ __global__ __launch_bounds__(256) void gray_unit_fused_kernel(const float* __res
             const int y = y0 + i - 8;
             if (y < lv.out_h) {  // wave-uniform
                 const long long px = base_px + (long long)y * lv.out_w + ox;
-                if (cs_out && out_lane) cs_out[px] = cw[1][1];
+                if (cs_out && out_lane) cs_out[px] = cw[1][1];  // (non-temporal here: 6 % SLOWER, unlike in gray_stream_kernel)
                 if (end_out) {
                     float acc[K];
 #pragma unroll
@@ -714,6 +712,12 @@ __global__ __launch_bounds__(256) void gray_stream_kernel(const float* __restric
     const bool out_lane = lane >= 4 && lane < 4 + kFusedCols && ox < lv.out_w;
 #endif
     const long long wave_px = base_px + (xw0 - 4);    // + row * out_w + lane: wave-uniform part of every address
+    // The two 1-channel maps of the unit level are written with NON-TEMPORAL stores (nt: streamed through L2 without
+    // displacing the frame rows that neighbouring tiles re-read): -6...-9 % in alternating A/B.  Measured with it:
+    // nt on the 16-byte end-map stores as well +3 %, on those alone 0; nt on the small line-sharing stores of pass 2
+    // +18 % (they then reach memory as partial lines); the same nt stores in gray_unit_fused_kernel +6 % (!), in
+    // pyramid_unit_kernel and gray_line_end_kernel within noise; a run-time switch between the two kinds of store
+    // costs 2.5 % by itself, hence no knob.
     // (Tried and dropped: a 3-instruction relu+clip (v_med3 + NaN select) instead of 4: no measurable change, the kernel
     // is not VALU-bound any more.  Parking 4 finished rows of the 1-channel maps in consumed LDS rows and writing them with one
     // global_store_dwordx4 per 4 rows -- 24 instead of 48 stores per tile -- was 3.5 % slower in an alternating A/B.)
@@ -758,7 +762,7 @@ __global__ __launch_bounds__(256) void gray_stream_kernel(const float* __restric
 #if defined(SILENT_EXPERIMENT) && SILENT_EXPERIMENT == 4   // stores only, and only the end maps
                     if (out_lane && clip_hi == -12345.0f) prow[lane] = v;
 #else
-                    if (out_lane) prow[lane] = v;
+                    if (out_lane) __builtin_nontemporal_store(v, prow + lane);
 #endif
                 }
 #pragma unroll
@@ -805,7 +809,7 @@ __global__ __launch_bounds__(256) void gray_stream_kernel(const float* __restric
 #if defined(SILENT_EXPERIMENT) && SILENT_EXPERIMENT == 4
                         if (out_lane && clip_hi == -12345.0f) crow[lane] = cw[1][1];
 #else
-                        if (out_lane) crow[lane] = cw[1][1];
+                        if (out_lane) __builtin_nontemporal_store(cw[1][1], crow + lane);
 #endif
                     }
                     if (end_out) {
@@ -837,7 +841,9 @@ __global__ __launch_bounds__(256) void gray_stream_kernel(const float* __restric
 #if defined(SILENT_EXPERIMENT) && SILENT_EXPERIMENT == 5   // stores only, and only the 1-channel maps
                             if (out_lane && clip_hi == -12345.0f) erow[lane] = make_float4(acc[0], acc[1], acc[2], acc[3]);
 #else
-                            if (out_lane) erow[lane] = make_float4(acc[0], acc[1], acc[2], acc[3]);
+                            if (out_lane) {
+                                erow[lane] = make_float4(acc[0], acc[1], acc[2], acc[3]);
+                            }
 #endif
                         } else {
                             float* __restrict__ po = end_out + row_px * K;

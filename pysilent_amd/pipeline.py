@@ -181,8 +181,9 @@ class LineEndPipeline(object):
             self.clip_hi, C.c_void_p(self.pyr.data_ptr()), C.c_void_p(self.cs.data_ptr()),
             C.c_void_p(self.end.data_ptr()), stream or self._stream()))
 
-    def set_profiling(self, enable=True):
-        self.ctx.check(self._lib.silent_set_profiling(self.ctx.handle, 1 if enable else 0))
+    def set_profiling(self, every=1):
+        """Bracket the dominant kernel with HIP events on every ``every``-th step (0 / False: off)."""
+        self.ctx.check(self._lib.silent_set_profiling(self.ctx.handle, int(every)))
 
     def profiled_kernel(self):
         """(milliseconds, pixels) of the dominant kernel of the last run_gray_pass (HIP events on its stream)."""

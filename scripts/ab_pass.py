@@ -33,9 +33,9 @@ for k in variants:
 
 # dominant kernel alone (HIP events recorded by the library around its launch) + a device copy for calibration
 os.environ["SILENT_GRAY_OPTS"] = os.environ.get("AB_BASE_OPTS", "0")
-pipe.set_profiling(True)
 ks = []
 for _ in range(30):
+    pipe.set_profiling(1)          # resets the sample ring: one pair per step here
     pipe.step(frames)
     torch.cuda.synchronize()
     ks.append(pipe.profiled_kernel()[0])
