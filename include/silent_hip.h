@@ -320,6 +320,12 @@ typedef struct silent_rgb_chain_params {
     int32_t pad;         /* 2                          recognition_testing.py:75 */
 } silent_rgb_chain_params;
 
+/* Host-only: which structure silent_rgb_line_end finds in the weights (no GPU needed).  flags: bit 0 rgc is
+ * channel-diagonal, bit 1 stripe does not depend on the input channel, bit 2 rgby / bit 3 end are "two-group" kernels
+ * (every tap vector K[t][i][:] a multiple of one of two vectors).  masks (may be NULL): 6 words, the group-A tap masks
+ * (bit dy * 3 + dx) of rgby and end per input channel. */
+int silent_rgb_chain_structure(const silent_rgb_chain_params* params, unsigned* flags, unsigned* masks);
+
 int silent_rgb_line_end(silent_ctx* ctx, const float* pyr, const silent_extent* levels, int n_levels, int n_frames,
                         const silent_rgb_chain_params* params, float* orient_out, float* line_end_out,
                         float* value_out);

@@ -33,6 +33,13 @@ struct RgbW {
     float rgc[81], rgby[81], stripe[81], end[81];  // [o][dy][dx][i] (repacked from HWIO by the host)
     float blur[49];                                // profile [dy][dx]
 };
+// Two-group ("centre / surround") form of a 3x3x3->3 kernel, stored in the first 45 floats of its dense slot:
+//   K[t][i][o] = scale[t][i] * (tap t of input i is in group A ? mixA[i][o] : mixB[i][o]),   scale >= 0
+// scale [dy][dx][i] at 0..26, mixA [i][o] at 27..35, mixB [i][o] at 36..44.  Which taps are in group A is a
+// compile-time mask per input channel (bit dy * 3 + dx).  This is how the reference's generators build
+// rgby_3 (one 3x3 profile, centre tap -> one channel-mix matrix, the 8 others -> another) and rgb_2d_end_tensors
+// (one-hot input per orientation, taps with z >= 0 -> center_out, z < 0 -> surround_out): 27 + 18 instead of 81 fmas.
+constexpr int kStructMixA = 27, kStructMixB = 36;
 
 struct RgbP {
     float rv, root;
@@ -107,6 +114,52 @@ __device__ __forceinline__ void conv3_roll(const float (&v)[3][3], kfloat_p wsta
     }
 }
 
+// One arriving row of a two-group kernel.  pa / pb hold, per pending output row, the partial sums of group A and of
+// group B for every input channel: [0..2] = A_i, [3..5] = B_i.  Rounding differs from the 81-term chain (re-association).
+template <unsigned M0, unsigned M1, unsigned M2>
+__device__ __forceinline__ void conv3_roll_struct(const float (&v)[3][3], kfloat_p wstage, float (&pa)[6], float (&pb)[6],
+                                                  float (&done)[3]) {
+    float acc[6][3];  // [group * 3 + i][dy]
+#pragma unroll
+    for (int q = 0; q < 6; ++q) {
+        acc[q][0] = 0.0f;
+        acc[q][1] = pb[q];
+        acc[q][2] = pa[q];
+    }
+    constexpr unsigned M[3] = {M0, M1, M2};
+#pragma unroll
+    for (int dy = 2; dy >= 0; --dy) {
+        const Chain3 w = load_chain3(wstage, dy * 9);  // scale[dy][dx][i]
+#pragma unroll
+        for (int dx = 0; dx < 3; ++dx)
+#pragma unroll
+            for (int i = 0; i < 3; ++i) {
+                const int q = ((M[i] >> (dy * 3 + dx)) & 1u) ? i : 3 + i;
+                acc[q][dy] = __builtin_fmaf(v[dx][i], w.k[dx * 3 + i], acc[q][dy]);
+            }
+#pragma unroll
+        for (int q = 0; q < 6; ++q) asm volatile("" : "+v"(acc[q][dy]));
+    }
+    // the completed row: out[o] = sum_i mixA[i][o] * A_i + mixB[i][o] * B_i
+    const Chain3 ma = load_chain3(wstage, kStructMixA), mb = load_chain3(wstage, kStructMixB);
+#pragma unroll
+    for (int o = 0; o < 3; ++o) {
+        float t = ma.k[0 * 3 + o] * acc[0][2];
+        t = __builtin_fmaf(ma.k[1 * 3 + o], acc[1][2], t);
+        t = __builtin_fmaf(ma.k[2 * 3 + o], acc[2][2], t);
+        t = __builtin_fmaf(mb.k[0 * 3 + o], acc[3][2], t);
+        t = __builtin_fmaf(mb.k[1 * 3 + o], acc[4][2], t);
+        t = __builtin_fmaf(mb.k[2 * 3 + o], acc[5][2], t);
+        done[o] = t;
+    }
+    asm volatile("" : "+v"(done[0]), "+v"(done[1]), "+v"(done[2]));
+#pragma unroll
+    for (int q = 0; q < 6; ++q) {
+        pa[q] = acc[q][1];
+        pb[q] = acc[q][0];
+    }
+}
+
 // The same for a kernel that does not depend on the input channel (rgb_2d_stripe_tensors with its default
 // in_channel = (1, 1, 1): every orientation reads the channel SUM): 27 fmas on the sum instead of 81.
 // s[dx]: channel sum at x-1, x, x+1.  Rounding differs from the 81-term chain like the blur's does.
@@ -164,7 +217,10 @@ struct RgbArgs {
 
 // RGC_PAIRS: (o, i) pairs of the rgc kernel that are not identically zero; STRIPE_SUM: the stripe kernel does not
 // depend on the input channel.  The host checks both on the actual weights and launches <0x1ff, false> otherwise.
-template <unsigned RGC_PAIRS, bool STRIPE_SUM>
+// RGBY_A: group-A tap mask of the two-group form of rgby (same for the three inputs), END_A0..2: of the end bank per
+// input channel; kDense = the dense 81-fma form.
+constexpr unsigned kDense = 0xffffffffu;
+template <unsigned RGC_PAIRS, bool STRIPE_SUM, unsigned RGBY_A, unsigned END_A0, unsigned END_A1, unsigned END_A2>
 __global__ __launch_bounds__(256) void rgb_line_end_kernel(const RgbArgs args) {
     constexpr int R = kRgbTH, D = kRgbChunk, NCH = (R + 2 * kRgbHalo) / D;
     const float* __restrict__ pyr = args.pyr;
@@ -195,9 +251,9 @@ __global__ __launch_bounds__(256) void rgb_line_end_kernel(const RgbArgs args) {
 
     // rolling state
     float a1[3] = {0, 0, 0}, b1[3] = {0, 0, 0};  // rgc
-    float a2[3] = {0, 0, 0}, b2[3] = {0, 0, 0};  // rgby
+    float a2[6] = {0, 0, 0, 0, 0, 0}, b2[6] = {0, 0, 0, 0, 0, 0};  // rgby (dense form: [0..2] only)
     float a3[3] = {0, 0, 0}, b3[3] = {0, 0, 0};  // stripe
-    float a5[3] = {0, 0, 0}, b5[3] = {0, 0, 0};  // end
+    float a5[6] = {0, 0, 0, 0, 0, 0}, b5[6] = {0, 0, 0, 0, 0, 0};  // end
     float pb[7] = {0, 0, 0, 0, 0, 0, 0};         // blur: pb[k] = pending output row (newest stripe row) - 3 + k
     float hist[4][3];                            // stripe rows q, q-1, q-2, q-3 (own column)
 #pragma unroll
@@ -238,7 +294,8 @@ __global__ __launch_bounds__(256) void rgb_line_end_kernel(const RgbArgs args) {
             }
             // ---- rgby: completes row yin - 2
             with_neighbours(g, v);
-            conv3_roll<0x1ffu>(v, wp + 1 * 81, a2, b2, g);
+            if constexpr (RGBY_A != kDense) conv3_roll_struct<RGBY_A, RGBY_A, RGBY_A>(v, wp + 1 * 81, a2, b2, g);
+            else conv3_roll<0x1ffu>(v, wp + 1 * 81, reinterpret_cast<float (&)[3]>(a2), reinterpret_cast<float (&)[3]>(b2), g);
             {
                 const bool ok = yin - 2 >= 0 && yin - 2 < H && col_ok;
 #pragma unroll
@@ -321,7 +378,8 @@ __global__ __launch_bounds__(256) void rgb_line_end_kernel(const RgbArgs args) {
             }
             // ---- end bank: completes row yout = yin - 7
             with_neighbours(o3, v);
-            conv3_roll<0x1ffu>(v, wp + 3 * 81, a5, b5, g);
+            if constexpr (END_A0 != kDense) conv3_roll_struct<END_A0, END_A1, END_A2>(v, wp + 3 * 81, a5, b5, g);
+            else conv3_roll<0x1ffu>(v, wp + 3 * 81, reinterpret_cast<float (&)[3]>(a5), reinterpret_cast<float (&)[3]>(b5), g);
             const int yout = yin - 7;
             if (yout >= y0 && yout < H && out_lane) {
                 const float mk = (pad_col && yout >= prm.pad && yout < H - prm.pad) ? 1.0f : 0.0f;

@@ -441,6 +441,26 @@ def test_rgb_chain(rt, kernels, policy, frame):
     assert_close(got["value"], want["value"], RTOL, scale=255.0, what="value")
 
 
+def test_rgb_chain_structured_and_dense_kernels_agree(rt, kernels, monkeypatch):
+    """The specialised chain kernel (diagonal rgc, channel-sum stripe, two-group rgby / end: 189 fmas per pixel) against
+    the dense one (SILENT_RGB_OPTS = 1: 373 fmas) and against the one without the two-group forms (2): re-association
+    only, well inside the 1e-5 budget."""
+    frames = np.stack([noise_frame(90 + i, 70, 131, 3) for i in range(2)])
+    fast = rt.rgb_line_end(frames, kernels)
+    monkeypatch.setenv("SILENT_RGB_OPTS", "1")
+    dense = rt.rgb_line_end(frames, kernels)
+    monkeypatch.setenv("SILENT_RGB_OPTS", "2")
+    mid = rt.rgb_line_end(frames, kernels)
+    monkeypatch.delenv("SILENT_RGB_OPTS")
+    for name in ("orient", "line_end", "value"):
+        assert_close(fast[name], dense[name], 2e-6, scale=255.0, what=name + " structured vs dense")
+        assert_close(mid[name], dense[name], 2e-6, scale=255.0, what=name + " basic vs dense")
+        assert not np.array_equal(fast[name], dense[name]) or name == "value"      # really different code paths
+    want = so.rgb_line_end_chain(frames, kernels)
+    assert_close(fast["line_end"], want["padded"], RTOL, scale=255.0, what="line_end vs oracle")
+    assert_close(fast["orient"], want["orient"], RTOL, what="orient vs oracle")
+
+
 def test_rgb_chain_on_packed_levels_and_keypoints(rt, kernels):
     from pysilent_amd.util.selection import max_value_indices_region
     extents = [(64, 96), (32, 48), (16, 24)]

@@ -123,3 +123,39 @@ def test_recovery_mode_mirrors_reference_errors():
     assert recovery_mode(False, True) == 1 and recovery_mode(True, False) == 2 and recovery_mode(True, True) == 3
     with pytest.raises(ValueError, match="You must choose a type of recovery"):
         recovery_mode(False, False)
+
+
+def _chain_structure(consts):
+    import ctypes as C
+    from pysilent_amd import _lib
+    lib = _lib.load()
+    fp = C.POINTER(C.c_float)
+    arrs = {k: np.ascontiguousarray(consts[k], np.float32) for k in ("rgc", "rgby", "stripe", "blur", "end")}
+    params = _lib.RgbChainParams(*[arrs[k].ctypes.data_as(fp) for k in ("rgc", "rgby", "stripe", "blur", "end")],
+                                 1.0, 0.1, 0, 255.0, 2)
+    flags, masks = C.c_uint(0), (C.c_uint * 6)()
+    assert lib.silent_rgb_chain_structure(C.byref(params), C.byref(flags), masks) == 0
+    return flags.value, list(masks)
+
+
+def test_rgb_chain_structure_of_the_reference_kernels():
+    """The structure the fused RGB kernel exploits is DETECTED in the weights, and the reference's generators have it:
+    diagonal rgc, channel-sum stripe, two-group rgby (centre tap | 8 surround taps) and end bank (per orientation the
+    taps on either side of the facet).  The masks are what the specialised kernel is compiled for."""
+    from pysilent_amd.pipeline import default_constants
+    consts = default_constants("rgb")
+    flags, masks = _chain_structure(consts)
+    assert flags == 0b1111
+    assert masks == [0x010, 0x010, 0x010, 0x1f9, 0x119, 0x11f]
+    # the end bank's groups are the signs of the three orientation profiles (oriented_end_detector.py:47-53)
+    end = consts["end"].astype(np.float64)
+    for i in range(3):
+        a = [t for t in range(9) if masks[3 + i] >> t & 1]
+        va = end.reshape(9, 3, 3)[a, i, :]
+        assert np.linalg.matrix_rank(va, tol=1e-6) == 1
+    # generic weights: nothing is found, the dense kernel runs
+    rng = np.random.default_rng(0)
+    noise = {k: rng.standard_normal(np.shape(v)).astype(np.float32) for k, v in consts.items()}
+    assert _chain_structure(noise)[0] == 0
+    mixed = dict(consts, rgby=noise["rgby"])
+    assert _chain_structure(mixed)[0] == 0b1011
