@@ -360,7 +360,14 @@ __global__ __launch_bounds__(256) void rgb_line_end_kernel(const RgbArgs args) {
             float o3[3];
             {
                 const float m = bdone > 1.0f ? 1.0f : bdone;
-                const float r = prm.rv / powf(m, prm.root);
+                // m ** root as exp2(root * log2(m)) on the transcendental unit (v_log_f32 / v_exp_f32, 1 ulp each: <= 3 ulp
+                // here since |root * log2 m| stays small) instead of the ~100-instruction powf; m is in (0, 1] or 0.
+                // v_log_f32 treats denormal inputs as 0: below 2^-100 the accurate powf runs (a lane-divergent branch that no
+                // lane takes in practice).  silent_regulate / conv2d_same_kernel keep powf.
+                float pw;
+                if (m > 0.0f && m < 7.8886e-31f) pw = powf(m, prm.root);
+                else pw = __builtin_amdgcn_exp2f(prm.root * __builtin_amdgcn_logf(m));
+                const float r = prm.rv / pw;
                 const bool ok = t >= 0 && t < H && col_ok;
 #pragma unroll
                 for (int c = 0; c < 3; ++c) {
