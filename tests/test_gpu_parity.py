@@ -109,6 +109,43 @@ def test_bad_arguments_raise_value_error(rt, kernels):
         rt.gray_line_end(np.zeros((1, 8, 8, 1), np.float32), kernels["cs_gray"], np.zeros((3, 3, 1, 5)))
 
 
+def test_bad_arguments_of_the_widened_entry_points(rt, kernels):
+    """C ABI status codes of the section-8f entry points surface as ValueError / TypeError, never as a crash."""
+    import ctypes as C
+    from pysilent_amd import _lib
+    from pysilent_amd.util import get_centroids
+    from pysilent_amd.util.energy import get_boosting
+    v1 = np.ones((1, 8, 8, 1), np.float32)
+    v3 = np.ones((1, 8, 8, 3), np.float32)
+    with pytest.raises(ValueError):
+        get_centroids(v3, [1, 3, 3])                                   # needs a 1-channel value map
+    with pytest.raises(ValueError):
+        get_centroids(v1, [1, 0, 3])                                   # empty region
+    with pytest.raises(TypeError):
+        get_centroids([[1.0]], [1, 3, 3])                              # the reference's TypeError for foreign types
+    with pytest.raises(ValueError):
+        get_boosting(v1, np.ones((1, 4, 4, 1), np.float32))            # state geometry differs
+    with pytest.raises(ValueError):
+        rt.select_peaks(np.ones((1, 8, 8, 2), np.float32))             # 1 or 3 channels
+    with pytest.raises(ValueError):
+        rt.select_peaks(v3, 0.1, want=())                              # no output requested
+    with pytest.raises(ValueError):
+        rt.resize_nearest(v1, (0, 4))
+    with pytest.raises(ValueError):
+        rt.centroids(v1, -1, 2)
+    lib, ctx = _lib.load(), rt.get_context(None)
+    lev = (_lib.Extent * 1)(_lib.Extent(8, 8))
+    assert lib.silent_affine_clip(ctx.handle, None, 4, None, None) == _lib.SILENT_E_INVALID
+    assert lib.silent_boosting_step(ctx.handle, v1.ctypes.data, lev, 1, 1, None, v1.ctypes.data, v1.ctypes.data, None) \
+        == _lib.SILENT_E_INVALID
+    assert b"params" in lib.silent_last_error(ctx.handle)
+    bad = _lib.BoostingParams(1.0, 1.0, 0, 10.0, 0.8, 0)               # recovery mode 0: "You must choose a type of recovery"
+    out = np.empty_like(v1)
+    assert lib.silent_boosting_step(ctx.handle, v1.ctypes.data, lev, 1, 1, C.byref(bad), v1.copy().ctypes.data,
+                                    out.ctypes.data, None) == _lib.SILENT_E_INVALID
+    assert b"recovery" in lib.silent_last_error(ctx.handle)
+
+
 # ----------------------------------------------------------------------------- regulator
 
 @pytest.mark.parametrize("policy", ["ieee", "zero"])
