@@ -22,6 +22,9 @@ What it restates (all citations relative to /root/reference):
     independent restatement of that resampler (``spline5_zoom``) which is what the C oracle
     and the HIP kernel implement.
   * the op order of the chain  slam_recognition/recognition_testing.py:69-90
+  * (SURVEY 8f) ``get_centroids`` util/centroids.py:21-46 with ``index_tensor.from_shape`` util/index_tensor.py:7-20;
+    ``get_boosting`` / ``generate_recovery`` util/energy/boosting.py:6-42, util/energy/recovery.py:4-22;
+    the rest of ``LineEndDisplayer.compile`` recognition_testing.py:77-100 (``line_end_displayer_tail``)
 
 PINNING STATUS.  The constant kernels are pinned by the reference's own generators
 (tests/golden/kernels.npz, produced by tests/golden/make_golden.py importing the reference)
