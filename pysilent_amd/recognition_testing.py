@@ -24,8 +24,13 @@ from .util.energy.recovery import recovery_mode
 
 
 class LineEndDisplayer(PyramidDisplayer):
-    def __init__(self, n_dimensions=2, **argv):
+    def __init__(self, n_dimensions=2, use_graph=False, **argv):
+        """``use_graph``: capture the ~20 launches of one frame into a HIP graph the first time a pyramid shape is
+        seen and replay it per frame (torch.cuda.CUDAGraph is only the capture / replay plumbing; every node is one
+        of this library's kernels)."""
         super(LineEndDisplayer, self).__init__(**argv)
+        self.use_graph = bool(use_graph)
+        self._graph = None
         if n_dimensions != 2:
             raise ValueError("only 2-D images are supported")
         self.kernels = default_constants("rgb")
@@ -46,6 +51,7 @@ class LineEndDisplayer(PyramidDisplayer):
         self.energy_values = torch.full((n, -(-h // rh), -(-w // rw), 1), 8.0, dtype=torch.float32,
                                         device=torch.device("cuda", self.device_index))
         self.pyramid_tensor_shape = tuple(pyramid_tensor.shape)
+        self._graph = None
 
     def get_state(self):
         """Host copy of the boosting state (checkpoint); None before the first run."""
@@ -72,6 +78,33 @@ class LineEndDisplayer(PyramidDisplayer):
             raise ValueError("pyramid tensor must be [levels, h, w, 3]")
         if self.pyramid_tensor_shape != tuple(x.shape):
             self.pre_compile(x)
+        if self.use_graph:
+            return self._replay(x)
+        return self._launch(x)
+
+    def _replay(self, x):
+        import torch
+        if self._graph is None:
+            static_in = torch.empty_like(x)
+            static_in.copy_(x)
+            saved = self.energy_values.clone()
+            side = torch.cuda.Stream(device=x.device)
+            side.wait_stream(torch.cuda.current_stream(x.device))
+            with torch.cuda.stream(side):          # eager warm-up: grows the library's workspace outside the capture
+                self._launch(static_in)
+            torch.cuda.current_stream(x.device).wait_stream(side)
+            self.energy_values.copy_(saved)        # the warm-up advanced the boosting state: put it back
+            graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(graph):
+                static_out = self._launch(static_in)
+            self._graph = (graph, static_in, static_out)
+        graph, static_in, static_out = self._graph
+        static_in.copy_(x)
+        graph.replay()
+        return static_out
+
+    def _launch(self, x):
+        rt = _runtime
         ch = rt.rgb_line_end(x, self.kernels)
         gray = ch["value"]
         centroids, importances = rt.centroids(rt.affine_clip(gray, div=255.0), *self.centroid_region_shape[1:])

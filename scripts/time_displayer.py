@@ -4,7 +4,8 @@ import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
 from pysilent_amd.recognition_testing import LineEndDisplayer
-disp = LineEndDisplayer()
+disp = LineEndDisplayer(use_graph="--graph" in sys.argv)
+print("HIP graph replay" if disp.use_graph else "eager launches")
 frame = np.random.default_rng(0).integers(0, 256, (480, 640, 3)).astype(np.uint8)
 for _ in range(10):
     disp.callback(frame)

@@ -448,6 +448,15 @@ def test_line_end_displayer_three_frames(rt, kernels):
             scale = 255.0 * (64 + 96) if i < 2 else 255.0
             assert_close(got[1 + i], tail[i], RTOL, scale=scale, what="%s, frame %d" % (name, step))
         assert_close(disp.get_state(), want_state, RTOL, what="state, frame %d" % step)
+    # the same three frames through a captured HIP graph: bit-identical outputs and state
+    eager = LineEndDisplayer(output_size=(96, 64))
+    graphed = LineEndDisplayer(output_size=(96, 64), use_graph=True)
+    for step in range(3):
+        frame = structured_frame(40 + step, 150, 230, 3)
+        a, b = eager.callback(frame), graphed.callback(frame)
+        for i in range(1, 7):
+            np.testing.assert_array_equal(np.stack(a[i]), np.stack(b[i]))
+        np.testing.assert_array_equal(eager.get_state(), graphed.get_state())
     saved = disp.get_state()
     disp.set_state(saved * 0 + 8)
     assert (disp.get_state() == 8).all()
