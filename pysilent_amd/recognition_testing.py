@@ -122,7 +122,9 @@ class LineEndDisplayer(PyramidDisplayer):
         return [t.cpu().numpy() for t in self.run_device(pyramid_tensor)]
 
     def callback(self, frame, cam_id=None, depth=2):
-        z_tensor = np.asarray(frame, dtype=np.float32)
+        import torch
+        # frame -> GPU once; the zoom pyramid stays on the device between from_image and the graph
+        z_tensor = torch.from_numpy(np.ascontiguousarray(frame, dtype=np.float32)).to(torch.device("cuda", self.device_index))
         z_tensor = zoom.from_image(z_tensor, self.output_colors, self.output_size, self.zoom_ratio)
         tensors = self.run(z_tensor)
         return [frame] + [[tensors[x][y] for y in range(len(tensors[x]))] for x in range(6)]
