@@ -1228,7 +1228,33 @@ static int launch_pyramid(silent_ctx* ctx, const char* who, const silent_pyramid
     const long long b_zero = (long long)tab.zero_chunks_per_frame * n_frames;
     if (b_unit > 0x7fffffffll || b_region > 0x7fffffffll || b_zero > 0x7fffffffll)
         return fail(ctx, SILENT_E_INVALID, std::string(who) + ": too many tiles for one launch");
-    if (tab.C == 1) {
+    unsigned kopts = 0;
+    if (const char* e = std::getenv("SILENT_PYRAMID_OPTS")) kopts = (unsigned)std::strtoul(e, nullptr, 0);  // 1: no stream kernel
+    if (plan->stream_ok && with_unit && with_region && !(kopts & 1u)) {
+        // single-read pyramid: frame -> every level in one kernel (pyramid_stream_kernel; single-channel plans only:
+        // on interleaved RGB the stride-3 accesses of the same kernel made it 1.5x SLOWER than unit + region kernels)
+        const PyrLevelDev& d = tab.lv[plan->stream_unit_level];
+        FusedTab ft;
+        std::memset(&ft, 0, sizeof(ft));
+        ft.n = 1;
+        for (int j = 0; j < 5; ++j) ft.wx[j] = ft.wy[j] = plan->unit_w[j];
+        FusedLevel& f = ft.lv[0];
+        f.src_y0 = d.src_y0; f.src_x0 = d.src_x0; f.src_h = d.src_h; f.src_w = d.src_w;
+        f.zoom_h = d.zoom_h; f.zoom_w = d.zoom_w; f.out_h = d.out_h; f.out_w = d.out_w;
+        f.tiles_x = (d.out_w + kFusedTW - 1) / kFusedTW;
+        f.px_off = tab.px_off[plan->stream_unit_level];
+        ft.tiles_per_frame = f.tiles_x * ((d.out_h + kFusedTH - 1) / kFusedTH);
+        ft.H = tab.H;
+        ft.W = tab.W;
+        ft.frame_px = tab.frame_px_out;
+        const long long blocks = (long long)ft.tiles_per_frame * n_frames;
+        if (blocks > 0x7fffffffll) return fail(ctx, SILENT_E_INVALID, std::string(who) + ": too many tiles for one launch");
+#define PYR_STREAM(G_) \
+    hipLaunchKernelGGL((pyramid_stream_kernel<1, G_>), dim3((unsigned)blocks), dim3(256), 0, s, frames, pyr, ft, plan->stream)
+        if (plan->stream.G <= 4) PYR_STREAM(4);
+        else PYR_STREAM(7);
+#undef PYR_STREAM
+    } else if (tab.C == 1) {
         if (b_unit) hipLaunchKernelGGL(pyramid_unit_kernel<1>, dim3((unsigned)b_unit), dim3(256), 0, s, frames, pyr, tab);
         if (b_region) hipLaunchKernelGGL(pyramid_region_kernel<1>, dim3((unsigned)b_region), dim3(256), 0, s, frames, pyr, tab);
     } else {

@@ -859,4 +859,146 @@ __global__ __launch_bounds__(256) void gray_stream_kernel(const float* __restric
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// pyramid_stream_kernel<C, G>: the single-read PYRAMID (no filters) for silent_pyramid: gray_stream_kernel without
+// the CS / end stages, looped over the C interleaved channels of the frame.  Lane = pixel column exactly as in the
+// gray kernel (same plan tables, same row programs, same column records for every channel); channel ch of a row is
+// read and written at a stride of C floats.  Used for C = 1 only: two-step gray pyramids 0.58 -> 0.51 ms per 64 1080p
+// frames; with C = 3 the stride-3 loads and partial-line stores made it 1.5 ms against 1.0 ms for unit + region
+// kernels on 32 RGB frames (measured, bit-identical either way), so RGB plans are not marked streamable.
+template <int C, int G>
+__global__ __launch_bounds__(256) void pyramid_stream_kernel(const float* __restrict__ frames, float* __restrict__ pyr,
+                                                             const FusedTab tab, const StreamTab st) {
+    constexpr int R = kFusedTH, NR = kStreamRows;
+    __shared__ float s_rows[4][NR][64];
+    const unsigned bid = blockIdx.x;
+    const int frame = (int)(bid / (unsigned)tab.tiles_per_frame);
+    const int rem = (int)(bid - (unsigned)frame * (unsigned)tab.tiles_per_frame);
+    const FusedLevel& lv = tab.lv[0];
+    const int ty = rem / lv.tiles_x, tx = rem - ty * lv.tiles_x;
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int xw0 = tx * kFusedTW + wave * kFusedCols;
+    if (xw0 >= lv.out_w) return;  // wave-uniform (no barrier in this kernel)
+    const int wx_tile = tx * 4 + wave;
+    const int y0 = ty * R;
+    const int ox = xw0 + lane - 4;
+    const long long WC = (long long)tab.W * C;
+    const float* __restrict__ src = frames + (long long)frame * tab.H * WC;
+    const long long frame_px0 = (long long)frame * tab.frame_px;
+    const long long base_px = frame_px0 + lv.px_off;
+    const long long sx = (long long)(mirror_near(ox, lv.src_w) + lv.src_x0) * C;
+
+    int gx0[G], gn[G], glane[G];
+    float gw[G][6];
+#pragma unroll
+    for (int g = 0; g < G; ++g) {
+        const int gg = min(g, st.G - 1);
+        const int* __restrict__ h = st.col_hdr + ((long long)gg * st.waves_x + wx_tile) * 2;
+        gx0[g] = h[0];
+        gn[g] = g < st.G ? h[1] : 0;
+        const int4* __restrict__ rec = reinterpret_cast<const int4*>(st.col_rec + (((long long)gg * st.waves_x + wx_tile) * 64 + lane) * 8);
+        const int4 a = rec[0], b = rec[1];
+        glane[g] = a.x * 4;
+        gw[g][0] = __int_as_float(a.y);
+        gw[g][1] = __int_as_float(a.z);
+        gw[g][2] = __int_as_float(a.w);
+        gw[g][3] = __int_as_float(b.x);
+        gw[g][4] = __int_as_float(b.y);
+        gw[g][5] = __int_as_float(b.z);
+    }
+    const int eff_h = min(lv.zoom_h, lv.out_h), eff_w = min(lv.zoom_w, lv.out_w);
+    const bool col_eff = ox >= 0 && ox < eff_w;
+    const bool out_lane = lane >= 4 && lane < 4 + kFusedCols && ox < lv.out_w;
+    static_assert(G == stream_pad_levels(G), "row programs are padded to 4 or 7 levels");
+    constexpr int PR = kStreamProgRow(G);
+    typedef const __attribute__((address_space(4))) int* const_int_ptr;
+    const_int_ptr prog = (const_int_ptr)(st.row_prog + (long long)ty * (NR * PR));
+
+#pragma unroll 1
+    for (int ch = 0; ch < C; ++ch) {
+        float in[R + 8];
+#pragma unroll
+        for (int i = 0; i < R + 8; ++i)
+            in[i] = src[(long long)(mirror_near(y0 - 4 + i, lv.src_h) + lv.src_y0) * WC + sx + ch];
+#pragma unroll
+        for (int i = 0; i < R + 8; ++i) asm volatile("" ::"v"(in[i]));  // retire loads before the first store
+#pragma unroll
+        for (int i = 0; i < R + 8; ++i) s_rows[wave][i][lane] = in[i];
+
+        // ---- pass 2: the other levels
+        {
+            float vacc[G][kStreamSlots];
+#pragma unroll
+            for (int g = 0; g < G; ++g)
+#pragma unroll
+                for (int k = 0; k < kStreamSlots; ++k) vacc[g][k] = 0.0f;
+            int cur[PR], nxt[PR];
+#pragma unroll
+            for (int e = 0; e < PR; ++e) cur[e] = prog[e];
+            float c0 = s_rows[wave][0][lane];
+#pragma unroll 1
+            for (int i = 0; i < NR; ++i) {
+                const int inx = min(i + 1, NR - 1);
+#pragma unroll
+                for (int e = 0; e < PR; ++e) nxt[e] = prog[inx * PR + e];
+                const float c_next = s_rows[wave][inx][lane];
+#pragma unroll
+                for (int g = 0; g < G; ++g) {
+                    const int meta = cur[g];
+                    if (!(meta & 128)) continue;
+#pragma unroll
+                    for (int k = 0; k < stream_slots(g); ++k) {
+                        const float w = __int_as_float(cur[stream_w_off(G, g) + k]);
+                        const float prev = (meta >> k) & 1 ? 0.0f : vacc[g][k];
+                        vacc[g][k] = __builtin_fmaf(w, c0, prev);
+                    }
+                    const int done = (meta >> 4) & 7;
+                    if (done < kStreamSlots) {
+                        const int oy = meta >> 8;
+                        float v = vacc[g][0];
+#pragma unroll
+                        for (int k = 1; k < stream_slots(g); ++k) v = done == k ? vacc[g][k] : v;
+                        const int vbits = __float_as_int(v);
+                        float acc = gw[g][0] * __int_as_float(__builtin_amdgcn_ds_bpermute(glane[g], vbits));
+#pragma unroll
+                        for (int q = 1; q < 6; ++q)
+                            acc = __builtin_fmaf(gw[g][q], __int_as_float(__builtin_amdgcn_ds_bpermute(glane[g] + 4 * q, vbits)), acc);
+                        if (lane < gn[g])
+                            pyr[(frame_px0 + st.px_off[g] + (long long)oy * st.out_w[g] + gx0[g] + lane) * C + ch] = acc;
+                    }
+                }
+#pragma unroll
+                for (int e = 0; e < PR; ++e) cur[e] = nxt[e];
+                c0 = c_next;
+            }
+        }
+
+        // ---- pass 1: the unit level (same fma order as pyramid_unit_kernel)
+        float hw[5] = {0, 0, 0, 0, 0};
+#pragma unroll
+        for (int i = 0; i < R + 8; ++i) {
+            const float c0 = s_rows[wave][i][lane];
+            const float l1 = from_lane_below(c0), l2 = from_lane_below(l1);
+            const float r1 = from_lane_above(c0), r2 = from_lane_above(r1);
+            float h = tab.wx[0] * l2;
+            h = __builtin_fmaf(tab.wx[1], l1, h);
+            h = __builtin_fmaf(tab.wx[2], c0, h);
+            h = __builtin_fmaf(tab.wx[3], r1, h);
+            h = __builtin_fmaf(tab.wx[4], r2, h);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) hw[j] = hw[j + 1];
+            hw[4] = h;
+            if (i >= 6 && i < R + 6) {
+                const int p = y0 + i - 6;
+                float v = tab.wy[0] * hw[0];
+#pragma unroll
+                for (int j = 1; j < 5; ++j) v = __builtin_fmaf(tab.wy[j], hw[j], v);
+                v = (p < eff_h && col_eff) ? v : 0.0f;
+                if (p < lv.out_h && out_lane) pyr[(base_px + (long long)p * lv.out_w + ox) * C + ch] = v;
+            }
+        }
+    }
+}
+
 }  // namespace silent

@@ -251,6 +251,26 @@ def test_classic_pyramid(rt, shape, scale, n):
             assert_close(got.level(l)[f:f + 1], want[l], RTOL, scale=255.0, what="frame %d level %d" % (f, l))
 
 
+@pytest.mark.parametrize("shape,scale,n", [((135, 240, 3), 2.0, 4), ((97, 131, 1), 1.7, 4), ((64, 64, 3), 2.0, 3), ((65, 129, 3), 2.0, 2),
+                                           ((270, 480, 3), 2.0, 8), ((270, 480, 1), math.e ** .5, 6), ((33, 17, 3), 2.0, 2),
+                                           ((100, 260, 3), 1.2, 3)])
+def test_pyramid_single_read_kernel_equals_unit_plus_region(rt, shape, scale, n, monkeypatch):
+    """silent_pyramid on classic pyramids: the single-read kernel (pyramid_stream_kernel, 1 and 3 channels) is
+    bit-identical to the unit + region kernels (SILENT_PYRAMID_OPTS = 1 selects those) and matches the oracle."""
+    from pysilent_amd.util.zoom.from_image import classic_levels
+    frames = np.stack([noise_frame(60 + s_, *shape) for s_ in range(3)])
+    plan = rt.PyramidPlan(shape[0], shape[1], shape[2], classic_levels(shape[:2], scale, n))
+    assert plan.streamable == (scale > 1.25 and shape[2] == 1)       # RGB plans keep unit + region kernels
+    got = plan.run(frames)
+    monkeypatch.setenv("SILENT_PYRAMID_OPTS", "1")
+    two = plan.run(frames)
+    monkeypatch.delenv("SILENT_PYRAMID_OPTS")
+    np.testing.assert_array_equal(got.data, two.data)
+    want = so.classic_pyramid(frames[2], scale, n)
+    for l in range(n):
+        assert_close(got.level(l)[2:3], want[l], RTOL, scale=255.0, what="level %d" % l)
+
+
 def test_pyramid_known_answers(rt):
     from pysilent_amd.util.zoom import classic_pyramid
     img = np.zeros((11, 11, 1), np.float32)
