@@ -63,8 +63,30 @@ def default_device():
     return int(os.environ.get("LOCAL_RANK", "0"))
 
 
+_override = []      # stack of private contexts (use_context)
+
+
+class use_context(object):
+    """``with use_context(ctx): ...`` -- every op inside runs on ``ctx`` instead of the shared per-device context.
+    A caller that bakes device pointers into a HIP graph needs this: the workspace of its private context only
+    grows for its own calls, so what the graph captured stays valid."""
+
+    def __init__(self, ctx):
+        self.ctx = ctx
+
+    def __enter__(self):
+        _override.append(self.ctx)
+        return self.ctx
+
+    def __exit__(self, *exc):
+        _override.pop()
+        return False
+
+
 def get_context(device=None):
     device = default_device() if device is None else int(device)
+    if _override and _override[-1].device == device:
+        return _override[-1]
     ctx = _contexts.get(device)
     if ctx is None:
         ctx = _contexts[device] = Context(device)

@@ -31,6 +31,7 @@ class LineEndDisplayer(PyramidDisplayer):
         super(LineEndDisplayer, self).__init__(**argv)
         self.use_graph = bool(use_graph)
         self._graph = None
+        self._ctx = None        # graph mode: a private silent_ctx, so that no other caller regrows the captured workspace
         if n_dimensions != 2:
             raise ValueError("only 2-D images are supported")
         self.kernels = default_constants("rgb")
@@ -79,7 +80,10 @@ class LineEndDisplayer(PyramidDisplayer):
         if self.pyramid_tensor_shape != tuple(x.shape):
             self.pre_compile(x)
         if self.use_graph:
-            return self._replay(x)
+            if self._ctx is None:
+                self._ctx = _runtime.Context(self.device_index)
+            with _runtime.use_context(self._ctx):
+                return self._replay(x)
         return self._launch(x)
 
     def _replay(self, x):
