@@ -753,6 +753,44 @@ def test_config5_4k_8_levels_8_orientations_against_c_oracle(rt, kernels):
         assert_close(end.level(l), wend, RTOL, scale=255.0, what="end %d" % l)
 
 
+def test_config3_1080p_rgb_full_size_against_c_oracle(rt, kernels):
+    """BASELINE config 3 at full size, one frame: 1080p RGB, 6-level pyramid, rgc > rgby > stripe > regulate > end > pad >
+    value, top 10 %, NMS, keypoints.  Chain maps within tolerance of the C oracle; every index-like stage bit-exact
+    against the oracle applied to the GPU's own line-end map."""
+    import torch
+    from pysilent_amd.pipeline import LineEndPipeline
+    frame = noise_frame(2, 1080, 1920, 3)
+    pipe = LineEndPipeline((1080, 1920), mode="rgb", n_levels=6, batch=1, selection=True, keep_selection_maps=True,
+                           max_keypoints_per_frame=1 << 18)
+    pipe.step(torch.from_numpy(frame[None]).cuda())
+    torch.cuda.synchronize()
+    out = pipe.outputs()
+    host = lambda name, l: np.ascontiguousarray(out[name].level(l).cpu().numpy())
+    want_pyr = co.classic_pyramid(frame, pipe.extents)
+    rows = []
+    for l, (h, w) in enumerate(pipe.extents):
+        assert_close(host("pyramid", l), want_pyr[l], RTOL, scale=255.0, what="pyramid %d" % l)
+        x = want_pyr[l]
+        for name in ("rgc", "rgby", "stripe"):
+            x = co.conv2d_same(x, kernels[name], relu=True)
+        orient = co.regulate(x, kernels["blur"], 1.0, 0.1)
+        line = co.pad_inwards(co.conv2d_same(orient, kernels["end"], relu=True, clip_hi=255.0), [[0, 0], [2, 2], [2, 2], [0, 0]])
+        assert_close(host("orient", l), orient, RTOL, what="orient %d" % l)
+        assert_close(host("line_end", l), line, RTOL, scale=255.0, what="line_end %d" % l)
+        g_line, g_val = host("line_end", l), host("value", l)
+        np.testing.assert_array_equal(g_val, co.value_from_color(g_line))
+        top = co.top_value_points(g_line, 0.1, g_val)
+        peaks = co.nms3x3(top, "product")
+        pv = co.value_from_color(peaks)
+        np.testing.assert_array_equal(host("top", l), top)
+        np.testing.assert_array_equal(host("peaks", l), peaks)
+        np.testing.assert_array_equal(host("peak_value", l), pv)
+        r = co.max_value_indices_region(None, (1, max(h // 2, 1), max(w // 2, 1), 3), pv)
+        r[:, 0] = l
+        rows.append(r)
+    np.testing.assert_array_equal(out["keypoints"][0], np.concatenate(rows))
+
+
 # ----------------------------------------------------------------------------- full size (BASELINE config 2)
 
 def test_config2_1080p_full_size_against_c_oracle(rt, kernels):
