@@ -230,6 +230,10 @@ def main():
                                                                / elapsed / 1e9, 1),
                    "whole_pass_frac_of_hbm_peak": round(pipe.algorithmic_bytes_per_frame() * B * args.steps
                                                         / elapsed / 1e9 / HBM_PEAK_GBS, 4),
+                   # SURVEY.md section 8d quotes the fraction against the measured float4-copy peak as well (6.29 TB/s,
+                   # /opt/skills/guides/MI355X_MICROARCH.md)
+                   "whole_pass_frac_of_measured_copy_peak": round(pipe.algorithmic_bytes_per_frame() * B * args.steps
+                                                                  / elapsed / 1e9 / 6290.0, 4),
                    "launches_per_step": "gray_stream_kernel (whole pyramid + level-0 CS/line-end, frame read once) + "
                                         "gray_line_end_kernel (levels >= 1)"
                    if gray else "unit + region pyramid, fused RGB chain, 5 keypoint kernels",
