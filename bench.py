@@ -236,7 +236,8 @@ def main():
                                                                   / elapsed / 1e9 / 6290.0, 4),
                    "launches_per_step": "gray_stream_kernel (whole pyramid + level-0 CS/line-end, frame read once) + "
                                         "gray_line_end_kernel (levels >= 1)"
-                   if gray else "unit + region pyramid, fused RGB chain, 5 keypoint kernels",
+                   if gray else "unit + region pyramid, fused RGB chain, max/min + fused selection (top 10 % > NMS > value), "
+                                   "cell-max / count / scan / write keypoint kernels",
                    "pyramid_kernels_ms": None if pyr_ms is None else round(pyr_ms, 4),
                    "filter_kernel_ms": None if filt_ms is None else round(filt_ms, 4),
                    "sharding": "frame i -> rank i mod N; one RCCL broadcast of constants at init"},
