@@ -235,6 +235,19 @@ int silent_select_peaks_dev(silent_ctx* ctx, const float* color, const float* va
                             int n_levels, int n_frames, int channels, double top_percent, float* top_out,
                             float* peaks_out, float* peak_value_out, silent_stream stream);
 
+/* SURVEY 8d config 3 in one call: silent_select_peaks followed by silent_max_value_indices_region on its peak value
+ * (a-10 -> a-9 -> a-8 -> a-11), with the cell maxima of the keypoint search folded into the selection pass (one pass
+ * over the value map less).  Outputs exactly as those two calls: peak_value_out [1 ch] (required by the _dev form),
+ * idx / counts as silent_max_value_indices_region. */
+int silent_select_keypoints(silent_ctx* ctx, const float* color, const float* value, const silent_extent* levels,
+                            int n_levels, int n_frames, int channels, double top_percent,
+                            const silent_extent* regions, float* peak_value_out, int64_t* idx, size_t cap_per_frame,
+                            int64_t* counts);
+int silent_select_keypoints_dev(silent_ctx* ctx, const float* color, const float* value, const silent_extent* levels,
+                                int n_levels, int n_frames, int channels, double top_percent,
+                                const silent_extent* regions, float* peak_value_out, int64_t* idx,
+                                size_t cap_per_frame, int64_t* counts, silent_stream stream);
+
 /* ---------------------------------------------------------------------------- centroids
  * Replaces get_centroids, slam_recognition/util/centroids.py:21-46 (with index_tensor.from_shape,
  * util/index_tensor.py:7-20, dimensions reversed: channel 0 = x, channel 1 = y): per cell of region_h x

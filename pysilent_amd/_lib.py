@@ -108,6 +108,8 @@ _SIGNATURES = {
     "silent_max_value_indices_region_dev": [_vp, _fp, _ep, _i, _i, _ep, _vp, _sz, _vp, _vp],
     "silent_select_peaks": [_vp, _fp, _fp, _ep, _i, _i, _i, _d, _fp, _fp, _fp],
     "silent_select_peaks_dev": [_vp, _fp, _fp, _ep, _i, _i, _i, _d, _fp, _fp, _fp, _vp],
+    "silent_select_keypoints": [_vp, _fp, _fp, _ep, _i, _i, _i, _d, _ep, _fp, _vp, _sz, _vp],
+    "silent_select_keypoints_dev": [_vp, _fp, _fp, _ep, _i, _i, _i, _d, _ep, _fp, _vp, _sz, _vp, _vp],
     "silent_centroids": [_vp, _fp, _ep, _i, _i, _i, _i, _fp, _fp],
     "silent_centroids_dev": [_vp, _fp, _ep, _i, _i, _i, _i, _fp, _fp, _vp],
     "silent_boosting_step": [_vp, _fp, _ep, _i, _i, C.POINTER(BoostingParams), _fp, _fp, _fp],

@@ -485,12 +485,14 @@ SILENT_EXPORT int silent_select_peaks_dev(silent_ctx* ctx, const float* color, c
     hipLaunchKernelGGL(level_maxmin_kernel, dim3((unsigned)rblocks), dim3(256), 0, s, value, value ? nullptr : color,
                        channels, rtab, mm);
     const float a = (float)(1.0 - top_percent), b = (float)top_percent;
+    RegionTab no_regions;
+    std::memset(&no_regions, 0, sizeof(no_regions));
     if (channels == 3)
-        hipLaunchKernelGGL(select_peaks_kernel<3>, dim3((unsigned)blocks), dim3(256), 0, s, color, value, top_out, peaks_out,
-                           peak_value_out, tab, a, b, mm);
+        hipLaunchKernelGGL((select_peaks_kernel<3, false>), dim3((unsigned)blocks), dim3(256), 0, s, color, value, top_out,
+                           peaks_out, peak_value_out, tab, a, b, mm, no_regions, nullptr);
     else
-        hipLaunchKernelGGL(select_peaks_kernel<1>, dim3((unsigned)blocks), dim3(256), 0, s, color, value, top_out, peaks_out,
-                           peak_value_out, tab, a, b, mm);
+        hipLaunchKernelGGL((select_peaks_kernel<1, false>), dim3((unsigned)blocks), dim3(256), 0, s, color, value, top_out,
+                           peaks_out, peak_value_out, tab, a, b, mm, no_regions, nullptr);
     return check_launch(ctx, who);
 }
 
@@ -531,6 +533,54 @@ static int region_axis(int size, int stride, int* n_win, int* nseg, int* cut, in
     return 0;
 }
 
+// Region tables of max_value_indices_region (TF1 max_pool geometry per level)
+static int build_region_tab(silent_ctx* ctx, const char* who, const silent_extent* levels, int n_levels,
+                            const silent_extent* regions, RegionTab* rt) {
+    std::memset(rt, 0, sizeof(*rt));
+    for (int l = 0; l < n_levels; ++l) {
+        RegionLevel& r = rt->lv[l];
+        int rc = region_axis(levels[l].h, regions[l].h, &r.oh, &r.nrs, r.rcut, r.wy_lo, r.wy_hi, &r.yscale);
+        if (rc == 0) rc = region_axis(levels[l].w, regions[l].w, &r.ow, &r.ncs, r.ccut, r.wx_lo, r.wx_hi, &r.xscale);
+        if (rc == -1) return fail(ctx, SILENT_E_INVALID, std::string(who) + ": region extents must be >= 1");
+        if (rc == -2)
+            return fail(ctx, SILENT_E_UNSUPPORTED,
+                        std::string(who) + ": more than " + std::to_string(kMaxWin) + " windows per axis at level " + std::to_string(l));
+    }
+    return SILENT_OK;
+}
+
+// workspace of the keypoint passes, after `reserve` bytes the caller keeps for itself: cells | chunk_counts | offsets
+struct KeypointWs {
+    unsigned* cells;
+    int* chunk_counts;
+    long long* chunk_offsets;
+    size_t n_cells;
+};
+
+static int keypoint_workspace(silent_ctx* ctx, int n_levels, int n_frames, long long blocks, size_t reserve, KeypointWs* w) {
+    w->n_cells = (size_t)n_frames * n_levels * kCells;
+    const size_t off_cells = align_up(reserve);
+    const size_t off_counts = off_cells + align_up(w->n_cells * sizeof(unsigned));
+    const size_t off_offsets = off_counts + align_up((size_t)blocks * sizeof(int));
+    const size_t total = off_offsets + align_up((size_t)blocks * sizeof(long long));
+    TRY(grow(ctx, ctx->ws, total));
+    w->cells = (unsigned*)((char*)ctx->ws.p + off_cells);
+    w->chunk_counts = (int*)((char*)ctx->ws.p + off_counts);
+    w->chunk_offsets = (long long*)((char*)ctx->ws.p + off_offsets);
+    return SILENT_OK;
+}
+
+// count -> scan -> ordered write, given the cell maxima
+static void keypoint_passes(const float* value, const LevelTab& tab, long long blocks, const RegionTab& rt, const KeypointWs& w,
+                            int n_frames, int64_t* idx, size_t cap_per_frame, int64_t* counts, hipStream_t s) {
+    hipLaunchKernelGGL(region_count_kernel, dim3((unsigned)blocks), dim3(256), 0, s, value, tab, rt, w.cells, w.chunk_counts);
+    hipLaunchKernelGGL(region_scan_kernel, dim3((unsigned)n_frames), dim3(256), 0, s, w.chunk_counts, w.chunk_offsets,
+                       tab.tiles_per_frame, counts);
+    if (cap_per_frame)
+        hipLaunchKernelGGL(region_write_kernel, dim3((unsigned)blocks), dim3(256), 0, s, value, tab, rt, w.cells,
+                           w.chunk_offsets, idx, (long long)cap_per_frame);
+}
+
 SILENT_EXPORT int silent_max_value_indices_region_dev(silent_ctx* ctx, const float* value, const silent_extent* levels,
                                                       int n_levels, int n_frames, const silent_extent* regions,
                                                       int64_t* idx, size_t cap_per_frame, int64_t* counts,
@@ -544,34 +594,51 @@ SILENT_EXPORT int silent_max_value_indices_region_dev(silent_ctx* ctx, const flo
     TRY(build_level_tab(ctx, who, levels, n_levels, n_frames, kKpChunk, 0, &tab, &blocks));   // count / write chunks
     TRY(build_level_tab(ctx, who, levels, n_levels, n_frames, kRedChunk, 0, &ctab, &cblocks));  // cell maxima
     RegionTab rt;
-    std::memset(&rt, 0, sizeof(rt));
-    for (int l = 0; l < n_levels; ++l) {
-        RegionLevel& r = rt.lv[l];
-        int rc = region_axis(levels[l].h, regions[l].h, &r.oh, &r.nrs, r.rcut, r.wy_lo, r.wy_hi, &r.yscale);
-        if (rc == 0) rc = region_axis(levels[l].w, regions[l].w, &r.ow, &r.ncs, r.ccut, r.wx_lo, r.wx_hi, &r.xscale);
-        if (rc == -1) return fail(ctx, SILENT_E_INVALID, std::string(who) + ": region extents must be >= 1");
-        if (rc == -2)
-            return fail(ctx, SILENT_E_UNSUPPORTED,
-                        std::string(who) + ": more than " + std::to_string(kMaxWin) + " windows per axis at level " + std::to_string(l));
-    }
-    // workspace: cells | chunk_counts | chunk_offsets
-    const size_t n_cells = (size_t)n_frames * n_levels * kCells;
-    const size_t off_counts = align_up(n_cells * sizeof(unsigned));
-    const size_t off_offsets = off_counts + align_up((size_t)blocks * sizeof(int));
-    const size_t total = off_offsets + align_up((size_t)blocks * sizeof(long long));
-    TRY(grow(ctx, ctx->ws, total));
-    unsigned* cells = (unsigned*)ctx->ws.p;
-    int* chunk_counts = (int*)((char*)ctx->ws.p + off_counts);
-    long long* chunk_offsets = (long long*)((char*)ctx->ws.p + off_offsets);
+    TRY(build_region_tab(ctx, who, levels, n_levels, regions, &rt));
+    KeypointWs w;
+    TRY(keypoint_workspace(ctx, n_levels, n_frames, blocks, 0, &w));
     hipStream_t s = (hipStream_t)stream;
-    hipLaunchKernelGGL(init_cells_kernel, dim3((unsigned)((n_cells + 255) / 256)), dim3(256), 0, s, cells, (long long)n_cells);
-    hipLaunchKernelGGL(region_cell_max_kernel, dim3((unsigned)cblocks), dim3(256), 0, s, value, ctab, rt, cells);
-    hipLaunchKernelGGL(region_count_kernel, dim3((unsigned)blocks), dim3(256), 0, s, value, tab, rt, cells, chunk_counts);
-    hipLaunchKernelGGL(region_scan_kernel, dim3((unsigned)n_frames), dim3(256), 0, s, chunk_counts, chunk_offsets,
-                       tab.tiles_per_frame, counts);
-    if (cap_per_frame)
-        hipLaunchKernelGGL(region_write_kernel, dim3((unsigned)blocks), dim3(256), 0, s, value, tab, rt, cells,
-                           chunk_offsets, idx, (long long)cap_per_frame);
+    hipLaunchKernelGGL(init_cells_kernel, dim3((unsigned)((w.n_cells + 255) / 256)), dim3(256), 0, s, w.cells, (long long)w.n_cells);
+    hipLaunchKernelGGL(region_cell_max_kernel, dim3((unsigned)cblocks), dim3(256), 0, s, value, ctab, rt, w.cells);
+    keypoint_passes(value, tab, blocks, rt, w, n_frames, idx, cap_per_frame, counts, s);
+    return check_launch(ctx, who);
+}
+
+// SURVEY 8d config 3 as one call: top-percent -> NMS -> value -> per-region keypoint indices of the peak value.
+// = silent_select_peaks + silent_max_value_indices_region, with the cell maxima folded into the selection pass.
+SILENT_EXPORT int silent_select_keypoints_dev(silent_ctx* ctx, const float* color, const float* value,
+                                              const silent_extent* levels, int n_levels, int n_frames, int channels,
+                                              double top_percent, const silent_extent* regions, float* peak_value_out,
+                                              int64_t* idx, size_t cap_per_frame, int64_t* counts, silent_stream stream) {
+    NEED_CTX(ctx);
+    const char* who = "silent_select_keypoints";
+    if (!color || !regions || !peak_value_out || !counts || (!idx && cap_per_frame))
+        return fail(ctx, SILENT_E_INVALID, std::string(who) + ": NULL pointer");
+    if (channels != 1 && channels != 3) return fail(ctx, SILENT_E_UNSUPPORTED, std::string(who) + ": channels must be 1 or 3");
+    LevelTab rtab, stab, tab;
+    long long rblocks, sblocks, blocks;
+    TRY(build_level_tab(ctx, who, levels, n_levels, n_frames, kRedChunk, 0, &rtab, &rblocks));
+    TRY(build_level_tab(ctx, who, levels, n_levels, n_frames, kSelTW, kSelTH, &stab, &sblocks));
+    TRY(build_level_tab(ctx, who, levels, n_levels, n_frames, kKpChunk, 0, &tab, &blocks));
+    RegionTab rt;
+    TRY(build_region_tab(ctx, who, levels, n_levels, regions, &rt));
+    const int nmm = n_frames * n_levels;
+    KeypointWs w;
+    TRY(keypoint_workspace(ctx, n_levels, n_frames, blocks, sizeof(unsigned) * 2 * (size_t)nmm, &w));
+    unsigned* mm = (unsigned*)ctx->ws.p;
+    hipStream_t s = (hipStream_t)stream;
+    hipLaunchKernelGGL(init_maxmin_kernel, dim3((nmm + 255) / 256), dim3(256), 0, s, mm, nmm);
+    hipLaunchKernelGGL(init_cells_kernel, dim3((unsigned)((w.n_cells + 255) / 256)), dim3(256), 0, s, w.cells, (long long)w.n_cells);
+    hipLaunchKernelGGL(level_maxmin_kernel, dim3((unsigned)rblocks), dim3(256), 0, s, value, value ? nullptr : color,
+                       channels, rtab, mm);
+    const float a = (float)(1.0 - top_percent), b = (float)top_percent;
+    if (channels == 3)
+        hipLaunchKernelGGL((select_peaks_kernel<3, true>), dim3((unsigned)sblocks), dim3(256), 0, s, color, value, nullptr, nullptr,
+                           peak_value_out, stab, a, b, mm, rt, w.cells);
+    else
+        hipLaunchKernelGGL((select_peaks_kernel<1, true>), dim3((unsigned)sblocks), dim3(256), 0, s, color, value, nullptr, nullptr,
+                           peak_value_out, stab, a, b, mm, rt, w.cells);
+    keypoint_passes(peak_value_out, tab, blocks, rt, w, n_frames, idx, cap_per_frame, counts, s);
     return check_launch(ctx, who);
 }
 
@@ -1772,4 +1839,30 @@ SILENT_EXPORT int silent_select_peaks(silent_ctx* ctx, const float* color, const
     if (peaks_out) TRY(d2h(ctx, peaks_out, st.ptr<float>(i_p), bc));
     if (peak_value_out) TRY(d2h(ctx, peak_value_out, st.ptr<float>(i_o), bv));
     return SILENT_OK;
+}
+
+SILENT_EXPORT int silent_select_keypoints(silent_ctx* ctx, const float* color, const float* value, const silent_extent* levels,
+                                          int n_levels, int n_frames, int channels, double top_percent,
+                                          const silent_extent* regions, float* peak_value_out, int64_t* idx,
+                                          size_t cap_per_frame, int64_t* counts) {
+    NEED_CTX(ctx);
+    if (!color || !regions || !counts || (!idx && cap_per_frame))
+        return fail(ctx, SILENT_E_INVALID, "silent_select_keypoints: NULL pointer");
+    if (channels != 1 && channels != 3) return fail(ctx, SILENT_E_UNSUPPORTED, "silent_select_keypoints: channels must be 1 or 3");
+    long long px;
+    TRY(check_levels(ctx, "silent_select_keypoints", levels, n_levels, n_frames, &px));
+    Stage st(ctx);
+    const size_t bc = (size_t)px * channels * 4, bv = (size_t)px * 4;
+    const size_t bi = (size_t)n_frames * cap_per_frame * 4 * sizeof(int64_t), bn = (size_t)n_frames * sizeof(int64_t);
+    const size_t i_c = st.add(bc), i_v = st.add(bv), i_o = st.add(bv), i_i = st.add(bi), i_n = st.add(bn);
+    TRY(st.commit());
+    TRY(h2d(ctx, st.ptr<float>(i_c), color, bc));
+    if (value) TRY(h2d(ctx, st.ptr<float>(i_v), value, bv));
+    TRY(silent_select_keypoints_dev(ctx, st.ptr<float>(i_c), value ? st.ptr<float>(i_v) : nullptr, levels, n_levels, n_frames,
+                                    channels, top_percent, regions, st.ptr<float>(i_o), st.ptr<int64_t>(i_i), cap_per_frame,
+                                    st.ptr<int64_t>(i_n), nullptr));
+    TRY(sync0(ctx));
+    if (peak_value_out) TRY(d2h(ctx, peak_value_out, st.ptr<float>(i_o), bv));
+    if (cap_per_frame) TRY(d2h(ctx, idx, st.ptr<int64_t>(i_i), bi));
+    return d2h(ctx, counts, st.ptr<int64_t>(i_n), bn);
 }

@@ -186,6 +186,30 @@ __global__ __launch_bounds__(256) void top_value_points_kernel(const float* __re
     }
 }
 
+// ---- a-11 max_value_indices_region
+// The TF1 op is max_pool(k = full extent, stride = region, SAME): every window is the level clipped to
+// a shifted copy of itself, i.e. a PREFIX or a SUFFIX of rows (and of columns).  The distinct window
+// edges cut each axis into <= kMaxSeg segments; one pass computes the max of every (row segment x
+// column segment) cell, and a window maximum is the max over the cells it covers.
+constexpr int kMaxWin = 4;  // windows per axis (the reference uses 2); keeps RegionTab inside the kernarg budget
+constexpr int kMaxSeg = 8;  // segments per axis (<= 2 * windows)
+
+struct RegionLevel {
+    int oh, ow;          // windows per axis
+    int nrs, ncs;        // segments per axis
+    int rcut[kMaxSeg + 1];  // row segment s = [rcut[s], rcut[s+1])
+    int ccut[kMaxSeg + 1];
+    int wy_lo[kMaxWin], wy_hi[kMaxWin];  // window j covers row SEGMENTS [lo, hi)
+    int wx_lo[kMaxWin], wx_hi[kMaxWin];
+    float yscale, xscale;  // float32 (windows / extent): TF1 CalculateResizeScale
+};
+
+struct RegionTab {
+    RegionLevel lv[kMaxLevels];
+};
+
+constexpr int kCells = kMaxSeg * kMaxSeg;
+
 // ---- a-10 -> a-9 -> a-8 in one streaming pass ("top 10 %, NMS" between the chain and the keypoints)
 //   top   = color * (value >= thr ? 1 : 0)                          top_value_points_kernel
 //   peaks = top * (top == maxpool3x3 SAME(top) ? top : 0)           nms3x3_kernel, SILENT_NMS_PRODUCT
@@ -196,13 +220,17 @@ __global__ __launch_bounds__(256) void top_value_points_kernel(const float* __re
 // row maximum by DPP followed by a 3-row window; out-of-image taps are -inf (max_pool ignores them).
 constexpr int kSelCols = 60, kSelTW = 4 * kSelCols, kSelTH = 32;
 
-template <int C>
+// CELLS: also fold the cell maxima of max_value_indices_region (region_cell_max_kernel) over the peak value into this
+// pass -- the lane's column segment is fixed, the row segment is wave-uniform, so it is one running maximum per lane
+// and a segmented wave reduction + one atomic per (row segment, column segment) and tile.
+template <int C, bool CELLS>
 __global__ __launch_bounds__(256) void select_peaks_kernel(const float* __restrict__ color,
                                                            const float* __restrict__ value,
                                                            float* __restrict__ top_out, float* __restrict__ peaks_out,
                                                            float* __restrict__ pv_out, const LevelTab tab,
                                                            float one_minus_p, float p_f,
-                                                           const unsigned* __restrict__ mm) {
+                                                           const unsigned* __restrict__ mm, const RegionTab rt,
+                                                           unsigned* __restrict__ cells) {
     constexpr int R = kSelTH;
     const TileCoord tc = locate_tile(tab, blockIdx.x);
     const int H = tab.h[tc.level], W = tab.w[tc.level];
@@ -220,6 +248,29 @@ __global__ __launch_bounds__(256) void select_peaks_kernel(const float* __restri
     const float thr = __fadd_rn(__fmul_rn(one_minus_p, ord2f(slot[0])), __fmul_rn(p_f, ord2f(slot[1])));
     const float inv = 1.0f / (float)C;
 
+    // CELLS state: column segment of this lane, row segment of the rows seen so far, running maximum
+    const RegionLevel& rl = rt.lv[tc.level];
+    int cseg = 0, cur_rs = -1;
+    float cmax = -INFINITY;
+    if constexpr (CELLS) {
+        for (int s_ = 1; s_ < rl.ncs; ++s_) cseg = x >= rl.ccut[s_] ? s_ : cseg;
+    }
+    auto flush_cells = [&]() {
+        if (cur_rs < 0) return;  // wave-uniform
+        unsigned* dst = cells + ((long long)tc.frame * tab.n_levels + tc.level) * kCells + cur_rs * kMaxSeg;
+        int key = out_lane ? cseg : -1;
+        unsigned long long left = __ballot(key >= 0);
+        while (left) {
+            const int first = __ffsll((long long)left) - 1;
+            const int k = __builtin_amdgcn_readlane(key, first);
+            const bool mine = key == k;
+            const float m = wave_max(mine ? cmax : -INFINITY);
+            if (lane == first) atomicMax(dst + k, f2ord(m));
+            key = mine ? -1 : key;
+            left = __ballot(key >= 0);
+        }
+        cmax = -INFINITY;
+    };
     float hm[C][2], ctr[C];  // row maxima of rows y-2, y-1; centre values of row y-1
 #pragma unroll
     for (int c = 0; c < C; ++c) {
@@ -282,42 +333,34 @@ __global__ __launch_bounds__(256) void select_peaks_kernel(const float* __restri
 #pragma unroll
                     for (int c = 0; c < C; ++c) peaks_out[px * C + c] = o[c];
                 }
-                if (pv_out) {
+                if (pv_out || CELLS) {
                     float pv = o[0];
 #pragma unroll
                     for (int c = 1; c < C; ++c) pv = __fadd_rn(pv, o[c]);
-                    pv_out[px] = __fmul_rn(pv, inv);
+                    pv = __fmul_rn(pv, inv);
+                    if (pv_out) pv_out[px] = pv;
+                    if constexpr (CELLS) cmax = cmax < pv ? pv : cmax;
+                }
+            }
+            if constexpr (CELLS) {
+                // the NEXT output row may start a new row segment: hand the finished one over first (wave-uniform)
+                const int yn = yo + 1;
+                if (i >= 1 && yn < H && yn < y0 + R) {
+                    int rs = 0;
+                    for (int s_ = 1; s_ < rl.nrs; ++s_) rs = yn >= rl.rcut[s_] ? s_ : rs;
+                    if (rs != cur_rs) {
+                        flush_cells();
+                        cur_rs = rs;
+                    }
                 }
             }
 #pragma unroll
             for (int c = 0; c < C; ++c) ctr[c] = t[c];
         }
     }
+    if constexpr (CELLS) flush_cells();
 }
 
-// ---- a-11 max_value_indices_region
-// The TF1 op is max_pool(k = full extent, stride = region, SAME): every window is the level clipped to
-// a shifted copy of itself, i.e. a PREFIX or a SUFFIX of rows (and of columns).  The distinct window
-// edges cut each axis into <= kMaxSeg segments; one pass computes the max of every (row segment x
-// column segment) cell, and a window maximum is the max over the cells it covers.
-constexpr int kMaxWin = 4;  // windows per axis (the reference uses 2); keeps RegionTab inside the kernarg budget
-constexpr int kMaxSeg = 8;  // segments per axis (<= 2 * windows)
-
-struct RegionLevel {
-    int oh, ow;          // windows per axis
-    int nrs, ncs;        // segments per axis
-    int rcut[kMaxSeg + 1];  // row segment s = [rcut[s], rcut[s+1])
-    int ccut[kMaxSeg + 1];
-    int wy_lo[kMaxWin], wy_hi[kMaxWin];  // window j covers row SEGMENTS [lo, hi)
-    int wx_lo[kMaxWin], wx_hi[kMaxWin];
-    float yscale, xscale;  // float32 (windows / extent): TF1 CalculateResizeScale
-};
-
-struct RegionTab {
-    RegionLevel lv[kMaxLevels];
-};
-
-constexpr int kCells = kMaxSeg * kMaxSeg;
 
 // (y, x) of pixel p are carried by the caller: the kernels walk their pixels with a fixed stride, so one integer
 // division per thread replaces one per pixel

@@ -157,19 +157,23 @@ class LineEndPipeline(object):
 
     def run_keypoints(self, stream=None):
         s = stream or self._stream()
+        p = lambda t: C.c_void_p(t.data_ptr())
+        geom = (self.levels_c, self.n_levels, self.batch)
+        if self.selection and not self.keep_selection_maps:
+            # a-10 -> a-9 -> a-8 -> a-11 as one composite: the keypoint search's cell maxima come out of the selection pass
+            self.ctx.check(self._lib.silent_select_keypoints_dev(
+                self.ctx.handle, p(self.line_end), p(self.value), *geom, 3, self.top_percent, self.regions,
+                p(self.peak_value), p(self.kp_idx), self.kp_cap, p(self.kp_counts), s))
+            return
         value = self.value
         if self.selection:
-            geom = (self.levels_c, self.n_levels, self.batch)
-            p = lambda t: C.c_void_p(t.data_ptr())
-            # a-10 -> a-9 -> a-8 in one streaming pass; the intermediate colour maps are only written when kept
+            # the same with the two intermediate colour maps kept (tests, visualisation)
             self.ctx.check(self._lib.silent_select_peaks_dev(
-                self.ctx.handle, p(self.line_end), p(self.value), *geom, 3, self.top_percent,
-                p(self.top) if self.keep_selection_maps else None, p(self.peaks) if self.keep_selection_maps else None,
+                self.ctx.handle, p(self.line_end), p(self.value), *geom, 3, self.top_percent, p(self.top), p(self.peaks),
                 p(self.peak_value), s))
             value = self.peak_value
         self.ctx.check(self._lib.silent_max_value_indices_region_dev(
-            self.ctx.handle, C.c_void_p(value.data_ptr()), self.levels_c, self.n_levels, self.batch, self.regions,
-            C.c_void_p(self.kp_idx.data_ptr()), self.kp_cap, C.c_void_p(self.kp_counts.data_ptr()), s))
+            self.ctx.handle, p(value), *geom, self.regions, p(self.kp_idx), self.kp_cap, p(self.kp_counts), s))
 
     def run_gray_pass(self, frames, stream=None):
         """Whole grayscale hot path in one C-ABI call (silent_gray_pass_dev): region kernel for the non-unit

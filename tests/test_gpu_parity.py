@@ -573,6 +573,31 @@ def test_select_peaks_equals_the_three_separate_ops(rt, c, with_value):
         np.testing.assert_array_equal(got["peaks"].level(l), so.nms3x3(so.top_value_points(lev, 0.1, v), "product"))
 
 
+@pytest.mark.parametrize("keep", [False, True])
+def test_rgb_pipeline_composite_selection_equals_separate_calls(rt, kernels, keep):
+    """silent_select_keypoints (cell maxima folded into the selection pass) gives the same peak value and the same
+    keypoints as silent_select_peaks + silent_max_value_indices_region, on levels that cross region cuts inside a tile."""
+    import torch
+    from pysilent_amd.pipeline import LineEndPipeline
+    frames = torch.from_numpy(np.stack([noise_frame(80 + i, 150, 260, 3) for i in range(3)])).cuda()
+    pipe = LineEndPipeline((150, 260), mode="rgb", n_levels=4, batch=3, selection=True, keep_selection_maps=keep,
+                           max_keypoints_per_frame=1 << 16)
+    pipe.step(frames)
+    torch.cuda.synchronize()
+    out = pipe.outputs()
+    for f in range(3):
+        rows = []
+        for l, (h, w) in enumerate(pipe.extents):
+            line = np.ascontiguousarray(out["line_end"].level(l)[f:f + 1].cpu().numpy())
+            value = np.ascontiguousarray(out["value"].level(l)[f:f + 1].cpu().numpy())
+            pv = so.value_from_color(so.nms3x3(so.top_value_points(line, 0.1, value), "product"))
+            np.testing.assert_array_equal(out["peak_value"].level(l)[f:f + 1].cpu().numpy(), pv)
+            r = so.max_value_indices_region(None, (1, max(h // 2, 1), max(w // 2, 1), 3), pv)
+            r[:, 0] = l
+            rows.append(r)
+        np.testing.assert_array_equal(out["keypoints"][f], np.concatenate(rows))
+
+
 def test_rgb_pipeline_with_selection_stage(rt, kernels):
     """chain -> top-percent (a-10, p = 0.1) -> NMS (a-9) -> value -> keypoints (a-11); every stage
     after the chain is index-like and compared bit for bit with the oracle applied to the GPU's own line-end map."""
