@@ -365,7 +365,7 @@ __global__ __launch_bounds__(256) void rgb_line_end_kernel(const RgbArgs args) {
                 // v_log_f32 treats denormal inputs as 0: below 2^-100 the accurate powf runs (a lane-divergent branch that no
                 // lane takes in practice).  silent_regulate / conv2d_same_kernel keep powf.
                 float pw;
-                if (m > 0.0f && m < 7.8886e-31f) pw = powf(m, prm.root);
+                if ((m > 0.0f && m < 7.8886e-31f) || prm.root == 0.0f) pw = powf(m, prm.root);  // (0 * -inf: pow(0, 0) = 1)
                 else pw = __builtin_amdgcn_exp2f(prm.root * __builtin_amdgcn_logf(m));
                 const float r = prm.rv / pw;
                 const bool ok = t >= 0 && t < H && col_ok;

@@ -527,6 +527,17 @@ def test_rgb_chain_structured_and_dense_kernels_agree(rt, kernels, monkeypatch):
     assert_close(fast["orient"], want["orient"], RTOL, what="orient vs oracle")
 
 
+@pytest.mark.parametrize("root", [0.0, 0.5, 1.0])
+def test_rgb_chain_regulation_roots(rt, kernels, root):
+    """The fused chain's regulator power (exp2(root * log2 m), powf for root = 0 and denormal m) against the oracle for
+    other roots than the reference's 0.1, on frames with flat (m = 0) regions under the 'zero' policy."""
+    frames = structured_frame(12, 64, 90, 3)[None]
+    got = rt.rgb_line_end(frames, kernels, regulation_root=root, flat_policy="zero")
+    want = so.rgb_line_end_chain(frames, kernels, flat_policy="zero", blur_root=root)
+    assert_close(got["orient"], want["orient"], RTOL, what="orient root %g" % root)
+    assert_close(got["line_end"], want["padded"], RTOL, scale=255.0, what="line_end root %g" % root)
+
+
 def test_rgb_chain_on_packed_levels_and_keypoints(rt, kernels):
     from pysilent_amd.util.selection import max_value_indices_region
     extents = [(64, 96), (32, 48), (16, 24)]
