@@ -682,8 +682,8 @@ SILENT_EXPORT int silent_centroids_dev(silent_ctx* ctx, const float* value, cons
     TRY(grow(ctx, ctx->ws, (size_t)cells * 2 * sizeof(float)));
     float* cxy = (float*)ctx->ws.p;
     hipStream_t s = (hipStream_t)stream;
-    hipLaunchKernelGGL(centroid_cells_kernel, dim3((unsigned)((cells + 255) / 256), (unsigned)n_frames), dim3(256), 0, s,
-                       value, tab, ct, total_out, cxy);
+    hipLaunchKernelGGL(centroid_cells_kernel, dim3((unsigned)((cells + 255) / 256)), dim3(256), 0, s, value, tab, ct, n_frames,
+                       total_out, cxy);
     hipLaunchKernelGGL(centroid_dist_kernel, dim3((unsigned)blocks), dim3(256), 0, s, tab, ct, cxy, dist_out);
     return check_launch(ctx, who);
 }
@@ -736,9 +736,9 @@ SILENT_EXPORT int silent_affine_clip_dev(silent_ctx* ctx, const float* in, size_
     const char* who = "silent_affine_clip";
     if (!in || !out || !params) return fail(ctx, SILENT_E_INVALID, std::string(who) + ": NULL pointer");
     if (n_values == 0) return fail(ctx, SILENT_E_INVALID, std::string(who) + ": empty tensor");
-    if ((n_values + 255) / 256 > 0x7fffffffull) return fail(ctx, SILENT_E_INVALID, std::string(who) + ": too many values");
+    if ((n_values + 2047) / 2048 > 0x7fffffffull) return fail(ctx, SILENT_E_INVALID, std::string(who) + ": too many values");
     const AffineP ap = {params->mul, params->div, params->add, params->lo, params->hi, params->post_add};
-    hipLaunchKernelGGL(affine_clip_kernel, dim3((unsigned)((n_values + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+    hipLaunchKernelGGL(affine_clip_kernel, dim3((unsigned)((n_values + 2047) / 2048)), dim3(256), 0, (hipStream_t)stream,
                        in, out, (long long)n_values, ap);
     return check_launch(ctx, who);
 }

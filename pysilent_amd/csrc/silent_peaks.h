@@ -569,11 +569,11 @@ struct CellTab {
 };
 
 __global__ __launch_bounds__(256) void centroid_cells_kernel(const float* __restrict__ value, const LevelTab tab,
-                                                             const CellTab ct, float* __restrict__ total_out,
-                                                             float* __restrict__ cxy) {
+                                                             const CellTab ct, int n_frames,
+                                                             float* __restrict__ total_out, float* __restrict__ cxy) {
     const long long gid = (long long)blockIdx.x * 256 + threadIdx.x;
     const int frame = (int)(gid / ct.frame_cells);
-    if (frame >= (int)gridDim.y) return;
+    if (frame >= n_frames) return;
     long long rem = gid - (long long)frame * ct.frame_cells;
     int l = 0;
 #pragma unroll
@@ -694,12 +694,19 @@ struct AffineP {
 
 __global__ __launch_bounds__(256) void affine_clip_kernel(const float* __restrict__ in, float* __restrict__ out,
                                                           long long n, const AffineP ap) {
-    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
-    if (i >= n) return;
-    float y = __fadd_rn(__fdiv_rn(__fmul_rn(in[i], ap.mul), ap.div), ap.add);
-    y = y < ap.lo ? ap.lo : y;
-    y = y > ap.hi ? ap.hi : y;
-    out[i] = __fadd_rn(y, ap.post_add);
+    // 8 elements per thread, 256 apart (coalesced), all requested before the first use
+    const long long i0 = (long long)blockIdx.x * 2048 + threadIdx.x;
+    float v[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) v[k] = in[min(i0 + k * 256, n - 1)];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        const long long i = i0 + k * 256;
+        float y = __fadd_rn(__fdiv_rn(__fmul_rn(v[k], ap.mul), ap.div), ap.add);
+        y = y < ap.lo ? ap.lo : y;
+        y = y > ap.hi ? ap.hi : y;
+        if (i < n) out[i] = __fadd_rn(y, ap.post_add);
+    }
 }
 
 // tf.image.resize_nearest_neighbor (TF1, align_corners = False): src = min(floor(dst * float32(in / out)), in - 1).
