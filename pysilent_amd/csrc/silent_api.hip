@@ -429,6 +429,14 @@ SILENT_EXPORT int silent_nms3x3_dev(silent_ctx* ctx, const float* in, const sile
         return fail(ctx, SILENT_E_INVALID, std::string(who) + ": mode must be SILENT_NMS_PRODUCT or SILENT_NMS_FIRED");
     LevelTab tab;
     long long blocks;
+    if (channels == 1 || channels == 3) {  // streaming stencil
+        TRY(build_level_tab(ctx, who, levels, n_levels, n_frames, kNmsTW, kNmsTH, &tab, &blocks));
+        if (channels == 3)
+            hipLaunchKernelGGL(nms3x3_stream_kernel<3>, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, in, out, tab, mode);
+        else
+            hipLaunchKernelGGL(nms3x3_stream_kernel<1>, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, in, out, tab, mode);
+        return check_launch(ctx, who);
+    }
     TRY(build_level_tab(ctx, who, levels, n_levels, n_frames, 0, 0, &tab, &blocks));
     hipLaunchKernelGGL(nms3x3_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, in, out, tab, channels,
                        mode);
