@@ -332,6 +332,28 @@ SILENT_EXPORT int silent_regulate_dev(silent_ctx* ctx, const float* in, const si
     NEED_CTX(ctx);
     if (flat_policy != SILENT_FLAT_IEEE && flat_policy != SILENT_FLAT_ZERO)
         return fail(ctx, SILENT_E_INVALID, "silent_regulate: flat_policy must be SILENT_FLAT_IEEE or SILENT_FLAT_ZERO");
+    // 7x7 channel-uniform blur on 3-channel maps (the reference's orientation_filter): 49-tap filter of the channel sum
+    if (channels == 3 && kh == 7 && kw == 7 && in && out && blur_hwio && levels) {
+        bool uniform = true;
+        for (int t = 0; t < 49 && uniform; ++t)
+            for (int io = 1; io < 9; ++io)
+                if (blur_hwio[t * 9 + io] != blur_hwio[t * 9]) uniform = false;
+        unsigned kopts = 0;
+        if (const char* e = std::getenv("SILENT_RGB_OPTS")) kopts = (unsigned)std::strtoul(e, nullptr, 0);
+        if (uniform && !(kopts & 1u)) {
+            RegArgs a;
+            long long blocks;
+            TRY(build_level_tab(ctx, "silent_regulate", levels, n_levels, n_frames, kRegTW, kRegTH, &a.tab, &blocks));
+            a.in = in;
+            a.out = out;
+            for (int t = 0; t < 49; ++t) a.blur[t] = blur_hwio[t * 9];
+            a.rv = regulation_value;
+            a.root = regulation_root;
+            a.flat_policy = flat_policy;
+            hipLaunchKernelGGL(regulate_sum_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, a);
+            return check_launch(ctx, "silent_regulate");
+        }
+    }
     Epilogue ep{0u, 0.f, regulation_value, regulation_root, flat_policy};
     return conv_dispatch(ctx, "silent_regulate", in, levels, n_levels, n_frames, channels, blur_hwio, kh, kw, channels,
                          true, ep, out, (hipStream_t)stream);

@@ -411,4 +411,112 @@ __global__ __launch_bounds__(256) void rgb_line_end_kernel(const RgbArgs args) {
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// regulate_sum_kernel: silent_regulate for a 7x7 channel-uniform blur on 3-channel maps (what blur_tensor generates and
+// orientation_filter uses, filters/orientation.py:20,31-33) -- the regulator stage of rgb_line_end_kernel on its own:
+// the blur is a 49-tap filter of the channel SUM (rolling row accumulators, DPP neighbours, halo 3 lanes per side),
+// then y = x * (rv / pow(min(b, 1), root)) with powf.  The dense 441-fma form (conv2d_same_kernel<7,7,3,3,true>) ran at
+// 0.6 TB/s on 1080p maps.
+constexpr int kRegCols = 58, kRegTW = 4 * kRegCols, kRegTH = 58;  // 58 + 6 = 64 streamed rows per tile
+
+struct RegArgs {
+    const float* in;
+    float* out;
+    LevelTab tab;
+    float blur[49];  // profile [dy][dx]
+    float rv, root;
+    int flat_policy;
+};
+
+__global__ __launch_bounds__(256) void regulate_sum_kernel(const RegArgs args) {
+    constexpr int R = kRegTH;
+    const LevelTab& tab = args.tab;
+    typedef const __attribute__((address_space(4))) char* kchar_p;
+    const kfloat_p kb0 = (kfloat_p)((kchar_p)__builtin_amdgcn_kernarg_segment_ptr() + offsetof(RegArgs, blur));
+    const TileCoord tc = locate_tile(tab, blockIdx.x);
+    const int H = tab.h[tc.level], W = tab.w[tc.level];
+    const long long base_px = (long long)tc.frame * tab.frame_px + tab.px_off[tc.level];
+    const float* __restrict__ src = args.in + base_px * 3;
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int xw0 = tc.tx * kRegTW + wave * kRegCols;
+    if (xw0 >= W) return;  // wave-uniform
+    const int y0 = tc.ty * R;
+    const int x = xw0 + lane - 3;
+    const bool col_ok = x >= 0 && x < W;
+    const long long xoff = (long long)min(max(x, 0), W - 1) * 3;
+    const bool out_lane = lane >= 3 && lane < 3 + kRegCols && x < W;
+    float pb[7] = {0, 0, 0, 0, 0, 0, 0};  // pending blur rows: pb[k] = output row (newest input row) - 3 + k
+    float hist[4][3];                     // input rows q, q-1, q-2, q-3 (own column)
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+#pragma unroll
+        for (int c = 0; c < 3; ++c) hist[k][c] = 0.0f;
+#pragma unroll 1
+    for (int i0 = 0; i0 < R + 6; i0 += 4) {
+        float g4[4][3];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int y = y0 - 3 + i0 + j;
+            const bool ok = y >= 0 && y < H && col_ok;
+            const float* __restrict__ p = src + (long long)min(max(y, 0), H - 1) * W * 3 + xoff;
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+                const float t = p[c];
+                g4[j][c] = ok ? t : 0.0f;
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int q = y0 - 3 + i0 + j;  // arriving input row; blur row t = q - 3 completes
+#pragma unroll
+            for (int k = 3; k > 0; --k)
+#pragma unroll
+                for (int c = 0; c < 3; ++c) hist[k][c] = hist[k - 1][c];
+#pragma unroll
+            for (int c = 0; c < 3; ++c) hist[0][c] = g4[j][c];
+            float s7[7];
+            s7[3] = (g4[j][0] + g4[j][1]) + g4[j][2];
+            s7[2] = from_lane_below(s7[3]);
+            s7[1] = from_lane_below(s7[2]);
+            s7[0] = from_lane_below(s7[1]);
+            s7[4] = from_lane_above(s7[3]);
+            s7[5] = from_lane_above(s7[4]);
+            s7[6] = from_lane_above(s7[5]);
+            float nb[7];
+#pragma unroll
+            for (int k = 0; k < 7; ++k) {
+                kfloat_p kb = kb0 + (6 - k) * 7;
+                __builtin_amdgcn_sched_barrier(0);
+                asm volatile("" : "+s"(kb));
+                float kw[7];
+#pragma unroll
+                for (int dx = 0; dx < 7; ++dx) kw[dx] = kb[dx];
+                float acc = pb[k];
+#pragma unroll
+                for (int dx = 0; dx < 7; ++dx) acc = __builtin_fmaf(s7[dx], kw[dx], acc);
+                asm volatile("" : "+v"(acc));
+                nb[k] = acc;
+            }
+            const float bdone = nb[0];
+#pragma unroll
+            for (int k = 0; k < 6; ++k) pb[k] = nb[k + 1];
+            pb[6] = 0.0f;
+            const int t = q - 3;
+            if (t >= y0 && t < y0 + R && t < H && out_lane) {
+                const float m = bdone > 1.0f ? 1.0f : bdone;
+                const float r = args.rv / powf(m, args.root);
+                float* __restrict__ po = args.out + (base_px + (long long)t * W + x) * 3;
+#pragma unroll
+                for (int c = 0; c < 3; ++c) {
+                    const float xs = hist[3][c];
+                    float yv = xs * r;
+                    if (args.flat_policy == SILENT_FLAT_ZERO && xs == 0.0f) yv = 0.0f;
+                    po[c] = yv;
+                }
+            }
+        }
+    }
+}
+
 }  // namespace silent
