@@ -14,6 +14,11 @@ state = torch.full_like(cells, 8.0)
 from pysilent_amd import constant_convolutions as cc
 blur = cc.blur_tensor(2, 7)
 k333 = cc.midget_rgc(2)
+from pysilent_amd.util.normalize import normalize_tensor_positive_negative as _norm
+kcs = _norm(cc.center_surround_tensor(2, [1], [1], [1], [-1]))
+kend = cc.end_bank(4)
+from pysilent_amd.constant_convolutions import edge_orientation_detector as _eod
+k7733 = _eod.rgb_2d_edge_tensors()
 
 
 def timed(fn, reps=20):
@@ -43,6 +48,11 @@ rows = [
     ("top_value_points (3 ch + value)", lambda: rt.top_value_points(color, 0.1, value), px * (4 + 12 + 4 + 12)),
     ("regulate 7x7 (3 ch)", lambda: rt.regulate(color, blur, 1.0, 0.1), px * 24),
     ("conv2d_same 3x3x3x3 + relu", lambda: rt.conv2d_same(color, k333, relu=True), px * 24),
+    ("conv2d_same 3x3x1x1 + relu (gray CS)", lambda: rt.conv2d_same(value, kcs, relu=True), px * 8),
+    ("conv2d_same 3x3x1x4 + relu + clip (gray end bank)", lambda: rt.conv2d_same(value, kend, relu=True, clip_hi=255.0), px * 20),
+    ("conv2d_same 7x7x3x3 (thick-edge bank)", lambda: rt.conv2d_same(color, k7733), px * 24),
+    ("max_value_indices_region (value -> int64 keypoints)", lambda: rt.max_value_indices_region(value, [(H // 2, W // 2)]), px * 4 * 3),
+    ("boosting_step visualise (3-channel outputs)", lambda: rt.boosting_step(cells, state, 1.0, 1.0, 1, True), cells.numel() * 40),
 ]
 for name, fn, nbytes in rows:
     ms = timed(fn)
