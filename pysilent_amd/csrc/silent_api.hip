@@ -1078,7 +1078,8 @@ SILENT_EXPORT int silent_pyramid_plan_create(silent_ctx* ctx, int frame_h, int f
     tab.C = channels;
     const int RW = channels == 1 ? region_w(1) : region_w(3);
     tab.regions_x = (frame_w + RW - 1) / RW;
-    tab.regions_y = (frame_h + kRegionH - 1) / kRegionH;
+    const int RH = channels == 1 ? region_h(1) : region_h(3);
+    tab.regions_y = (frame_h + RH - 1) / RH;
     long long cols = 0, rows = 0, px = 0;
     for (int l = 0; l < n_levels; ++l) {
         const silent_pyr_level& L = levels[l];
@@ -1140,7 +1141,7 @@ SILENT_EXPORT int silent_pyramid_plan_create(silent_ctx* ctx, int frame_h, int f
         }
         o = 0;
         for (int r = 0; r <= tab.regions_y; ++r) {
-            while (o < zr && yb[o] + d.src_y0 < r * kRegionH) ++o;
+            while (o < zr && yb[o] + d.src_y0 < r * RH) ++o;
             yreg.push_back(r == tab.regions_y ? zr : o);
         }
         // every mirrored tap of an anchored output must lie inside its region's staged tile (see the kernel)
@@ -1154,10 +1155,10 @@ SILENT_EXPORT int silent_pyramid_plan_create(silent_ctx* ctx, int frame_h, int f
             }
         }
         for (int oy = 0; oy < zr; ++oy) {
-            const int Y0 = ((yb[oy] + d.src_y0) / kRegionH) * kRegionH;
+            const int Y0 = ((yb[oy] + d.src_y0) / RH) * RH;
             for (int j = 0; j < 6; ++j) {
                 const int p = yi[(size_t)oy * 6 + j] + d.src_y0 - (Y0 - kRegionHaloT);
-                if (p < 0 || p >= kRegionSH) tap_range_ok = false;
+                if (p < 0 || p >= RH + kRegionHaloT + kRegionHaloB) tap_range_ok = false;
             }
         }
         if (d.out_h > d.zoom_h || d.out_w > d.zoom_w) zero_chunks += ((long long)d.out_h * d.out_w + 1023) / 1024;

@@ -6,7 +6,7 @@
 //   pyramid_unit_kernel    levels whose zoom factor is exactly 1 (level 0, 75 % of all pixels).  The
 //                          resampler degenerates to the fixed 5-tap smoother [1,26,66,26,1]/120 per axis;
 //                          wave-autonomous streaming stencil (DPP neighbour exchange, no LDS, no barrier).
-//   pyramid_region_kernel  every other level.  One block per 128 x 32 source region: the region (+ halo)
+//   pyramid_region_kernel  every other level.  One block per source region (128 x 32 px for 1 channel, 64 x 16 for 3): the region (+ halo)
 //                          is staged into LDS once with float4 loads, and each level's outputs ANCHORED in
 //                          the region (floor(source coordinate) inside it) are produced from that copy:
 //                          6-tap vertical pass into LDS, 6-tap horizontal pass, coalesced store.
@@ -29,12 +29,15 @@ constexpr int kUnitTH = 16;               // rows per tile
 
 // ---- region kernel geometry
 __host__ __device__ constexpr int region_w(int C) { return C == 1 ? 128 : 64; }
-constexpr int kRegionH = 32;
+// rows per region: the LDS copy of a region bounds the blocks per CU, and the kernel is latency-bound (staging
+// loads, LDS round trips, barriers), so 3-channel frames use half-height regions: 22 KB -> 7 blocks per CU
+// instead of 3 (measured -19 % on 32 x 1080p RGB; for 1 channel 32 rows stay better, 25 KB -> 6 blocks)
+__host__ __device__ constexpr int region_h(int C) { return C == 1 ? 32 : 16; }
 constexpr int kRegionHaloL = 4, kRegionHaloR = 4;   // staged columns [X0-4, X0+RW+4): float4 aligned, covers taps -3..+3
 constexpr int kRegionHaloT = 3, kRegionHaloB = 3;   // staged rows    [Y0-3, Y0+RH+3)
-constexpr int kRegionVR = 16;                       // output rows per vertical-pass chunk
+__host__ __device__ constexpr int region_vr(int C) { return C == 1 ? 8 : 4; }   // output rows per vertical-pass chunk
 __host__ __device__ constexpr int region_sw(int C) { return region_w(C) + kRegionHaloL + kRegionHaloR; }
-constexpr int kRegionSH = kRegionH + kRegionHaloT + kRegionHaloB;
+__host__ __device__ constexpr int region_sh(int C) { return region_h(C) + kRegionHaloT + kRegionHaloB; }
 
 struct PyrLevelDev {
     int src_y0, src_x0, src_h, src_w;
@@ -170,21 +173,22 @@ __global__ __launch_bounds__(256) void pyramid_unit_kernel(const float* __restri
 // ------------------------------------------------------------------------------------------ REGION
 // One block per source region: the region (+ halo) is staged into LDS once (batched float4 loads), then each
 // general level's outputs anchored in the region are produced from that copy: 6-tap vertical pass into LDS
-// for every staged column, barrier, 6-tap horizontal pass, coalesced store.  29 KB of LDS -> 5 blocks per CU
-// cover each other's table-load and barrier latencies.
+// for every staged column, barrier, 6-tap horizontal pass, coalesced store.  The kernel is latency-bound
+// (staging loads, LDS round trips, barriers), so the LDS footprint is kept small: 25 KB (1 channel) / 22 KB
+// (3 channels) -> 6 / 7 blocks per CU that cover each other's waits.
 template <int C>
 __global__ __launch_bounds__(256) void pyramid_region_kernel(const float* __restrict__ frames,
                                                              float* __restrict__ pyr, const PyrTab tab) {
-    constexpr int RW = region_w(C), SW = region_sw(C), SH = kRegionSH, ROWF = SW * C;
+    constexpr int RW = region_w(C), SW = region_sw(C), SH = region_sh(C), ROWF = SW * C, VR = region_vr(C);
     __shared__ __attribute__((aligned(16))) float s_src[SH * ROWF];
-    __shared__ __attribute__((aligned(16))) float s_v[kRegionVR * ROWF];
+    __shared__ __attribute__((aligned(16))) float s_v[VR * ROWF];
 
     const int per_frame = tab.regions_x * tab.regions_y;
     const unsigned bid = blockIdx.x;
     const int frame = (int)(bid / (unsigned)per_frame);
     const int rem = (int)(bid - (unsigned)frame * (unsigned)per_frame);
     const int ry = rem / tab.regions_x, rx = rem - ry * tab.regions_x;
-    const int X0 = rx * RW, Y0 = ry * kRegionH;
+    const int X0 = rx * RW, Y0 = ry * region_h(C);
     const int W = tab.W, H = tab.H;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -239,17 +243,33 @@ __global__ __launch_bounds__(256) void pyramid_region_kernel(const float* __rest
         if (xs >= xe || ys >= ye) continue;  // block-uniform
         float* __restrict__ dst = pyr + ((long long)frame * tab.frame_px_out + tab.px_off[l]) * C;
         const int xshift = lv.src_x0 - (X0 - kRegionHaloL), yshift = lv.src_y0 - (Y0 - kRegionHaloT);
-        for (int yc = ys; yc < ye; yc += kRegionVR) {
-            const int nr = min(kRegionVR, ye - yc);
+        // this lane's horizontal taps (first 64 output columns of the region) are requested before the vertical
+        // pass, so their latency is covered by it; the vertical taps are wave-uniform -> scalar loads
+        int co0[6];
+        float wx0[6];
+        {
+            const long long xe6 = (long long)(lv.xtab_off + min(xs + lane, xe - 1)) * 6;
+#pragma unroll
+            for (int i = 0; i < 6; ++i) {
+                co0[i] = min(max(tab.xidx[xe6 + i] + xshift, 0), SW - 1) * C;
+                wx0[i] = tab.xw[xe6 + i];
+            }
+        }
+        typedef const __attribute__((address_space(4))) int* const_int_ptr;
+        typedef const __attribute__((address_space(4))) float* const_float_ptr;
+        for (int yc = ys; yc < ye; yc += VR) {
+            const int nr = min(VR, ye - yc);
             // vertical 6 taps for every staged float of the rows this chunk needs (lanes = consecutive floats)
             for (int orow = wave; orow < nr; orow += 4) {
                 const long long ye6 = (long long)(lv.ytab_off + yc + orow) * 6;
+                const_int_ptr yi = (const_int_ptr)(tab.yidx + ye6);
+                const_float_ptr yw = (const_float_ptr)(tab.yw + ye6);
                 int ro[6];
                 float wy[6];
 #pragma unroll
                 for (int j = 0; j < 6; ++j) {
-                    ro[j] = min(max(tab.yidx[ye6 + j] + yshift, 0), SH - 1) * ROWF;
-                    wy[j] = tab.yw[ye6 + j];
+                    ro[j] = min(max(yi[j] + yshift, 0), SH - 1) * ROWF;
+                    wy[j] = yw[j];
                 }
                 for (int c = lane; c < ROWF; c += 64) {
                     float acc = wy[0] * s_src[ro[0] + c];
@@ -261,13 +281,18 @@ __global__ __launch_bounds__(256) void pyramid_region_kernel(const float* __rest
             __syncthreads();
             // horizontal 6 taps and store (lanes = consecutive output columns)
             for (int oc = xs + lane; oc < xe; oc += 64) {
-                const long long xe6 = (long long)(lv.xtab_off + oc) * 6;
                 int co[6];
                 float wx[6];
+                if (oc < xs + 64) {  // wave-uniform
 #pragma unroll
-                for (int i = 0; i < 6; ++i) {
-                    co[i] = min(max(tab.xidx[xe6 + i] + xshift, 0), SW - 1) * C;
-                    wx[i] = tab.xw[xe6 + i];
+                    for (int i = 0; i < 6; ++i) co[i] = co0[i], wx[i] = wx0[i];
+                } else {
+                    const long long xe6 = (long long)(lv.xtab_off + oc) * 6;
+#pragma unroll
+                    for (int i = 0; i < 6; ++i) {
+                        co[i] = min(max(tab.xidx[xe6 + i] + xshift, 0), SW - 1) * C;
+                        wx[i] = tab.xw[xe6 + i];
+                    }
                 }
                 for (int orow = wave; orow < nr; orow += 4) {
                     float* __restrict__ po = dst + ((long long)(yc + orow) * lv.out_w + oc) * C;

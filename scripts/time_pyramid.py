@@ -26,10 +26,13 @@ def time_plan(levels, frames, reps=20):
 
 if __name__ == '__main__':
     B = int(sys.argv[1]) if len(sys.argv) > 1 else 64
+    Cc = int(sys.argv[2]) if len(sys.argv) > 2 else 1
+    G = int(sys.argv[3]) if len(sys.argv) > 3 else 5
     H, W = 1080, 1920
-    frames = torch.randint(0, 256, (B, H, W, 1), device='cuda').float()
-    allv = classic_levels((H, W), 2.0, 5)
-    for name, lv in [('all', allv)] + [('L%d' % i, [allv[i]]) for i in range(5)]:
+    frames = torch.randint(0, 256, (B, H, W, Cc), device='cuda').float()
+    allv = classic_levels((H, W), 2.0, G)
+    per_level = [] if os.environ.get('PYR_ALL_ONLY') else [('L%d' % i, [allv[i]]) for i in range(G)]
+    for name, lv in [('all', allv)] + per_level:
         ms, px = time_plan(lv, frames)
-        rd = H * W * 4 * B; wr = px * 4 * B
+        rd = H * W * 4 * B * Cc; wr = px * 4 * B * Cc
         print('%-4s %.4f ms  out px/frame %8d  write GB/s %.0f  (read+write)/t GB/s %.0f' % (name, ms, px, wr / ms / 1e6, (rd + wr) / ms / 1e6))
