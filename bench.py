@@ -55,16 +55,16 @@ def pmc_traffic_per_launch(kernel_substr, frames_in_launch):
     cands = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*", "pmc_hbm_bytes.json")))
     if not cands:
         return None
-    path = cands[-1]
-    try:
-        prof = json.load(open(path))
-    except (OSError, ValueError):
-        return None
-    for name, c in prof.items():
-        if kernel_substr in name and "FETCH_SIZE" in c and "WRITE_SIZE" in c:
-            per64 = (2.0 * c["FETCH_SIZE"]["mean_KiB_per_dispatch"] + c["WRITE_SIZE"]["mean_KiB_per_dispatch"]) * 1024.0
-            per64 *= 64.0 / c.get("frames_per_dispatch", 64)
-            return int(per64 * frames_in_launch / 64.0)
+    for path in reversed(cands):  # latest profile that holds this kernel
+        try:
+            prof = json.load(open(path))
+        except (OSError, ValueError):
+            continue
+        for name, c in prof.items():
+            if kernel_substr in name and "FETCH_SIZE" in c and "WRITE_SIZE" in c:
+                per64 = (2.0 * c["FETCH_SIZE"]["mean_KiB_per_dispatch"] + c["WRITE_SIZE"]["mean_KiB_per_dispatch"]) * 1024.0
+                per64 *= 64.0 / c.get("frames_per_dispatch", 64)
+                return int(per64 * frames_in_launch / 64.0)
     return None
 
 

@@ -184,7 +184,9 @@ __global__ __launch_bounds__(256) void pyramid_region_kernel(const float* __rest
     __shared__ __attribute__((aligned(16))) float s_v[VR * ROWF];
 
     const int per_frame = tab.regions_x * tab.regions_y;
-    const unsigned bid = blockIdx.x;
+    // XCD-contiguous order: regions that share halo rows / columns meet in one L2 (-1.5 % on RGB; the same
+    // remap made the streaming filter kernels slower)
+    const unsigned bid = xcd_swizzle(blockIdx.x, gridDim.x);
     const int frame = (int)(bid / (unsigned)per_frame);
     const int rem = (int)(bid - (unsigned)frame * (unsigned)per_frame);
     const int ry = rem / tab.regions_x, rx = rem - ry * tab.regions_x;
