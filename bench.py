@@ -208,7 +208,8 @@ def main():
         filt_bytes = pipe.filter_bytes_per_frame() * B
         roof = {"bound": "hbm", "kernel": "rgb_line_end_kernel", "achieved": round(filt_bytes / (filt_ms * 1e-3) / 1e9, 1),
                 "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(filt_bytes / (filt_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
-                "traffic": None, "algorithmic_bytes_per_launch": filt_bytes, "avg_launch_ms": round(filt_ms, 4)}
+                "traffic": pmc_traffic_per_launch("rgb_line_end_kernel", B),
+                "algorithmic_bytes_per_launch": filt_bytes, "avg_launch_ms": round(filt_ms, 4)}
     out = {
         "metric": METRIC if h == 1080 else "Mpx/s full pyramid line-end pass @4K",
         "value": round(mpx_in, 2),
