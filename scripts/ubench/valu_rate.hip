@@ -7,6 +7,11 @@
 #define REP8(x) x x x x x x x x
 template <int MODE>
 __global__ void rate_kernel(float* out, int iters, float w) {
+    __shared__ float4 s_w[64];
+    if (MODE == 11 || MODE == 12) {
+        if (threadIdx.x < 64) s_w[threadIdx.x] = make_float4(w, w + 1e-7f, w - 1e-7f, w);
+        __syncthreads();
+    }
     float a0 = threadIdx.x, a1 = a0 + 1, a2 = a0 + 2, a3 = a0 + 3, a4 = a0 + 4, a5 = a0 + 5, a6 = a0 + 6, a7 = a0 + 7;
     unsigned long long mask = 0x5555555555555555ull + (unsigned long long)iters;
     asm volatile("" : "+s"(mask));
@@ -54,6 +59,25 @@ __global__ void rate_kernel(float* out, int iters, float w) {
             REP8(asm volatile("v_lshl_add_u64 %0, %0, 2, %4\n v_lshl_add_u64 %1, %1, 2, %4\n v_lshl_add_u64 %2, %2, 2, %4\n v_lshl_add_u64 %3, %3, 2, %4\n"
                               "v_lshl_add_u64 %0, %0, 2, %4\n v_lshl_add_u64 %1, %1, 2, %4\n v_lshl_add_u64 %2, %2, 2, %4\n v_lshl_add_u64 %3, %3, 2, %4\n"
                               : "+v"(*(double*)&a0), "+v"(*(double*)&a2), "+v"(*(double*)&a4), "+v"(*(double*)&a6) : "v"(*(double*)&b0));)
+        } else if (MODE == 11) {  // 64 fmas whose weights arrive by broadcast ds_read_b128 (4 weights per read)
+#pragma unroll
+            for (int g = 0; g < 8; ++g) {
+                const float4 wa = s_w[(i + 2 * g) & 63], wb = s_w[(i + 2 * g + 1) & 63];
+                a0 = __builtin_fmaf(a0, wa.x, a0); a1 = __builtin_fmaf(a1, wa.y, a1);
+                a2 = __builtin_fmaf(a2, wa.z, a2); a3 = __builtin_fmaf(a3, wa.w, a3);
+                a4 = __builtin_fmaf(a4, wb.x, a4); a5 = __builtin_fmaf(a5, wb.y, a5);
+                a6 = __builtin_fmaf(a6, wb.z, a6); a7 = __builtin_fmaf(a7, wb.w, a7);
+            }
+        } else if (MODE == 12) {  // same with one weight per ds_read_b32
+#pragma unroll
+            for (int g = 0; g < 8; ++g) {
+                const float* sw = (const float*)s_w;
+                const int b = (i + 8 * g) & 127;
+                a0 = __builtin_fmaf(a0, sw[b], a0); a1 = __builtin_fmaf(a1, sw[b + 1], a1);
+                a2 = __builtin_fmaf(a2, sw[b + 2], a2); a3 = __builtin_fmaf(a3, sw[b + 3], a3);
+                a4 = __builtin_fmaf(a4, sw[b + 4], a4); a5 = __builtin_fmaf(a5, sw[b + 5], a5);
+                a6 = __builtin_fmaf(a6, sw[b + 6], a6); a7 = __builtin_fmaf(a7, sw[b + 7], a7);
+            }
         } else if (MODE == 4) {  // fmac with dpp source (VGPR weight)
             REP8(asm volatile("v_fmac_f32_dpp %0, %1, %8 wave_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n v_fmac_f32_dpp %1, %2, %8 wave_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n"
                               "v_fmac_f32_dpp %2, %3, %8 wave_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n v_fmac_f32_dpp %3, %4, %8 wave_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n"
@@ -93,7 +117,7 @@ double run(int waves_per_simd, float* out, const char* name, double per_instr_wo
 int main() {
     float* out;
     hipMalloc(&out, 256 * 1024 * 4 * 8);
-    for (int w : {1, 4}) {
+    for (int w : {1, 2, 4}) {
         run<0>(w, out, "v_fmac_f32", 1);
         run<1>(w, out, "v_pk_fma_f32", 2);
         run<2>(w, out, "v_mov_b32_dpp", 1);
@@ -105,6 +129,8 @@ int main() {
         run<8>(w, out, "cmp+nop+cndmask", 1);
         run<9>(w, out, "v_max+v_min", 1);
         run<10>(w, out, "v_lshl_add_u64", 1);
+        run<11>(w, out, "fma + lds b128 w", 1);
+        run<12>(w, out, "fma + lds b32 w", 1);
     }
     return 0;
 }
