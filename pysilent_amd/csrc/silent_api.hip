@@ -936,6 +936,11 @@ SILENT_EXPORT int silent_rgb_line_end_dev(silent_ctx* ctx, const float* pyr, con
         LevelTab tab;
         long long blocks;
         TRY(build_level_tab(ctx, who, levels, n_levels, n_frames, kRgbTW, kRgbTH, &tab, &blocks));
+        unsigned kopts = 0;
+        if (const char* e = std::getenv("SILENT_RGB_OPTS")) kopts = (unsigned)std::strtoul(e, nullptr, 0);  // 1: dense, 2: no two-group, 8: no short tiles
+        // few tiles: latency of one wave's row walk, not throughput, sets the time -> short tiles (silent_rgb.h)
+        const bool small = blocks < kRgbSmallBlocks && !(kopts & 8u);
+        if (small) TRY(build_level_tab(ctx, who, levels, n_levels, n_frames, kRgbTW, kRgbTHSmall, &tab, &blocks));
         if (p->flat_policy != SILENT_FLAT_IEEE && p->flat_policy != SILENT_FLAT_ZERO)
             return fail(ctx, SILENT_E_INVALID, std::string(who) + ": flat_policy must be SILENT_FLAT_IEEE or SILENT_FLAT_ZERO");
         RgbArgs a;
@@ -961,8 +966,6 @@ SILENT_EXPORT int silent_rgb_line_end_dev(silent_ctx* ctx, const float* pyr, con
         // (27 + 18 each): 189 instead of 373 fmas per pixel.  Anything else runs the dense instantiation.
         RgbStructure rs;
         analyze_rgb_chain(p, &rs);
-        unsigned kopts = 0;
-        if (const char* e = std::getenv("SILENT_RGB_OPTS")) kopts = (unsigned)std::strtoul(e, nullptr, 0);  // 1: dense, 2: no two-group
         const bool basic = rs.rgc_diag && rs.stripe_sum && !(kopts & 1u);
         const bool two = basic && !(kopts & 2u) && rs.rgby_two && rs.end_two && rs.rgby_mask[0] == kRgbyA &&
                          rs.rgby_mask[1] == kRgbyA && rs.rgby_mask[2] == kRgbyA && rs.end_mask[0] == kEndA0 &&
@@ -970,14 +973,26 @@ SILENT_EXPORT int silent_rgb_line_end_dev(silent_ctx* ctx, const float* pyr, con
         if (two) {
             std::memcpy(a.w.rgby, rs.rgby_w, sizeof(rs.rgby_w));
             std::memcpy(a.w.end, rs.end_w, sizeof(rs.end_w));
-            hipLaunchKernelGGL((rgb_line_end_kernel<0x111u, true, kRgbyA, kEndA0, kEndA1, kEndA2>), dim3((unsigned)blocks),
-                               dim3(256), 0, s, a);
+            if (small)
+                hipLaunchKernelGGL((rgb_line_end_kernel<0x111u, true, kRgbyA, kEndA0, kEndA1, kEndA2, kRgbTHSmall>),
+                                   dim3((unsigned)blocks), dim3(256), 0, s, a);
+            else
+                hipLaunchKernelGGL((rgb_line_end_kernel<0x111u, true, kRgbyA, kEndA0, kEndA1, kEndA2>),
+                                   dim3((unsigned)blocks), dim3(256), 0, s, a);
         } else if (basic) {
-            hipLaunchKernelGGL((rgb_line_end_kernel<0x111u, true, kDense, kDense, kDense, kDense>), dim3((unsigned)blocks),
-                               dim3(256), 0, s, a);
+            if (small)
+                hipLaunchKernelGGL((rgb_line_end_kernel<0x111u, true, kDense, kDense, kDense, kDense, kRgbTHSmall>),
+                                   dim3((unsigned)blocks), dim3(256), 0, s, a);
+            else
+                hipLaunchKernelGGL((rgb_line_end_kernel<0x111u, true, kDense, kDense, kDense, kDense>),
+                                   dim3((unsigned)blocks), dim3(256), 0, s, a);
         } else {
-            hipLaunchKernelGGL((rgb_line_end_kernel<0x1ffu, false, kDense, kDense, kDense, kDense>), dim3((unsigned)blocks),
-                               dim3(256), 0, s, a);
+            if (small)
+                hipLaunchKernelGGL((rgb_line_end_kernel<0x1ffu, false, kDense, kDense, kDense, kDense, kRgbTHSmall>),
+                                   dim3((unsigned)blocks), dim3(256), 0, s, a);
+            else
+                hipLaunchKernelGGL((rgb_line_end_kernel<0x1ffu, false, kDense, kDense, kDense, kDense>),
+                                   dim3((unsigned)blocks), dim3(256), 0, s, a);
         }
         return check_launch(ctx, who);
     }

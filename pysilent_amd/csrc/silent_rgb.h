@@ -53,7 +53,14 @@ constexpr int kRgbCols = 64 - 2 * kRgbHalo;  // 50 output columns per wave
 constexpr int kRgbTW = 4 * kRgbCols;         // 4 waves side by side
 constexpr int kRgbTH = 90;                   // output rows per tile (50 / 72 / 90 / 108 / 120 measured: 1.44 / 1.36 / 1.33 / 1.34 / 1.40 ms)
 constexpr int kRgbChunk = 2;                 // input rows per prefetch chunk; (TH + 14) % chunk == 0
-static_assert((kRgbTH + 2 * kRgbHalo) % kRgbChunk == 0, "row pipeline works in whole chunks");
+// A wave walks its TH + 14 rows one after the other (~1.8 us per row when it has a SIMD to itself), so a launch with
+// few tiles -- one 480p frame of the reference application has 36 waves' worth -- takes 104 row steps = 190 us whatever
+// its size.  Such launches use 18-row tiles: 5x as many waves, 32 row steps each (1.78x the rows of work instead of 1.16x,
+// which only matters once the chip is full).
+constexpr int kRgbTHSmall = 18;
+constexpr long long kRgbSmallBlocks = 512;   // use the short tiles while the 90-row grid has fewer blocks than this
+static_assert((kRgbTH + 2 * kRgbHalo) % kRgbChunk == 0 && (kRgbTHSmall + 2 * kRgbHalo) % kRgbChunk == 0,
+              "row pipeline works in whole chunks");
 
 
 // Weights stay in the kernarg segment and are re-read per fma chain with scalar loads (scalar cache) through
@@ -220,9 +227,10 @@ struct RgbArgs {
 // RGBY_A: group-A tap mask of the two-group form of rgby (same for the three inputs), END_A0..2: of the end bank per
 // input channel; kDense = the dense 81-fma form.
 constexpr unsigned kDense = 0xffffffffu;
-template <unsigned RGC_PAIRS, bool STRIPE_SUM, unsigned RGBY_A, unsigned END_A0, unsigned END_A1, unsigned END_A2>
+template <unsigned RGC_PAIRS, bool STRIPE_SUM, unsigned RGBY_A, unsigned END_A0, unsigned END_A1, unsigned END_A2,
+          int TH = kRgbTH>
 __global__ __launch_bounds__(256) void rgb_line_end_kernel(const RgbArgs args) {
-    constexpr int R = kRgbTH, D = kRgbChunk, NCH = (R + 2 * kRgbHalo) / D;
+    constexpr int R = TH, D = kRgbChunk, NCH = (R + 2 * kRgbHalo) / D;
     const float* __restrict__ pyr = args.pyr;
     float* __restrict__ orient_out = args.orient_out;
     float* __restrict__ line_out = args.line_out;

@@ -517,7 +517,14 @@ def test_rgb_chain_structured_and_dense_kernels_agree(rt, kernels, monkeypatch):
     dense = rt.rgb_line_end(frames, kernels)
     monkeypatch.setenv("SILENT_RGB_OPTS", "2")
     mid = rt.rgb_line_end(frames, kernels)
+    monkeypatch.setenv("SILENT_RGB_OPTS", "8")       # 90-row tiles although the launch is small (default here: 18 rows)
+    tall = rt.rgb_line_end(frames, kernels)
+    monkeypatch.setenv("SILENT_RGB_OPTS", "9")
+    tall_dense = rt.rgb_line_end(frames, kernels)
     monkeypatch.delenv("SILENT_RGB_OPTS")
+    for name in ("orient", "line_end", "value"):
+        np.testing.assert_array_equal(fast[name], tall[name])           # the tile height does not change a bit
+        np.testing.assert_array_equal(dense[name], tall_dense[name])
     for name in ("orient", "line_end", "value"):
         assert_close(fast[name], dense[name], 2e-6, scale=255.0, what=name + " structured vs dense")
         assert_close(mid[name], dense[name], 2e-6, scale=255.0, what=name + " basic vs dense")
