@@ -123,12 +123,27 @@ class LineEndDisplayer(PyramidDisplayer):
                 rt.affine_clip(fired, 255.0), update, ch["line_end"]]
 
     def run(self, pyramid_tensor):
-        return [t.cpu().numpy() for t in self.run_device(pyramid_tensor)]
+        import torch
+        outs = self.run_device(pyramid_tensor)
+        if any(t.dtype != torch.float32 for t in outs):
+            return [t.cpu().numpy() for t in outs]
+        # one device-to-host copy (and one synchronisation) for the six maps instead of six
+        host = torch.cat([t.reshape(-1) for t in outs]).cpu().numpy()
+        res, o = [], 0
+        for t in outs:
+            res.append(host[o:o + t.numel()].reshape(tuple(t.shape)))
+            o += t.numel()
+        return res
 
     def callback(self, frame, cam_id=None, depth=2):
         import torch
         # frame -> GPU once; the zoom pyramid stays on the device between from_image and the graph
-        z_tensor = torch.from_numpy(np.ascontiguousarray(frame, dtype=np.float32)).to(torch.device("cuda", self.device_index))
+        dev = torch.device("cuda", self.device_index)
+        if isinstance(frame, np.ndarray) and frame.dtype == np.uint8:
+            # camera frames: 1 byte per sample over PCIe, widened on the device (exact)
+            z_tensor = torch.from_numpy(np.ascontiguousarray(frame)).to(dev).to(torch.float32)
+        else:
+            z_tensor = torch.from_numpy(np.ascontiguousarray(frame, dtype=np.float32)).to(dev)
         z_tensor = zoom.from_image(z_tensor, self.output_colors, self.output_size, self.zoom_ratio)
         tensors = self.run(z_tensor)
         return [frame] + [[tensors[x][y] for y in range(len(tensors[x]))] for x in range(6)]
