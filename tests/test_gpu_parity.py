@@ -477,6 +477,13 @@ def test_line_end_displayer_three_frames(rt, kernels):
         for i in range(1, 7):
             np.testing.assert_array_equal(np.stack(a[i]), np.stack(b[i]))
         np.testing.assert_array_equal(eager.get_state(), graphed.get_state())
+    # camera frames are uint8: they cross PCIe as bytes and are widened on the device -- same maps as the float path
+    cam = np.clip(structured_frame(43, 150, 230, 3), 0, 255).astype(np.uint8)
+    a = LineEndDisplayer(output_size=(96, 64)).callback(cam)
+    b = LineEndDisplayer(output_size=(96, 64)).callback(cam.astype(np.float32))
+    assert a[0] is cam
+    for i in range(1, 7):
+        np.testing.assert_array_equal(np.stack(a[i]), np.stack(b[i]))
     saved = disp.get_state()
     disp.set_state(saved * 0 + 8)
     assert (disp.get_state() == 8).all()
