@@ -1,0 +1,197 @@
+#!/usr/bin/env python3
+"""Time-bounded random parity testing on the GPU box: random extents, zoom steps, level counts, banks and batch
+sizes through the C ABI against the oracle (the fixed cases live in tests/test_gpu_parity.py; this looks for the
+extent / tile-boundary combination nobody thought of).  usage: scripts/fuzz_gpu.py [seconds] [seed]
+
+Every failure prints the case so that it can be replayed (FUZZ_ONLY=<case name> fuzz_gpu.py 0 <seed>); the exit code
+is the number of failing cases."""
+import math, os, sys, time, traceback
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "oracle"))
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+import numpy as np
+import silent_oracle as so
+from conftest import assert_close, noise_frame, structured_frame
+from pysilent_amd import _runtime as rt
+from pysilent_amd.util.zoom.from_image import classic_levels
+
+RTOL = 1e-5
+
+
+def make_kernels():
+    from pysilent_amd.pipeline import default_constants
+    k = dict(default_constants("rgb"))
+    for K in (3, 4, 8):
+        g = default_constants("gray", K)
+        k["end%d" % K] = g["end"]
+        k["cs_gray"] = g["cs"]
+    return k
+
+
+def frame(rng, h, w, c):
+    seed = int(rng.integers(0, 1 << 30))
+    kind = rng.integers(0, 3)
+    if kind == 0:
+        return noise_frame(seed, h, w, c)
+    if kind == 1:
+        return structured_frame(seed, h, w, c, int(rng.integers(1, 60)))
+    f = np.floor(np.random.default_rng(seed).random((h, w, c)) * 4).astype(np.float32) * 64   # plateaus and ties
+    return f
+
+
+def case_gray_pass(rng, k):
+    h, w = int(rng.integers(1, 260)), int(rng.integers(1, 420))
+    scale = float(rng.choice([1.3, 1.5, 1.7, 2.0, 2.5, math.e ** .5]))
+    n = int(rng.integers(1, 7))
+    K = int(rng.choice([3, 4, 8]))
+    B = int(rng.integers(1, 4))
+    desc = "gray_pass h=%d w=%d scale=%.3f n=%d K=%d B=%d" % (h, w, scale, n, K, B)
+    try:
+        levels = classic_levels((h, w), scale, n)
+    except ValueError:
+        return desc + " (no such pyramid)"
+    frames = np.stack([frame(rng, h, w, 1) for _ in range(B)])
+    try:
+        plan = rt.PyramidPlan(h, w, 1, levels)
+    except ValueError as e:
+        return desc + " (plan refused: %s)" % str(e)[:60]
+    bank = k["end%d" % K]
+    pyr, cs, end = plan.gray_pass(frames, k["cs_gray"], bank)
+    pyr2 = plan.run(frames)
+    cs2, end2 = rt.gray_line_end(pyr2, k["cs_gray"], bank)
+    np.testing.assert_array_equal(pyr.data, pyr2.data, err_msg=desc)
+    np.testing.assert_array_equal(cs.data, cs2.data, err_msg=desc)
+    np.testing.assert_array_equal(end.data, end2.data, err_msg=desc)
+    f = int(rng.integers(0, B))
+    want = so.classic_pyramid(frames[f], scale, n)
+    for l, (wcs, wend) in enumerate(so.gray_line_end_pass(want, k["cs_gray"], bank)):
+        assert_close(pyr.level(l)[f:f + 1], want[l], RTOL, scale=255.0, what=desc + " pyr %d" % l)
+        assert_close(cs.level(l)[f:f + 1], wcs, RTOL, scale=255.0, what=desc + " cs %d" % l)
+        assert_close(end.level(l)[f:f + 1], wend, RTOL, scale=255.0, what=desc + " end %d" % l)
+    return desc + (" [stream]" if plan.streamable else " [region]")
+
+
+def case_rgb(rng, k):
+    h, w = int(rng.integers(3, 200)), int(rng.integers(3, 330))
+    scale = float(rng.choice([1.5, 2.0, 2.5, math.e ** .5]))
+    n = int(rng.integers(1, 5))
+    B = int(rng.integers(1, 3))
+    desc = "rgb h=%d w=%d scale=%.3f n=%d B=%d" % (h, w, scale, n, B)
+    try:
+        levels = classic_levels((h, w), scale, n)
+    except ValueError:
+        return desc + " (no such pyramid)"
+    frames = np.stack([frame(rng, h, w, 3) for _ in range(B)])
+    try:
+        plan = rt.PyramidPlan(h, w, 3, levels)
+    except ValueError as e:
+        return desc + " (plan refused: %s)" % str(e)[:60]
+    pyr = plan.run(frames)
+    f = int(rng.integers(0, B))
+    want = so.classic_pyramid(frames[f], scale, n)
+    for l in range(n):
+        assert_close(pyr.level(l)[f:f + 1], want[l], RTOL, scale=255.0, what=desc + " pyr %d" % l)
+    ks = {x: k[x] for x in ("rgc", "rgby", "stripe", "blur", "end")}
+    policy = "zero" if rng.integers(0, 2) else "ieee"
+    got = rt.rgb_line_end(pyr, ks, flat_policy=policy)
+    for l in range(n):
+        lev = np.ascontiguousarray(pyr.level(l)[f:f + 1])
+        w_ = so.rgb_line_end_chain(lev, ks, policy)
+        if policy == "ieee" and np.isnan(w_["padded"]).any():
+            # 0 / 0 of the regulator on flat regions: NaNs must be where the oracle has them
+            gn, wn = np.isnan(got["orient"].level(l)[f:f + 1]), np.isnan(w_["orient"])
+            if not np.array_equal(gn, wn):
+                b = so.conv2d_same(w_["stripe"], ks["blur"])
+                bad = gn != wn
+                print("NaN pattern differs at %d positions: oracle blur there min %.3g max %.3g; stripe max in frame %.3g"
+                      % (bad.sum(), b[bad].min(), b[bad].max(), w_["stripe"].max()))
+                # a NaN is 0 * inf = stripe 0 and blur exactly 0: where the blur is rounding residue of cancelling taps
+                # (relative to the level's responses) the two summation orders may disagree on "exactly 0"
+                assert b[bad].max() <= 1e-5 * max(1.0, float(w_["stripe"].max())), desc + " NaN pattern"
+            continue
+        assert_close(got["orient"].level(l)[f:f + 1], w_["orient"], RTOL, what=desc + " orient %d" % l)
+        le = so.pad_inwards(so.conv2d_same(np.ascontiguousarray(got["orient"].level(l)[f:f + 1]), ks["end"], relu=True,
+                                           clip_hi=255.0), [[0, 0], [2, 2], [2, 2], [0, 0]])
+        assert_close(got["line_end"].level(l)[f:f + 1], le, RTOL, scale=255.0, what=desc + " line_end %d" % l)
+        np.testing.assert_array_equal(got["value"].level(l)[f:f + 1],
+                                      so.value_from_color(np.ascontiguousarray(got["line_end"].level(l)[f:f + 1])), err_msg=desc)
+    return desc + " " + policy
+
+
+def case_select(rng, k):
+    from pysilent_amd.util.selection import max_value_indices_region
+    nl = int(rng.integers(1, 5))
+    extents = [(int(rng.integers(1, 150)), int(rng.integers(1, 330))) for _ in range(nl)]
+    c = int(rng.choice([1, 3]))
+    B = int(rng.integers(1, 3))
+    p = float(rng.choice([0.0, 0.1, 0.37, 0.5, 1.0]))
+    desc = "select extents=%s c=%d B=%d p=%g" % (extents, c, B, p)
+    levels = [np.stack([frame(rng, h, w, c) for _ in range(B)]) for h, w in extents]
+    packed = rt.PackedPyramid.from_levels(levels)
+    got = rt.select_peaks(packed, p, None)
+    for l, lev in enumerate(levels):
+        v = so.value_from_color(lev)
+        peaks = so.nms3x3(so.top_value_points(lev, p, v), "product")
+        np.testing.assert_array_equal(got["peaks"].level(l), peaks, err_msg=desc + " peaks %d" % l)
+        np.testing.assert_array_equal(got["peak_value"].level(l), so.value_from_color(peaks), err_msg=desc + " pv %d" % l)
+    regions = [(max(1, h // int(rng.integers(1, 4))), max(1, w // int(rng.integers(1, 4)))) for h, w in extents]
+    try:
+        kp = max_value_indices_region(got["peaks"], regions, got["peak_value"])
+    except ValueError as e:
+        return desc + " (keypoints refused: %s)" % str(e)[:60]
+    for f in range(B):
+        rows = []
+        for l in range(nl):
+            v = np.ascontiguousarray(got["peak_value"].level(l)[f:f + 1])
+            r = so.max_value_indices_region(None, (1,) + regions[l] + (c,), v)
+            r[:, 0] = l
+            rows.append(r)
+        np.testing.assert_array_equal(kp[f], np.concatenate(rows), err_msg=desc + " keypoints frame %d" % f)
+    return desc
+
+
+CASES = {"gray_pass": case_gray_pass, "rgb": case_rgb, "select": case_select}
+
+
+def main():
+    budget = float(sys.argv[1]) if len(sys.argv) > 1 else 60.0
+    seed = int(sys.argv[2]) if len(sys.argv) > 2 else int(time.time())
+    only = os.environ.get("FUZZ_ONLY")
+    k = make_kernels()
+    rng = np.random.default_rng(seed)
+    t0, n, fails = time.time(), 0, 0
+    tally = {}
+    names = [only] if only else list(CASES)
+    last = t0
+    replay = os.environ.get("FUZZ_SUB")
+    while True:
+        name = names[n % len(names)]
+        sub = int(replay) if replay else int(rng.integers(0, 1 << 31))
+        try:
+            desc = CASES[name](np.random.default_rng(sub), k)
+            kind = name + " ok"
+            for mark in ("(no such pyramid)", "(plan refused", "(keypoints refused", "[stream]", "[region]"):
+                if mark in desc:
+                    kind = name + " " + mark
+            tally[kind] = tally.get(kind, 0) + 1
+        except Exception:
+            fails += 1
+            print("FAIL case=%s sub_seed=%d" % (name, sub))
+            traceback.print_exc(limit=3)
+            sys.stdout.flush()
+        n += 1
+        if time.time() - last > 30:
+            last = time.time()
+            print("[%4.0f s] %d cases, %d failures; last: %s" % (last - t0, n, fails, desc))
+            sys.stdout.flush()
+        if time.time() - t0 > budget:
+            break
+    for kind in sorted(tally):
+        print("  %-60s %d" % (kind, tally[kind]))
+    print("seed %d: %d cases in %.0f s, %d failures" % (seed, n, time.time() - t0, fails))
+    return fails
+
+
+if __name__ == "__main__":
+    sys.exit(min(main(), 100))
