@@ -110,7 +110,9 @@ def pad_inwards(x, paddings):
     """tensor * pad(ones(shape - sum(paddings)), paddings): zero a border, by MULTIPLICATION."""
     x = np.asarray(x, dtype=F32)
     mask = np.zeros(x.shape, dtype=F32)
-    sl = tuple(slice(int(a), x.shape[d] - int(b)) for d, (a, b) in enumerate(paddings))
+    # paddings that use up an axis leave nothing (the reference cannot even build that graph: tf.ones of a negative
+    # extent, isolate_rectangle.py:20; a ragged pyramid's smallest levels get there, and are zeroed)
+    sl = tuple(slice(int(a), max(int(a), x.shape[d] - int(b))) for d, (a, b) in enumerate(paddings))
     mask[sl] = 1
     with np.errstate(invalid="ignore"):
         return (mask * x).astype(F32)

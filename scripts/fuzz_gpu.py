@@ -151,7 +151,55 @@ def case_select(rng, k):
     return desc
 
 
-CASES = {"gray_pass": case_gray_pass, "rgb": case_rgb, "select": case_select}
+def case_ops(rng, k):
+    """Stand-alone entry points on one random NHWC tensor: conv2d_same (specialised and generic shapes), resize_nearest,
+    affine_clip, nms3x3, pad_inwards, get_centroids, regulate (zero policy)."""
+    from pysilent_amd.util import get_centroids
+    B, h, w = int(rng.integers(1, 4)), int(rng.integers(1, 90)), int(rng.integers(1, 200))
+    kh, kw = int(rng.choice([1, 2, 3, 3, 3, 5, 7])), int(rng.choice([1, 3, 3, 3, 4, 7]))
+    ci, co = int(rng.choice([1, 1, 2, 3, 3])), int(rng.choice([1, 3, 4, 5, 8]))
+    desc = "ops B=%d h=%d w=%d k=%dx%dx%dx%d" % (B, h, w, kh, kw, ci, co)
+    g = np.random.default_rng(int(rng.integers(0, 1 << 30)))
+    x = (g.standard_normal((B, h, w, ci)) * 40).astype(np.float32)
+    kern = g.standard_normal((kh, kw, ci, co))
+    relu = bool(rng.integers(0, 2))
+    clip = float(rng.choice([30.0, 255.0])) if relu and rng.integers(0, 2) else None
+    try:
+        got = rt.conv2d_same(x, kern, relu=relu, clip_hi=clip)
+    except ValueError as e:
+        if "exceeds" not in str(e):
+            raise
+        got = None                     # documented capacity of the constant-memory weight block
+    if got is not None:
+        # random-sign taps cancel: the float32 accumulation error scales with sum|k| * max|x|, not with the result
+        assert_close(got, so.conv2d_same(x, kern, relu=relu, clip_hi=clip), RTOL,
+                     scale=float(np.abs(kern).sum() * np.abs(x).max()), what=desc + " conv")
+    oh, ow = int(rng.integers(1, 120)), int(rng.integers(1, 220))
+    np.testing.assert_array_equal(rt.resize_nearest(x, (oh, ow)), so.resize_nearest_tf1(x, oh, ow), err_msg=desc + " resize")
+    kwargs = dict(mul=float(g.standard_normal() * 10), add=float(g.standard_normal() * 5), lo=-50.0, hi=60.0, post_add=-1.0)
+    np.testing.assert_array_equal(rt.affine_clip(x, **kwargs), so.affine_clip(x, **kwargs), err_msg=desc + " affine")
+    q = np.floor(x / 16).astype(np.float32)     # ties
+    for mode in ("product", "fired"):
+        np.testing.assert_array_equal(rt.nms3x3(q, mode), so.nms3x3(q, mode), err_msg=desc + " nms " + mode)
+    pads = [int(v) for v in rng.integers(0, 4, 4)]
+    np.testing.assert_array_equal(rt.pad_inwards(x, *pads),
+                                  so.pad_inwards(x, [[0, 0], [pads[0], pads[1]], [pads[2], pads[3]], [0, 0]]), err_msg=desc + " pad")
+    if ci == 1:
+        v = (np.abs(x) * (g.random(x.shape) > 0.5)).astype(np.float32)
+        region = [1, int(rng.integers(1, 6)), int(rng.integers(1, 6))]
+        dist, total = get_centroids(v, region)
+        wd, wt = so.get_centroids(v, region)
+        assert_close(total, wt, RTOL, what=desc + " centroid totals")
+        assert_close(dist, wd, RTOL, scale=float(max(h, w)), what=desc + " centroid distances")
+    if ci == 3:
+        xs = np.abs(x) * np.float32(10.0 ** float(rng.integers(-3, 1)))
+        root = float(rng.choice([0.1, 0.5, 1.0]))
+        assert_close(rt.regulate(xs, k["blur"], 1.0, root, "zero"), so.regulate(xs, k["blur"], 1.0, root, "zero"), RTOL,
+                     what=desc + " regulate root %g" % root)
+    return desc
+
+
+CASES = {"gray_pass": case_gray_pass, "rgb": case_rgb, "select": case_select, "ops": case_ops}
 
 
 def main():

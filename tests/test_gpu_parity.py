@@ -299,6 +299,9 @@ def test_pad_value_nms_bit_exact(rt):
     np.testing.assert_array_equal(pad_inwards(x, pads), so.pad_inwards(x, pads))
     np.testing.assert_array_equal(pad_inwards(x, [[0, 0], [1, 3], [0, 5], [0, 0]]),
                                   so.pad_inwards(x, [[0, 0], [1, 3], [0, 5], [0, 0]]))
+    for big in ([[0, 0], [0, 30], [0, 0], [0, 0]], [[0, 0], [15, 15], [1, 1], [0, 0]], [[0, 0], [0, 0], [40, 3], [0, 0]]):
+        assert not pad_inwards(x, big).any()                # paddings that use up an axis leave nothing (as the oracle)
+        np.testing.assert_array_equal(pad_inwards(x, big), so.pad_inwards(x, big))
     np.testing.assert_array_equal(get_value_from_color(x), so.value_from_color(x))
     np.testing.assert_array_equal(local_maxima(x), so.nms3x3(x, "product"))
     np.testing.assert_array_equal(has_fired(x), so.nms3x3(x, "fired"))

@@ -76,6 +76,9 @@ def test_pad_value_nms_known_answers():
     x = np.arange(1 * 5 * 6 * 3, dtype=np.float32).reshape(1, 5, 6, 3)
     p = so.pad_inwards(x, [[0, 0], [2, 2], [2, 2], [0, 0]])
     assert p[0, 2, 2:4].tolist() == x[0, 2, 2:4].tolist() and p.sum() == x[0, 2, 2:4].sum()
+    # paddings that use up an axis (a ragged pyramid's smallest levels): nothing is left, in both oracles
+    for pads in ([[0, 0], [0, 6], [0, 0], [0, 0]], [[0, 0], [3, 3], [1, 1], [0, 0]], [[0, 0], [0, 0], [4, 3], [0, 0]]):
+        assert not so.pad_inwards(x, pads).any() and not co.pad_inwards(x, pads).any()
     v = so.value_from_color(x)
     npt.assert_array_equal(v[..., 0], ((x[..., 0] + x[..., 1]) + x[..., 2]) * (np.float32(1) / np.float32(3)))
     m = np.zeros((1, 4, 4, 1), np.float32)
