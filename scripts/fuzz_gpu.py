@@ -42,11 +42,17 @@ def frame(rng, h, w, c):
 
 def case_gray_pass(rng, k):
     h, w = int(rng.integers(1, 260)), int(rng.integers(1, 420))
+    if rng.integers(0, 8) == 0:
+        w = int(rng.integers(420, 1400))          # several 224-column blocks per row
     scale = float(rng.choice([1.3, 1.5, 1.7, 2.0, 2.5, math.e ** .5]))
     n = int(rng.integers(1, 7))
     K = int(rng.choice([3, 4, 8]))
     B = int(rng.integers(1, 4))
-    desc = "gray_pass h=%d w=%d scale=%.3f n=%d K=%d B=%d" % (h, w, scale, n, K, B)
+    # development knobs select other (bit-identical) code paths: tile order, 32-row tiles, no stream path, unit + region pyramid
+    os.environ["SILENT_GRAY_OPTS"] = str(int(rng.choice([0, 0, 1, 2, 3, 8, 16, 24])))
+    os.environ["SILENT_PYRAMID_OPTS"] = str(int(rng.choice([0, 0, 1])))
+    desc = "gray_pass h=%d w=%d scale=%.3f n=%d K=%d B=%d knobs=%s/%s" % (
+        h, w, scale, n, K, B, os.environ["SILENT_GRAY_OPTS"], os.environ["SILENT_PYRAMID_OPTS"])
     try:
         levels = classic_levels((h, w), scale, n)
     except ValueError:
@@ -77,7 +83,9 @@ def case_rgb(rng, k):
     scale = float(rng.choice([1.5, 2.0, 2.5, math.e ** .5]))
     n = int(rng.integers(1, 5))
     B = int(rng.integers(1, 3))
-    desc = "rgb h=%d w=%d scale=%.3f n=%d B=%d" % (h, w, scale, n, B)
+    # 0: specialised kernel, 18-row tiles; 8: 90-row tiles; 1 / 2: dense / no two-group forms; 9, 10: combinations
+    os.environ["SILENT_RGB_OPTS"] = str(int(rng.choice([0, 0, 8, 1, 2, 9, 10])))
+    desc = "rgb h=%d w=%d scale=%.3f n=%d B=%d knob=%s" % (h, w, scale, n, B, os.environ["SILENT_RGB_OPTS"])
     try:
         levels = classic_levels((h, w), scale, n)
     except ValueError:
@@ -98,7 +106,7 @@ def case_rgb(rng, k):
     for l in range(n):
         lev = np.ascontiguousarray(pyr.level(l)[f:f + 1])
         w_ = so.rgb_line_end_chain(lev, ks, policy)
-        if policy == "ieee" and np.isnan(w_["padded"]).any():
+        if policy == "ieee" and (np.isnan(w_["orient"]).any() or np.isnan(got["orient"].level(l)[f:f + 1]).any()):
             # 0 / 0 of the regulator on flat regions: NaNs must be where the oracle has them
             gn, wn = np.isnan(got["orient"].level(l)[f:f + 1]), np.isnan(w_["orient"])
             if not np.array_equal(gn, wn):
