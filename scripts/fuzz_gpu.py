@@ -207,7 +207,51 @@ def case_ops(rng, k):
     return desc
 
 
+def case_big(rng, k):
+    """Frames of camera size against the C port of the oracle (multi-block rows, many tiles, the 90-row RGB tiles)."""
+    import c_oracle as co
+    h, w = int(rng.integers(300, 1300)), int(rng.integers(400, 2300))
+    scale = float(rng.choice([1.7, 2.0, 2.0, math.e ** .5]))
+    n = int(rng.integers(2, 8))
+    gray = bool(rng.integers(0, 2))
+    B = int(rng.integers(1, 3)) if gray else int(rng.integers(1, 5))
+    desc = "big %s h=%d w=%d scale=%.3f n=%d B=%d" % ("gray" if gray else "rgb", h, w, scale, n, B)
+    try:
+        levels = classic_levels((h, w), scale, n)
+    except ValueError:
+        return desc + " (no such pyramid)"
+    c = 1 if gray else 3
+    frames = np.stack([noise_frame(int(rng.integers(0, 1 << 30)), h, w, c) for _ in range(B)])
+    plan = rt.PyramidPlan(h, w, c, levels)
+    f = int(rng.integers(0, B))
+    want = co.classic_pyramid(frames[f], plan.extents)
+    if gray:
+        K = int(rng.choice([4, 8]))
+        pyr, cs, end = plan.gray_pass(frames, k["cs_gray"], k["end%d" % K])
+        for l in range(n):
+            assert_close(pyr.level(l)[f:f + 1], want[l], RTOL, scale=255.0, what=desc + " pyr %d" % l)
+            wcs, wend = co.gray_line_end_level(want[l], k["cs_gray"], k["end%d" % K])
+            assert_close(cs.level(l)[f:f + 1], wcs, RTOL, scale=255.0, what=desc + " cs %d" % l)
+            assert_close(end.level(l)[f:f + 1], wend, RTOL, scale=255.0, what=desc + " end %d" % l)
+        return desc + (" [stream]" if plan.streamable else " [region]")
+    pyr = plan.run(frames)
+    ks = {x: k[x] for x in ("rgc", "rgby", "stripe", "blur", "end")}
+    got = rt.rgb_line_end(pyr, ks)
+    for l in range(n):
+        assert_close(pyr.level(l)[f:f + 1], want[l], RTOL, scale=255.0, what=desc + " pyr %d" % l)
+        x = np.ascontiguousarray(pyr.level(l)[f:f + 1])
+        for name in ("rgc", "rgby", "stripe"):
+            x = co.conv2d_same(x, ks[name], relu=True)
+        orient = co.regulate(x, ks["blur"], 1.0, 0.1)
+        assert_close(got["orient"].level(l)[f:f + 1], orient, RTOL, what=desc + " orient %d" % l)
+        g_or = np.ascontiguousarray(got["orient"].level(l)[f:f + 1])
+        line = co.pad_inwards(co.conv2d_same(g_or, ks["end"], relu=True, clip_hi=255.0), [[0, 0], [2, 2], [2, 2], [0, 0]])
+        assert_close(got["line_end"].level(l)[f:f + 1], line, RTOL, scale=255.0, what=desc + " line_end %d" % l)
+    return desc
+
+
 CASES = {"gray_pass": case_gray_pass, "rgb": case_rgb, "select": case_select, "ops": case_ops}
+BIG = {"big": case_big}
 
 
 def main():
@@ -225,9 +269,9 @@ def main():
         name = names[n % len(names)]
         sub = int(replay) if replay else int(rng.integers(0, 1 << 31))
         try:
-            desc = CASES[name](np.random.default_rng(sub), k)
+            desc = {**CASES, **BIG}[name](np.random.default_rng(sub), k)
             kind = name + " ok"
-            for mark in ("(no such pyramid)", "(plan refused", "(keypoints refused", "[stream]", "[region]"):
+            for mark in ("big gray", "big rgb", "(no such pyramid)", "(plan refused", "(keypoints refused", "[stream]", "[region]"):
                 if mark in desc:
                     kind = name + " " + mark
             tally[kind] = tally.get(kind, 0) + 1
