@@ -134,3 +134,27 @@ def test_gpu_keypoints_sorted_and_selection_monotone_at_1080p(rt, kernels):
     keep10 = top_value_points(x, 0.1, v) != 0
     keep30 = top_value_points(x, 0.3, v) != 0
     assert not (keep10 & ~keep30).any() and keep30.sum() > keep10.sum()
+
+
+@pytest.mark.gpu
+def test_random_cases_through_the_c_abi():
+    """A fixed-seed slice of scripts/fuzz_gpu.py (random extents, zoom steps, level counts, banks, batch sizes, frame kinds and
+    development knobs against the oracle): 40 cases of each kind."""
+    import importlib.util, os
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("fuzz_gpu", os.path.join(root, "scripts", "fuzz_gpu.py"))
+    fz = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(fz)
+    k = fz.make_kernels()
+    saved = {v: os.environ.get(v) for v in ("SILENT_GRAY_OPTS", "SILENT_PYRAMID_OPTS", "SILENT_RGB_OPTS")}
+    try:
+        rng = np.random.default_rng(2026)
+        for i in range(160):
+            name = list(fz.CASES)[i % len(fz.CASES)]
+            fz.CASES[name](np.random.default_rng(int(rng.integers(0, 1 << 31))), k)
+    finally:
+        for v, val in saved.items():
+            if val is None:
+                os.environ.pop(v, None)
+            else:
+                os.environ[v] = val
