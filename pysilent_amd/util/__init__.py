@@ -2,4 +2,4 @@
 math / relativity)."""
 from . import attractor, color, energy, normalize, orientation, regulator, selection, zoom
 from . import apply_filter, get_dimensions, index_tensor
-from .centroids import get_centroids
+from .centroids import additive_filter, get_centroids

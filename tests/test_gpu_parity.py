@@ -425,6 +425,22 @@ def test_get_boosting_first_step_from_initial_state_and_packed(rt):
 
 # ----------------------------------------------------------------------------- display graph
 
+def test_to_channels(rt):
+    """util/color/to_channels.py:6-16: tile the single channel; other channel counts cannot satisfy its set_shape."""
+    from pysilent_amd.util.color import to_channels
+    x = noise_frame(8, 19, 23, 1)[None]
+    x[0, 0, 0, 0] = np.nan
+    x[0, 0, 1, 0] = np.inf
+    np.testing.assert_array_equal(to_channels(x), np.tile(x, (1, 1, 1, 3)))
+    np.testing.assert_array_equal(to_channels(x, 2), np.tile(x, (1, 1, 1, 2)))
+    packed, levels = ragged_pyramid(rt, 5, [(12, 20), (7, 9)], c=1, n_frames=2)
+    got = to_channels(packed, 4)
+    for l in range(2):
+        np.testing.assert_array_equal(got.level(l), np.tile(levels[l], (1, 1, 1, 4)))
+    with pytest.raises(ValueError):
+        to_channels(noise_frame(8, 5, 5, 3)[None])
+
+
 def test_affine_clip_and_resize_nearest(rt):
     rng = np.random.default_rng(77)
     x = (rng.standard_normal((2, 13, 17, 3)) * 100).astype(np.float32)

@@ -159,3 +159,14 @@ def test_rgb_chain_structure_of_the_reference_kernels():
     assert _chain_structure(noise)[0] == 0
     mixed = dict(consts, rgby=noise["rgby"])
     assert _chain_structure(mixed)[0] == 0b1011
+
+
+def test_additive_filter_mirrors_the_reference_constant():
+    """centroids.py:9-18: identity over the two index channels at every tap of the region; the literal 2 x 2 identity makes
+    every other channel count a broadcast error, as in the reference."""
+    from pysilent_amd.util import additive_filter
+    k = additive_filter([3, 4], 2)
+    assert k.shape == (3, 4, 2, 2) and k.dtype == np.float32
+    assert (k == np.eye(2, dtype=np.float32)).all()
+    with pytest.raises(ValueError):
+        additive_filter([3, 3], 3)
