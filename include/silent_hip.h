@@ -189,6 +189,12 @@ int silent_value_from_color(silent_ctx* ctx, const float* in, const silent_exten
                             int n_frames, int channels, float* out);
 int silent_value_from_color_dev(silent_ctx* ctx, const float* in, const silent_extent* levels, int n_levels,
                                 int n_frames, int channels, float* out, silent_stream stream);
+/* get_bw_from_color      slam_recognition/util/color/get_bw.py:6-13: 1 where the channel sum (x . ones, summed left to
+ * right in float32) is not 0 -- NaN counts as not 0, like tf.not_equal -- else 0; one output channel. */
+int silent_bw_from_color(silent_ctx* ctx, const float* in, const silent_extent* levels, int n_levels, int n_frames,
+                         int channels, float* out);
+int silent_bw_from_color_dev(silent_ctx* ctx, const float* in, const silent_extent* levels, int n_levels,
+                             int n_frames, int channels, float* out, silent_stream stream);
 
 /* ---------------------------------------------------------------------------- a-9 non-max suppression */
 int silent_nms3x3(silent_ctx* ctx, const float* in, const silent_extent* levels, int n_levels, int n_frames,

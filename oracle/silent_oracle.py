@@ -129,6 +129,16 @@ def value_from_color(x):
     return (s * inv).astype(F32)[..., None]
 
 
+def bw_from_color(x):
+    """get_bw_from_color, util/color/get_bw.py:6-13: tensordot with ones (left-to-right float32 sum), then
+    where(sum != 0, 1, 0); NaN != 0 is true."""
+    x = np.asarray(x, dtype=F32)
+    s = x[..., 0].copy()
+    for i in range(1, x.shape[-1]):
+        s = (s + x[..., i]).astype(F32)
+    return np.where(s != 0, F32(1), F32(0)).astype(F32)[..., None]
+
+
 def maxpool3x3_same(x):
     """tf.nn.max_pool 3x3 stride 1 SAME: out-of-image taps are ignored (-inf padding)."""
     x = np.asarray(x, dtype=F32)

@@ -100,6 +100,8 @@ _SIGNATURES = {
     "silent_pad_inwards_dev": [_vp, _fp, _ep, _i, _i, _i, _i, _i, _i, _i, _fp, _vp],
     "silent_value_from_color": [_vp, _fp, _ep, _i, _i, _i, _fp],
     "silent_value_from_color_dev": [_vp, _fp, _ep, _i, _i, _i, _fp, _vp],
+    "silent_bw_from_color": [_vp, _fp, _ep, _i, _i, _i, _fp],
+    "silent_bw_from_color_dev": [_vp, _fp, _ep, _i, _i, _i, _fp, _vp],
     "silent_nms3x3": [_vp, _fp, _ep, _i, _i, _i, _i, _fp],
     "silent_nms3x3_dev": [_vp, _fp, _ep, _i, _i, _i, _i, _fp, _vp],
     "silent_top_value_points": [_vp, _fp, _fp, _ep, _i, _i, _i, _d, _fp],

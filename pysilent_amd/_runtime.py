@@ -303,6 +303,15 @@ def value_from_color(x):
     return op.wrap(out, 1)
 
 
+def bw_from_color(x):
+    op = _Operand(x)
+    out, optr = op.alloc(1)
+    lib, ctx = _lib.load(), op.ctx
+    args = (ctx.handle, op.ptr) + op.geom() + (op.c, optr)
+    ctx.check(lib.silent_bw_from_color_dev(*(args + (op.stream,))) if op.dev else lib.silent_bw_from_color(*args))
+    return op.wrap(out, 1)
+
+
 def nms3x3(x, mode="product"):
     op = _Operand(x)
     try:

@@ -441,6 +441,23 @@ SILENT_EXPORT int silent_value_from_color_dev(silent_ctx* ctx, const float* in, 
     return check_launch(ctx, who);
 }
 
+SILENT_EXPORT int silent_bw_from_color_dev(silent_ctx* ctx, const float* in, const silent_extent* levels,
+                                              int n_levels, int n_frames, int channels, float* out,
+                                              silent_stream stream) {
+    NEED_CTX(ctx);
+    const char* who = "silent_bw_from_color";
+    if (!in || !out) return fail(ctx, SILENT_E_INVALID, std::string(who) + ": NULL pointer");
+    if (channels < 1) return fail(ctx, SILENT_E_INVALID, std::string(who) + ": channels must be >= 1");
+    LevelTab tab;
+    long long blocks;
+    TRY(build_level_tab(ctx, who, levels, n_levels, n_frames, 0, 0, &tab, &blocks));
+    const long long npx = tab.frame_px * n_frames;
+    const long long grid = std::min<long long>((npx + 255) / 256, 256 * 32);
+    hipLaunchKernelGGL(bw_from_color_kernel, dim3((unsigned)grid), dim3(256), 0, (hipStream_t)stream, in, out, npx,
+                       channels);
+    return check_launch(ctx, who);
+}
+
 SILENT_EXPORT int silent_nms3x3_dev(silent_ctx* ctx, const float* in, const silent_extent* levels, int n_levels,
                                     int n_frames, int channels, int mode, float* out, silent_stream stream) {
     NEED_CTX(ctx);
@@ -1652,6 +1669,24 @@ SILENT_EXPORT int silent_value_from_color(silent_ctx* ctx, const float* in, cons
     TRY(st.commit());
     TRY(h2d(ctx, st.ptr<float>(i_in), in, bi));
     TRY(silent_value_from_color_dev(ctx, st.ptr<float>(i_in), levels, n_levels, n_frames, channels,
+                                    st.ptr<float>(i_out), nullptr));
+    TRY(sync0(ctx));
+    return d2h(ctx, out, st.ptr<float>(i_out), bo);
+}
+
+SILENT_EXPORT int silent_bw_from_color(silent_ctx* ctx, const float* in, const silent_extent* levels, int n_levels,
+                                          int n_frames, int channels, float* out) {
+    NEED_CTX(ctx);
+    if (!in || !out) return fail(ctx, SILENT_E_INVALID, "silent_bw_from_color: NULL pointer");
+    if (channels < 1) return fail(ctx, SILENT_E_INVALID, "silent_bw_from_color: channels must be >= 1");
+    long long px;
+    TRY(check_levels(ctx, "silent_bw_from_color", levels, n_levels, n_frames, &px));
+    Stage st(ctx);
+    const size_t bi = (size_t)px * channels * 4, bo = (size_t)px * 4;
+    const size_t i_in = st.add(bi), i_out = st.add(bo);
+    TRY(st.commit());
+    TRY(h2d(ctx, st.ptr<float>(i_in), in, bi));
+    TRY(silent_bw_from_color_dev(ctx, st.ptr<float>(i_in), levels, n_levels, n_frames, channels,
                                     st.ptr<float>(i_out), nullptr));
     TRY(sync0(ctx));
     return d2h(ctx, out, st.ptr<float>(i_out), bo);

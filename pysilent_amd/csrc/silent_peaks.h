@@ -61,6 +61,16 @@ __global__ __launch_bounds__(256) void value_from_color_kernel(const float* __re
     }
 }
 
+// ---- get_bw_from_color: (x0 + x1 + ... != 0) ? 1 : 0 (NaN != 0 is true)
+__global__ __launch_bounds__(256) void bw_from_color_kernel(const float* __restrict__ in, float* __restrict__ out,
+                                                            long long npx, int C) {
+    for (long long p = (long long)blockIdx.x * 256 + threadIdx.x; p < npx; p += (long long)gridDim.x * 256) {
+        float s = in[p * C];
+        for (int c = 1; c < C; ++c) s = __fadd_rn(s, in[p * C + c]);
+        out[p] = (s != 0.0f) ? 1.0f : 0.0f;
+    }
+}
+
 // ---- a-9 3x3 non-max suppression (max-pool SAME ignores out-of-level taps)
 __global__ __launch_bounds__(256) void nms3x3_kernel(const float* __restrict__ in, float* __restrict__ out,
                                                      const LevelTab tab, int C, int mode) {

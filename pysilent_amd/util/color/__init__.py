@@ -1,5 +1,6 @@
 """Colour helpers.  ``get_value_from_color`` mirrors slam_recognition/util/color/get_value.py:6-12:
-channel sum times float32(1/C), keepdims; ``to_channels`` mirrors util/color/to_channels.py:6-16."""
+channel sum times float32(1/C), keepdims; ``get_bw_from_color`` util/color/get_bw.py:6-13; ``to_channels``
+util/color/to_channels.py:6-16."""
 import numpy as np
 
 from ... import _runtime
@@ -9,6 +10,12 @@ from ..get_dimensions import get_dimensions
 def get_value_from_color(color_tensor):
     get_dimensions(color_tensor)
     return _runtime.value_from_color(color_tensor)
+
+
+def get_bw_from_color(color_tensor):
+    """Mirror of util/color/get_bw.py:6-13: 1 where the channel sum is not 0, else 0 (one channel)."""
+    get_dimensions(color_tensor)
+    return _runtime.bw_from_color(color_tensor)
 
 
 def to_channels(images, num_channels=3, name=None):

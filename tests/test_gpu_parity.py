@@ -425,6 +425,24 @@ def test_get_boosting_first_step_from_initial_state_and_packed(rt):
 
 # ----------------------------------------------------------------------------- display graph
 
+def test_get_bw_from_color(rt):
+    from pysilent_amd.util.color import get_bw_from_color
+    rng = np.random.default_rng(3)
+    x = (np.floor(rng.random((2, 21, 37, 3)) * 3) - 1).astype(np.float32)       # -1 / 0 / 1: many cancelling sums
+    x[0, 0, 0] = [np.nan, 0, 0]
+    x[0, 0, 1] = [np.inf, -np.inf, 0]
+    x[0, 0, 2] = [1e-30, 0, 0]
+    got = get_bw_from_color(x)
+    want = so.bw_from_color(x)
+    assert 0.2 < want.mean() < 0.95
+    np.testing.assert_array_equal(got, want)
+    np.testing.assert_array_equal(get_bw_from_color(x[..., :1]), so.bw_from_color(x[..., :1]))
+    packed, levels = ragged_pyramid(rt, 9, [(12, 20), (7, 9)], c=3, n_frames=2)
+    gp = get_bw_from_color(packed)
+    for l in range(2):
+        np.testing.assert_array_equal(gp.level(l), so.bw_from_color(levels[l]))
+
+
 def test_to_channels(rt):
     """util/color/to_channels.py:6-16: tile the single channel; other channel counts cannot satisfy its set_shape."""
     from pysilent_amd.util.color import to_channels

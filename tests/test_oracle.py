@@ -81,6 +81,9 @@ def test_pad_value_nms_known_answers():
         assert not so.pad_inwards(x, pads).any() and not co.pad_inwards(x, pads).any()
     v = so.value_from_color(x)
     npt.assert_array_equal(v[..., 0], ((x[..., 0] + x[..., 1]) + x[..., 2]) * (np.float32(1) / np.float32(3)))
+    # get_bw_from_color (get_bw.py:6-13): 1 where the channel sum is not 0; cancelling channels give 0, NaN gives 1
+    q = np.array([[[[0, 0, 0], [1, -1, 0], [0, 0, 2], [np.nan, 0, 0], [-3, 1, 1], [1e-30, 0, 0]]]], np.float32)
+    assert so.bw_from_color(q)[0, 0, :, 0].tolist() == [0, 0, 1, 1, 1, 1]
     m = np.zeros((1, 4, 4, 1), np.float32)
     m[0, 1, 1, 0] = 3.0
     m[0, 3, 3, 0] = 2.0
