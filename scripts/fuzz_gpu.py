@@ -192,7 +192,11 @@ def case_ops(rng, k):
     pads = [int(v) for v in rng.integers(0, 4, 4)]
     np.testing.assert_array_equal(rt.pad_inwards(x, *pads),
                                   so.pad_inwards(x, [[0, 0], [pads[0], pads[1]], [pads[2], pads[3]], [0, 0]]), err_msg=desc + " pad")
+    np.testing.assert_array_equal(rt.bw_from_color(q), so.bw_from_color(q), err_msg=desc + " bw")
+    np.testing.assert_array_equal(rt.value_from_color(x), so.value_from_color(x), err_msg=desc + " value")
     if ci == 1:
+        from pysilent_amd.util.color import to_channels
+        np.testing.assert_array_equal(to_channels(x, co), np.tile(x, (1, 1, 1, co)), err_msg=desc + " to_channels")
         v = (np.abs(x) * (g.random(x.shape) > 0.5)).astype(np.float32)
         region = [1, int(rng.integers(1, 6)), int(rng.integers(1, 6))]
         dist, total = get_centroids(v, region)
