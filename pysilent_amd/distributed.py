@@ -84,7 +84,11 @@ def max_over_ranks(value):
 def barrier():
     import torch.distributed as dist
     if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
-        dist.barrier()
+        if dist.get_backend() == "nccl":
+            import torch
+            dist.barrier(device_ids=[torch.cuda.current_device()])      # this rank's GPU, not a guess from the rank
+        else:
+            dist.barrier()
 
 
 def finalize():
