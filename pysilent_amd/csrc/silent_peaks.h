@@ -515,14 +515,14 @@ __device__ __forceinline__ void load_pooled(const unsigned* __restrict__ cells, 
     }
 }
 
-__device__ __forceinline__ bool region_pred(const float* __restrict__ value, long long base_px, int p, int y, int x,
-                                            const RegionLevel& rl, const float* s_pooled) {
+// threshold of pixel (y, x): the window maximum its cell maps back to
+__device__ __forceinline__ float region_thr(int y, int x, const RegionLevel& rl, const float* s_pooled) {
     // TF1 ResizeNearestNeighbor: min(floorf(dst * scale), in - 1), float32
     int sy = (int)floorf(__fmul_rn((float)y, rl.yscale));
     int sx = (int)floorf(__fmul_rn((float)x, rl.xscale));
     sy = sy > rl.oh - 1 ? rl.oh - 1 : sy;
     sx = sx > rl.ow - 1 ? rl.ow - 1 : sx;
-    return value[base_px + p] >= s_pooled[sy * kMaxWin + sx];
+    return s_pooled[sy * kMaxWin + sx];
 }
 
 // pass 1: matches per chunk.  A chunk is kKpChunk pixels: wave w owns the w-th quarter, lane l the pixels
@@ -539,16 +539,20 @@ __global__ __launch_bounds__(256) void region_count_kernel(const float* __restri
     const int W = tab.w[tc.level];
     const int npx = tab.h[tc.level] * W;
     const long long base_px = (long long)tc.frame * tab.frame_px + tab.px_off[tc.level];
-    load_pooled(cells + ((long long)tc.frame * tab.n_levels + tc.level) * kCells, rl, s_pooled);
-    __syncthreads();
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int seg = tc.tx * kKpChunk + wave * (kKpChunk / 4);
+    // the chunk's values are requested before the window maxima are staged: the two latencies overlap
+    float v[kKpPer];
+#pragma unroll
+    for (int k = 0; k < kKpPer; ++k) v[k] = value[base_px + min(seg + k * 64 + lane, npx - 1)];
+    load_pooled(cells + ((long long)tc.frame * tab.n_levels + tc.level) * kCells, rl, s_pooled);
+    __syncthreads();
     int n = 0;
     int y = (seg + lane) / W, x = seg + lane - y * W;
-#pragma unroll 4
+#pragma unroll
     for (int k = 0; k < kKpPer; ++k, advance_yx(y, x, 64, W)) {
         const int p = seg + k * 64 + lane;
-        const bool hit = p < npx && region_pred(value, base_px, min(p, npx - 1), y, x, rl, s_pooled);
+        const bool hit = p < npx && v[k] >= region_thr(y, x, rl, s_pooled);
         n += __popcll(__ballot(hit));
     }
     if (lane == 0) s_cnt[wave] = n;
@@ -600,10 +604,13 @@ __global__ __launch_bounds__(256) void region_write_kernel(const float* __restri
     const int W = tab.w[tc.level];
     const int npx = tab.h[tc.level] * W;
     const long long base_px = (long long)tc.frame * tab.frame_px + tab.px_off[tc.level];
-    load_pooled(cells + ((long long)tc.frame * tab.n_levels + tc.level) * kCells, rl, s_pooled);
-    __syncthreads();
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int seg = tc.tx * kKpChunk + wave * (kKpChunk / 4);
+    float v[kKpPer];
+#pragma unroll
+    for (int k = 0; k < kKpPer; ++k) v[k] = value[base_px + min(seg + k * 64 + lane, npx - 1)];
+    load_pooled(cells + ((long long)tc.frame * tab.n_levels + tc.level) * kCells, rl, s_pooled);
+    __syncthreads();
     unsigned long long hits[kKpPer];
     int n = 0;
     const int y0 = (seg + lane) / W, x0 = seg + lane - y0 * W;
@@ -611,7 +618,7 @@ __global__ __launch_bounds__(256) void region_write_kernel(const float* __restri
 #pragma unroll
     for (int k = 0; k < kKpPer; ++k, advance_yx(y, x, 64, W)) {
         const int p = seg + k * 64 + lane;
-        const bool hit = p < npx && region_pred(value, base_px, min(p, npx - 1), y, x, rl, s_pooled);
+        const bool hit = p < npx && v[k] >= region_thr(y, x, rl, s_pooled);
         hits[k] = __ballot(hit);
         n += __popcll(hits[k]);
     }
