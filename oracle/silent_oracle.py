@@ -134,8 +134,9 @@ def bw_from_color(x):
     where(sum != 0, 1, 0); NaN != 0 is true."""
     x = np.asarray(x, dtype=F32)
     s = x[..., 0].copy()
-    for i in range(1, x.shape[-1]):
-        s = (s + x[..., i]).astype(F32)
+    with np.errstate(invalid="ignore"):          # inf + (-inf) = NaN is part of the semantics
+        for i in range(1, x.shape[-1]):
+            s = (s + x[..., i]).astype(F32)
     return np.where(s != 0, F32(1), F32(0)).astype(F32)[..., None]
 
 
