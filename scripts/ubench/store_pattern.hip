@@ -15,7 +15,7 @@ __device__ __forceinline__ unsigned xcd_swizzle(unsigned bid, unsigned n) {
     return x * per + (x < rem ? x : rem) + k;
 }
 
-template <int MODE, bool NT, int WAVES = 4, bool XCD = false>
+template <int MODE, bool NT, int WAVES = 4, bool XCD = false, bool BAR = false>
 __global__ __launch_bounds__(WAVES * 64) void pattern(float* __restrict__ a, float* __restrict__ b, float4* __restrict__ e,
                                                       int tiles_x, int tiles_per_frame) {
     constexpr int TW = WAVES * COLS;
@@ -31,6 +31,7 @@ __global__ __launch_bounds__(WAVES * 64) void pattern(float* __restrict__ a, flo
         for (int r = 0; r < TH; ++r) {
             const int y = ty * TH + r;
             if (y >= H) break;
+            if (BAR) __builtin_amdgcn_s_barrier();      // the block's waves store a row at the same time
             const long long p = base + (long long)y * W + x;
             if (NT) {
                 __builtin_nontemporal_store(v, a + p);
@@ -59,7 +60,7 @@ __global__ __launch_bounds__(WAVES * 64) void pattern(float* __restrict__ a, flo
     }
 }
 
-template <int MODE, bool NT, int WAVES = 4, bool XCD = false>
+template <int MODE, bool NT, int WAVES = 4, bool XCD = false, bool BAR = false>
 void run(const char* name, float* a, float* b, float4* e, int frames) {
     constexpr int TW = WAVES * COLS;
     const int tiles_x = (W + TW - 1) / TW, tiles_y = (H + TH - 1) / TH;
@@ -70,7 +71,7 @@ void run(const char* name, float* a, float* b, float4* e, int frames) {
     std::vector<float> ts;
     for (int it = 0; it < 12; ++it) {
         (void)hipEventRecord(e0);
-        hipLaunchKernelGGL((pattern<MODE, NT, WAVES, XCD>), dim3(blocks), dim3(WAVES * 64), 0, 0, a, b, e, tiles_x, tiles_x * tiles_y);
+        hipLaunchKernelGGL((pattern<MODE, NT, WAVES, XCD, BAR>), dim3(blocks), dim3(WAVES * 64), 0, 0, a, b, e, tiles_x, tiles_x * tiles_y);
         (void)hipEventRecord(e1);
         (void)hipEventSynchronize(e1);
         float ms;
@@ -226,6 +227,9 @@ int main() {
     run_wide<4, false, false>("4 px per lane (wave = 224 px, block 896)", a, b, e, frames);
     run_wide<4, true, false>("4 px per lane, nt", a, b, e, frames);
     run_wide<4, false, true>("4 px per lane, XCD order", a, b, e, frames);
+    run<0, false, 4, false, true>("tile pattern, barrier before every row", a, b, e, frames);
+    run<0, true, 4, false, true>("tile pattern, barrier per row, nt", a, b, e, frames);
+    run<0, true, 16, false, true>("16 waves side by side, barrier per row, nt", a, b, e, frames);
     run_strips<2, false>("2 adjacent strips per wave, scalar stores", a, b, e, frames);
     run_strips<2, true>("2 adjacent strips per wave, nt", a, b, e, frames);
     run_strips<3, true>("3 adjacent strips per wave, nt", a, b, e, frames);
