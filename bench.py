@@ -8,13 +8,23 @@ zoom pyramid -> center-surround -> ReLU -> oriented line-end bank -> ReLU -> cli
 reference's RGB chain + keypoints (config 3).  Frames shard over ranks (frame i -> rank i mod N, no
 per-frame collective); the constant kernels are generated on rank 0 and broadcast once over RCCL.
 
+Launching: under torchrun (RANK / WORLD_SIZE / LOCAL_RANK in the environment) this process is one rank.
+Without them, ``--gpus N`` with N > 1 makes THIS process a launcher: it starts N fresh rank processes (one
+per GPU, rendezvous on 127.0.0.1) BEFORE touching the GPU itself, relays rank 0's JSON line and exits
+non-zero if any rank failed.  It never re-execs a process that has initialised the GPU.
+
 Rank 0 prints ONE JSON line.  ``value`` = input-frame megapixels per second over all ranks, inputs
-resident in HBM when the timed region starts.  ``roofline`` prices the dominant kernel (the fused filter
-pass) against HBM; ``cpu_baseline`` is the C port of the oracle timed on the host cores (N = 1 only).
+resident in HBM when the timed region starts; the timed region holds nothing but the K steps (no event
+records, no host reads).  AFTER it, and outside ``value``: ``roofline`` prices the dominant kernel against
+HBM from HIP events recorded around its launches in a loop of their own; ``other_workloads`` carries short
+runs of configs 3 and 5; ``cpu_baseline`` times the CPU oracle on the host cores (N = 1 only).
 """
 import argparse
+import hashlib
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -25,15 +35,17 @@ import numpy as np  # noqa: E402
 
 WORKLOADS = {
     # BASELINE.json configs[1]: 1080p grayscale, 5-level pyramid, center-surround + 4-orientation line-end
-    "config2": dict(hw=(1080, 1920), mode="gray", n_levels=5, n_orient=4,
+    "config2": dict(hw=(1080, 1920), mode="gray", n_levels=5, n_orient=4, frames=64,
                     name="1080p gray, 5-level pyramid (scale 2), CS + 4-orientation line-end"),
     # configs[2]: 1080p RGB, 6-level pyramid, normalize + peak extraction
-    "config3": dict(hw=(1080, 1920), mode="rgb", n_levels=6, n_orient=3,
+    "config3": dict(hw=(1080, 1920), mode="rgb", n_levels=6, n_orient=3, frames=32,
                     name="1080p RGB, 6-level pyramid (scale 2), rgc>rgby>stripe>regulate>end>pad>value, top 10 %, NMS, keypoints"),
     # configs[4]: 4K, 8-level pyramid, 8-orientation bank
-    "config5": dict(hw=(2160, 3840), mode="gray", n_levels=8, n_orient=8,
+    "config5": dict(hw=(2160, 3840), mode="gray", n_levels=8, n_orient=8, frames=16,
                     name="4K gray, 8-level pyramid (scale 2), CS + 8-orientation line-end"),
 }
+
+
 def _metric_name():
     """BASELINE.json's own wording of the metric (the file travels with the repo); a literal copy as fallback."""
     try:
@@ -44,33 +56,104 @@ def _metric_name():
 
 METRIC = _metric_name()
 HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+COPY_PEAK_GBS = 6290.0  # same guide: measured float4 copy
+
+
+# ------------------------------------------------------------------------------------------ launcher (no GPU here)
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def launch_ranks(n, argv, timeout_s=None):
+    """Start n rank processes of this script (RANK = LOCAL_RANK = 0..n-1), relay rank 0's stdout, return the exit
+    code (0 only if every rank exited 0).  The parent has not imported torch and makes no HIP call."""
+    port = os.environ.get("MASTER_PORT") or str(_free_port())
+    timeout_s = timeout_s or float(os.environ.get("SILENT_BENCH_LAUNCH_TIMEOUT", "1500"))
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1",
+                   MASTER_PORT=port)
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + list(argv), env=env,
+                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL, text=True))
+    deadline = time.time() + timeout_s
+    rc, failed = 0, None
+    pending = set(range(n))
+    while pending and time.time() < deadline and failed is None:
+        for r in sorted(pending):
+            code = procs[r].poll()
+            if code is not None:
+                pending.discard(r)
+                if code != 0:
+                    failed, rc = r, code
+        time.sleep(0.05)
+    if pending:  # a rank failed or the deadline passed: stop exactly the processes started here
+        for r in pending:
+            procs[r].terminate()
+        for r in pending:
+            try:
+                procs[r].wait(timeout=10)
+            except subprocess.TimeoutExpired:
+                procs[r].kill()
+        if failed is None:
+            rc = 124
+            print("bench.py launcher: ranks %s still running after %.0f s" % (sorted(pending), timeout_s), file=sys.stderr)
+    out = procs[0].stdout.read() if procs[0].stdout else ""
+    if failed is not None:
+        print("bench.py launcher: rank %d exited with code %d" % (failed, rc), file=sys.stderr)
+    sys.stdout.write(out)
+    sys.stdout.flush()
+    return rc if rc else 0
+
+
+# ------------------------------------------------------------------------------------------ measured traffic (PMC)
+
+def csrc_revision():
+    """sha256 over the kernel sources: the PMC summaries under profiles/ carry the revision they were taken at."""
+    h = hashlib.sha256()
+    d = os.path.join(ROOT, "pysilent_amd", "csrc")
+    for name in sorted(os.listdir(d)):
+        if name.endswith((".h", ".hip")):
+            h.update(name.encode())
+            h.update(open(os.path.join(d, name), "rb").read())
+    return h.hexdigest()[:16]
 
 
 def pmc_traffic_per_launch(kernel_substr, frames_in_launch):
     """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes
-    (profiles/<latest>/pmc_hbm_bytes.json: separate --pmc FETCH_SIZE / WRITE_SIZE runs of this same bench at 64
-    frames per launch), corrected as MI355X_MICROARCH.md prescribes for gfx950: FETCH_SIZE counts 64 B per
-    128-B request -> x2; WRITE_SIZE exact; both in KiB.  Scaled linearly to this run's frames per launch."""
+    (profiles/<tag>/pmc_hbm_bytes.json: separate --pmc FETCH_SIZE / WRITE_SIZE runs of this bench), corrected as
+    MI355X_MICROARCH.md prescribes for gfx950: FETCH_SIZE counts 64 B per 128-B request -> x2; WRITE_SIZE exact;
+    both in KiB.  Only a summary stamped with the CURRENT revision of csrc/ counts: after any kernel change the
+    figure is null until scripts/profile_bench.sh + summarize_profile.py have been run again."""
     import glob
-    cands = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*", "pmc_hbm_bytes.json")))
-    if not cands:
-        return None
-    for path in reversed(cands):  # latest profile that holds this kernel
+    rev = csrc_revision()
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*", "pmc_hbm_bytes.json")), reverse=True):
         try:
             prof = json.load(open(path))
         except (OSError, ValueError):
             continue
+        if prof.get("_csrc_revision") != rev:
+            continue
         for name, c in prof.items():
-            if kernel_substr in name and "FETCH_SIZE" in c and "WRITE_SIZE" in c:
-                per64 = (2.0 * c["FETCH_SIZE"]["mean_KiB_per_dispatch"] + c["WRITE_SIZE"]["mean_KiB_per_dispatch"]) * 1024.0
-                per64 *= 64.0 / c.get("frames_per_dispatch", 64)
-                return int(per64 * frames_in_launch / 64.0)
+            if isinstance(c, dict) and kernel_substr in name and "FETCH_SIZE" in c and "WRITE_SIZE" in c:
+                per = (2.0 * c["FETCH_SIZE"]["mean_KiB_per_dispatch"] + c["WRITE_SIZE"]["mean_KiB_per_dispatch"]) * 1024.0
+                return int(per * frames_in_launch / c.get("frames_per_dispatch", 64))
     return None
 
 
+# ------------------------------------------------------------------------------------------ CPU baselines
+
 def cpu_baseline(wl, consts, budget_s=12.0):
-    """Time the C port of the oracle (oracle/silent_oracle.c, OpenMP over the host cores) on a bounded sample
-    of the same workload.  The oracle is the thing timed here, never part of the GPU path."""
+    """The CPU oracle timed on this box's host cores, on a bounded sample of the same workload; the oracle is the
+    thing timed here, never part of the GPU path.
+      B2 (the reported ``value``, kind "port"): oracle/silent_oracle.c, one frame per OpenMP thread.
+      B1 ("numpy_scipy"): oracle/silent_oracle.py, the closest analogue of the reference's host path -- the same
+          scipy.ndimage.zoom(order=5, prefilter=False) call for the pyramid, NumPy for the stencils, one process."""
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import c_oracle as co
     import silent_oracle as so
@@ -79,41 +162,170 @@ def cpu_baseline(wl, consts, budget_s=12.0):
     if wl["mode"] != "gray":
         return None
     extents = so.classic_extents(h, w, 2.0, wl["n_levels"])
-
-    def one(i):
-        frame = synthetic_frame(i, h, w, 1)
-        t = time.perf_counter()
-        pyr = co.classic_pyramid(frame, extents)
-        for lev in pyr:
-            co.gray_line_end_level(lev, consts["cs"], consts["end"])
-        return time.perf_counter() - t
-
-    one(0)                       # warm (page faults, OpenMP team start)
+    threads = co.num_threads()
+    batch = max(threads, 1)
+    frames = np.empty((batch, h, w, 1), np.float32)
+    for i in range(batch):
+        frames[i] = synthetic_frame(i % 16, h, w, 1)
+    co.gray_pass_frames(frames[:min(batch, 8)], extents, consts["cs"], consts["end"])      # warm: page faults, OpenMP team
     n, total = 0, 0.0
-    while (total < budget_s and n < 4096) or n < 4:     # bounded sample: ~12 s of CPU work
-        total += one(1 + n)
-        n += 1
-    return {"value": round(n * h * w / total / 1e6, 3), "unit": "Mpx/s", "cores": co.num_threads(), "kind": "port",
-            "sample": "%d synthetic %dx%d frames, whole pass (pyramid + CS + %d-orientation line-end), "
-                      "oracle/silent_oracle.c -O3 -fopenmp float64 accumulation, %.1f s of CPU work"
-                      % (n, w, h, wl["n_orient"], total),
-            "host_cpus": os.cpu_count(), "affinity": len(os.sched_getaffinity(0))}
+    while total < budget_s and n < 64 * batch:
+        t = time.perf_counter()
+        co.gray_pass_frames(frames, extents, consts["cs"], consts["end"])
+        total += time.perf_counter() - t
+        n += batch
+    out = {"value": round(n * h * w / total / 1e6, 3), "unit": "Mpx/s", "cores": threads, "kind": "port",
+           "sample": "%d synthetic %dx%d frames, whole pass (pyramid + CS + %d-orientation line-end), "
+                     "oracle/silent_oracle.c -O3 -fopenmp, one frame per thread, float64 accumulation, %.1f s wall"
+                     % (n, w, h, wl["n_orient"], total),
+           "host_cpus": os.cpu_count(), "affinity": len(os.sched_getaffinity(0))}
+    # B1: a handful of frames through the NumPy / SciPy oracle
+    n1, t1 = 0, 0.0
+    while t1 < 8.0 and n1 < 8:
+        frame = synthetic_frame(n1, h, w, 1)
+        t = time.perf_counter()
+        pyr = so.classic_pyramid(frame, 2.0, wl["n_levels"])
+        so.gray_line_end_pass(pyr, consts["cs"], consts["end"])
+        t1 += time.perf_counter() - t
+        n1 += 1
+    out["numpy_scipy"] = {"value": round(n1 * h * w / t1 / 1e6, 3), "unit": "Mpx/s", "kind": "reference-like",
+                          "threads": "1 process; scipy.ndimage.zoom is single-threaded, NumPy stencils use its own BLAS-free loops",
+                          "sample": "%d frames, oracle/silent_oracle.py (scipy.ndimage.zoom order=5 prefilter=False + NumPy), %.1f s"
+                                    % (n1, t1)}
+    return out
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=100)
-    ap.add_argument("--warmup", type=int, default=10)
-    ap.add_argument("--frames", type=int, default=0, help="frames per rank per step (0 = workload default)")
-    ap.add_argument("--workload", default="config2", choices=sorted(WORKLOADS))
-    ap.add_argument("--no-cpu-baseline", action="store_true")
-    args = ap.parse_args()
+# ------------------------------------------------------------------------------------------ one rank
+
+def make_pipeline(wl, B, local, consts):
+    from pysilent_amd.pipeline import LineEndPipeline
+    h, w = wl["hw"]
+    return LineEndPipeline((h, w), mode=wl["mode"], n_levels=wl["n_levels"], n_orient=wl["n_orient"], batch=B,
+                           device=local, constants=consts, max_keypoints_per_frame=1 << 16,
+                           **({"selection": True} if wl["mode"] == "rgb" else {}))
+
+
+def make_frames(torch, D, wl, B, rank, world, dev):
+    h, w = wl["hw"]
+    c = 1 if wl["mode"] == "gray" else 3
+    frames = torch.empty((B, h, w, c), dtype=torch.float32, device=dev)
+    for j, gi in enumerate(D.shard_frame_indices(B * world, rank, world)):
+        frames[j] = torch.from_numpy(D.synthetic_frame(gi, h, w, c)).to(dev)
+    return frames
+
+
+def timed_steps(torch, D, pipe, frames, steps, warmup, dev):
+    """W untimed steps, then EXACTLY K steps between barrier + synchronize on both sides; MAX over ranks."""
+    for _ in range(warmup):
+        pipe.step(frames)
+    torch.cuda.synchronize(dev)
+    D.barrier()
+    torch.cuda.synchronize(dev)
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        pipe.step(frames)
+    torch.cuda.synchronize(dev)
+    elapsed = time.perf_counter() - t0
+    D.barrier()
+    return D.max_over_ranks(elapsed)
+
+
+def dominant_kernel(torch, pipe, frames, wl, B, dev, launches=24):
+    """Average launch duration of the dominant kernel from HIP events, in a loop of its own AFTER the timed region.
+    gray: the library brackets gray_stream_kernel with an event pair on the stream it launches on
+    (silent_set_profiling / silent_profile_elapsed_ms); rgb: torch events around run_filters on torch's current
+    stream, which is the stream the launch is given."""
+    if wl["mode"] == "gray":
+        pipe.set_profiling(1)
+        ms = []
+        for _ in range(launches // 8):
+            for _ in range(8):                       # the library keeps a ring of 8 event pairs
+                pipe.step(frames)
+            torch.cuda.synchronize(dev)
+            t, px = pipe.profiled_kernel()
+            ms.append(float(t))
+            pipe.set_profiling(1)                    # restart the ring
+        pipe.set_profiling(0)
+        dom_ms = float(np.mean(ms))
+        other_px = pipe.frame_px * B - px
+        # per level-0 pixel: frame read (4 B), pyramid + CS written (4 + 4), K end maps (4K); plus the pyramid of every
+        # other level written once (4 B per pixel of those levels)
+        nbytes = px * (4 + 4 + 4 + 4 * wl["n_orient"]) + other_px * 4
+        return {"kernel": "gray_stream_kernel<%d>" % wl["n_orient"], "ms": dom_ms, "bytes": int(nbytes),
+                "unit_level_pixels_per_launch": int(px), "pmc_name": pipe.dominant_kernel_name()}
+    evs = []
+    for _ in range(launches):
+        pipe.run_pyramid(frames)
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record()
+        pipe.run_filters()
+        b.record()
+        pipe.run_keypoints()
+        evs.append((a, b))
+    torch.cuda.synchronize(dev)
+    return {"kernel": "rgb_line_end_kernel", "ms": float(np.mean([a.elapsed_time(b) for a, b in evs])),
+            "bytes": int(pipe.filter_bytes_per_frame() * B), "pmc_name": "rgb_line_end_kernel"}
+
+
+def roofline_of(dom, B):
+    gbs = dom["bytes"] / (dom["ms"] * 1e-3) / 1e9
+    roof = {"bound": "hbm", "kernel": dom["kernel"], "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "frac": round(gbs / HBM_PEAK_GBS, 4), "traffic": pmc_traffic_per_launch(dom["pmc_name"], B),
+            "algorithmic_bytes_per_launch": dom["bytes"], "avg_launch_ms": round(dom["ms"], 4),
+            "timing": "HIP events around the kernel's launches in a separate loop after the timed region"}
+    if "unit_level_pixels_per_launch" in dom:
+        roof["unit_level_pixels_per_launch"] = dom["unit_level_pixels_per_launch"]
+    return roof
+
+
+def side_workload(torch, D, name, local, dev, rank, world):
+    """Short run of another BASELINE config on this rank (N = 1 only): ms/step, whole-pass and dominant-kernel
+    fractions of the HBM peak, in the same JSON line as the headline."""
+    wl = WORKLOADS[name]
+    B = wl["frames"]
+    consts = D.broadcast_constants(wl["mode"], wl["n_orient"], device=local)
+    pipe = make_pipeline(wl, B, local, consts)
+    frames = make_frames(torch, D, wl, B, rank, world, dev)
+    torch.cuda.synchronize(dev)
+    steps = 10
+    elapsed = timed_steps(torch, D, pipe, frames, steps, 3, dev)
+    dom = dominant_kernel(torch, pipe, frames, wl, B, dev, launches=16)
+    h, w = wl["hw"]
+    whole = pipe.algorithmic_bytes_per_frame() * B * steps / elapsed / 1e9
+    out = {"workload": wl["name"], "frames_per_step": B, "ms_per_step": round(elapsed / steps * 1e3, 4),
+           "mpx_in_per_s": round(B * steps * h * w / elapsed / 1e6, 1),
+           "whole_pass_frac_of_hbm_peak": round(whole / HBM_PEAK_GBS, 4),
+           "dominant_kernel": dom["kernel"], "dominant_kernel_ms": round(dom["ms"], 4),
+           "dominant_kernel_frac_of_hbm_peak": round(dom["bytes"] / (dom["ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}
+    del pipe, frames
+    torch.cuda.empty_cache()
+    return out
+
+
+def dry_run(args):
+    """SILENT_BENCH_DRY=1 (the CPU test of the launcher): everything a rank does except the GPU work."""
+    from pysilent_amd import distributed as D
     wl = WORKLOADS[args.workload]
+    rank, world, _ = D.init(backend=os.environ.get("SILENT_DIST_BACKEND", "gloo"))
+    if world != args.gpus:
+        raise SystemExit("--gpus %d but WORLD_SIZE is %d" % (args.gpus, world))
+    consts = D.broadcast_constants(wl["mode"], wl["n_orient"])
+    mine = D.shard_frame_indices(4 * world, rank, world)
+    D.barrier()
+    slow = D.max_over_ranks(1.0 + rank)
+    if rank == 0:
+        print(json.dumps({"metric": METRIC, "value": None, "dry_run": True, "n_gpus": world, "slowest_rank_time": slow,
+                          "frames_of_rank0": mine, "constants": sorted(consts)}))
+    D.finalize()
+
+
+def run_rank(args):
+    wl = WORKLOADS[args.workload]
+    if os.environ.get("SILENT_BENCH_DRY") == "1":
+        return dry_run(args)
 
     import torch
     from pysilent_amd import distributed as D
-    from pysilent_amd.pipeline import LineEndPipeline
 
     # rehearsal knobs (one-GPU box): SILENT_BENCH_SHARE_GPU=1 puts every rank on GPU 0, SILENT_DIST_BACKEND=gloo
     # moves the (init-only) collectives to the CPU; the driver's real multi-GPU runs use neither
@@ -124,8 +336,7 @@ def main():
     if share:
         local = 0
     if world != args.gpus:
-        raise SystemExit("--gpus %d but WORLD_SIZE is %d: launch with torch.distributed.run --nproc-per-node %d"
-                         % (args.gpus, world, args.gpus))
+        raise SystemExit("--gpus %d but WORLD_SIZE is %d" % (args.gpus, world))
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
 
@@ -135,81 +346,22 @@ def main():
     h, w = wl["hw"]
     c = 1 if wl["mode"] == "gray" else 3
     # working set per rank well beyond the 256 MiB Infinity Cache (hard part 6)
-    B = args.frames or {"config2": 64, "config3": 32, "config5": 16}[args.workload]
-    pipe = LineEndPipeline((h, w), mode=wl["mode"], n_levels=wl["n_levels"], n_orient=wl["n_orient"], batch=B,
-                           device=local, constants=consts, max_keypoints_per_frame=1 << 16,
-                           **({"selection": True} if wl["mode"] == "rgb" else {}))
-    frames = torch.empty((B, h, w, c), dtype=torch.float32, device=dev)
-    for j, gi in enumerate(D.shard_frame_indices(B * world, rank, world)):
-        frames[j] = torch.from_numpy(D.synthetic_frame(gi, h, w, c)).to(dev)
+    B = args.frames or wl["frames"]
+    pipe = make_pipeline(wl, B, local, consts)
+    frames = make_frames(torch, D, wl, B, rank, world, dev)
     torch.cuda.synchronize(dev)
 
-    for _ in range(args.warmup):
-        pipe.step(frames)
-    torch.cuda.synchronize(dev)
-    D.barrier()
+    elapsed = timed_steps(torch, D, pipe, frames, args.steps, args.warmup, dev)
 
+    # ---- everything below is outside the timed region ----
+    dom = dominant_kernel(torch, pipe, frames, wl, B, dev)
     gray = wl["mode"] == "gray"
-    if gray:
-        # the dominant kernel (fused pyramid + CS + line-end for the unit-zoom level) is bracketed by HIP events
-        # INSIDE the library, on the stream it is launched on (silent_set_profiling / silent_profile_elapsed_ms)
-        # ... on a few steps of the timed region only (an event pair per step costs ~5 % of this 1 ms pass)
-        pipe.set_profiling(max(1, args.steps // 6))
-    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True),
-           torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
-    dom_ms = []
-    torch.cuda.synchronize(dev)
-    t0 = time.perf_counter()
-    for k in range(args.steps):
-        a, b, e = ev[k]
-        if gray:
-            pipe.step(frames)                 # silent_gray_pass_dev: 3 launches, events around the dominant one
-        else:
-            a.record()
-            pipe.run_pyramid(frames)
-            b.record()
-            pipe.run_filters()
-            e.record()
-            pipe.run_keypoints()
-    torch.cuda.synchronize(dev)
-    elapsed = time.perf_counter() - t0
-    D.barrier()
-    elapsed = D.max_over_ranks(elapsed)
-
-    if gray:
-        # per-launch duration of the dominant kernel: mean over the event pairs recorded inside the timed region
-        dom_ms, dom_px = pipe.profiled_kernel()
-        dom_ms = float(dom_ms)
-        pipe.set_profiling(0)
-        pyr_ms = filt_ms = None
-    else:
-        pyr_ms = float(np.mean([a.elapsed_time(b) for a, b, _ in ev]))
-        filt_ms = float(np.mean([b.elapsed_time(e) for _, b, e in ev]))
-
     if rank != 0:
         D.finalize()
         return
     total_frames = B * world * args.steps
     mpx_in = total_frames * h * w / elapsed / 1e6
-    mpx_pyr = total_frames * pipe.frame_px / elapsed / 1e6
-    if gray:
-        # dominant kernel = gray_stream_kernel: per level-0 pixel it reads the frame (4 B) and writes pyramid (4), CS (4)
-        # and K end maps (4K); it also writes the pyramid of every other level (4 B per pixel of those levels)
-        other_px = (pipe.frame_px * B) - dom_px
-        dom_bytes = dom_px * (4 + 4 + 4 + 4 * wl["n_orient"]) + other_px * 4
-        kname = "gray_stream_kernel<%d," % wl["n_orient"]
-        roof = {"bound": "hbm", "kernel": "gray_stream_kernel<%d>" % wl["n_orient"],
-                "achieved": round(dom_bytes / (dom_ms * 1e-3) / 1e9, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": round(dom_bytes / (dom_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
-                "traffic": pmc_traffic_per_launch(kname, B),
-                "algorithmic_bytes_per_launch": int(dom_bytes), "avg_launch_ms": round(dom_ms, 4),
-                "unit_level_pixels_per_launch": int(dom_px)}
-    else:
-        filt_bytes = pipe.filter_bytes_per_frame() * B
-        roof = {"bound": "hbm", "kernel": "rgb_line_end_kernel", "achieved": round(filt_bytes / (filt_ms * 1e-3) / 1e9, 1),
-                "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(filt_bytes / (filt_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
-                "traffic": pmc_traffic_per_launch("rgb_line_end_kernel", B),
-                "algorithmic_bytes_per_launch": filt_bytes, "avg_launch_ms": round(filt_ms, 4)}
+    whole = pipe.algorithmic_bytes_per_frame() * B * args.steps / elapsed / 1e9
     out = {
         "metric": METRIC if h == 1080 else "Mpx/s full pyramid line-end pass @4K",
         "value": round(mpx_in, 2),
@@ -225,31 +377,47 @@ def main():
         "data": "synthetic",
         "config": {"workload": wl["name"], "frames_per_gpu_per_step": B, "frame": "%dx%dx%d f32" % (w, h, c),
                    "pyramid_px_per_frame": pipe.frame_px, "level_extents": pipe.extents,
-                   "mpx_pyramid_per_s": round(mpx_pyr, 2), "frames_per_s": round(total_frames / elapsed, 1),
+                   "mpx_pyramid_per_s": round(total_frames * pipe.frame_px / elapsed / 1e6, 2),
+                   "frames_per_s": round(total_frames / elapsed, 1),
                    "algorithmic_bytes_per_frame": pipe.algorithmic_bytes_per_frame(),
-                   "whole_pass_algorithmic_GBs_per_gpu": round(pipe.algorithmic_bytes_per_frame() * B * args.steps
-                                                               / elapsed / 1e9, 1),
-                   "whole_pass_frac_of_hbm_peak": round(pipe.algorithmic_bytes_per_frame() * B * args.steps
-                                                        / elapsed / 1e9 / HBM_PEAK_GBS, 4),
-                   # SURVEY.md section 8d quotes the fraction against the measured float4-copy peak as well (6.29 TB/s,
-                   # /opt/skills/guides/MI355X_MICROARCH.md)
-                   "whole_pass_frac_of_measured_copy_peak": round(pipe.algorithmic_bytes_per_frame() * B * args.steps
-                                                                  / elapsed / 1e9 / 6290.0, 4),
-                   "launches_per_step": "gray_stream_kernel (whole pyramid + level-0 CS/line-end, frame read once) + "
-                                        "gray_line_end_kernel (levels >= 1)"
-                   if gray else "unit + region pyramid, fused RGB chain, max/min + fused selection (top 10 % > NMS > value), "
-                                   "cell-max / count / scan / write keypoint kernels",
-                   "pyramid_kernels_ms": None if pyr_ms is None else round(pyr_ms, 4),
-                   "filter_kernel_ms": None if filt_ms is None else round(filt_ms, 4),
-                   "sharding": "frame i -> rank i mod N; one RCCL broadcast of constants at init"},
-        "roofline": roof,
+                   "whole_pass_algorithmic_GBs_per_gpu": round(whole, 1),
+                   "whole_pass_frac_of_hbm_peak": round(whole / HBM_PEAK_GBS, 4),
+                   # SURVEY.md section 8d quotes the fraction against the measured float4-copy peak as well
+                   "whole_pass_frac_of_measured_copy_peak": round(whole / COPY_PEAK_GBS, 4),
+                   "launches_per_step": pipe.launch_summary(),
+                   "sharding": "frame i -> rank i mod N; one RCCL broadcast of constants at init",
+                   "csrc_revision": csrc_revision()},
+        "roofline": roofline_of(dom, B),
     }
+    del pipe, frames
+    torch.cuda.empty_cache()
+    if world == 1 and not args.no_side_workloads:
+        out["other_workloads"] = {k: side_workload(torch, D, k, local, dev, rank, world)
+                                  for k in ("config3", "config5") if k != args.workload}
     if world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(wl, consts)
     else:
         out["cpu_baseline"] = None
     print(json.dumps(out))
     D.finalize()
+
+
+def main(argv=None):
+    argv = sys.argv[1:] if argv is None else list(argv)
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=100)
+    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--frames", type=int, default=0, help="frames per rank per step (0 = workload default)")
+    ap.add_argument("--workload", default="config2", choices=sorted(WORKLOADS))
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-side-workloads", action="store_true")
+    args = ap.parse_args(argv)
+    if args.gpus < 1:
+        raise SystemExit("--gpus must be >= 1")
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(launch_ranks(args.gpus, argv))
+    run_rank(args)
 
 
 if __name__ == "__main__":

@@ -41,6 +41,9 @@ def lib():
         L.so_top_value_points.argtypes = [_f, _f] + [C.c_int] * 4 + [C.c_double, _f]
         L.so_zoom_level.argtypes = [_f] + [C.c_int] * 11 + [_f]
         L.so_gray_line_end_level.argtypes = [_f, C.c_int, C.c_int, _f, _f, C.c_int, C.c_float, _f, _f]
+        L.so_gray_pass_frames.restype = C.c_double
+        L.so_gray_pass_frames.argtypes = [_f, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int), C.c_int, _f, _f, C.c_int,
+                                          C.c_float]
         _lib = L
     return _lib
 
@@ -146,3 +149,13 @@ def gray_line_end_level(lev, cs_k, end_k, clip_hi=255.0):
     end = np.empty((1, h, w, K), np.float32)
     lib().so_gray_line_end_level(_p(lev), h, w, _p(cs_k), _p(end_k), K, float(clip_hi), _p(cs), _p(end))
     return cs, end
+
+
+def gray_pass_frames(frames, extents, cs_k, end_k, clip_hi=255.0):
+    """Whole gray pass on a batch [B, H, W] of frames, one frame per OpenMP thread (bench.py's cpu_baseline leg).
+    Returns the checksum the C side keeps the work alive with."""
+    frames, cs_k, end_k = _c32(frames), _c32(cs_k), _c32(end_k)
+    B, H, W = frames.shape[:3]
+    ext = np.ascontiguousarray(np.asarray(extents, dtype=np.int32).reshape(-1, 2))
+    return lib().so_gray_pass_frames(_p(frames), B, H, W, ext.ctypes.data_as(C.POINTER(C.c_int)), ext.shape[0],
+                                     _p(cs_k), _p(end_k), end_k.shape[-1], float(clip_hi))

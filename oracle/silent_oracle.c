@@ -305,3 +305,30 @@ SO_API void so_gray_line_end_level(const float* lev, int h, int w, const float* 
     so_conv2d_same(lev, 1, h, w, 1, cs_k, 3, 3, 1, 1, 0.0f, cs_out);
     so_conv2d_same(cs_out, 1, h, w, 1, end_k, 3, 3, K, 3, clip_hi, end_out);
 }
+
+/* Whole gray pass (BASELINE configs 2/5) on a BATCH of frames, one frame per OpenMP thread: classic pyramid
+ * (every level = the whole frame resampled to extents[l]) -> CS -> ReLU -> K end bank -> ReLU -> clip.
+ * The per-op `omp parallel for`s above become serial inside this region (nested parallelism is off by
+ * default), so the host cores are used across frames -- bench.py's cpu_baseline leg; outputs are dropped
+ * except for a checksum that keeps the work alive.  Returns the sum of all end-map values. */
+SO_API double so_gray_pass_frames(const float* frames, int n_frames, int H, int W, const int* extents /* [L][2] */,
+                                  int L, const float* cs_k, const float* end_k, int K, float clip_hi) {
+    double total = 0.0;
+#pragma omp parallel for schedule(dynamic, 1) reduction(+ : total)
+    for (int f = 0; f < n_frames; ++f) {
+        const float* frame = frames + (size_t)f * H * W;
+        double acc = 0.0;
+        for (int l = 0; l < L; ++l) {
+            const int h = extents[2 * l], w = extents[2 * l + 1];
+            float* lev = (float*)malloc(sizeof(float) * (size_t)h * w * (2 + K));
+            float* cs = lev + (size_t)h * w;
+            float* end = cs + (size_t)h * w;
+            so_zoom_level(frame, H, W, 1, 0, 0, H, W, h, w, h, w, lev);
+            so_gray_line_end_level(lev, h, w, cs_k, end_k, K, clip_hi, cs, end);
+            for (size_t i = 0; i < (size_t)h * w * K; i += 97) acc += end[i];
+            free(lev);
+        }
+        total += acc;
+    }
+    return total;
+}

@@ -126,6 +126,17 @@ class LineEndPipeline(object):
         h, w, c = self.frame_shape
         return 4 * c * (h * w + self.frame_px)
 
+    def dominant_kernel_name(self):
+        """Substring of the rocprofv3 kernel name of the launch that moves most bytes (bench.py matches PMC rows by it)."""
+        return ("gray_stream_kernel<%d," % self.n_orient) if self.mode == "gray" else "rgb_line_end_kernel"
+
+    def launch_summary(self):
+        if self.mode == "gray":
+            return ("gray_stream_kernel (whole pyramid + level-0 CS/line-end, frame read once) + "
+                    "gray_line_end_kernel (levels >= 1)")
+        return ("unit + region pyramid, fused RGB chain, max/min + fused selection (top 10 % > NMS > value), "
+                "cell-max / count / scan / write keypoint kernels")
+
     # -- launches --------------------------------------------------------------------------------------
     def _stream(self):
         return C.c_void_p(self.torch.cuda.current_stream(self.tdev).cuda_stream)

@@ -22,6 +22,9 @@ for name, f in (("FETCH_SIZE", "pmc_fetch/fetch_counter_collection.csv"), ("WRIT
     for k, v in agg.items():
         if "silent" in k:
             summ.setdefault(k, {"frames_per_dispatch": frames})[name] = {"dispatches": len(v), "mean_KiB_per_dispatch": sum(v) / len(v)}
+sys.path.insert(0, root)
+import bench  # noqa: E402  (csrc_revision: bench.py only trusts a summary taken at the current kernel sources)
+summ["_csrc_revision"] = bench.csrc_revision()
 json.dump(summ, open(os.path.join(out, "pmc_hbm_bytes.json"), "w"), indent=1)
 rows = [r for r in csv.DictReader(open(os.path.join(P, "trace", "trace_kernel_trace.csv"))) if "silent" in r["Kernel_Name"]]
 cols = ["Kernel_Name", "Grid_Size", "Workgroup_Size", "LDS_Block_Size", "VGPR_Count", "SGPR_Count", "Start_Timestamp", "End_Timestamp"]
@@ -33,4 +36,6 @@ with open(os.path.join(out, "kernel_trace_silent.csv"), "w") as fh:
 for line in open(os.path.join(out, "kernel_stats.csv")):
     print(line.strip()[:150])
 for k, v in summ.items():
+    if not isinstance(v, dict):
+        continue
     print(k[:70], {a: round(b["mean_KiB_per_dispatch"] * 1024 / 1e6, 1) for a, b in v.items() if isinstance(b, dict)}, "MB/dispatch (raw counters)")

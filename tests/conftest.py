@@ -58,10 +58,19 @@ def structured_frame(seed, h, w, c, n_lines=200):
     return img
 
 
-def assert_close(got, want, rtol=1e-5, scale=None, what=""):
-    """Response-map tolerance of BASELINE.json: 1e-5 relative.  The absolute floor is 1e-5 times the
-    dynamic range of the expected map (|a-b| <= rtol * (|b| + range)), so values that cancel to ~0 are
-    judged against the magnitude of the terms that produced them, not against 0."""
+WORST_REL = {}   # what -> (worst element-wise relative error at the asserted floor, same at the 1e-3 floor)
+
+
+def assert_close(got, want, rtol=1e-5, scale=None, what="", rel_floor=0.1):
+    """Response-map tolerance of BASELINE.json: 1e-5 relative, stated twice.
+    (1) Everywhere: |a-b| <= rtol * (|b| + range), range = dynamic range of the expected map, so values that cancel
+        to ~0 are judged against the magnitude of the terms that produced them, not against 0.
+    (2) Element-wise, wherever the expected value is significant (|b| >= rel_floor * range): |a-b| <= rtol * |b|.
+        The floor is where float32 arithmetic CAN hold 1e-5: a 9-tap stencil whose taps cancel (sum of |w x| up to
+        2 * range) carries an absolute rounding error of a few float32 ulps of the range (~3e-5 at range 255) in any
+        evaluation order -- the reference's own TF float32 convolution included -- so a value of 1e-3 * range cannot
+        be reproduced to 1e-5 of ITSELF by anyone.  The worst ratio at the 1e-3 floor is reported (not asserted) in
+        the test summary; the oracle accumulates in float64 and rounds once."""
     got, want = np.asarray(got), np.asarray(want)
     assert got.shape == want.shape, (what, got.shape, want.shape)
     nan_g, nan_w = np.isnan(got), np.isnan(want)
@@ -71,8 +80,28 @@ def assert_close(got, want, rtol=1e-5, scale=None, what=""):
     fin = ~nan_w & ~inf
     if scale is None:
         scale = float(np.max(np.abs(want[fin]))) if fin.any() else 1.0
+    w64 = np.abs(want[fin].astype(np.float64))
     err = np.abs(got[fin].astype(np.float64) - want[fin].astype(np.float64))
-    tol = rtol * (np.abs(want[fin].astype(np.float64)) + scale)
+    tol = rtol * (w64 + scale)
     bad = err > tol
     assert not bad.any(), "%s: %d / %d elements off; max err %.3e (tol %.3e)" % (
         what, bad.sum(), bad.size, err.max(), tol[np.argmax(err)])
+    worst = [0.0, 0.0]
+    for k, floor in enumerate((rel_floor, 1e-3)):
+        sig = w64 >= floor * scale
+        if sig.any() and scale > 0:
+            rel = err[sig] / w64[sig]
+            worst[k] = float(rel.max())
+            if k == 0:
+                assert worst[0] <= rtol, "%s: element-wise relative error %.3e > %.1e on a value of %.4g (floor %.3g)" % (
+                    what, worst[0], rtol, w64[sig][np.argmax(rel)], floor * scale)
+    old = WORST_REL.get(what, (0.0, 0.0))
+    WORST_REL[what] = (max(old[0], worst[0]), max(old[1], worst[1]))
+
+
+def pytest_terminal_summary(terminalreporter):
+    if WORST_REL:
+        worst = sorted(WORST_REL.items(), key=lambda kv: -kv[1][1])[:10]
+        terminalreporter.write_line("worst element-wise relative error per map, |want| >= 0.1 range (asserted <= 1e-5) / "
+                                    ">= 1e-3 range (reported): " +
+                                    ", ".join("%s %.1e/%.1e" % (k, v[0], v[1]) for k, v in worst))

@@ -78,3 +78,31 @@ def test_single_process_world_is_trivial():
         for k, v in env_backup.items():
             if v is not None:
                 os.environ[k] = v
+
+
+def test_bench_launcher_spawns_its_own_ranks():
+    """`python bench.py --gpus 2` without torchrun: the parent starts the ranks itself (before any GPU call), relays
+    rank 0's JSON line and exits 0.  SILENT_BENCH_DRY=1 keeps the ranks off the GPU: rendezvous, the one broadcast of
+    the constants, frame sharding, barrier and the MAX over ranks all run for real over gloo."""
+    import json
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT")}
+    env.update(SILENT_BENCH_DRY="1", SILENT_DIST_BACKEND="gloo")
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1"],
+                       env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=300)
+    assert p.returncode == 0, p.stderr[-2000:]
+    lines = [l for l in p.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, p.stdout
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["dry_run"] is True
+    assert out["slowest_rank_time"] == 2.0           # MAX over ranks of (1 + rank)
+    assert out["frames_of_rank0"] == [0, 2, 4, 6]    # frame i -> rank i mod N
+    assert out["constants"] == ["cs", "end"]
+
+
+def test_bench_launcher_reports_a_failed_rank():
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT")}
+    env.update(SILENT_BENCH_DRY="1", SILENT_DIST_BACKEND="no-such-backend", SILENT_BENCH_LAUNCH_TIMEOUT="120")
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2"], env=env, stdout=subprocess.PIPE,
+                       stderr=subprocess.PIPE, text=True, timeout=300)
+    assert p.returncode != 0
+    assert "rank" in p.stderr

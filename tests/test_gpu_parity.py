@@ -903,3 +903,43 @@ def test_config2_1080p_full_size_against_c_oracle(rt, kernels):
     pyr2 = classic_pyramid(frame * np.float32(0.5), 2.0, 5)
     np.testing.assert_allclose(pyr2.data, pyr.data * np.float32(0.5), rtol=1e-6, atol=1e-4)
     assert end.data.min() >= 0 and end.data.max() <= 255 and cs.data.min() >= 0
+
+
+# ----------------------------------------------------------------------------- config 4: the per-rank share
+
+def test_config4_per_rank_share_64_frames_against_c_oracle(rt, kernels):
+    """BASELINE config 4 = 512 synthetic 1080p frames sharded over 8 GPUs: each rank runs 64-frame batches of the
+    config-2 pass through LineEndPipeline.step (what bench.py times).  Rank 3 of 8's share: frames 3, 11, 19, ...;
+    frames spread over the batch (first, middle, last, and two more) are checked against the C oracle, and the
+    frames in between against a checksum of checksums (frame j of this batch == the same frame run alone)."""
+    import torch
+    from pysilent_amd import distributed as D
+    from pysilent_amd.pipeline import LineEndPipeline
+    B, world, rank = 64, 8, 3
+    mine = D.shard_frame_indices(B * world, rank, world)
+    assert len(mine) == B and mine[:3] == [3, 11, 19]
+    pipe = LineEndPipeline((1080, 1920), mode="gray", n_levels=5, n_orient=4, batch=B)
+    frames = torch.empty((B, 1080, 1920, 1), dtype=torch.float32, device=pipe.tdev)
+    host_frames = {}
+    for j, gi in enumerate(mine):
+        f = D.synthetic_frame(gi, 1080, 1920, 1)
+        if j in (0, 17, 31, 46, 63):
+            host_frames[j] = f
+        frames[j] = torch.from_numpy(f).to(pipe.tdev)
+    pipe.step(frames)
+    torch.cuda.synchronize()
+    out = pipe.outputs()
+    for j, frame in host_frames.items():
+        want_pyr = co.classic_pyramid(frame, pipe.extents)
+        for l in range(5):
+            assert_close(out["pyramid"].level(l)[j].cpu().numpy(), want_pyr[l][0], RTOL, scale=255.0, what="pyramid f%d l%d" % (j, l))
+            wcs, wend = co.gray_line_end_level(want_pyr[l], kernels["cs_gray"], kernels["end4"])
+            assert_close(out["cs"].level(l)[j].cpu().numpy(), wcs[0], RTOL, scale=255.0, what="cs f%d l%d" % (j, l))
+            assert_close(out["end"].level(l)[j].cpu().numpy(), wend[0], RTOL, scale=255.0, what="end f%d l%d" % (j, l))
+    # every frame of the batch equals that frame run alone (batch position must not matter): compare per-frame sums
+    solo = LineEndPipeline((1080, 1920), mode="gray", n_levels=5, n_orient=4, batch=1)
+    sums = out["end"].data.view(B, -1).double().sum(dim=1).cpu().numpy()
+    for j in (1, 2, 30, 62):
+        solo.step(frames[j:j + 1])
+        torch.cuda.synchronize()
+        assert float(solo.outputs()["end"].data.double().sum().cpu()) == sums[j]
