@@ -118,6 +118,12 @@ SO_API void so_value_from_color(const float* in, size_t npx, int c, float* out) 
     }
 }
 
+/* tf.nn.max_pool on the reference's device path ('/device:GPU:0'): TF 1.x MaxPoolForwardNHWC starts from
+ * lowest() and takes `x > maxval`, cuDNN runs with CUDNN_NOT_PROPAGATE_NAN (TF_ENABLE_MAXPOOL_NANPROP = false):
+ * a NaN never wins, an all-NaN window gives lowest().  See pool_max in silent_oracle.py. */
+#define POOL_LOWEST (-3.402823466e+38f)
+static inline float pool_max(float m, float v) { return v > m ? v : m; }
+
 /* mode 0: x * where(x == maxpool3x3(x), x, 0); mode 1: fired mask */
 SO_API void so_nms3x3(const float* in, int n, int h, int w, int c, int mode, float* out) {
 #pragma omp parallel for collapse(2) schedule(static)
@@ -125,15 +131,14 @@ SO_API void so_nms3x3(const float* in, int n, int h, int w, int c, int mode, flo
         for (int y = 0; y < h; ++y)
             for (int x = 0; x < w; ++x)
                 for (int i = 0; i < c; ++i) {
-                    float m = -INFINITY;
+                    float m = POOL_LOWEST;
                     for (int dy = -1; dy <= 1; ++dy) {
                         const int yy = y + dy;
                         if (yy < 0 || yy >= h) continue;
                         for (int dx = -1; dx <= 1; ++dx) {
                             const int xx = x + dx;
                             if (xx < 0 || xx >= w) continue;
-                            const float v = in[(((size_t)b * h + yy) * w + xx) * c + i];
-                            if (m < v) m = v;
+                            m = pool_max(m, in[(((size_t)b * h + yy) * w + xx) * c + i]);
                         }
                     }
                     const size_t o = (((size_t)b * h + y) * w + x) * c + i;
@@ -145,15 +150,16 @@ SO_API void so_nms3x3(const float* in, int n, int h, int w, int c, int mode, flo
 
 SO_API void so_level_max_min(const float* v, int n, size_t npx, float* mx, float* mn) {
     for (int b = 0; b < n; ++b) {
-        float hi = -INFINITY, lo = INFINITY;
+        /* max_pool(v) and -1.0 * max_pool(-v), NaNs ignored (top_value_points.py:16-21) */
+        float hi = POOL_LOWEST, nlo = POOL_LOWEST;
         const float* p = v + (size_t)b * npx;
-#pragma omp parallel for reduction(max : hi) reduction(min : lo) schedule(static)
+#pragma omp parallel for reduction(max : hi) reduction(max : nlo) schedule(static)
         for (size_t i = 0; i < npx; ++i) {
             if (p[i] > hi) hi = p[i];
-            if (p[i] < lo) lo = p[i];
+            if (-p[i] > nlo) nlo = -p[i];
         }
         mx[b] = hi;
-        mn[b] = lo;
+        mn[b] = -1.0f * nlo;
     }
 }
 
@@ -209,10 +215,9 @@ SO_API int64_t so_max_value_indices_region(const float* value, int n, int h, int
         const float* v = value + (size_t)b * h * w;
         for (int j = 0; j < oh; ++j)
             for (int i = 0; i < ow; ++i) {
-                float m = -INFINITY;
+                float m = POOL_LOWEST;
                 for (int y = ylo[j]; y < yhi[j]; ++y)
-                    for (int x = xlo[i]; x < xhi[i]; ++x)
-                        if (m < v[(size_t)y * w + x]) m = v[(size_t)y * w + x];
+                    for (int x = xlo[i]; x < xhi[i]; ++x) m = pool_max(m, v[(size_t)y * w + x]);
                 pooled[j * ow + i] = m;
             }
         for (int y = 0; y < h; ++y)

@@ -140,17 +140,39 @@ def bw_from_color(x):
     return np.where(s != 0, F32(1), F32(0)).astype(F32)[..., None]
 
 
+POOL_LOWEST = np.finfo(F32).min
+
+
+def pool_max(m, v):
+    """One step of tf.nn.max_pool as the reference's device path evaluates it: the reference pins its graph to
+    '/device:GPU:0' (recognition_testing.py:64), where TF 1.x runs either its own kernel
+    (tensorflow/core/kernels/maxpooling_op_gpu.cu.cc, MaxPoolForwardNHWC: ``maxval = lowest(); if (x > maxval)
+    maxval = x``) or cuDNN with CUDNN_NOT_PROPAGATE_NAN -- the default, maxpooling_op.cc reads
+    TF_ENABLE_MAXPOOL_NANPROP = false.  So: a NaN never wins, the result does not depend on the order of the taps,
+    and a window without a single value above lowest() (all NaN, all -inf, or empty) yields lowest() = -FLT_MAX.
+    ``m`` is the running maximum (never NaN), ``v`` the next tap."""
+    with np.errstate(invalid="ignore"):
+        return np.where(v > m, v, m).astype(F32)
+
+
+def pool_max_reduce(v, axis):
+    """max_pool over whole axes with the same rule (np.fmax ignores NaN; lowest() is the identity)."""
+    v = np.asarray(v, dtype=F32)
+    with np.errstate(invalid="ignore"):
+        m = np.fmax.reduce(np.where(np.isnan(v), POOL_LOWEST, v), axis=axis, initial=POOL_LOWEST)
+    return np.asarray(m, dtype=F32)
+
+
 def maxpool3x3_same(x):
-    """tf.nn.max_pool 3x3 stride 1 SAME: out-of-image taps are ignored (-inf padding)."""
+    """tf.nn.max_pool 3x3 stride 1 SAME: out-of-image taps are ignored, NaN taps too (see pool_max)."""
     x = np.asarray(x, dtype=F32)
     n, h, w, c = x.shape
-    xp = np.full((n, h + 2, w + 2, c), -np.inf, dtype=F32)
+    xp = np.full((n, h + 2, w + 2, c), POOL_LOWEST, dtype=F32)
     xp[:, 1:-1, 1:-1, :] = x
-    m = np.full(x.shape, -np.inf, dtype=F32)
+    m = np.full(x.shape, POOL_LOWEST, dtype=F32)
     for dy in range(3):
         for dx in range(3):
-            v = xp[:, dy:dy + h, dx:dx + w, :]
-            m = np.where(m < v, v, m)
+            m = pool_max(m, xp[:, dy:dy + h, dx:dx + w, :])
     return m
 
 
@@ -169,9 +191,13 @@ def nms3x3(x, mode="product"):
 
 
 def level_max_min(v):
-    """Per batch item global max and min (max_pool with k = stride = (H, W))."""
+    """Per batch item global max and min as top_value_points.py:16-21 computes them: max_pool(v) and
+    -1.0 * max_pool(-v) with k = stride = (H, W); NaNs are ignored by both (see pool_max), a level without any
+    finite value gives (-FLT_MAX, +FLT_MAX)."""
     v = np.asarray(v, dtype=F32)
-    return v.max(axis=(1, 2, 3)), v.min(axis=(1, 2, 3))
+    mx = pool_max_reduce(v, (1, 2, 3))
+    mn = (F32(-1.0) * pool_max_reduce(-v, (1, 2, 3))).astype(F32)
+    return mx, mn
 
 
 def top_value_points(color, top_percent=0.1, value=None):
@@ -184,9 +210,9 @@ def top_value_points(color, top_percent=0.1, value=None):
     a = F32(1.0 - top_percent)
     b = F32(top_percent)
     thr = ((a * mx).astype(F32) + (b * mn).astype(F32)).astype(F32)
-    mask = (value >= thr[:, None, None, None]).astype(F32)
     with np.errstate(invalid="ignore"):
-        return (color * mask).astype(F32)
+        mask = (value >= thr[:, None, None, None]).astype(F32)      # a NaN value compares false ...
+        return (color * mask).astype(F32)                           # ... and NaN * 0 stays NaN in the colour map
 
 
 def _region_pool_geometry(size, stride):
@@ -214,7 +240,7 @@ def region_threshold(value, region_h, region_w):
     pooled = np.empty((n, oh, ow), dtype=F32)
     for j, (y0, y1) in enumerate(wins_y):
         for i, (x0, x1) in enumerate(wins_x):
-            pooled[:, j, i] = value[:, y0:y1, x0:x1, 0].max(axis=(1, 2))
+            pooled[:, j, i] = pool_max_reduce(value[:, y0:y1, x0:x1, 0], (1, 2))
     return pooled[:, src_y][:, :, src_x][..., None]
 
 
@@ -224,7 +250,8 @@ def max_value_indices_region(color, region_shape, value=None):
         value = value_from_color(color)
     value = np.asarray(value, dtype=F32)
     thr = region_threshold(value, int(region_shape[1]), int(region_shape[2]))
-    return np.argwhere(value >= thr).astype(np.int64)
+    with np.errstate(invalid="ignore"):
+        return np.argwhere(value >= thr).astype(np.int64)           # NaN >= thr is false: a NaN pixel is never a keypoint
 
 
 # ----------------------------------------------------------------------------- centroids

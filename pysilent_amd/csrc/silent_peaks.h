@@ -16,20 +16,21 @@ __device__ __forceinline__ float ord2f(unsigned u) {
     return __uint_as_float((u & 0x80000000u) ? (u & 0x7fffffffu) : ~u);
 }
 
+// tf.nn.max_pool as the reference's device path evaluates it.  The reference pins its graph to '/device:GPU:0'
+// (slam_recognition/recognition_testing.py:64); there TF 1.x runs MaxPoolForwardNHWC (`maxval = lowest(); if (x > maxval)
+// maxval = x`) or cuDNN with CUDNN_NOT_PROPAGATE_NAN (TF_ENABLE_MAXPOOL_NANPROP defaults to false): a NaN never wins, the
+// result is independent of the tap order, a window with nothing above lowest() yields lowest() = -FLT_MAX.
+// Every maximum in this file (3x3 NMS, per-level max / min, window and cell maxima) goes through pool_max with the
+// RUNNING maximum as first argument, so an accumulator is never a NaN and atomics only ever see ordered floats.
+// Oracle: pool_max in oracle/silent_oracle.py.
+constexpr float kPoolLowest = -3.402823466e+38f;
+__device__ __forceinline__ float pool_max(float m, float v) { return v > m ? v : m; }
+__device__ __forceinline__ unsigned pool_lowest_ord() { return f2ord(kPoolLowest); }
+
+// v must already be NaN-free (a pool_max accumulator)
 __device__ __forceinline__ float wave_max(float v) {
 #pragma unroll
-    for (int o = 32; o > 0; o >>= 1) {
-        const float t = __shfl_xor(v, o);
-        v = v < t ? t : v;
-    }
-    return v;
-}
-__device__ __forceinline__ float wave_min(float v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) {
-        const float t = __shfl_xor(v, o);
-        v = t < v ? t : v;
-    }
+    for (int o = 32; o > 0; o >>= 1) v = pool_max(v, __shfl_xor(v, o));
     return v;
 }
 
@@ -85,15 +86,14 @@ __global__ __launch_bounds__(256) void nms3x3_kernel(const float* __restrict__ i
         if (p >= npx) break;
         const int y = p / W, x = p - y * W;
         for (int c = 0; c < C; ++c) {
-            float m = -INFINITY;
+            float m = kPoolLowest;
             for (int dy = -1; dy <= 1; ++dy) {
                 const int yy = y + dy;
                 if (yy < 0 || yy >= H) continue;
                 for (int dx = -1; dx <= 1; ++dx) {
                     const int xx = x + dx;
                     if (xx < 0 || xx >= W) continue;
-                    const float v = src[((long long)yy * W + xx) * C + c];
-                    m = m < v ? v : m;
+                    m = pool_max(m, src[((long long)yy * W + xx) * C + c]);
                 }
             }
             const float v = src[(long long)p * C + c];
@@ -104,12 +104,13 @@ __global__ __launch_bounds__(256) void nms3x3_kernel(const float* __restrict__ i
 }
 
 // ---- a-10 per-level max / min: wave shuffle reduction -> LDS -> one atomic pair per block.
-// mm[(frame * n_levels + level) * 2 + {0,1}] = ordered-uint max / min; pre-set by init_maxmin_kernel.
+// mm[(frame * n_levels + level) * 2 + {0,1}] = ordered-uint max_pool(v) / max_pool(-v); pre-set by init_maxmin_kernel.
+// NaN values are ignored by both (pool_max); read back with level_max / level_min.
 __global__ void init_maxmin_kernel(unsigned* mm, int n) {
     const int i = blockIdx.x * 256 + threadIdx.x;
     if (i < n) {
-        mm[2 * i] = 0u;            // below every float
-        mm[2 * i + 1] = 0xffffffffu;  // above every float
+        mm[2 * i] = pool_lowest_ord();      // max_pool(v)
+        mm[2 * i + 1] = pool_lowest_ord();  // max_pool(-v): the minimum is -1.0 * this (top_value_points.py:19-21)
     }
 }
 
@@ -120,12 +121,12 @@ constexpr int kRedChunk = 16384;
 __global__ __launch_bounds__(256) void level_maxmin_kernel(const float* __restrict__ value,
                                                            const float* __restrict__ color, int C,
                                                            const LevelTab tab, unsigned* __restrict__ mm) {
-    __shared__ float s_mx[4], s_mn[4];
+    __shared__ float s_mx[4], s_nmn[4];
     const TileCoord tc = locate_tile(tab, blockIdx.x);
     const int npx = tab.h[tc.level] * tab.w[tc.level];
     const long long base_px = (long long)tc.frame * tab.frame_px + tab.px_off[tc.level];
     const float inv = 1.0f / (float)C;
-    float mx = -INFINITY, mn = INFINITY;
+    float mx = kPoolLowest, nmn = kPoolLowest;   // running max_pool(v), max_pool(-v)
     const int p0 = tc.tx * kRedChunk + threadIdx.x;
     for (int k0 = 0; k0 < kRedChunk / 256; k0 += 8) {
         if (p0 + k0 * 256 >= npx) break;  // (the first lane of the block decides: block-uniform enough, see clamp)
@@ -144,28 +145,31 @@ __global__ __launch_bounds__(256) void level_maxmin_kernel(const float* __restri
         }
 #pragma unroll
         for (int k = 0; k < 8; ++k) {
-            mx = mx < v[k] ? v[k] : mx;
-            mn = v[k] < mn ? v[k] : mn;
+            mx = pool_max(mx, v[k]);
+            nmn = pool_max(nmn, -v[k]);
         }
     }
     mx = wave_max(mx);
-    mn = wave_min(mn);
+    nmn = wave_max(nmn);
     const int wave = threadIdx.x >> 6;
     if ((threadIdx.x & 63) == 0) {
         s_mx[wave] = mx;
-        s_mn[wave] = mn;
+        s_nmn[wave] = nmn;
     }
     __syncthreads();
     if (threadIdx.x == 0) {
         for (int i = 1; i < 4; ++i) {
-            mx = mx < s_mx[i] ? s_mx[i] : mx;
-            mn = s_mn[i] < mn ? s_mn[i] : mn;
+            mx = pool_max(mx, s_mx[i]);
+            nmn = pool_max(nmn, s_nmn[i]);
         }
         unsigned* slot = mm + ((long long)tc.frame * tab.n_levels + tc.level) * 2;
         atomicMax(slot, f2ord(mx));
-        atomicMin(slot + 1, f2ord(mn));
+        atomicMax(slot + 1, f2ord(nmn));
     }
 }
+
+__device__ __forceinline__ float level_max(const unsigned* slot) { return ord2f(slot[0]); }
+__device__ __forceinline__ float level_min(const unsigned* slot) { return __fmul_rn(-1.0f, ord2f(slot[1])); }
 
 // thr = (1-p)*max + p*min with every op rounded to float32 and NOT fused (TF runs mul, mul, add)
 __global__ __launch_bounds__(256) void top_value_points_kernel(const float* __restrict__ color,
@@ -177,8 +181,7 @@ __global__ __launch_bounds__(256) void top_value_points_kernel(const float* __re
     const int npx = tab.h[tc.level] * tab.w[tc.level];
     const long long base_px = (long long)tc.frame * tab.frame_px + tab.px_off[tc.level];
     const unsigned* slot = mm + ((long long)tc.frame * tab.n_levels + tc.level) * 2;
-    const float mx = ord2f(slot[0]), mn = ord2f(slot[1]);
-    const float thr = __fadd_rn(__fmul_rn(one_minus_p, mx), __fmul_rn(p_f, mn));
+    const float thr = __fadd_rn(__fmul_rn(one_minus_p, level_max(slot)), __fmul_rn(p_f, level_min(slot)));
     const float inv = 1.0f / (float)C;
     for (int k = 0; k < 4; ++k) {
         const int p = tc.tx * kChunk + k * 256 + threadIdx.x;
@@ -222,7 +225,7 @@ constexpr int kCells = kMaxSeg * kMaxSeg;
 
 // ---- a-9 as a streaming stencil (C = 1 or 3; other channel counts use nms3x3_kernel above): lane = column (halo 2
 // like the other streaming kernels), rows walk down, 3x3 maximum = row maximum by DPP then a 3-row window; taps
-// outside the image are -inf.  The per-pixel kernel with its 9 strided loads per channel ran at 1.0 TB/s on 3-channel
+// outside the image (and NaN taps) are ignored, see pool_max.  The per-pixel kernel with its 9 strided loads per channel ran at 1.0 TB/s on 3-channel
 // 1080p maps.  Same comparisons in the same order: identical results, NaNs included.
 constexpr int kNmsCols = 60, kNmsTW = 4 * kNmsCols, kNmsTH = 32;
 
@@ -245,7 +248,7 @@ __global__ __launch_bounds__(256) void nms3x3_stream_kernel(const float* __restr
     float hm[C][2], ctr[C];
 #pragma unroll
     for (int c = 0; c < C; ++c) {
-        hm[c][0] = hm[c][1] = -INFINITY;
+        hm[c][0] = hm[c][1] = kPoolLowest;
         ctr[c] = 0.0f;
     }
 #pragma unroll 1
@@ -267,15 +270,11 @@ __global__ __launch_bounds__(256) void nms3x3_stream_kernel(const float* __restr
             float o[C];
 #pragma unroll
             for (int c = 0; c < C; ++c) {
-                const float tp = in_img ? v[j][c] : -INFINITY;
+                const float tp = in_img ? v[j][c] : kPoolLowest;
                 const float l = from_lane_below(tp), r = from_lane_above(tp);
-                float h = -INFINITY;
-                h = h < l ? l : h;
-                h = h < tp ? tp : h;
-                h = h < r ? r : h;
-                float mx = hm[c][0];
-                mx = mx < hm[c][1] ? hm[c][1] : mx;
-                mx = mx < h ? h : mx;
+                // (the DPP shift feeds 0 into the wave's edge lanes: those are halo lanes whose result is never stored)
+                const float h = pool_max(pool_max(pool_max(kPoolLowest, l), tp), r);
+                const float mx = pool_max(pool_max(hm[c][0], hm[c][1]), h);
                 const float xv = ctr[c];
                 const bool is_max = xv == mx;
                 o[c] = mode == SILENT_NMS_FIRED ? (is_max ? 1.0f : 0.0f) : xv * (is_max ? xv : 0.0f);
@@ -328,13 +327,13 @@ __global__ __launch_bounds__(256) void select_peaks_kernel(const float* __restri
     const int xc = min(max(x, 0), W - 1);
     const bool out_lane = lane >= 2 && lane < 2 + kSelCols && x < W;
     const unsigned* slot = mm + ((long long)tc.frame * tab.n_levels + tc.level) * 2;
-    const float thr = __fadd_rn(__fmul_rn(one_minus_p, ord2f(slot[0])), __fmul_rn(p_f, ord2f(slot[1])));
+    const float thr = __fadd_rn(__fmul_rn(one_minus_p, level_max(slot)), __fmul_rn(p_f, level_min(slot)));
     const float inv = 1.0f / (float)C;
 
     // CELLS state: column segment of this lane, row segment of the rows seen so far, running maximum
     const RegionLevel& rl = rt.lv[tc.level];
     int cseg = 0, cur_rs = -1;
-    float cmax = -INFINITY;
+    float cmax = kPoolLowest;
     if constexpr (CELLS) {
         for (int s_ = 1; s_ < rl.ncs; ++s_) cseg = x >= rl.ccut[s_] ? s_ : cseg;
     }
@@ -347,17 +346,17 @@ __global__ __launch_bounds__(256) void select_peaks_kernel(const float* __restri
             const int first = __ffsll((long long)left) - 1;
             const int k = __builtin_amdgcn_readlane(key, first);
             const bool mine = key == k;
-            const float m = wave_max(mine ? cmax : -INFINITY);
+            const float m = wave_max(mine ? cmax : kPoolLowest);
             if (lane == first) atomicMax(dst + k, f2ord(m));
             key = mine ? -1 : key;
             left = __ballot(key >= 0);
         }
-        cmax = -INFINITY;
+        cmax = kPoolLowest;
     };
     float hm[C][2], ctr[C];  // row maxima of rows y-2, y-1; centre values of row y-1
 #pragma unroll
     for (int c = 0; c < C; ++c) {
-        hm[c][0] = hm[c][1] = -INFINITY;
+        hm[c][0] = hm[c][1] = kPoolLowest;
         ctr[c] = 0.0f;
     }
     constexpr int CH = 8;  // rows requested per batch
@@ -391,15 +390,10 @@ __global__ __launch_bounds__(256) void select_peaks_kernel(const float* __restri
 #pragma unroll
             for (int c = 0; c < C; ++c) {
                 t[c] = __fmul_rn(col[j][c], m);
-                const float tp = in_img ? t[c] : -INFINITY;  // max_pool SAME ignores taps outside the image
+                const float tp = in_img ? t[c] : kPoolLowest;  // max_pool SAME ignores taps outside the image
                 const float l = from_lane_below(tp), r = from_lane_above(tp);
-                float h = -INFINITY;                          // same NaN-ignoring order as nms3x3_kernel
-                h = h < l ? l : h;
-                h = h < tp ? tp : h;
-                h = h < r ? r : h;
-                float mx = hm[c][0];
-                mx = mx < hm[c][1] ? hm[c][1] : mx;
-                mx = mx < h ? h : mx;
+                const float h = pool_max(pool_max(pool_max(kPoolLowest, l), tp), r);   // NaN taps are ignored too
+                const float mx = pool_max(pool_max(hm[c][0], hm[c][1]), h);
                 const float xv = ctr[c];
                 o[c] = __fmul_rn(xv, xv == mx ? xv : 0.0f);
                 hm[c][0] = hm[c][1];
@@ -422,7 +416,7 @@ __global__ __launch_bounds__(256) void select_peaks_kernel(const float* __restri
                     for (int c = 1; c < C; ++c) pv = __fadd_rn(pv, o[c]);
                     pv = __fmul_rn(pv, inv);
                     if (pv_out) pv_out[px] = pv;
-                    if constexpr (CELLS) cmax = cmax < pv ? pv : cmax;
+                    if constexpr (CELLS) cmax = pool_max(cmax, pv);
                 }
             }
             if constexpr (CELLS) {
@@ -457,7 +451,7 @@ __device__ __forceinline__ void advance_yx(int& y, int& x, int step, int W) {
 
 __global__ void init_cells_kernel(unsigned* cells, long long n) {
     const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
-    if (i < n) cells[i] = 0u;
+    if (i < n) cells[i] = pool_lowest_ord();
 }
 
 // cells[(frame * n_levels + level) * kCells + rs * kMaxSeg + cs] = ordered-uint max of the cell
@@ -469,7 +463,7 @@ __global__ __launch_bounds__(256) void region_cell_max_kernel(const float* __res
     const int W = tab.w[tc.level];
     const int npx = tab.h[tc.level] * W;
     const long long base_px = (long long)tc.frame * tab.frame_px + tab.px_off[tc.level];
-    for (int i = threadIdx.x; i < kCells; i += 256) s_cell[i] = 0u;
+    for (int i = threadIdx.x; i < kCells; i += 256) s_cell[i] = pool_lowest_ord();
     __syncthreads();
     int y = (tc.tx * kRedChunk + (int)threadIdx.x) / W, x = tc.tx * kRedChunk + (int)threadIdx.x - y * W;
     for (int k = 0; k < kRedChunk / 256; ++k, advance_yx(y, x, 256, W)) {
@@ -477,13 +471,13 @@ __global__ __launch_bounds__(256) void region_cell_max_kernel(const float* __res
         if (tc.tx * kRedChunk + k * 256 >= npx) break;  // block-uniform
         const bool live = p < npx;
         int cell = -1;
-        float v = -INFINITY;
+        float v = kPoolLowest;
         if (live) {
             int rs = 0, cs = 0;
             for (int s = 1; s < rl.nrs; ++s) rs = y >= rl.rcut[s] ? s : rs;
             for (int s = 1; s < rl.ncs; ++s) cs = x >= rl.ccut[s] ? s : cs;
             cell = rs * kMaxSeg + cs;
-            v = value[base_px + p];
+            v = pool_max(kPoolLowest, value[base_px + p]);   // a NaN never reaches the reductions below
         }
         // common case: the whole wave sits in one cell -> one LDS atomic per wave
         const int first = __builtin_amdgcn_readfirstlane(cell);
@@ -497,7 +491,7 @@ __global__ __launch_bounds__(256) void region_cell_max_kernel(const float* __res
     __syncthreads();
     unsigned* dst = cells + ((long long)tc.frame * tab.n_levels + tc.level) * kCells;
     for (int i = threadIdx.x; i < kCells; i += 256)
-        if (s_cell[i] != 0u) atomicMax(dst + i, s_cell[i]);
+        if (s_cell[i] != pool_lowest_ord()) atomicMax(dst + i, s_cell[i]);
 }
 
 // window maxima of one (frame, level) into LDS: pooled[j * kMaxWin + i]
@@ -505,7 +499,7 @@ __device__ __forceinline__ void load_pooled(const unsigned* __restrict__ cells, 
                                             float* s_pooled) {
     for (int wi = threadIdx.x; wi < rl.oh * rl.ow; wi += 256) {
         const int j = wi / rl.ow, i = wi - j * rl.ow;
-        unsigned m = 0u;
+        unsigned m = pool_lowest_ord();
         for (int rs = rl.wy_lo[j]; rs < rl.wy_hi[j]; ++rs)
             for (int cs = rl.wx_lo[i]; cs < rl.wx_hi[i]; ++cs) {
                 const unsigned c = cells[rs * kMaxSeg + cs];
@@ -744,15 +738,14 @@ __global__ __launch_bounds__(256) void boost_update_kernel(const float* __restri
         const int p = tc.tx * kChunk + k * 256 + threadIdx.x;
         if (p >= npx) break;
         const int y = p / W, xx0 = p - y * W;
-        float mx = -INFINITY;
+        float mx = kPoolLowest;
         for (int dy = -1; dy <= 1; ++dy) {
             const int yy = y + dy;
             if (yy < 0 || yy >= H) continue;
             for (int dx = -1; dx <= 1; ++dx) {
                 const int xx = xx0 + dx;
                 if (xx < 0 || xx >= W) continue;
-                const float v = src[(long long)yy * W + xx];
-                mx = mx < v ? v : mx;
+                mx = pool_max(mx, src[(long long)yy * W + xx]);
             }
         }
         const float fired = src[p] == mx ? 1.0f : 0.0f;

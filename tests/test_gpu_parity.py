@@ -943,3 +943,94 @@ def test_config4_per_rank_share_64_frames_against_c_oracle(rt, kernels):
         solo.step(frames[j:j + 1])
         torch.cuda.synchronize()
         assert float(solo.outputs()["end"].data.double().sum().cpu()) == sums[j]
+
+
+# ----------------------------------------------------------------------------- NaN through the peak stage
+
+def _nan_bearing_levels(c):
+    """Ragged levels with NaN single pixels, NaN rows, a whole NaN quadrant, an all-NaN level and a NaN in every lane
+    position of a wave (columns 0 .. 70 of one row)."""
+    rng = np.random.default_rng(77 + c)
+    extents = [(37, 131), (70, 60), (5, 7), (64, 241)]
+    levels = [np.floor(rng.random((2, h, w, c)) * 16).astype(np.float32) * 16 for h, w in extents]
+    levels[0][0, 3, 5] = np.nan
+    levels[0][1, 10, :] = np.nan
+    levels[0][0, 20, np.arange(0, 71, 2)] = np.nan
+    levels[1][0, :35, :30] = np.nan                      # a keypoint window of the (35, 30) regions holds only NaN
+    levels[2][1] = np.nan                                # a level without a single value
+    levels[3][0, 0, 0] = np.nan
+    levels[3][1, 63, 240] = np.nan
+    levels[3][0, 17, 59:63] = np.nan                     # across the 60-column wave boundary
+    return extents, levels
+
+
+@pytest.mark.parametrize("c", [1, 3])
+def test_peak_stage_ignores_nan_like_tf1_max_pool(rt, c):
+    """a-10 / a-9 / a-11 on NaN-bearing maps: every max_pool ignores NaN taps (oracle.pool_max cites the TF 1.x kernel),
+    a NaN value is never selected and never a keypoint, NaN colours stay NaN.  Bit-exact against the oracle, NaN
+    patterns included, for the separate ops, the fused selection pass and the keypoint composite."""
+    from pysilent_amd.util.selection import top_value_points, max_value_indices_region
+    from pysilent_amd.util.color import get_value_from_color
+    extents, levels = _nan_bearing_levels(c)
+    packed = rt.PackedPyramid.from_levels(levels)
+    value = get_value_from_color(packed)
+    top = top_value_points(packed, 0.1, value)
+    peaks = rt.nms3x3(top, "product")
+    fired = rt.nms3x3(value, "fired")
+    fused = rt.select_peaks(packed, 0.1, value)
+    regions = [(max(h // 2, 1), max(w // 2, 1)) for h, w in extents]
+    for l, lev in enumerate(levels):
+        v = so.value_from_color(lev)
+        np.testing.assert_array_equal(value.level(l), v)
+        wtop = so.top_value_points(lev, 0.1, v)
+        wpeaks = so.nms3x3(wtop, "product")
+        np.testing.assert_array_equal(top.level(l), wtop)
+        np.testing.assert_array_equal(peaks.level(l), wpeaks)
+        np.testing.assert_array_equal(fired.level(l), so.nms3x3(v, "fired"))
+        np.testing.assert_array_equal(fused["top"].level(l), wtop)
+        np.testing.assert_array_equal(fused["peaks"].level(l), wpeaks)
+        np.testing.assert_array_equal(fused["peak_value"].level(l), so.value_from_color(wpeaks))
+    assert np.isnan(top.level(0)[0, 3, 5]).all() and not np.isnan(top.level(0)[0, 3, 6]).any()
+    # keypoints straight from the NaN-bearing value map, and from the NaN-bearing peak value
+    for vmap in (value, fused["peak_value"]):
+        kp = max_value_indices_region(packed, regions, vmap)
+        for f in range(2):
+            rows = []
+            for l in range(len(levels)):
+                r = so.max_value_indices_region(None, (1,) + regions[l] + (c,), np.ascontiguousarray(vmap.level(l)[f:f + 1]))
+                r[:, 0] = l
+                rows.append(r)
+            want = np.concatenate(rows)
+            np.testing.assert_array_equal(kp[f], want)
+            assert len(want) > 0 and not (want[:, 0] == 2).any() or f == 0       # frame 1's level 2 is all NaN: no keypoint there
+
+
+@pytest.mark.parametrize("keep", [False, True])
+def test_config3_chain_on_line_drawings_under_ieee_through_keypoints(rt, kernels, keep):
+    """The default flat policy (0 * inf = NaN on every flat region, gaussian_regulator_tensor.py:35-36) on line drawings --
+    the frames the detector is for: selection + keypoints after the chain, fused composite (keep=False) and separate
+    calls (keep=True) give the same keypoints, bit-exact against the oracle applied to the GPU's own line-end map."""
+    import torch
+    from pysilent_amd.pipeline import LineEndPipeline
+    frames = np.stack([structured_frame(40 + i, 150, 260, 3) for i in range(2)])
+    pipe = LineEndPipeline((150, 260), mode="rgb", n_levels=4, batch=2, selection=True, keep_selection_maps=keep,
+                           flat_policy="ieee", max_keypoints_per_frame=1 << 16)
+    pipe.step(torch.from_numpy(frames).cuda())
+    torch.cuda.synchronize()
+    out = pipe.outputs()
+    n_nan = 0
+    for f in range(2):
+        rows = []
+        for l, (h, w) in enumerate(pipe.extents):
+            line = np.ascontiguousarray(out["line_end"].level(l)[f:f + 1].cpu().numpy())
+            value = np.ascontiguousarray(out["value"].level(l)[f:f + 1].cpu().numpy())
+            n_nan += int(np.isnan(value).sum())
+            pv = so.value_from_color(so.nms3x3(so.top_value_points(line, 0.1, value), "product"))
+            np.testing.assert_array_equal(out["peak_value"].level(l)[f:f + 1].cpu().numpy(), pv)
+            r = so.max_value_indices_region(None, (1, max(h // 2, 1), max(w // 2, 1), 3), pv)
+            r[:, 0] = l
+            rows.append(r)
+        want = np.concatenate(rows)
+        np.testing.assert_array_equal(out["keypoints"][f], want)
+        assert len(want) > 0                                  # NaN regions no longer silence the level's threshold
+    assert n_nan > 1000                                       # the frames really exercise the NaN path

@@ -215,3 +215,97 @@ def test_boosting_known_answer():
     with pytest.raises(ValueError):
         so.generate_recovery(x, False, False)
     assert (so.initialize_boosting(x) == 8).all()
+
+
+# ----------------------------------------------------------------------------- second opinions for the TF-semantic ops
+# (everything below is checked against an independent torch-CPU implementation of the same rule)
+
+def test_maxpool3x3_same_against_torch():
+    torch = pytest.importorskip("torch")
+    x = noise_frame(3, 23, 31, 3)[None]
+    x[0, 5, 7, 1] = -np.inf
+    want = torch.nn.functional.max_pool2d(torch.from_numpy(x).permute(0, 3, 1, 2), 3, stride=1, padding=1)   # -inf padding
+    npt.assert_array_equal(so.maxpool3x3_same(x), want.permute(0, 2, 3, 1).numpy())
+    npt.assert_array_equal(co.nms3x3(x, "fired"), so.nms3x3(x, "fired"))
+
+
+def test_max_pool_ignores_nan_like_the_tf1_gpu_kernel():
+    """TF 1.x on '/device:GPU:0' (where the reference pins its graph): `maxval = lowest(); if (x > maxval) maxval = x`
+    and cuDNN NOT_PROPAGATE_NAN -- a NaN never wins, an all-NaN window gives lowest()."""
+    lowest = np.finfo(np.float32).min
+    x = np.array([[1.0, np.nan, 3.0], [np.nan, np.nan, np.nan], [0.5, 2.0, np.nan]], np.float32)[None, :, :, None]
+    m = so.maxpool3x3_same(x)[0, :, :, 0]
+    npt.assert_array_equal(m, [[1.0, 3.0, 3.0], [2.0, 3.0, 3.0], [2.0, 2.0, 2.0]])
+    allnan = np.full((1, 4, 4, 1), np.nan, np.float32)
+    assert (so.maxpool3x3_same(allnan) == lowest).all()
+    mx, mn = so.level_max_min(x)
+    assert mx[0] == 3.0 and mn[0] == 0.5
+    mx, mn = so.level_max_min(allnan)
+    assert mx[0] == lowest and mn[0] == -lowest
+    # the mask stages: a NaN value is never selected, and NaN * 0 stays NaN in the colour map
+    color = np.repeat(x, 3, axis=3)
+    top = so.top_value_points(color, 0.5)                     # thr = 0.5 * 3 + 0.5 * 0.5 = 1.75
+    assert np.isnan(top[0, 0, 1]).all() and (top[0, 0, 0] == 0).all() and (top[0, 0, 2] == 3).all()
+    idx = so.max_value_indices_region(None, (1, 3, 3, 1), x)
+    npt.assert_array_equal(idx, [[0, 0, 2, 0]])
+    assert len(so.max_value_indices_region(None, (1, 2, 2, 1), allnan)) == 0
+    # the C port follows the same rule
+    npt.assert_array_equal(co.nms3x3(x), so.nms3x3(x))
+    npt.assert_array_equal(co.top_value_points(color, 0.5), top)
+    npt.assert_array_equal(co.max_value_indices_region(None, (1, 3, 3, 1), x), idx)
+
+
+@pytest.mark.parametrize("h,w,oh,ow", [(192, 288, 116, 174), (7, 5, 3, 2), (5, 9, 5, 9), (3, 4, 7, 9)])
+def test_resize_nearest_tf1_against_torch(h, w, oh, ow):
+    """TF1 ResizeNearestNeighbor (align_corners=False): src = min(floor(dst * float32(in / out)), in - 1) -- the same
+    rule as torch's legacy 'nearest' mode."""
+    torch = pytest.importorskip("torch")
+    x = noise_frame(4, h, w, 2)[None]
+    want = torch.nn.functional.interpolate(torch.from_numpy(x).permute(0, 3, 1, 2), size=(oh, ow), mode="nearest")
+    npt.assert_array_equal(so.resize_nearest_tf1(x, oh, ow), want.permute(0, 2, 3, 1).numpy())
+
+
+@pytest.mark.parametrize("h,w,rh,rw", [(192, 288, 96, 144), (37, 53, 18, 26), (16, 16, 5, 7), (9, 31, 9, 4), (40, 40, 3, 3)])
+def test_region_pool_and_where_order_against_torch(h, w, rh, rw):
+    """max_value_indices_region = max_pool(k = (H, W), stride = region, SAME) > NEAREST resize > tf.where, rebuilt with
+    torch: explicit SAME padding (pad_before = pad_total // 2, -inf) + max_pool2d, legacy nearest interpolate, nonzero
+    (row-major, like tf.where)."""
+    torch = pytest.importorskip("torch")
+    F = torch.nn.functional
+    v = noise_frame(6, h, w, 1)[None]
+    v[0, :3, :3] = 300.0                                       # a tie plateau
+    t = torch.from_numpy(v).permute(0, 3, 1, 2)
+    oh, ow = -(-h // rh), -(-w // rw)
+    ph, pw = max((oh - 1) * rh + h - h, 0), max((ow - 1) * rw + w - w, 0)
+    padded = F.pad(t, (pw // 2, pw - pw // 2, ph // 2, ph - ph // 2), value=float("-inf"))
+    pooled = F.max_pool2d(padded, (h, w), stride=(rh, rw))
+    assert pooled.shape[-2:] == (oh, ow)
+    thr = F.interpolate(pooled, size=(h, w), mode="nearest")
+    want = torch.nonzero((t >= thr).permute(0, 2, 3, 1)).numpy()
+    npt.assert_array_equal(so.max_value_indices_region(None, (1, rh, rw, 1), v), want)
+    npt.assert_array_equal(co.max_value_indices_region(None, (1, rh, rw, 1), v), want)
+
+
+@pytest.mark.parametrize("h,w,r", [(192, 288, 3), (37, 53, 3), (10, 11, 4), (5, 5, 2)])
+def test_centroid_box_sums_against_torch(h, w, r):
+    """get_centroids' strided box sums (tf.nn.convolution, window = stride = region, SAME) rebuilt with torch conv2d on
+    explicitly SAME-padded inputs; float64 there, so compare at float32 resolution."""
+    torch = pytest.importorskip("torch")
+    F = torch.nn.functional
+    v = (noise_frame(8, h, w, 1)[None] / np.float32(255.0)).astype(np.float32)
+    cent, total = so.get_centroids(v, [1, r, r])
+    t = torch.from_numpy(v).permute(0, 3, 1, 2).double()
+    oh, ow = -(-h // r), -(-w // r)
+    ph, pw = max((oh - 1) * r + r - h, 0), max((ow - 1) * r + r - w, 0)
+    pad = (pw // 2, pw - pw // 2, ph // 2, ph - ph // 2)
+    ones = torch.ones(1, 1, r, r, dtype=torch.float64)
+    tot = F.conv2d(F.pad(t, pad), ones, stride=r)
+    xs = torch.arange(w, dtype=torch.float64)[None, None, None, :].expand(1, 1, h, w)
+    ys = torch.arange(h, dtype=torch.float64)[None, None, :, None].expand(1, 1, h, w)
+    cx = F.conv2d(F.pad(t * xs, pad), ones, stride=r) / tot
+    cy = F.conv2d(F.pad(t * ys, pad), ones, stride=r) / tot
+    npt.assert_allclose(total[0, :, :, 0], tot[0, 0].numpy(), rtol=2e-6)
+    cxr = F.interpolate(cx, size=(h, w), mode="nearest")
+    cyr = F.interpolate(cy, size=(h, w), mode="nearest")
+    want = ((cxr - xs).abs() + (cyr - ys).abs())[0, 0].numpy()
+    npt.assert_allclose(cent[0, :, :, 0], want, rtol=1e-5, atol=1e-4)
