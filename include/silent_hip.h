@@ -167,6 +167,20 @@ int silent_pyramid_plan_is_streamable(const silent_pyramid_plan* plan);
 int silent_set_profiling(silent_ctx* ctx, int enable);
 int silent_profile_elapsed_ms(silent_ctx* ctx, float* ms, int64_t* pixels);
 
+/* Kernel-selection knobs for tests and A/B timing (no reference counterpart: the reference has one code path).
+ * Every context starts from the environment variables SILENT_GRAY_OPTS / SILENT_RGB_OPTS / SILENT_PYRAMID_OPTS, read
+ * once in silent_create; silent_set_tuning changes a knob of one context afterwards.  Bits -- GRAY: 1 XCD-aware tile
+ * order, 2 32-row filter tiles, 8 32-row fused tiles, 16 no single-read stream kernel, 32 XCD order in the stream
+ * kernel, 64 no strip-walk kernel; RGB: 1 dense weights, 2 no two-group form, 8 no short tiles; PYRAMID: 1 no
+ * single-read pyramid.  All variants give the same results (bit-identical, or within the re-association tolerance
+ * for the RGB forms); the defaults are the fastest measured. */
+#define SILENT_TUNE_GRAY 0
+#define SILENT_TUNE_RGB 1
+#define SILENT_TUNE_PYRAMID 2
+#define SILENT_TUNE_COUNT 3
+int silent_set_tuning(silent_ctx* ctx, int which, unsigned value);
+int silent_get_tuning(const silent_ctx* ctx, int which, unsigned* value);
+
 /* ---------------------------------------------------------------------------- a-6 regulator
  * Replaces regulate_tensor, slam_recognition/util/regulator/gaussian_regulator_tensor.py:10-36:
  *   y = x * (rv / pow(min(conv(x, blur), 1), root)); blur is HWIO [kh, kw, C, C]. */

@@ -28,6 +28,7 @@ NMS_FIRED = 1
 RECOVERY_CONSTANT = 1
 RECOVERY_INPUT = 2
 MAX_LEVELS = 16
+TUNE_GRAY, TUNE_RGB, TUNE_PYRAMID = 0, 1, 2
 ABI_VERSION = 1
 
 
@@ -93,6 +94,8 @@ _SIGNATURES = {
     "silent_gray_pass_dev": [_vp, _vp, _fp, _i, _fp, _fp, _i, _f, _fp, _fp, _fp, _vp],
     "silent_pyramid_plan_is_streamable": [_vp],
     "silent_set_profiling": [_vp, _i],
+    "silent_set_tuning": [_vp, _i, _u],
+    "silent_get_tuning": [_vp, _i, C.POINTER(C.c_uint)],
     "silent_profile_elapsed_ms": [_vp, C.POINTER(_f), C.POINTER(C.c_int64)],
     "silent_regulate": [_vp, _fp, _ep, _i, _i, _i, _fp, _i, _i, _f, _f, _i, _fp],
     "silent_regulate_dev": [_vp, _fp, _ep, _i, _i, _i, _fp, _i, _i, _f, _f, _i, _fp, _vp],

@@ -42,6 +42,15 @@ class Context(object):
     def check(self, rc):
         _lib.check(rc, self.handle)
 
+    def set_tuning(self, which, value):
+        """Kernel-selection knob of this context (silent_set_tuning): _lib.TUNE_GRAY / TUNE_RGB / TUNE_PYRAMID."""
+        self.check(self._lib.silent_set_tuning(self.handle, int(which), C.c_uint(int(value))))
+
+    def get_tuning(self, which):
+        v = C.c_uint(0)
+        self.check(self._lib.silent_get_tuning(self.handle, int(which), C.byref(v)))
+        return int(v.value)
+
     def close(self):
         if self.handle:
             self._lib.silent_destroy(self.handle)
@@ -91,6 +100,23 @@ def get_context(device=None):
     if ctx is None:
         ctx = _contexts[device] = Context(device)
     return ctx
+
+
+class tuning(object):
+    """``with tuning(TUNE_RGB, 1): ...`` -- run the ops inside with a kernel-selection knob of the current context set."""
+
+    def __init__(self, which, value, device=None):
+        self.which, self.value, self.device = which, value, device
+
+    def __enter__(self):
+        self.ctx = get_context(self.device)
+        self.old = self.ctx.get_tuning(self.which)
+        self.ctx.set_tuning(self.which, self.value)
+        return self.ctx
+
+    def __exit__(self, *exc):
+        self.ctx.set_tuning(self.which, self.old)
+        return False
 
 
 def device_count():

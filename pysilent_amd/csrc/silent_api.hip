@@ -42,6 +42,33 @@ struct silent_ctx {
     int prof_period = 1, prof_calls = 0, prof_recorded = 0;
     bool prof_sample = false;
     long long prof_pixels = 0;
+    // kernel-selection knobs (silent_set_tuning; initial values from SILENT_GRAY_OPTS / SILENT_RGB_OPTS /
+    // SILENT_PYRAMID_OPTS read ONCE, in silent_create): tests and A/B scripts pick alternative kernels with them
+    unsigned tune[SILENT_TUNE_COUNT] = {0, 0, 0};
+};
+
+// Entry points run on the context's device and put the caller's device back before they return: torch tracks its
+// current device through hipGetDevice, so a context on another GPU must not move it.
+struct DeviceGuard {
+    int prev = -1;
+    bool ok = true;
+    explicit DeviceGuard(int dev) {
+        int cur = -1;
+        if (hipGetDevice(&cur) != hipSuccess) {
+            (void)hipGetLastError();
+            cur = -1;
+        }
+        if (cur != dev) {
+            ok = hipSetDevice(dev) == hipSuccess;
+            if (!ok) (void)hipGetLastError();
+            prev = cur;
+        }
+    }
+    ~DeviceGuard() {
+        if (prev >= 0) (void)hipSetDevice(prev);
+    }
+    DeviceGuard(const DeviceGuard&) = delete;
+    DeviceGuard& operator=(const DeviceGuard&) = delete;
 };
 
 struct silent_pyramid_plan {
@@ -122,7 +149,8 @@ SILENT_EXPORT int silent_create(int device, silent_ctx** out) {
         return fail(nullptr, SILENT_E_INVALID,
                     "silent_create: device " + std::to_string(device) + " out of range (" + std::to_string(n) +
                         " visible)");
-    HIP_TRY(nullptr, hipSetDevice(device));
+    DeviceGuard guard(device);
+    if (!guard.ok) return fail(nullptr, SILENT_E_HIP, "silent_create: hipSetDevice failed");
     hipDeviceProp_t prop;
     HIP_TRY(nullptr, hipGetDeviceProperties(&prop, device));
     silent_ctx* ctx = new (std::nothrow) silent_ctx();
@@ -134,13 +162,29 @@ SILENT_EXPORT int silent_create(int device, silent_ctx** out) {
         delete ctx;
         return fail(nullptr, SILENT_E_UNSUPPORTED, m);
     }
+    const char* names[SILENT_TUNE_COUNT] = {"SILENT_GRAY_OPTS", "SILENT_RGB_OPTS", "SILENT_PYRAMID_OPTS"};
+    for (int i = 0; i < SILENT_TUNE_COUNT; ++i)
+        if (const char* e = std::getenv(names[i])) ctx->tune[i] = (unsigned)std::strtoul(e, nullptr, 0);
     *out = ctx;
+    return SILENT_OK;
+}
+
+SILENT_EXPORT int silent_set_tuning(silent_ctx* ctx, int which, unsigned value) {
+    if (!ctx) return fail(nullptr, SILENT_E_INVALID, "silent_set_tuning: ctx is NULL");
+    if (which < 0 || which >= SILENT_TUNE_COUNT) return fail(ctx, SILENT_E_INVALID, "silent_set_tuning: unknown knob");
+    ctx->tune[which] = value;
+    return SILENT_OK;
+}
+
+SILENT_EXPORT int silent_get_tuning(const silent_ctx* ctx, int which, unsigned* value) {
+    if (!ctx || !value || which < 0 || which >= SILENT_TUNE_COUNT) return SILENT_E_INVALID;
+    *value = ctx->tune[which];
     return SILENT_OK;
 }
 
 SILENT_EXPORT void silent_destroy(silent_ctx* ctx) {
     if (!ctx) return;
-    (void)hipSetDevice(ctx->device);
+    DeviceGuard guard(ctx->device);
     if (ctx->arena.p) (void)hipFree(ctx->arena.p);
     if (ctx->ws.p) (void)hipFree(ctx->ws.p);
     for (auto& pr : ctx->prof_ev)
@@ -161,7 +205,8 @@ SILENT_EXPORT int silent_device_name(const silent_ctx* ctx, char* buf, size_t le
 
 #define NEED_CTX(ctx)                  \
     if (!(ctx)) return fail(nullptr, SILENT_E_INVALID, std::string(__func__) + ": ctx is NULL"); \
-    HIP_TRY(ctx, hipSetDevice((ctx)->device))
+    DeviceGuard device_guard_((ctx)->device);                                                    \
+    if (!device_guard_.ok) return fail(ctx, SILENT_E_HIP, std::string(__func__) + ": hipSetDevice failed")
 
 SILENT_EXPORT int silent_malloc(silent_ctx* ctx, size_t bytes, void** dptr) {
     NEED_CTX(ctx);
@@ -338,8 +383,7 @@ SILENT_EXPORT int silent_regulate_dev(silent_ctx* ctx, const float* in, const si
         for (int t = 0; t < 49 && uniform; ++t)
             for (int io = 1; io < 9; ++io)
                 if (blur_hwio[t * 9 + io] != blur_hwio[t * 9]) uniform = false;
-        unsigned kopts = 0;
-        if (const char* e = std::getenv("SILENT_RGB_OPTS")) kopts = (unsigned)std::strtoul(e, nullptr, 0);
+        const unsigned kopts = ctx->tune[SILENT_TUNE_RGB];
         if (uniform && !(kopts & 1u)) {
             RegArgs a;
             long long blocks;
@@ -371,8 +415,7 @@ static int launch_gray(silent_ctx* ctx, const char* who, const float* pyr, const
         return fail(ctx, SILENT_E_UNSUPPORTED, std::string(who) + ": n_orient must be 3, 4 or 8");
     // development knob for interleaved A/B timing (scripts/ab_gray.py): bit0 XCD-aware tile order (measured
     // 7 % slower, off), bit1 32-row tiles (3 % slower, off), bit2 non-temporal stores (no effect, off)
-    const char* knob = std::getenv("SILENT_GRAY_OPTS");
-    const unsigned opts = knob ? (unsigned)std::atoi(knob) : 0u;
+    const unsigned opts = ctx->tune[SILENT_TUNE_GRAY];
     const int th = (opts & 2u) ? 32 : kGrayTH;
     LevelTab tab;
     long long blocks;
@@ -953,8 +996,7 @@ SILENT_EXPORT int silent_rgb_line_end_dev(silent_ctx* ctx, const float* pyr, con
         LevelTab tab;
         long long blocks;
         TRY(build_level_tab(ctx, who, levels, n_levels, n_frames, kRgbTW, kRgbTH, &tab, &blocks));
-        unsigned kopts = 0;
-        if (const char* e = std::getenv("SILENT_RGB_OPTS")) kopts = (unsigned)std::strtoul(e, nullptr, 0);  // 1: dense, 2: no two-group, 8: no short tiles
+        const unsigned kopts = ctx->tune[SILENT_TUNE_RGB];  // 1: dense, 2: no two-group, 8: no short tiles
         // few tiles: latency of one wave's row walk, not throughput, sets the time -> short tiles (silent_rgb.h)
         const bool small = blocks < kRgbSmallBlocks && !(kopts & 8u);
         if (small) TRY(build_level_tab(ctx, who, levels, n_levels, n_frames, kRgbTW, kRgbTHSmall, &tab, &blocks));
@@ -1341,7 +1383,7 @@ SILENT_EXPORT int silent_pyramid_plan_create(silent_ctx* ctx, int frame_h, int f
 
 SILENT_EXPORT void silent_pyramid_plan_destroy(silent_pyramid_plan* plan) {
     if (!plan) return;
-    if (plan->ctx) (void)hipSetDevice(plan->ctx->device);
+    DeviceGuard guard(plan->ctx ? plan->ctx->device : 0);
     if (plan->tables) (void)hipFree(plan->tables);
     if (plan->stream_tables) (void)hipFree(plan->stream_tables);
     delete plan;
@@ -1358,8 +1400,7 @@ static int launch_pyramid(silent_ctx* ctx, const char* who, const silent_pyramid
     const long long b_zero = (long long)tab.zero_chunks_per_frame * n_frames;
     if (b_unit > 0x7fffffffll || b_region > 0x7fffffffll || b_zero > 0x7fffffffll)
         return fail(ctx, SILENT_E_INVALID, std::string(who) + ": too many tiles for one launch");
-    unsigned kopts = 0;
-    if (const char* e = std::getenv("SILENT_PYRAMID_OPTS")) kopts = (unsigned)std::strtoul(e, nullptr, 0);  // 1: no stream kernel
+    const unsigned kopts = ctx->tune[SILENT_TUNE_PYRAMID];  // 1: no stream kernel
     if (plan->stream_ok && with_unit && with_region && !(kopts & 1u)) {
         // single-read pyramid: frame -> every level in one kernel (pyramid_stream_kernel; single-channel plans only:
         // on interleaved RGB the stride-3 accesses of the same kernel made it 1.5x SLOWER than unit + region kernels)
@@ -1452,8 +1493,7 @@ SILENT_EXPORT int silent_gray_pass_dev(silent_ctx* ctx, const silent_pyramid_pla
     if (n_frames < 1) return fail(ctx, SILENT_E_INVALID, std::string(who) + ": n_frames must be >= 1");
     hipStream_t s = (hipStream_t)stream;
     const PyrTab& pt = plan->tab;
-    const char* knob = std::getenv("SILENT_GRAY_OPTS");  // A/B knobs: bit3 32-row fused tiles, bit4 disable the stream path
-    const int kopts = knob ? std::atoi(knob) : 0;
+    const int kopts = (int)ctx->tune[SILENT_TUNE_GRAY];  // A/B knobs: bit3 32-row fused tiles, bit4 disable the stream path
     const bool stream_path = plan->stream_ok && !(kopts & 16);
     // 1. non-unit levels of the pyramid: by the region kernel, unless the stream kernel of step 2 produces them
     //    from the same single read of the frame; plus the zero fill of canvases larger than their zoomed crop

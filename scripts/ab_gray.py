@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Interleaved A/B timing of gray_line_end_kernel variants in ONE process (dev tool, GPU box).
-Variants are selected through the SILENT_GRAY_OPTS environment knob read at every launch."""
+Variants are selected through the GRAY tuning knob of the context (silent_set_tuning)."""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
@@ -15,7 +15,7 @@ variants = [v for v in (sys.argv[1:] or ["0", "1"])]
 times = {v: [] for v in variants}
 for rnd in range(12):
     for v in variants:
-        os.environ["SILENT_GRAY_OPTS"] = v
+        pipe.ctx.set_tuning(0, int(v))
         a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         a.record()
         for _ in range(5):

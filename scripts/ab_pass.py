@@ -17,7 +17,7 @@ if os.environ.get("AB_QUICK"):
 times = {k: [] for k in variants}
 for rnd in range(12):
     for k, (opt, fn) in variants.items():
-        os.environ["SILENT_GRAY_OPTS"] = opt
+        pipe.ctx.set_tuning(0, int(opt))
         a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         a.record()
         for _ in range(5):
@@ -32,7 +32,7 @@ for k in variants:
     print("%-10s median %.4f ms  min %.4f  max %.4f   %.0f GB/s algorithmic = %.1f %% of 8 TB/s" % (k, np.median(t), t.min(), t.max(), byt / np.median(t) / 1e6, byt / np.median(t) / 1e6 / 80))
 
 # dominant kernel alone (HIP events recorded by the library around its launch) + a device copy for calibration
-os.environ["SILENT_GRAY_OPTS"] = os.environ.get("AB_BASE_OPTS", "0")
+pipe.ctx.set_tuning(0, int(os.environ.get("AB_BASE_OPTS", "0")))
 ks = []
 for _ in range(30):
     pipe.set_profiling(1)          # resets the sample ring: one pair per step here

@@ -13,7 +13,7 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 import numpy as np
 import silent_oracle as so
 from conftest import assert_close, noise_frame, structured_frame
-from pysilent_amd import _runtime as rt
+from pysilent_amd import _lib, _runtime as rt
 from pysilent_amd.util.zoom.from_image import classic_levels
 
 RTOL = 1e-5
@@ -49,10 +49,10 @@ def case_gray_pass(rng, k):
     K = int(rng.choice([3, 4, 8]))
     B = int(rng.integers(1, 4))
     # development knobs select other (bit-identical) code paths: tile order, 32-row tiles, no stream path, unit + region pyramid
-    os.environ["SILENT_GRAY_OPTS"] = str(int(rng.choice([0, 0, 1, 2, 3, 8, 16, 24])))
-    os.environ["SILENT_PYRAMID_OPTS"] = str(int(rng.choice([0, 0, 1])))
-    desc = "gray_pass h=%d w=%d scale=%.3f n=%d K=%d B=%d knobs=%s/%s" % (
-        h, w, scale, n, K, B, os.environ["SILENT_GRAY_OPTS"], os.environ["SILENT_PYRAMID_OPTS"])
+    kg, kp = int(rng.choice([0, 0, 1, 2, 3, 8, 16, 24, 64, 80])), int(rng.choice([0, 0, 1]))
+    rt.get_context().set_tuning(_lib.TUNE_GRAY, kg)
+    rt.get_context().set_tuning(_lib.TUNE_PYRAMID, kp)
+    desc = "gray_pass h=%d w=%d scale=%.3f n=%d K=%d B=%d knobs=%s/%s" % (h, w, scale, n, K, B, kg, kp)
     try:
         levels = classic_levels((h, w), scale, n)
     except ValueError:
@@ -84,8 +84,9 @@ def case_rgb(rng, k):
     n = int(rng.integers(1, 5))
     B = int(rng.integers(1, 3))
     # 0: specialised kernel, 18-row tiles; 8: 90-row tiles; 1 / 2: dense / no two-group forms; 9, 10: combinations
-    os.environ["SILENT_RGB_OPTS"] = str(int(rng.choice([0, 0, 8, 1, 2, 9, 10])))
-    desc = "rgb h=%d w=%d scale=%.3f n=%d B=%d knob=%s" % (h, w, scale, n, B, os.environ["SILENT_RGB_OPTS"])
+    kr = int(rng.choice([0, 0, 8, 1, 2, 9, 10]))
+    rt.get_context().set_tuning(_lib.TUNE_RGB, kr)
+    desc = "rgb h=%d w=%d scale=%.3f n=%d B=%d knob=%s" % (h, w, scale, n, B, kr)
     try:
         levels = classic_levels((h, w), scale, n)
     except ValueError:

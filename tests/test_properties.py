@@ -146,15 +146,14 @@ def test_random_cases_through_the_c_abi():
     fz = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(fz)
     k = fz.make_kernels()
-    saved = {v: os.environ.get(v) for v in ("SILENT_GRAY_OPTS", "SILENT_PYRAMID_OPTS", "SILENT_RGB_OPTS")}
+    from pysilent_amd import _runtime
+    ctx = _runtime.get_context()
+    saved = [ctx.get_tuning(i) for i in range(3)]
     try:
         rng = np.random.default_rng(2026)
         for i in range(160):
             name = list(fz.CASES)[i % len(fz.CASES)]
             fz.CASES[name](np.random.default_rng(int(rng.integers(0, 1 << 31))), k)
     finally:
-        for v, val in saved.items():
-            if val is None:
-                os.environ.pop(v, None)
-            else:
-                os.environ[v] = val
+        for i, v in enumerate(saved):
+            ctx.set_tuning(i, v)
