@@ -85,6 +85,10 @@ int silent_malloc(silent_ctx* ctx, size_t bytes, void** dptr);
 int silent_free(silent_ctx* ctx, void* dptr);
 int silent_memcpy_h2d(silent_ctx* ctx, void* dst_dev, const void* src_host, size_t bytes, silent_stream stream);
 int silent_memcpy_d2h(silent_ctx* ctx, void* dst_host, const void* src_dev, size_t bytes, silent_stream stream);
+/* n device buffers -> ONE host buffer, back to back, with a single synchronisation at the end: the fetch of
+ * session.run([t0 .. t5]) (slam_recognition/recognition_testing.py:132) for results that live on the device. */
+int silent_gather_d2h(silent_ctx* ctx, void* dst_host, const void* const* src_dev, const size_t* bytes, int n,
+                      silent_stream stream);
 int silent_synchronize(silent_ctx* ctx, silent_stream stream);
 
 /* ---------------------------------------------------------------------------- a-1 pyramid

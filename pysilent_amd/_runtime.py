@@ -477,6 +477,26 @@ def affine_clip(x, mul=1.0, add=0.0, lo=-float("inf"), hi=float("inf"), post_add
     return op.wrap(out, op.c)
 
 
+def gather_to_host(tensors):
+    """Contiguous float32 GPU tensors (torch) -> one flat float32 np.ndarray holding them back to back
+    (silent_gather_d2h: n async device-to-host copies on the tensors' current stream, ONE synchronisation)."""
+    import torch
+    n = len(tensors)
+    if n == 0:
+        return np.empty(0, np.float32)
+    dev = tensors[0].device
+    for t in tensors:
+        if not (t.is_cuda and t.device == dev and t.dtype == torch.float32 and t.is_contiguous()):
+            raise ValueError("gather_to_host: contiguous float32 tensors on one GPU expected")
+    ctx = get_context(dev.index)
+    host = np.empty(sum(t.numel() for t in tensors), np.float32)
+    srcs = (C.c_void_p * n)(*[t.data_ptr() for t in tensors])
+    sizes = (C.c_size_t * n)(*[t.numel() * 4 for t in tensors])
+    ctx.check(ctx._lib.silent_gather_d2h(ctx.handle, C.c_void_p(host.ctypes.data), srcs, sizes, n,
+                                          C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)))
+    return host
+
+
 def resize_nearest(x, out_extents):
     """silent_resize_nearest.  ``out_extents``: one (h, w) for an NHWC tensor, one per level for a PackedPyramid."""
     op = _Operand(x)

@@ -238,6 +238,20 @@ SILENT_EXPORT int silent_memcpy_d2h(silent_ctx* ctx, void* dst, const void* src,
     return SILENT_OK;
 }
 
+SILENT_EXPORT int silent_gather_d2h(silent_ctx* ctx, void* dst_host, const void* const* src_dev, const size_t* bytes,
+                                    int n, silent_stream stream) {
+    NEED_CTX(ctx);
+    if (n < 0 || (n && (!dst_host || !src_dev || !bytes))) return fail(ctx, SILENT_E_INVALID, "silent_gather_d2h: NULL pointer");
+    char* dst = (char*)dst_host;
+    for (int i = 0; i < n; ++i) {
+        if (bytes[i] && !src_dev[i]) return fail(ctx, SILENT_E_INVALID, "silent_gather_d2h: NULL source");
+        HIP_TRY(ctx, hipMemcpyAsync(dst, src_dev[i], bytes[i], hipMemcpyDeviceToHost, (hipStream_t)stream));
+        dst += bytes[i];
+    }
+    HIP_TRY(ctx, hipStreamSynchronize((hipStream_t)stream));
+    return SILENT_OK;
+}
+
 SILENT_EXPORT int silent_synchronize(silent_ctx* ctx, silent_stream stream) {
     NEED_CTX(ctx);
     HIP_TRY(ctx, hipStreamSynchronize((hipStream_t)stream));

@@ -127,8 +127,9 @@ class LineEndDisplayer(PyramidDisplayer):
         outs = self.run_device(pyramid_tensor)
         if any(t.dtype != torch.float32 for t in outs):
             return [t.cpu().numpy() for t in outs]
-        # one device-to-host copy (and one synchronisation) for the six maps instead of six
-        host = torch.cat([t.reshape(-1) for t in outs]).cpu().numpy()
+        # the six maps come back through ONE library call (silent_gather_d2h: six async copies into one host buffer,
+        # one synchronisation) -- no torch kernel anywhere on this path
+        host = _runtime.gather_to_host(outs)
         res, o = [], 0
         for t in outs:
             res.append(host[o:o + t.numel()].reshape(tuple(t.shape)))

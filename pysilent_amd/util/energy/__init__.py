@@ -19,3 +19,4 @@ def has_fired(tensor):
 
 
 from .boosting import get_boosting, initialize_boosting  # noqa: E402
+from .recovery import generate_recovery  # noqa: E402,F401

@@ -1,3 +1,6 @@
+// HISTORICAL COPY (round 1) of pysilent_amd/csrc/silent_conv.h WITH the leave-one-out experiment branches (-DSILENT_EXPERIMENT=n:
+// wrong results by design) that produced profiles/r01c/leave_one_out_*.txt.  Not part of the product; scripts/experiment_builds.sh
+// compiles it in a scratch copy of csrc/.
 // Stencil kernels: generic SAME conv2d (NHWC x HWIO) and the fused grayscale CS -> end-bank pass.
 // HBM-bound stencil/pointwise work: coalesced tile loads into LDS, filters unrolled in registers,
 // weights held in SGPRs (they arrive as kernel arguments), no MFMA.
@@ -585,9 +588,14 @@ __global__ __launch_bounds__(256) void gray_stream_kernel(const float* __restric
         for (int j = 0; j < 6; ++j) gw[g][j] = 0.0f;
     }
     if (live) {
+#if defined(SILENT_EXPERIMENT) && (SILENT_EXPERIMENT >= 3 && SILENT_EXPERIMENT != 8)   // no frame loads at all
+#pragma unroll
+        for (int i = 0; i < R + 8; ++i) in[i] = (float)(i + lane) + clip_hi;
+#else
 #pragma unroll
         for (int i = 0; i < R + 8; ++i)
             in[i] = src[(long long)(mirror_near(y0 - 4 + i, lv.src_h) + lv.src_y0) * W + sx];
+#endif
 #pragma unroll
         for (int g = 0; g < G; ++g) {
             const int gg = min(g, st.G - 1);
@@ -633,7 +641,11 @@ __global__ __launch_bounds__(256) void gray_stream_kernel(const float* __restric
 #pragma unroll
     for (int e = 0; e < PR; ++e) cur[e] = prog[e];
     float c0 = s_rows[wave][0][lane];
+#if defined(SILENT_EXPERIMENT) && (SILENT_EXPERIMENT == 7 || SILENT_EXPERIMENT == 8)
+    const int nr_run = clip_hi == -12345.0f ? NR : 0;
+#else
     const int nr_run = NR;
+#endif
 #pragma unroll 1
     for (int i = 0; i < nr_run; ++i) {
         // record and row of the NEXT step are requested before this step's work
@@ -697,7 +709,11 @@ __global__ __launch_bounds__(256) void gray_stream_kernel(const float* __restric
     const int eff_h = min(lv.zoom_h, lv.out_h), eff_w = min(lv.zoom_w, lv.out_w);
     const bool col_eff = ox >= 0 && ox < eff_w;       // inside the zoomed crop (zero outside it)
     const bool col_in = ox >= 0 && ox < lv.out_w;     // inside the level (zero padding of the convolutions)
+#if defined(SILENT_EXPERIMENT) && (SILENT_EXPERIMENT == 1 || SILENT_EXPERIMENT == 6 || SILENT_EXPERIMENT == 7)   // no stores from pass 1
+    const bool out_lane = lane >= 4 && lane < 4 + kFusedCols && ox < lv.out_w && clip_hi == -12345.0f;
+#else
     const bool out_lane = lane >= 4 && lane < 4 + kFusedCols && ox < lv.out_w;
+#endif
     const long long wave_px = base_px + (xw0 - 4);    // + row * out_w + lane: wave-uniform part of every address
     // The two 1-channel maps of the unit level are written with NON-TEMPORAL stores (nt: streamed through L2 without
     // displacing the frame rows that neighbouring tiles re-read): -6...-9 % in alternating A/B.  Measured with it:
@@ -719,6 +735,9 @@ __global__ __launch_bounds__(256) void gray_stream_kernel(const float* __restric
         for (int i = 0; i < R + 8; ++i) {
             {
                 const float c0 = s_rows[wave][i][lane];
+#if defined(SILENT_EXPERIMENT) && (SILENT_EXPERIMENT >= 2 && SILENT_EXPERIMENT < 8)   // no arithmetic (loads + stores only)
+                float h = c0;
+#else
                 const float l1 = from_lane_below(c0), l2 = from_lane_below(l1);
                 const float r1 = from_lane_above(c0), r2 = from_lane_above(r1);
                 float h = wv[0] * l2;
@@ -726,19 +745,28 @@ __global__ __launch_bounds__(256) void gray_stream_kernel(const float* __restric
                 h = __builtin_fmaf(wv[2], c0, h);
                 h = __builtin_fmaf(wv[3], r1, h);
                 h = __builtin_fmaf(wv[4], r2, h);
+#endif
 #pragma unroll
                 for (int j = 0; j < 4; ++j) hw[j] = hw[j + 1];
                 hw[4] = h;
             }
             if (i >= 4) {
                 const int p = y0 + i - 6;
+#if defined(SILENT_EXPERIMENT) && (SILENT_EXPERIMENT >= 2 && SILENT_EXPERIMENT < 8)
+                float v = hw[2];
+#else
                 float v = wv[0] * hw[0];
 #pragma unroll
                 for (int j = 1; j < 5; ++j) v = __builtin_fmaf(wv[j], hw[j], v);
                 v = (p >= 0 && p < eff_h && col_eff) ? v : 0.0f;
+#endif
                 if (p >= y0 && p < y0 + R && p < lv.out_h) {  // wave-uniform
                     float* __restrict__ prow = pyr + (wave_px + (long long)p * lv.out_w);
+#if defined(SILENT_EXPERIMENT) && SILENT_EXPERIMENT == 4   // stores only, and only the end maps
+                    if (out_lane && clip_hi == -12345.0f) prow[lane] = v;
+#else
                     if (out_lane) __builtin_nontemporal_store(v, prow + lane);
+#endif
                 }
 #pragma unroll
                 for (int b = 0; b < 3; ++b) {
@@ -746,11 +774,16 @@ __global__ __launch_bounds__(256) void gray_stream_kernel(const float* __restric
                     iw[1][b] = iw[2][b];
                 }
                 iw[2][1] = v;
+#if !(defined(SILENT_EXPERIMENT) && (SILENT_EXPERIMENT >= 2 && SILENT_EXPERIMENT < 8))
                 iw[2][0] = from_lane_below(v);
                 iw[2][2] = from_lane_above(v);
+#endif
             }
             if (i >= 6) {
                 const int c = y0 + i - 7;
+#if defined(SILENT_EXPERIMENT) && (SILENT_EXPERIMENT >= 2 && SILENT_EXPERIMENT < 8)
+                const float cs = iw[1][1];
+#else
                 float acc = 0.0f;
 #pragma unroll
                 for (int dy = 0; dy < 3; ++dy)
@@ -758,14 +791,17 @@ __global__ __launch_bounds__(256) void gray_stream_kernel(const float* __restric
                     for (int dx = 0; dx < 3; ++dx) acc = __builtin_fmaf(iw[dy][dx], csw[dy * 3 + dx], acc);
                 // relu (a NaN stays a NaN) and the zero padding of the end convolution in one select
                 const float cs = (c >= 0 && c < lv.out_h && col_in && !(acc < 0.0f)) ? acc : 0.0f;
+#endif
 #pragma unroll
                 for (int b = 0; b < 3; ++b) {
                     cw[0][b] = cw[1][b];
                     cw[1][b] = cw[2][b];
                 }
                 cw[2][1] = cs;
+#if !(defined(SILENT_EXPERIMENT) && (SILENT_EXPERIMENT >= 2 && SILENT_EXPERIMENT < 8))
                 cw[2][0] = from_lane_below(cs);
                 cw[2][2] = from_lane_above(cs);
+#endif
             }
             if (i >= 8) {
                 const int y = y0 + i - 8;
@@ -773,12 +809,20 @@ __global__ __launch_bounds__(256) void gray_stream_kernel(const float* __restric
                     const long long row_px = wave_px + (long long)y * lv.out_w;
                     if (cs_out) {
                         float* __restrict__ crow = cs_out + row_px;
+#if defined(SILENT_EXPERIMENT) && SILENT_EXPERIMENT == 4
+                        if (out_lane && clip_hi == -12345.0f) crow[lane] = cw[1][1];
+#else
                         if (out_lane) __builtin_nontemporal_store(cw[1][1], crow + lane);
+#endif
                     }
                     if (end_out) {
                         float acc[K];
 #pragma unroll
                         for (int k = 0; k < K; ++k) acc[k] = 0.0f;
+#if defined(SILENT_EXPERIMENT) && (SILENT_EXPERIMENT >= 2 && SILENT_EXPERIMENT < 8)
+#pragma unroll
+                        for (int k = 0; k < K; ++k) acc[k] = cw[1][1];
+#else
 #pragma unroll
                         for (int dy = 0; dy < 3; ++dy)
 #pragma unroll
@@ -791,14 +835,19 @@ __global__ __launch_bounds__(256) void gray_stream_kernel(const float* __restric
                                 }
 #pragma unroll
                         for (int k = 0; k < K; ++k) acc[k] = clip_hi_tf(relu_tf(acc[k]), clip_hi);
+#endif
                         if constexpr (K == 8) {
                             const int ncols = min(kFusedCols, lv.out_w - xw0);
                             store_row_k8(end_out + row_px * 8, acc, s_slab + wave * 512, lane, 4, ncols);
                         } else if constexpr (K == 4) {
                             float4* __restrict__ erow = reinterpret_cast<float4*>(end_out + row_px * 4);
+#if defined(SILENT_EXPERIMENT) && SILENT_EXPERIMENT == 5   // stores only, and only the 1-channel maps
+                            if (out_lane && clip_hi == -12345.0f) erow[lane] = make_float4(acc[0], acc[1], acc[2], acc[3]);
+#else
                             if (out_lane) {
                                 erow[lane] = make_float4(acc[0], acc[1], acc[2], acc[3]);
                             }
+#endif
                         } else {
                             float* __restrict__ po = end_out + row_px * K;
                             if (out_lane) {

@@ -69,8 +69,10 @@ def assert_close(got, want, rtol=1e-5, scale=None, what="", rel_floor=0.1):
         The floor is where float32 arithmetic CAN hold 1e-5: a 9-tap stencil whose taps cancel (sum of |w x| up to
         2 * range) carries an absolute rounding error of a few float32 ulps of the range (~3e-5 at range 255) in any
         evaluation order -- the reference's own TF float32 convolution included -- so a value of 1e-3 * range cannot
-        be reproduced to 1e-5 of ITSELF by anyone.  The worst ratio at the 1e-3 floor is reported (not asserted) in
-        the test summary; the oracle accumulates in float64 and rounds once."""
+        be reproduced to 1e-5 of ITSELF by anyone.  The noise grows with the number of taps and their cancellation, so
+        tests of many-tap random kernels (5 x 5 x 3 and larger, Gaussian weights) pass a higher floor.  The worst ratio
+        at the 1e-3 floor is reported (not asserted) in the test summary; the oracle accumulates in float64 and rounds
+        once."""
     got, want = np.asarray(got), np.asarray(want)
     assert got.shape == want.shape, (what, got.shape, want.shape)
     nan_g, nan_w = np.isnan(got), np.isnan(want)
@@ -88,6 +90,8 @@ def assert_close(got, want, rtol=1e-5, scale=None, what="", rel_floor=0.1):
         what, bad.sum(), bad.size, err.max(), tol[np.argmax(err)])
     worst = [0.0, 0.0]
     for k, floor in enumerate((rel_floor, 1e-3)):
+        if floor is None:                  # caller compares two float32 evaluation orders with a tolerance of its own
+            continue
         sig = w64 >= floor * scale
         if sig.any() and scale > 0:
             rel = err[sig] / w64[sig]

@@ -60,8 +60,11 @@ def test_conv2d_shapes_including_generic_path(rt, kshape):
     rng = np.random.default_rng(11)
     x = (rng.standard_normal((2, 23, 71, kshape[2])) * 40).astype(np.float32)
     k = rng.standard_normal(kshape)
-    assert_close(rt.conv2d_same(x, k), so.conv2d_same(x, k), RTOL, what=str(kshape))
-    assert_close(rt.conv2d_same(x, k, relu=True, clip_hi=30.0), so.conv2d_same(x, k, relu=True, clip_hi=30.0), RTOL)
+    raw = so.conv2d_same(x, k)
+    assert_close(rt.conv2d_same(x, k), raw, RTOL, what=str(kshape))
+    # clipped at 30 while the Gaussian-weight sums reach hundreds: the rounding noise follows the unclipped magnitude
+    assert_close(rt.conv2d_same(x, k, relu=True, clip_hi=30.0), so.conv2d_same(x, k, relu=True, clip_hi=30.0), RTOL,
+                 scale=float(np.abs(raw).max()), what=str(kshape) + " relu clip")
 
 
 def test_conv2d_known_answers(rt, kernels):
@@ -571,8 +574,9 @@ def test_rgb_chain_structured_and_dense_kernels_agree(rt, kernels):
         np.testing.assert_array_equal(fast[name], tall[name])           # the tile height does not change a bit
         np.testing.assert_array_equal(dense[name], tall_dense[name])
     for name in ("orient", "line_end", "value"):
-        assert_close(fast[name], dense[name], 2e-6, scale=255.0, what=name + " structured vs dense")
-        assert_close(mid[name], dense[name], 2e-6, scale=255.0, what=name + " basic vs dense")
+        # two float32 evaluation orders against each other: range-relative only (rel_floor=None)
+        assert_close(fast[name], dense[name], 2e-6, scale=255.0, what=name + " structured vs dense", rel_floor=None)
+        assert_close(mid[name], dense[name], 2e-6, scale=255.0, what=name + " basic vs dense", rel_floor=None)
         assert not np.array_equal(fast[name], dense[name]) or name == "value"      # really different code paths
     want = so.rgb_line_end_chain(frames, kernels)
     assert_close(fast["line_end"], want["padded"], RTOL, scale=255.0, what="line_end vs oracle")
@@ -939,11 +943,12 @@ def test_config4_per_rank_share_64_frames_against_c_oracle(rt, kernels):
             assert_close(out["end"].level(l)[j].cpu().numpy(), wend[0], RTOL, scale=255.0, what="end f%d l%d" % (j, l))
     # every frame of the batch equals that frame run alone (batch position must not matter): compare per-frame sums
     solo = LineEndPipeline((1080, 1920), mode="gray", n_levels=5, n_orient=4, batch=1)
-    sums = out["end"].data.view(B, -1).double().sum(dim=1).cpu().numpy()
     for j in (1, 2, 30, 62):
         solo.step(frames[j:j + 1])
         torch.cuda.synchronize()
-        assert float(solo.outputs()["end"].data.double().sum().cpu()) == sums[j]
+        alone = solo.outputs()
+        for name in ("pyramid", "cs", "end"):
+            assert torch.equal(out[name].data.view(B, -1)[j], alone[name].data.view(-1)), (name, j)
 
 
 # ----------------------------------------------------------------------------- NaN through the peak stage
@@ -1037,3 +1042,26 @@ def test_config3_chain_on_line_drawings_under_ieee_through_keypoints(rt, kernels
         np.testing.assert_array_equal(out["keypoints"][f], want)
         assert len(want) > 0                                  # NaN regions no longer silence the level's threshold
     assert n_nan > 1000                                       # the frames really exercise the NaN path
+
+
+def test_generate_recovery_and_gather_to_host(rt):
+    import torch
+    from pysilent_amd.util.energy import generate_recovery
+    x = np.array([[1.0, 20.0], [300.0, 0.0]], np.float32)[None, :, :, None]
+    np.testing.assert_array_equal(generate_recovery(x, True, False), so.generate_recovery(x, True, False))
+    np.testing.assert_array_equal(generate_recovery(x, True, True), so.generate_recovery(x, True, True))
+    np.testing.assert_array_equal(generate_recovery(x, False, True), so.generate_recovery(x, False, True))
+    a = torch.arange(7, dtype=torch.float32, device="cuda")
+    b = torch.full((3, 5), 2.5, dtype=torch.float32, device="cuda")
+    host = rt.gather_to_host([a, b, a[:0]])
+    np.testing.assert_array_equal(host, np.concatenate([np.arange(7, dtype=np.float32), np.full(15, 2.5, np.float32)]))
+    with pytest.raises(ValueError):
+        rt.gather_to_host([a.double()])
+
+
+def test_entry_points_leave_the_callers_device_alone(rt):
+    """A context call must not move the caller's current HIP device (torch tracks it through hipGetDevice)."""
+    import torch
+    before = torch.cuda.current_device()
+    rt.nms3x3(noise_frame(1, 9, 9, 1)[None], "fired")
+    assert torch.cuda.current_device() == before

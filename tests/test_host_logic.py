@@ -170,3 +170,17 @@ def test_additive_filter_mirrors_the_reference_constant():
     assert (k == np.eye(2, dtype=np.float32)).all()
     with pytest.raises(ValueError):
         additive_filter([3, 3], 3)
+
+
+def test_generate_recovery_mirrors_the_reference_on_host_arrays():
+    """slam_recognition/util/energy/recovery.py:12-22 under its own name; the constant branch needs no GPU."""
+    import numpy as np
+    import pytest
+    from pysilent_amd.util.energy import generate_recovery
+    from pysilent_amd.util.energy.recovery import generate_recovery as gr2
+    assert generate_recovery is gr2
+    x = np.array([[1.0, np.nan], [300.0, 0.0]], np.float32)
+    r = generate_recovery(x)                                   # constant: ones_like * 10, NaN input does not show
+    assert r.dtype == np.float32 and (r == 10.0).all() and r.shape == x.shape
+    with pytest.raises(ValueError, match="You must choose a type of recovery"):
+        generate_recovery(x, is_input_based=False, is_constant=False)
