@@ -16,6 +16,7 @@
 #include "silent_peaks.h"
 #include "silent_pyramid.h"
 #include "silent_rgb.h"
+#include "silent_walk.h"
 
 using namespace silent;
 
@@ -32,6 +33,7 @@ struct silent_ctx {
     int device = 0;
     std::string err;
     std::string name;
+    int n_cus = 256;
     DevBuf arena;  // staging for the host-pointer entry points
     DevBuf ws;     // scratch for reductions / compaction / the RGB chain temporaries
     bool profiling = false;
@@ -157,6 +159,7 @@ SILENT_EXPORT int silent_create(int device, silent_ctx** out) {
     if (!ctx) return fail(nullptr, SILENT_E_NOMEM, "silent_create: out of host memory");
     ctx->device = device;
     ctx->name = std::string(prop.name) + " (" + prop.gcnArchName + ")";
+    ctx->n_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
     if (std::string(prop.gcnArchName).rfind("gfx950", 0) != 0) {
         std::string m = "silent_create: device is " + ctx->name + "; this library holds gfx950 code objects only";
         delete ctx;
@@ -1491,6 +1494,41 @@ SILENT_EXPORT int silent_profile_elapsed_ms(silent_ctx* ctx, float* ms, int64_t*
     return SILENT_OK;
 }
 
+// Strip-walk kernel (silent_walk.h) for the unit level: eligible when there is exactly one unit level, rows / crop /
+// canvas are 16-byte aligned, the bank has 4 or 8 orientations, and the batch is large enough to give every CU two blocks
+// of at least 64 rows (small batches keep the tile kernels: they have 30x the blocks).  force: tuning bit 128.
+static bool walk_plan(const silent_ctx* ctx, const silent_pyramid_plan* plan, int n_frames, int n_orient, bool force,
+                      WalkTab* wt, int* unit_level) {
+    const PyrTab& pt = plan->tab;
+    if (pt.C != 1 || (n_orient != 4 && n_orient != 8)) return false;
+    int unit = -1, n_unit = 0;
+    for (int l = 0; l < pt.n_levels; ++l)
+        if (pt.lv[l].kind == kPyrUnit) { unit = l; ++n_unit; }
+    if (n_unit != 1) return false;
+    const PyrLevelDev& d = pt.lv[unit];
+    if (pt.W % 4 || d.src_x0 % 4 || d.src_w % 4 || d.out_w % 4 || pt.frame_px_out % 2 || pt.px_off[unit] % 2) return false;
+    if (d.out_h < d.src_h || d.out_w < d.src_w) return false;
+    std::memset(wt, 0, sizeof(*wt));
+    wt->H = pt.H; wt->W = pt.W;
+    wt->src_y0 = d.src_y0; wt->src_x0 = d.src_x0; wt->src_h = d.src_h; wt->src_w = d.src_w;
+    wt->out_h = d.out_h; wt->out_w = d.out_w;
+    wt->eff_h = std::min(d.zoom_h, d.out_h); wt->eff_w = std::min(d.zoom_w, d.out_w);
+    wt->strips_x = (d.out_w + kWalkStripW - 1) / kWalkStripW;
+    const long long per_seg = (long long)n_frames * wt->strips_x;
+    const int max_segs = std::max(1, d.out_h / 64);
+    int segs = (int)std::min<long long>(max_segs, (2ll * ctx->n_cus + per_seg - 1) / per_seg);
+    if (per_seg * segs < 2ll * ctx->n_cus && !force) return false;
+    int seg_rows = (d.out_h + segs - 1) / segs;
+    seg_rows = (seg_rows + kWalkCH - 1) / kWalkCH * kWalkCH;
+    wt->seg_rows = seg_rows;
+    wt->segs_y = (d.out_h + seg_rows - 1) / seg_rows;
+    wt->frame_px = pt.frame_px_out;
+    wt->px_off = pt.px_off[unit];
+    for (int j = 0; j < 5; ++j) wt->wx[j] = plan->unit_w[j];
+    *unit_level = unit;
+    return true;
+}
+
 SILENT_EXPORT int silent_gray_pass_dev(silent_ctx* ctx, const silent_pyramid_plan* plan, const float* frames,
                                        int n_frames, const float* cs_kernel, const float* end_bank, int n_orient,
                                        float clip_hi, float* pyr, float* cs_out, float* end_out,
@@ -1508,7 +1546,11 @@ SILENT_EXPORT int silent_gray_pass_dev(silent_ctx* ctx, const silent_pyramid_pla
     hipStream_t s = (hipStream_t)stream;
     const PyrTab& pt = plan->tab;
     const int kopts = (int)ctx->tune[SILENT_TUNE_GRAY];  // A/B knobs: bit3 32-row fused tiles, bit4 disable the stream path
-    const bool stream_path = plan->stream_ok && !(kopts & 16);
+    // strip-walk kernel for the unit level (bit 64: off, bit 128: also for small batches, bit 256: plain stores)
+    WalkTab wt;
+    int walk_unit = -1;
+    const bool walk_path = !(kopts & 64) && end_out && walk_plan(ctx, plan, n_frames, n_orient, (kopts & 128) != 0, &wt, &walk_unit);
+    const bool stream_path = plan->stream_ok && !(kopts & 16) && !walk_path;
     // 1. non-unit levels of the pyramid: by the region kernel, unless the stream kernel of step 2 produces them
     //    from the same single read of the frame; plus the zero fill of canvases larger than their zoomed crop
     TRY(launch_pyramid(ctx, who, plan, frames, n_frames, pyr, s, false, !stream_path));
@@ -1550,7 +1592,15 @@ SILENT_EXPORT int silent_gray_pass_dev(silent_ctx* ctx, const silent_pyramid_pla
         ctx->prof_sample = ctx->profiling && (ctx->prof_calls++ % ctx->prof_period) == 0;
         const int prof_slot = ctx->prof_recorded % silent_ctx::kProfPairs;
         if (ctx->prof_sample) HIP_TRY(ctx, hipEventRecord(ctx->prof_ev[prof_slot][0], s));
-        if (stream_path) {
+        if (walk_path) {
+            const long long wblocks = (long long)n_frames * wt.segs_y * wt.strips_x;
+#define WALK_LAUNCH(K_, NT_) \
+    hipLaunchKernelGGL((gray_walk_kernel<K_, NT_>), dim3((unsigned)wblocks), dim3(kWalkThreads), 0, s, frames, pyr, cs_out, end_out, wt, w, clip_hi)
+            const bool nt = !(kopts & 256);
+            if (n_orient == 4) { if (nt) WALK_LAUNCH(4, true); else WALK_LAUNCH(4, false); }
+            else { if (nt) WALK_LAUNCH(8, true); else WALK_LAUNCH(8, false); }
+#undef WALK_LAUNCH
+        } else if (stream_path) {
             const StreamTab& st = plan->stream;
 #define STREAM_LAUNCH(K_, G_) \
     hipLaunchKernelGGL((gray_stream_kernel<K_, G_>), dim3((unsigned)blocks), dim3(256), 0, s, frames, pyr, cs_out, end_out, ft, st, w, clip_hi, (unsigned)((kopts >> 5) & 1))

@@ -1,0 +1,303 @@
+// gray_walk_kernel: the unit level of the gray pass (pyramid + CS + K-orientation line-end) as a STRIP WALK with a
+// dedicated loader wave -- the round-2 answer to what round 1 measured on gray_stream_kernel:
+//   * that kernel's time is the time of its write stream, and the write stream is slow because it leaves each wave as
+//     224-byte (1-channel maps) / 896-byte (end maps) row fragments; a store-only kernel with 2 pixels per lane
+//     (448 / 1792-byte runs) reaches the contiguous-fill rate (profiles/r01d/store_pattern.txt);
+//   * every attempt to widen the runs inside the tile kernel lost the occupancy it needs to hide the frame loads:
+//     loads and stores share one in-order vmcnt queue per wave, so a wave cannot prefetch behind its own stores.
+// Here the two are separated.  A block owns a 480-column strip of one frame segment and walks DOWN it:
+//   * wave 4 (the loader) does nothing but LDS-DMA (global_load_lds_dwordx4) of frame rows into a ring of 3 chunks x 8
+//     rows, two chunks ahead; its vmcnt queue holds loads only, so `s_waitcnt vmcnt(16)` means "chunk c has landed";
+//   * waves 0-3 (the consumers) own 120 output columns each, TWO ADJACENT PIXELS PER LANE (lane l = columns 2l, 2l+1 of
+//     the wave's 128, halo 4 columns = 2 lanes per side), read their two values of a row from the ring and run the same
+//     arithmetic, in the same order, as gray_unit_fused_kernel (bit-identical, tested): 5x5 smoother -> level 0 -> CS ->
+//     ReLU -> end bank -> ReLU -> clip.  Their vmcnt queue holds stores only and is never waited on.
+//   * one raw s_barrier per chunk hands chunk c to the consumers and the slot of chunk c-1 back to the loader.  Every
+//     wave of the block executes exactly n_chunks barriers (uniform trip counts, no spinning: nothing can hang).
+// Walking down removes the row halo of the tiles (24 streamed rows per 16 outputs -> seg_rows + 8 per seg_rows), two
+// pixels per lane halve the DPP neighbour traffic and take the column halo from 64/56 to 128/120.
+// Eligibility is host-checked (silent_api.hip, walk_plan): single-channel unit level, 16-byte aligned rows and crop
+// (W, src_x0, out_w multiples of 4; even pyramid offsets), K = 4 or 8.  Everything else keeps gray_stream_kernel.
+#pragma once
+
+#include "silent_common.h"
+#include "silent_conv.h"
+
+namespace silent {
+
+constexpr int kWalkNC = 4;                          // consumer waves per block
+constexpr int kWalkCols = 120;                      // output columns per consumer wave
+constexpr int kWalkStripW = kWalkNC * kWalkCols;    // 480 output columns per block
+constexpr int kWalkRowF = 512;                      // floats per ring row (488 used: strip + 4 halo columns per side)
+constexpr int kWalkCH = 8;                          // rows per chunk
+constexpr int kWalkSlots = 3;                       // chunks in the ring
+constexpr int kWalkThreads = (kWalkNC + 1) * 64;
+constexpr int kWalkLoadsPerChunk = 2 * kWalkCH;     // LDS-DMA instructions the loader issues per chunk
+
+struct WalkTab {
+    int H, W;                            // frame extents
+    int src_y0, src_x0, src_h, src_w;    // crop the unit level resamples (zoom 1)
+    int out_h, out_w, eff_h, eff_w;      // canvas, and the part of it the zoomed crop covers
+    int strips_x, segs_y, seg_rows;      // decomposition: block = (frame, segment of seg_rows output rows, strip)
+    long long frame_px, px_off;          // pixels of one pyramid, offset of the unit level in it
+    float wx[5];                         // [1, 26, 66, 26, 1] / 120 as float32 (both axes)
+};
+
+typedef __attribute__((address_space(3))) void* walk_lds_ptr;
+typedef const __attribute__((address_space(1))) void* walk_glb_ptr;
+
+template <int K, bool NT>
+__global__ __launch_bounds__(kWalkThreads) void gray_walk_kernel(const float* __restrict__ frames,
+                                                                  float* __restrict__ pyr, float* __restrict__ cs_out,
+                                                                  float* __restrict__ end_out, const WalkTab tab,
+                                                                  const GrayW wts, float clip_hi) {
+    static_assert(K == 4 || K == 8, "two-pixel store layouts exist for K = 4 and K = 8");
+    __shared__ __attribute__((aligned(16))) float s_ring[kWalkSlots * kWalkCH][kWalkRowF];   // 48 KB
+    __shared__ __attribute__((aligned(16))) float s_slab[K == 8 ? kWalkNC * 1024 : 4];       // K = 8 store transpose
+
+    const unsigned bid = blockIdx.x;
+    const int strip = (int)(bid % (unsigned)tab.strips_x);
+    const unsigned rest = bid / (unsigned)tab.strips_x;
+    const int seg = (int)(rest % (unsigned)tab.segs_y);
+    const int frame = (int)(rest / (unsigned)tab.segs_y);
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int seg_y0 = seg * tab.seg_rows;
+    const int seg_h = min(tab.seg_rows, tab.out_h - seg_y0);
+    const int n_rows = seg_h + 8;                              // stream rows seg_y0 - 4 .. seg_y0 + seg_h + 3
+    const int n_chunks = (n_rows + kWalkCH - 1) / kWalkCH;
+    const int X0 = strip * kWalkStripW;
+
+    if (wave == kWalkNC) {
+        // ------------------------------------------------------------------ loader: LDS-DMA only
+        const float* __restrict__ src = frames + (long long)frame * tab.H * tab.W;
+        // ring row = columns X0 - 4 .. X0 + 507 of the crop, 16 bytes per lane and instruction; 4-column groups are
+        // aligned (host-checked), so a group lies wholly inside the crop or wholly outside; outside groups are
+        // clamped to a valid address and never read (the consumers read mirrored columns instead)
+        const int c0 = min(max(X0 - 4 + lane * 4, 0), tab.src_w - 4) + tab.src_x0;
+        const int c1 = min(max(X0 + 252 + lane * 4, 0), tab.src_w - 4) + tab.src_x0;
+        auto issue = [&](int c, int slot) {
+#pragma unroll
+            for (int r = 0; r < kWalkCH; ++r) {
+                const int y = seg_y0 - 4 + c * kWalkCH + r;     // rows past the segment (padding of the last chunk) clamp
+                const float* rp = src + (long long)(mirror_near(y, tab.src_h) + tab.src_y0) * tab.W;
+                float* dst = &s_ring[slot * kWalkCH + r][0];
+                __builtin_amdgcn_global_load_lds((walk_glb_ptr)(rp + c0), (walk_lds_ptr)dst, 16, 0, 0);
+                __builtin_amdgcn_global_load_lds((walk_glb_ptr)(rp + c1), (walk_lds_ptr)(dst + 256), 16, 0, 0);
+            }
+        };
+        issue(0, 0);
+        if (n_chunks > 1) issue(1, 1);
+        int slot2 = 2;                                          // slot of chunk c + 2
+        for (int c = 0; c < n_chunks; ++c) {
+            // chunks 0 .. c + 1 have been issued: leave only the newest one in flight -> chunk c has landed
+            if (c + 1 < n_chunks) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(kWalkLoadsPerChunk) : "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();                       // barrier c: consumers are done with chunk c - 1
+            if (c + 2 < n_chunks) issue(c + 2, slot2);          // ... whose slot is the one chunk c + 2 goes to
+            slot2 = slot2 == kWalkSlots - 1 ? 0 : slot2 + 1;
+        }
+        return;
+    }
+
+    // ---------------------------------------------------------------------- consumers
+    const FusedLevel* unused = nullptr;
+    (void)unused;
+    const int xw0 = X0 + wave * kWalkCols;                      // first output column of this wave
+    const bool live = xw0 < tab.out_w;                          // wave-uniform; a dead wave still meets every barrier
+    const int colA = xw0 - 4 + 2 * lane, colB = colA + 1;       // the lane's two columns (level = crop coordinates)
+    // ring offsets of the (mirrored) columns: the ring row starts at column X0 - 4
+    const int offA = min(max(mirror_near(colA, tab.src_w) - (X0 - 4), 0), kWalkRowF - 1);
+    const int offB = min(max(mirror_near(colB, tab.src_w) - (X0 - 4), 0), kWalkRowF - 1);
+    const bool effA = colA >= 0 && colA < tab.eff_w, effB = colB >= 0 && colB < tab.eff_w;
+    const bool inA = colA >= 0 && colA < tab.out_w, inB = colB >= 0 && colB < tab.out_w;
+    const bool out_lane = lane >= 2 && lane < 62 && colA < tab.out_w;   // out_w is even: both columns or neither
+    const long long base_px = (long long)frame * tab.frame_px + tab.px_off;
+    const long long lane_px = base_px + colA;                   // + row * out_w
+
+    // conv weights in VGPRs (all-VGPR fmas issue at ~2.7 cycles, SGPR-operand ones at ~4.2: profiles/r01b/valu_rate.txt)
+    constexpr bool VW = K <= 4;
+    float wv[5], csw[9], endw[VW ? 9 * K : 1];
+#pragma unroll
+    for (int j = 0; j < 5; ++j) {
+        wv[j] = tab.wx[j];
+        asm volatile("" : "+v"(wv[j]));
+    }
+#pragma unroll
+    for (int j = 0; j < 9; ++j) {
+        csw[j] = wts.cs[j];
+        asm volatile("" : "+v"(csw[j]));
+    }
+    if constexpr (VW) {
+#pragma unroll
+        for (int j = 0; j < 9 * K; ++j) {
+            endw[j] = wts.end[j];
+            asm volatile("" : "+v"(endw[j]));
+        }
+    }
+
+    float hA[5] = {0, 0, 0, 0, 0}, hB[5] = {0, 0, 0, 0, 0};   // horizontally smoothed rows y-4 .. y of the two columns
+    float iw[3][4], cw[3][4];                                   // level-0 rows / CS rows x columns (A-1, A, B, B+1)
+#pragma unroll
+    for (int a = 0; a < 3; ++a)
+#pragma unroll
+        for (int b = 0; b < 4; ++b) iw[a][b] = cw[a][b] = 0.0f;
+
+    int slot = 0;
+    for (int c = 0; c < n_chunks; ++c) {
+        __builtin_amdgcn_s_barrier();                           // barrier c: chunk c is in the ring
+        asm volatile("" ::: "memory");
+        if (live) {
+#pragma unroll
+            for (int r = 0; r < kWalkCH; ++r) {
+                const int s = c * kWalkCH + r;                  // stream row index; source row y = seg_y0 - 4 + s
+                if (s >= n_rows) break;                         // wave-uniform (padding of the last chunk)
+                const float* __restrict__ row = &s_ring[slot * kWalkCH + r][0];
+                const float a = row[offA], b = row[offB];
+                // ---- horizontal 5 taps (same fma order as gray_unit_fused_kernel)
+                {
+                    const float La = from_lane_below(a), Lb = from_lane_below(b);
+                    const float Ra = from_lane_above(a), Rb = from_lane_above(b);
+                    float h0 = wv[0] * La;
+                    h0 = __builtin_fmaf(wv[1], Lb, h0);
+                    h0 = __builtin_fmaf(wv[2], a, h0);
+                    h0 = __builtin_fmaf(wv[3], b, h0);
+                    h0 = __builtin_fmaf(wv[4], Ra, h0);
+                    float h1 = wv[0] * Lb;
+                    h1 = __builtin_fmaf(wv[1], a, h1);
+                    h1 = __builtin_fmaf(wv[2], b, h1);
+                    h1 = __builtin_fmaf(wv[3], Ra, h1);
+                    h1 = __builtin_fmaf(wv[4], Rb, h1);
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        hA[j] = hA[j + 1];
+                        hB[j] = hB[j + 1];
+                    }
+                    hA[4] = h0;
+                    hB[4] = h1;
+                }
+                // ---- level-0 row p = y - 2 (vertical 5 taps); rows above the segment's first are warm-up garbage that
+                // is never stored and has left every window before the first stored row needs it
+                const int p = seg_y0 + s - 6;
+                {
+                    float v0 = wv[0] * hA[0], v1 = wv[0] * hB[0];
+#pragma unroll
+                    for (int j = 1; j < 5; ++j) {
+                        v0 = __builtin_fmaf(wv[j], hA[j], v0);
+                        v1 = __builtin_fmaf(wv[j], hB[j], v1);
+                    }
+                    const bool prow = p >= 0 && p < tab.eff_h;
+                    v0 = (prow && effA) ? v0 : 0.0f;
+                    v1 = (prow && effB) ? v1 : 0.0f;
+                    if (p >= seg_y0 && p < seg_y0 + seg_h && out_lane) {
+                        typedef float nf2 __attribute__((ext_vector_type(2)));
+                        nf2* dst = reinterpret_cast<nf2*>(pyr + (lane_px + (long long)p * tab.out_w));
+                        const nf2 v = {v0, v1};
+                        if constexpr (NT) __builtin_nontemporal_store(v, dst);
+                        else *dst = v;
+                    }
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        iw[0][q] = iw[1][q];
+                        iw[1][q] = iw[2][q];
+                    }
+                    iw[2][1] = v0;
+                    iw[2][2] = v1;
+                    iw[2][0] = from_lane_below(v1);
+                    iw[2][3] = from_lane_above(v0);
+                }
+                // ---- CS row cr = p - 1
+                const int cr = p - 1;
+                {
+                    float a0 = 0.0f, a1 = 0.0f;
+#pragma unroll
+                    for (int dy = 0; dy < 3; ++dy)
+#pragma unroll
+                        for (int dx = 0; dx < 3; ++dx) {
+                            a0 = __builtin_fmaf(iw[dy][dx], csw[dy * 3 + dx], a0);
+                            a1 = __builtin_fmaf(iw[dy][dx + 1], csw[dy * 3 + dx], a1);
+                        }
+                    const bool crow = cr >= 0 && cr < tab.out_h;
+                    // relu (a NaN stays a NaN) and the zero padding of the end convolution in one select
+                    const float cs0 = (crow && inA && !(a0 < 0.0f)) ? a0 : 0.0f;
+                    const float cs1 = (crow && inB && !(a1 < 0.0f)) ? a1 : 0.0f;
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        cw[0][q] = cw[1][q];
+                        cw[1][q] = cw[2][q];
+                    }
+                    cw[2][1] = cs0;
+                    cw[2][2] = cs1;
+                    cw[2][0] = from_lane_below(cs1);
+                    cw[2][3] = from_lane_above(cs0);
+                }
+                // ---- output row yo = p - 2
+                const int yo = p - 2;
+                if (yo >= seg_y0 && yo < seg_y0 + seg_h) {      // wave-uniform
+                    const long long row_px = lane_px + (long long)yo * tab.out_w;
+                    if (cs_out && out_lane) {
+                        typedef float nf2 __attribute__((ext_vector_type(2)));
+                        nf2* dst = reinterpret_cast<nf2*>(cs_out + row_px);
+                        const nf2 v = {cw[1][1], cw[1][2]};
+                        if constexpr (NT) __builtin_nontemporal_store(v, dst);
+                        else *dst = v;
+                    }
+                    if (end_out) {
+                        float e0[K], e1[K];
+#pragma unroll
+                        for (int k = 0; k < K; ++k) e0[k] = e1[k] = 0.0f;
+#pragma unroll
+                        for (int dy = 0; dy < 3; ++dy)
+#pragma unroll
+                            for (int dx = 0; dx < 3; ++dx)
+#pragma unroll
+                                for (int k = 0; k < K; ++k) {
+                                    const int wi = (dy * 3 + dx) * K + k;
+                                    const float w = VW ? endw[VW ? wi : 0] : wts.end[wi];
+                                    e0[k] = __builtin_fmaf(cw[dy][dx], w, e0[k]);
+                                    e1[k] = __builtin_fmaf(cw[dy][dx + 1], w, e1[k]);
+                                }
+#pragma unroll
+                        for (int k = 0; k < K; ++k) {
+                            e0[k] = clip_hi_tf(relu_tf(e0[k]), clip_hi);
+                            e1[k] = clip_hi_tf(relu_tf(e1[k]), clip_hi);
+                        }
+                        typedef float nf4 __attribute__((ext_vector_type(4)));
+                        if constexpr (K == 4) {
+                            if (out_lane) {
+                                nf4* dst = reinterpret_cast<nf4*>(end_out + row_px * 4);
+                                dst[0] = nf4{e0[0], e0[1], e0[2], e0[3]};
+                                dst[1] = nf4{e1[0], e1[1], e1[2], e1[3]};
+                            }
+                        } else {
+                            // K = 8: the lane's two pixels are 64 contiguous bytes; four 16-byte stores per lane would each
+                            // write 16-byte pieces at a 64-byte stride.  Transpose through a wave-private LDS slab instead:
+                            // store instruction q writes pieces 64 q .. 64 q + 63 of the row, 1 KiB contiguous each.
+                            nf4* slab = reinterpret_cast<nf4*>(s_slab + wave * 1024);
+                            slab[lane * 4 + 0] = nf4{e0[0], e0[1], e0[2], e0[3]};
+                            slab[lane * 4 + 1] = nf4{e0[4], e0[5], e0[6], e0[7]};
+                            slab[lane * 4 + 2] = nf4{e1[0], e1[1], e1[2], e1[3]};
+                            slab[lane * 4 + 3] = nf4{e1[4], e1[5], e1[6], e1[7]};
+                            __builtin_amdgcn_wave_barrier();
+                            nf4 piece[4];
+#pragma unroll
+                            for (int q = 0; q < 4; ++q) piece[q] = slab[q * 64 + lane];
+                            __builtin_amdgcn_wave_barrier();
+                            // piece i (16 bytes) belongs to column (xw0 - 4) + i / 2; stored columns: xw0 .. xw0 + ncols - 1
+                            const int ncols = min(kWalkCols, tab.out_w - xw0);
+                            nf4* dst = reinterpret_cast<nf4*>(end_out + (base_px + (long long)yo * tab.out_w + (xw0 - 4)) * 8);
+#pragma unroll
+                            for (int q = 0; q < 4; ++q) {
+                                const int col = (q * 64 + lane) >> 1;   // column index inside the wave's 128
+                                if (col >= 4 && col < 4 + ncols) dst[q * 64 + lane] = piece[q];
+                            }
+                        }
+                    }
+                }
+            }
+        }
+        slot = slot == kWalkSlots - 1 ? 0 : slot + 1;
+    }
+}
+
+}  // namespace silent

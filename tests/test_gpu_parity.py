@@ -1065,3 +1065,55 @@ def test_entry_points_leave_the_callers_device_alone(rt):
     before = torch.cuda.current_device()
     rt.nms3x3(noise_frame(1, 9, 9, 1)[None], "fired")
     assert torch.cuda.current_device() == before
+
+
+# ----------------------------------------------------------------------------- strip-walk kernel (silent_walk.h)
+
+@pytest.mark.parametrize("shape,scale,n,K,B", [((135, 240, 1), 2.0, 5, 4, 2),         # two segments of 72 rows, one strip
+                                               ((97, 132, 1), 1.7, 4, 8, 3),           # K = 8 store transpose, ragged strip
+                                               ((64, 300, 1), 2.0, 3, 4, 1),
+                                               ((200, 1000, 1), 2.0, 4, 4, 2),         # three strips (480 + 480 + 40 columns)
+                                               ((200, 964, 1), 2.0, 2, 8, 1),          # last strip holds 4 columns only
+                                               ((270, 480, 1), math.e ** .5, 6, 4, 2), # exactly one full strip
+                                               ((8, 8, 1), 2.0, 1, 4, 2),              # one chunk, fewer rows than a chunk
+                                               ((9, 484, 1), 2.0, 2, 4, 1),
+                                               ((1080, 1920, 1), 2.0, 5, 4, 2)])       # config 2 geometry, 15 seams per frame
+def test_gray_walk_kernel_is_bit_identical_to_the_tile_kernels(rt, kernels, shape, scale, n, K, B):
+    """The strip-walk kernel (loader wave + two pixels per lane, tuning bit 128 forces it on small batches) against the
+    round-1 path (bit 64 switches it off): the same arithmetic in the same order, so every map is equal bit for bit --
+    across segment seams, strip seams, ragged right edges and both store layouts."""
+    from pysilent_amd.util.zoom.from_image import classic_levels
+    frames = np.stack([structured_frame(20 + s, *shape, n_lines=60) + noise_frame(s, *shape) * np.float32(0.25) for s in range(B)])
+    plan = rt.PyramidPlan(shape[0], shape[1], 1, classic_levels(shape[:2], scale, n))
+    bank = kernels["end%d" % K]
+    with rt.tuning(TUNE_GRAY, 128):
+        pyr, cs, end = plan.gray_pass(frames, kernels["cs_gray"], bank)
+    with rt.tuning(TUNE_GRAY, 128 | 256):                       # plain instead of non-temporal stores
+        pyr_p, cs_p, end_p = plan.gray_pass(frames, kernels["cs_gray"], bank)
+    with rt.tuning(TUNE_GRAY, 64):
+        pyr2, cs2, end2 = plan.gray_pass(frames, kernels["cs_gray"], bank)
+    for a, b_, c_ in ((pyr, pyr_p, pyr2), (cs, cs_p, cs2), (end, end_p, end2)):
+        np.testing.assert_array_equal(a.data, c_.data)
+        np.testing.assert_array_equal(b_.data, c_.data)
+    want = so.classic_pyramid(frames[B - 1], scale, n)
+    wcs, wend = so.gray_line_end_pass(want[:1], kernels["cs_gray"], bank)[0]
+    assert_close(cs.level(0)[B - 1:B], wcs, RTOL, scale=255.0, what="walk cs")
+    assert_close(end.level(0)[B - 1:B], wend, RTOL, scale=255.0, what="walk end")
+
+
+def test_gray_walk_kernel_nan_and_inf_frames(rt, kernels):
+    """Non-finite pixels propagate through the walk kernel exactly as through the tile kernels."""
+    from pysilent_amd.util.zoom.from_image import classic_levels
+    frames = np.stack([noise_frame(s, 150, 488, 1) for s in range(2)])
+    frames[0, 70:74, 100:104] = np.nan
+    frames[1, 0, 0] = np.inf
+    frames[1, 149, 487] = -np.inf
+    frames[0, 71, 479:482] = np.inf                              # across the strip seam
+    plan = rt.PyramidPlan(150, 488, 1, classic_levels((150, 488), 2.0, 3))
+    with rt.tuning(TUNE_GRAY, 128):
+        got = plan.gray_pass(frames, kernels["cs_gray"], kernels["end4"])
+    with rt.tuning(TUNE_GRAY, 64):
+        ref = plan.gray_pass(frames, kernels["cs_gray"], kernels["end4"])
+    for a, b_ in zip(got, ref):
+        np.testing.assert_array_equal(a.data, b_.data)
+    assert np.isnan(got[2].data).any()
