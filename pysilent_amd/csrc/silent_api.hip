@@ -84,6 +84,11 @@ struct silent_pyramid_plan {
     void* stream_tables = nullptr;
     StreamTab stream{};
     int stream_unit_level = -1;
+    // in-walk pyramid of gray_walk_kernel (silent_walk.h): row program over the whole crop + column records per
+    // 120-column wave tile, when every general level resamples the unit level's crop with <= 64 outputs per tile
+    bool walk_pyr_ok = false;
+    void* walk_tables = nullptr;
+    WalkPyr walk{};
 };
 
 static thread_local std::string g_create_err;
@@ -1394,6 +1399,100 @@ SILENT_EXPORT int silent_pyramid_plan_create(silent_ctx* ctx, int frame_h, int f
             }
         }
     }
+    // ---- in-walk pyramid tables (see gray_walk_kernel): same eligibility as the stream path plus the walk's own
+    {
+        int unit = -1, n_unit = 0;
+        for (int l = 0; l < n_levels; ++l)
+            if (tab.lv[l].kind == kPyrUnit) { unit = l; ++n_unit; }
+        bool ok = channels == 1 && n_unit == 1 && tab.n_general >= 1 && tab.n_general <= 7;
+        if (ok) {
+            const PyrLevelDev& u = tab.lv[unit];
+            ok = u.out_h >= u.src_h && u.out_w >= u.src_w;
+            for (int l = 0; l < n_levels && ok; ++l) {
+                const PyrLevelDev& d = tab.lv[l];
+                if (d.kind != kPyrGeneral) continue;
+                ok = d.src_y0 == u.src_y0 && d.src_x0 == u.src_x0 && d.src_h == u.src_h && d.src_w == u.src_w;
+            }
+        }
+        if (ok) {
+            const PyrLevelDev& u = tab.lv[unit];
+            const int G = tab.n_general;
+            const int waves_x = ((u.out_w + kWalkStripW - 1) / kWalkStripW) * kWalkNC;
+            const int Gp = stream_pad_levels(G), PR = kStreamProgRow(Gp);
+            const size_t n_rec = (size_t)u.out_h + 8;                 // stream rows y = -4 .. out_h + 3 at index y + 4
+            std::vector<int> prog(n_rec * PR, 0), hdr((size_t)G * waves_x * 2, 0), rec((size_t)G * waves_x * 64 * 8, 0);
+            for (size_t r = 0; r < n_rec; ++r)
+                for (int gg = 0; gg < Gp; ++gg) prog[r * PR + gg] = 7 << 4;  // inert: feeds nothing, no slot completes
+            std::vector<char> used(n_rec * G * kStreamSlots, 0);
+            int g = 0;
+            for (int l = 0; l < n_levels && ok; ++l) {
+                const PyrLevelDev& d = tab.lv[l];
+                if (d.kind != kPyrGeneral) continue;
+                const int zc = std::min(d.zoom_w, d.out_w), zr = std::min(d.zoom_h, d.out_h);
+                const int* yb = ybase.data() + d.ytab_off;
+                const int* xb = xbase.data() + d.xtab_off;
+                for (int oy = 0; oy < zr && ok; ++oy) {
+                    if (yb[oy] < 0 || yb[oy] >= u.out_h) { ok = false; break; }
+                    const int slot = oy % stream_slots(g);
+                    for (int j = 0; j < 6; ++j) {
+                        const size_t r = (size_t)(yb[oy] + 2 + j);       // tap j sits on stream row y = yb - 2 + j
+                        if (r >= n_rec) { ok = false; break; }
+                        const size_t e = r * G + g;
+                        if (used[e * kStreamSlots + slot]) { ok = false; break; }  // two live rows in one slot: step too small
+                        used[e * kStreamSlots + slot] = 1;
+                        int* pr = prog.data() + r * PR;
+                        int& meta = pr[g];
+                        std::memcpy(pr + stream_w_off(Gp, g) + slot, &yw[(size_t)(d.ytab_off + oy) * 6 + j], 4);
+                        meta |= 128;
+                        if (j == 0) meta |= 1 << slot;
+                        if (j == 5) {
+                            if (((meta >> 4) & 7) != 7) { ok = false; break; }  // two rows completing together
+                            meta = (meta & 0x8f) | (slot << 4) | (oy << 8);
+                        }
+                    }
+                }
+                int ox = 0;
+                for (int wx = 0; wx < waves_x && ok; ++wx) {
+                    const int xw0 = wx * kWalkCols;
+                    while (ox < zc && xb[ox] < xw0) ++ox;
+                    int n = 0;
+                    while (ox + n < zc && xb[ox + n] < xw0 + kWalkCols) ++n;
+                    if (n > 64) { ok = false; break; }                   // one output per lane: zoom step >= 1.875
+                    hdr[((size_t)g * waves_x + wx) * 2] = ox;
+                    hdr[((size_t)g * waves_x + wx) * 2 + 1] = n;
+                    for (int j = 0; j < n; ++j) {
+                        int* r = rec.data() + (((size_t)g * waves_x + wx) * 64 + j) * 8;
+                        r[0] = xb[ox + j] - xw0 + 2;  // index of tap 0 in the wave's 128 columns (index 0 <-> column xw0 - 4)
+                        if (r[0] < 0 || r[0] + 5 > 127) { ok = false; break; }
+                        std::memcpy(r + 1, &xw[(size_t)(d.xtab_off + ox + j) * 6], 24);
+                    }
+                    ox += n;
+                }
+                plan->walk.px_off[g] = tab.px_off[l];
+                plan->walk.out_w[g] = d.out_w;
+                ++g;
+            }
+            if (ok) {
+                const size_t b0 = align_up(prog.size() * 4), b1 = align_up(hdr.size() * 4), b2 = align_up(rec.size() * 4);
+                hipError_t se = hipMalloc(&plan->walk_tables, b0 + b1 + b2);
+                if (se == hipSuccess) se = hipMemcpy(plan->walk_tables, prog.data(), prog.size() * 4, hipMemcpyHostToDevice);
+                if (se == hipSuccess) se = hipMemcpy((char*)plan->walk_tables + b0, hdr.data(), hdr.size() * 4, hipMemcpyHostToDevice);
+                if (se == hipSuccess) se = hipMemcpy((char*)plan->walk_tables + b0 + b1, rec.data(), rec.size() * 4, hipMemcpyHostToDevice);
+                if (se != hipSuccess) {
+                    (void)hipGetLastError();
+                    if (plan->walk_tables) (void)hipFree(plan->walk_tables);
+                    plan->walk_tables = nullptr;
+                } else {
+                    plan->walk.G = G;
+                    plan->walk.waves_x = waves_x;
+                    plan->walk.row_prog = (const int*)plan->walk_tables;
+                    plan->walk.col_hdr = (const int*)((char*)plan->walk_tables + b0);
+                    plan->walk.col_rec = (const int*)((char*)plan->walk_tables + b0 + b1);
+                    plan->walk_pyr_ok = true;
+                }
+            }
+        }
+    }
     *out = plan;
     return SILENT_OK;
 }
@@ -1403,6 +1502,7 @@ SILENT_EXPORT void silent_pyramid_plan_destroy(silent_pyramid_plan* plan) {
     DeviceGuard guard(plan->ctx ? plan->ctx->device : 0);
     if (plan->tables) (void)hipFree(plan->tables);
     if (plan->stream_tables) (void)hipFree(plan->stream_tables);
+    if (plan->walk_tables) (void)hipFree(plan->walk_tables);
     delete plan;
 }
 
@@ -1550,10 +1650,11 @@ SILENT_EXPORT int silent_gray_pass_dev(silent_ctx* ctx, const silent_pyramid_pla
     WalkTab wt;
     int walk_unit = -1;
     const bool walk_path = !(kopts & 64) && end_out && walk_plan(ctx, plan, n_frames, n_orient, (kopts & 128) != 0, &wt, &walk_unit);
+    const bool walk_pyr = walk_path && plan->walk_pyr_ok && !(kopts & 512);   // other levels from the same walk
     const bool stream_path = plan->stream_ok && !(kopts & 16) && !walk_path;
     // 1. non-unit levels of the pyramid: by the region kernel, unless the stream kernel of step 2 produces them
     //    from the same single read of the frame; plus the zero fill of canvases larger than their zoomed crop
-    TRY(launch_pyramid(ctx, who, plan, frames, n_frames, pyr, s, false, !stream_path));
+    TRY(launch_pyramid(ctx, who, plan, frames, n_frames, pyr, s, false, !stream_path && !walk_pyr));
     // 2. unit levels: pyramid + CS + end in one kernel
     const int fth = (!stream_path && (kopts & 8)) ? 32 : kFusedTH;
     FusedTab ft;
@@ -1594,11 +1695,20 @@ SILENT_EXPORT int silent_gray_pass_dev(silent_ctx* ctx, const silent_pyramid_pla
         if (ctx->prof_sample) HIP_TRY(ctx, hipEventRecord(ctx->prof_ev[prof_slot][0], s));
         if (walk_path) {
             const long long wblocks = (long long)n_frames * wt.segs_y * wt.strips_x;
-#define WALK_LAUNCH(K_, NT_) \
-    hipLaunchKernelGGL((gray_walk_kernel<K_, NT_>), dim3((unsigned)wblocks), dim3(kWalkThreads), 0, s, frames, pyr, cs_out, end_out, wt, w, clip_hi)
+#define WALK_LAUNCH(K_, NT_, G_) \
+    hipLaunchKernelGGL((gray_walk_kernel<K_, NT_, G_>), dim3((unsigned)wblocks), dim3(kWalkThreads), 0, s, frames, pyr, cs_out, end_out, wt, wpyr, w, clip_hi)
+#define WALK_G(K_, NT_)                                   \
+    do {                                                  \
+        if (!walk_pyr) WALK_LAUNCH(K_, NT_, 0);           \
+        else if (plan->walk.G <= 4) WALK_LAUNCH(K_, NT_, 4); \
+        else WALK_LAUNCH(K_, NT_, 7);                     \
+    } while (0)
+            WalkPyr wpyr{};
+            if (walk_pyr) wpyr = plan->walk;
             const bool nt = !(kopts & 256);
-            if (n_orient == 4) { if (nt) WALK_LAUNCH(4, true); else WALK_LAUNCH(4, false); }
-            else { if (nt) WALK_LAUNCH(8, true); else WALK_LAUNCH(8, false); }
+            if (n_orient == 4) { if (nt) WALK_G(4, true); else WALK_G(4, false); }
+            else { if (nt) WALK_G(8, true); else WALK_G(8, false); }
+#undef WALK_G
 #undef WALK_LAUNCH
         } else if (stream_path) {
             const StreamTab& st = plan->stream;

@@ -18,6 +18,15 @@
 // pixels per lane halve the DPP neighbour traffic and take the column halo from 64/56 to 128/120.
 // Eligibility is host-checked (silent_api.hip, walk_plan): single-channel unit level, 16-byte aligned rows and crop
 // (W, src_x0, out_w multiples of 4; even pyramid offsets), K = 4 or 8.  Everything else keeps gray_stream_kernel.
+//
+// The OTHER levels of the pyramid (template G > 0) come out of the same walk, exactly as in gray_stream_kernel's pass 2
+// and with its arithmetic order (vertical 6 taps in the lane, then horizontal 6 taps by gather: bit-identical to the region
+// kernel): the consumer keeps, per level, up to stream_slots(g) output rows in flight for its two columns; a wave-uniform
+// ROW PROGRAM (one record per source row of the level-0 crop, built by the host from the float64 tap tables, read with
+// scalar loads one record ahead) says which slot takes which weight, which restarts and which completes.  A completed
+// row goes through a wave-private 128-float LDS line, from which the outputs ANCHORED in the wave's 120 columns (one per
+// lane; host-checked <= 64, i.e. zoom steps >= 1.875) gather their 6 taps.  A segment stores the rows whose anchor row it
+// owns; their taps lie inside its streamed rows because the walk carries 4 halo rows per side.
 #pragma once
 
 #include "silent_common.h"
@@ -34,6 +43,17 @@ constexpr int kWalkSlots = 3;                       // chunks in the ring
 constexpr int kWalkThreads = (kWalkNC + 1) * 64;
 constexpr int kWalkLoadsPerChunk = 2 * kWalkCH;     // LDS-DMA instructions the loader issues per chunk
 
+// tables of the in-walk pyramid (device memory owned by the plan)
+struct WalkPyr {
+    int G;                        // general levels (<= template G; the rest are inert)
+    int waves_x;                  // 120-column wave tiles per row = strips_x * 4
+    const int* row_prog;          // [out_h + 8][kStreamProgRow(Gp)]: record of stream row y at index y + 4
+    const int* col_hdr;           // [G][waves_x][2]: first output column, number of outputs (<= 64)
+    const int* col_rec;           // [G][waves_x][64][8]: index of tap 0 in the wave's 128 columns, 6 weights, pad
+    long long px_off[8];          // pixel offset of level g inside one pyramid
+    int out_w[8];
+};
+
 struct WalkTab {
     int H, W;                            // frame extents
     int src_y0, src_x0, src_h, src_w;    // crop the unit level resamples (zoom 1)
@@ -46,14 +66,16 @@ struct WalkTab {
 typedef __attribute__((address_space(3))) void* walk_lds_ptr;
 typedef const __attribute__((address_space(1))) void* walk_glb_ptr;
 
-template <int K, bool NT>
+template <int K, bool NT, int G>
 __global__ __launch_bounds__(kWalkThreads) void gray_walk_kernel(const float* __restrict__ frames,
                                                                   float* __restrict__ pyr, float* __restrict__ cs_out,
                                                                   float* __restrict__ end_out, const WalkTab tab,
-                                                                  const GrayW wts, float clip_hi) {
+                                                                  const WalkPyr wp, const GrayW wts, float clip_hi) {
     static_assert(K == 4 || K == 8, "two-pixel store layouts exist for K = 4 and K = 8");
+    static_assert(G == 0 || G == stream_pad_levels(G), "row programs are padded to 4 or 7 levels");
     __shared__ __attribute__((aligned(16))) float s_ring[kWalkSlots * kWalkCH][kWalkRowF];   // 48 KB
     __shared__ __attribute__((aligned(16))) float s_slab[K == 8 ? kWalkNC * 1024 : 4];       // K = 8 store transpose
+    __shared__ __attribute__((aligned(16))) float s_line[G > 0 ? kWalkNC * 128 : 4];         // completed rows of other levels
 
     const unsigned bid = blockIdx.x;
     const int strip = (int)(bid % (unsigned)tab.strips_x);
@@ -136,6 +158,51 @@ __global__ __launch_bounds__(kWalkThreads) void gray_walk_kernel(const float* __
         }
     }
 
+    // ---- in-walk pyramid state (G > 0): column records of this lane's output per level, vertical accumulators
+    constexpr int GG = G > 0 ? G : 1;
+    constexpr int PR = G > 0 ? kStreamProgRow(GG) : 1;
+    typedef const __attribute__((address_space(4))) int* const_int_ptr;
+    int gx0[GG], gn[GG], gtap[GG];
+    float gw[GG][6];
+    float vacc[GG][kStreamSlots][2];
+    const long long frame_px0 = (long long)frame * tab.frame_px;
+    if constexpr (G > 0) {
+        const int wx_tile = strip * kWalkNC + wave;
+#pragma unroll
+        for (int g = 0; g < G; ++g) {
+            const int gg = min(g, wp.G - 1);
+            const_int_ptr h = (const_int_ptr)(wp.col_hdr + ((long long)gg * wp.waves_x + wx_tile) * 2);
+            gx0[g] = h[0];
+            gn[g] = g < wp.G ? h[1] : 0;
+            const int4* __restrict__ rec =
+                reinterpret_cast<const int4*>(wp.col_rec + (((long long)gg * wp.waves_x + wx_tile) * 64 + lane) * 8);
+            const int4 ra = rec[0], rb = rec[1];
+            gtap[g] = ra.x;
+            gw[g][0] = __int_as_float(ra.y);
+            gw[g][1] = __int_as_float(ra.z);
+            gw[g][2] = __int_as_float(ra.w);
+            gw[g][3] = __int_as_float(rb.x);
+            gw[g][4] = __int_as_float(rb.y);
+            gw[g][5] = __int_as_float(rb.z);
+#pragma unroll
+            for (int k = 0; k < kStreamSlots; ++k) vacc[g][k][0] = vacc[g][k][1] = 0.0f;
+        }
+        // retire these loads here: they are the only vector loads of a consumer, and the only thing its vmcnt queue
+        // will ever be waited for
+#pragma unroll
+        for (int g = 0; g < G; ++g) {
+            asm volatile("" ::"v"(gtap[g]));
+#pragma unroll
+            for (int j = 0; j < 6; ++j) asm volatile("" ::"v"(gw[g][j]));
+        }
+    }
+    const_int_ptr prog = (const_int_ptr)(wp.row_prog + (long long)seg_y0 * PR);   // record of stream row s at s * PR
+    int cur[PR];
+    if constexpr (G > 0) {
+#pragma unroll
+        for (int e = 0; e < PR; ++e) cur[e] = prog[e];
+    }
+
     float hA[5] = {0, 0, 0, 0, 0}, hB[5] = {0, 0, 0, 0, 0};   // horizontally smoothed rows y-4 .. y of the two columns
     float iw[3][4], cw[3][4];                                   // level-0 rows / CS rows x columns (A-1, A, B, B+1)
 #pragma unroll
@@ -154,6 +221,50 @@ __global__ __launch_bounds__(kWalkThreads) void gray_walk_kernel(const float* __
                 if (s >= n_rows) break;                         // wave-uniform (padding of the last chunk)
                 const float* __restrict__ row = &s_ring[slot * kWalkCH + r][0];
                 const float a = row[offA], b = row[offB];
+                // ---- the other levels: vertical taps of this source row, gather + store of a row that completes
+                if constexpr (G > 0) {
+                    int nxt[PR];
+                    const int sn = min(s + 1, n_rows - 1);      // record of the NEXT row, requested before this row's work
+#pragma unroll
+                    for (int e = 0; e < PR; ++e) nxt[e] = prog[sn * PR + e];
+#pragma unroll
+                    for (int g = 0; g < G; ++g) {
+                        const int meta = cur[g];
+                        if (!(meta & 128)) continue;            // wave-uniform: this source row carries no tap of level g
+#pragma unroll
+                        for (int k = 0; k < stream_slots(g); ++k) {
+                            const float w = __int_as_float(cur[stream_w_off(G, g) + k]);
+                            const bool restart = (meta >> k) & 1;
+                            vacc[g][k][0] = __builtin_fmaf(w, a, restart ? 0.0f : vacc[g][k][0]);
+                            vacc[g][k][1] = __builtin_fmaf(w, b, restart ? 0.0f : vacc[g][k][1]);
+                        }
+                        const int done = (meta >> 4) & 7;
+                        // the row's anchor is source row y - 3 = seg_y0 + s - 7: stored by the segment that owns it
+                        const int anchor = seg_y0 + s - 7;
+                        if (done < kStreamSlots && anchor >= seg_y0 && anchor < seg_y0 + seg_h) {   // wave-uniform
+                            const int oy = meta >> 8;
+                            float v0 = vacc[g][0][0], v1 = vacc[g][0][1];
+#pragma unroll
+                            for (int k = 1; k < stream_slots(g); ++k) {
+                                v0 = done == k ? vacc[g][k][0] : v0;
+                                v1 = done == k ? vacc[g][k][1] : v1;
+                            }
+                            float* line = s_line + wave * 128;
+                            typedef float nf2 __attribute__((ext_vector_type(2)));
+                            *reinterpret_cast<nf2*>(line + 2 * lane) = nf2{v0, v1};
+                            __builtin_amdgcn_wave_barrier();
+                            const float* tp = line + gtap[g];
+                            float acc = gw[g][0] * tp[0];
+#pragma unroll
+                            for (int t = 1; t < 6; ++t) acc = __builtin_fmaf(gw[g][t], tp[t], acc);
+                            __builtin_amdgcn_wave_barrier();
+                            if (lane < gn[g])
+                                pyr[frame_px0 + wp.px_off[g] + (long long)oy * wp.out_w[g] + gx0[g] + lane] = acc;
+                        }
+                    }
+#pragma unroll
+                    for (int e = 0; e < PR; ++e) cur[e] = nxt[e];
+                }
                 // ---- horizontal 5 taps (same fma order as gray_unit_fused_kernel)
                 {
                     const float La = from_lane_below(a), Lb = from_lane_below(b);

@@ -1077,7 +1077,9 @@ def test_entry_points_leave_the_callers_device_alone(rt):
                                                ((270, 480, 1), math.e ** .5, 6, 4, 2), # exactly one full strip
                                                ((8, 8, 1), 2.0, 1, 4, 2),              # one chunk, fewer rows than a chunk
                                                ((9, 484, 1), 2.0, 2, 4, 1),
-                                               ((1080, 1920, 1), 2.0, 5, 4, 2)])       # config 2 geometry, 15 seams per frame
+                                               ((1080, 1920, 1), 2.0, 5, 4, 2),        # config 2 geometry, 15 seams per frame
+                                               ((540, 960, 1), 2.0, 8, 8, 2),          # 7 general levels (config 5 shape / 4)
+                                               ((300, 480, 1), 2.5, 4, 4, 1)])         # zoom step 2.5
 def test_gray_walk_kernel_is_bit_identical_to_the_tile_kernels(rt, kernels, shape, scale, n, K, B):
     """The strip-walk kernel (loader wave + two pixels per lane, tuning bit 128 forces it on small batches) against the
     round-1 path (bit 64 switches it off): the same arithmetic in the same order, so every map is equal bit for bit --
@@ -1088,8 +1090,8 @@ def test_gray_walk_kernel_is_bit_identical_to_the_tile_kernels(rt, kernels, shap
     bank = kernels["end%d" % K]
     with rt.tuning(TUNE_GRAY, 128):
         pyr, cs, end = plan.gray_pass(frames, kernels["cs_gray"], bank)
-    with rt.tuning(TUNE_GRAY, 128 | 256):                       # plain instead of non-temporal stores
-        pyr_p, cs_p, end_p = plan.gray_pass(frames, kernels["cs_gray"], bank)
+    with rt.tuning(TUNE_GRAY, 128 | 256 | 512):                 # plain instead of non-temporal stores; other levels by
+        pyr_p, cs_p, end_p = plan.gray_pass(frames, kernels["cs_gray"], bank)   # the region kernel instead of the walk
     with rt.tuning(TUNE_GRAY, 64):
         pyr2, cs2, end2 = plan.gray_pass(frames, kernels["cs_gray"], bank)
     for a, b_, c_ in ((pyr, pyr_p, pyr2), (cs, cs_p, cs2), (end, end_p, end2)):
