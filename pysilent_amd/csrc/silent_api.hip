@@ -1417,13 +1417,15 @@ SILENT_EXPORT int silent_pyramid_plan_create(silent_ctx* ctx, int frame_h, int f
         if (ok) {
             const PyrLevelDev& u = tab.lv[unit];
             const int G = tab.n_general;
-            const int waves_x = ((u.out_w + kWalkStripW - 1) / kWalkStripW) * kWalkNC;
-            const int Gp = stream_pad_levels(G), PR = kStreamProgRow(Gp);
+            const int strips_x = (u.out_w + kWalkStripW - 1) / kWalkStripW;
+            const int Gp = stream_pad_levels(G), PR = walk_prog_row(Gp);
             const size_t n_rec = (size_t)u.out_h + 8;                 // stream rows y = -4 .. out_h + 3 at index y + 4
-            std::vector<int> prog(n_rec * PR, 0), hdr((size_t)G * waves_x * 2, 0), rec((size_t)G * waves_x * 64 * 8, 0);
-            for (size_t r = 0; r < n_rec; ++r)
+            const size_t n_rec_pad = n_rec + 2 * kWalkCH;             // the loader fetches whole chunks of records
+            const int rec_total = walk_rec_total(Gp);
+            std::vector<int> prog(n_rec_pad * PR, 0), hdr((size_t)G * strips_x * 2, 0), rec((size_t)strips_x * rec_total * 8, 0);
+            for (size_t r = 0; r < n_rec_pad; ++r)
                 for (int gg = 0; gg < Gp; ++gg) prog[r * PR + gg] = 7 << 4;  // inert: feeds nothing, no slot completes
-            std::vector<char> used(n_rec * G * kStreamSlots, 0);
+            std::vector<char> used(n_rec * G * kWalkMaxSlots, 0);
             int g = 0;
             for (int l = 0; l < n_levels && ok; ++l) {
                 const PyrLevelDev& d = tab.lv[l];
@@ -1433,16 +1435,16 @@ SILENT_EXPORT int silent_pyramid_plan_create(silent_ctx* ctx, int frame_h, int f
                 const int* xb = xbase.data() + d.xtab_off;
                 for (int oy = 0; oy < zr && ok; ++oy) {
                     if (yb[oy] < 0 || yb[oy] >= u.out_h) { ok = false; break; }
-                    const int slot = oy % stream_slots(g);
+                    const int slot = oy % walk_slots(g);
                     for (int j = 0; j < 6; ++j) {
                         const size_t r = (size_t)(yb[oy] + 2 + j);       // tap j sits on stream row y = yb - 2 + j
                         if (r >= n_rec) { ok = false; break; }
                         const size_t e = r * G + g;
-                        if (used[e * kStreamSlots + slot]) { ok = false; break; }  // two live rows in one slot: step too small
-                        used[e * kStreamSlots + slot] = 1;
+                        if (used[e * kWalkMaxSlots + slot]) { ok = false; break; }  // two live rows in one slot: step too small
+                        used[e * kWalkMaxSlots + slot] = 1;
                         int* pr = prog.data() + r * PR;
                         int& meta = pr[g];
-                        std::memcpy(pr + stream_w_off(Gp, g) + slot, &yw[(size_t)(d.ytab_off + oy) * 6 + j], 4);
+                        std::memcpy(pr + walk_w_off(Gp, g) + slot, &yw[(size_t)(d.ytab_off + oy) * 6 + j], 4);
                         meta |= 128;
                         if (j == 0) meta |= 1 << slot;
                         if (j == 5) {
@@ -1452,18 +1454,18 @@ SILENT_EXPORT int silent_pyramid_plan_create(silent_ctx* ctx, int frame_h, int f
                     }
                 }
                 int ox = 0;
-                for (int wx = 0; wx < waves_x && ok; ++wx) {
-                    const int xw0 = wx * kWalkCols;
-                    while (ox < zc && xb[ox] < xw0) ++ox;
+                for (int sx = 0; sx < strips_x && ok; ++sx) {
+                    const int X0 = sx * kWalkStripW;
+                    while (ox < zc && xb[ox] < X0) ++ox;
                     int n = 0;
-                    while (ox + n < zc && xb[ox + n] < xw0 + kWalkCols) ++n;
-                    if (n > 64) { ok = false; break; }                   // one output per lane: zoom step >= 1.875
-                    hdr[((size_t)g * waves_x + wx) * 2] = ox;
-                    hdr[((size_t)g * waves_x + wx) * 2 + 1] = n;
+                    while (ox + n < zc && xb[ox + n] < X0 + kWalkStripW) ++n;
+                    if (n > walk_rec_cap(g)) { ok = false; break; }      // <= 4 outputs per lane at level 0, halving per level
+                    hdr[((size_t)g * strips_x + sx) * 2] = ox;
+                    hdr[((size_t)g * strips_x + sx) * 2 + 1] = n;
                     for (int j = 0; j < n; ++j) {
-                        int* r = rec.data() + (((size_t)g * waves_x + wx) * 64 + j) * 8;
-                        r[0] = xb[ox + j] - xw0 + 2;  // index of tap 0 in the wave's 128 columns (index 0 <-> column xw0 - 4)
-                        if (r[0] < 0 || r[0] + 5 > 127) { ok = false; break; }
+                        int* r = rec.data() + ((size_t)sx * rec_total + walk_rec_base(g) + j) * 8;
+                        r[0] = xb[ox + j] - X0 + 2;   // ring index of tap 0 (ring index 0 <-> column X0 - 4)
+                        if (r[0] < 0 || r[0] + 5 > kWalkStripW + 7) { ok = false; break; }
                         std::memcpy(r + 1, &xw[(size_t)(d.xtab_off + ox + j) * 6], 24);
                     }
                     ox += n;
@@ -1484,7 +1486,6 @@ SILENT_EXPORT int silent_pyramid_plan_create(silent_ctx* ctx, int frame_h, int f
                     plan->walk_tables = nullptr;
                 } else {
                     plan->walk.G = G;
-                    plan->walk.waves_x = waves_x;
                     plan->walk.row_prog = (const int*)plan->walk_tables;
                     plan->walk.col_hdr = (const int*)((char*)plan->walk_tables + b0);
                     plan->walk.col_rec = (const int*)((char*)plan->walk_tables + b0 + b1);
@@ -1696,7 +1697,7 @@ SILENT_EXPORT int silent_gray_pass_dev(silent_ctx* ctx, const silent_pyramid_pla
         if (walk_path) {
             const long long wblocks = (long long)n_frames * wt.segs_y * wt.strips_x;
 #define WALK_LAUNCH(K_, NT_, G_) \
-    hipLaunchKernelGGL((gray_walk_kernel<K_, NT_, G_>), dim3((unsigned)wblocks), dim3(kWalkThreads), 0, s, frames, pyr, cs_out, end_out, wt, wpyr, w, clip_hi)
+    hipLaunchKernelGGL((gray_walk_kernel<K_, NT_, G_>), dim3((unsigned)wblocks), dim3(walk_threads(G_)), 0, s, frames, pyr, cs_out, end_out, wt, wpyr, w, clip_hi)
 #define WALK_G(K_, NT_)                                   \
     do {                                                  \
         if (!walk_pyr) WALK_LAUNCH(K_, NT_, 0);           \

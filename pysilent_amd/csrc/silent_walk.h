@@ -19,14 +19,17 @@
 // Eligibility is host-checked (silent_api.hip, walk_plan): single-channel unit level, 16-byte aligned rows and crop
 // (W, src_x0, out_w multiples of 4; even pyramid offsets), K = 4 or 8.  Everything else keeps gray_stream_kernel.
 //
-// The OTHER levels of the pyramid (template G > 0) come out of the same walk, exactly as in gray_stream_kernel's pass 2
-// and with its arithmetic order (vertical 6 taps in the lane, then horizontal 6 taps by gather: bit-identical to the region
-// kernel): the consumer keeps, per level, up to stream_slots(g) output rows in flight for its two columns; a wave-uniform
-// ROW PROGRAM (one record per source row of the level-0 crop, built by the host from the float64 tap tables, read with
-// scalar loads one record ahead) says which slot takes which weight, which restarts and which completes.  A completed
-// row goes through a wave-private 128-float LDS line, from which the outputs ANCHORED in the wave's 120 columns (one per
-// lane; host-checked <= 64, i.e. zoom steps >= 1.875) gather their 6 taps.  A segment stores the rows whose anchor row it
-// owns; their taps lie inside its streamed rows because the walk carries 4 halo rows per side.
+// The OTHER levels of the pyramid (template G > 0) come out of the same walk, from a sixth wave of the block (the
+// PYRAMID WAVE), with the arithmetic order of gray_stream_kernel's pass 2 and of the region kernel (vertical 6 taps in
+// the lane, then horizontal 6 taps by gather: bit-identical, tested).  It owns all 488 ring columns, 8 per lane, and
+// keeps per level up to walk_slots(g) output rows in flight; a wave-uniform ROW PROGRAM (one record per source row of
+// the level-0 crop, built by the host from the float64 tap tables) says which slot takes which weight, which restarts,
+// which completes.  The loader DMAs the records of a chunk into the ring slot beside its rows, so the pyramid wave reads
+// them from LDS (first version: scalar loads inside the consumers -- s_load shares lgkmcnt with the ring reads and the
+// records overflowed the SGPR file: 2x slower).  A completed row goes through a 512-float LDS line; the outputs
+// ANCHORED in the strip's 480 columns (<= 256 per level, host-checked: zoom steps >= 1.875) gather their 6 taps from it,
+// 4 outputs per lane, with column records (tap index + 6 weights) that the wave staged into LDS at its start.  A segment
+// stores the rows whose anchor row it owns; their taps lie inside its streamed rows (4 halo rows per side).
 #pragma once
 
 #include "silent_common.h"
@@ -40,16 +43,30 @@ constexpr int kWalkStripW = kWalkNC * kWalkCols;    // 480 output columns per bl
 constexpr int kWalkRowF = 512;                      // floats per ring row (488 used: strip + 4 halo columns per side)
 constexpr int kWalkCH = 8;                          // rows per chunk
 constexpr int kWalkSlots = 3;                       // chunks in the ring
-constexpr int kWalkThreads = (kWalkNC + 1) * 64;
-constexpr int kWalkLoadsPerChunk = 2 * kWalkCH;     // LDS-DMA instructions the loader issues per chunk
+constexpr int kWalkLoadsPerChunk = 2 * kWalkCH;     // LDS-DMA instructions the loader issues per chunk (+1 with a pyramid wave)
+constexpr int kWalkMaxOut = 256;                    // outputs of one general level anchored in a strip (4 per lane)
+__host__ __device__ constexpr int walk_threads(int g) { return (kWalkNC + 1 + (g > 0 ? 1 : 0)) * 64; }
+// output rows of general level g in flight at once in the pyramid wave.  The walk only takes zoom steps >= 1.875 per
+// level (host-checked through the slot-conflict test), so 3 / 2 / 1 rows suffice where gray_stream_kernel keeps 4 / 3 / 2.
+__host__ __device__ constexpr int walk_slots(int g) { return g == 0 ? 3 : (g == 1 ? 2 : 1); }
+constexpr int kWalkMaxSlots = 3;
+// row record: [meta(0) .. meta(Gp-1)] [weights of level 0 (3)] [level 1 (2)] [level 2 (1)] ...; padded to 12 / 20 dwords
+__host__ __device__ constexpr int walk_w_off(int gp, int g) {
+    int o = gp;
+    for (int h = 0; h < g; ++h) o += (h == 0 ? 3 : (h == 1 ? 2 : 1));
+    return o;
+}
+__host__ __device__ constexpr int walk_prog_row(int gp) { return gp <= 4 ? 12 : 20; }   // >= walk_w_off(gp, gp), multiple of 4
+// LDS column-record table of the pyramid wave: level g holds kWalkMaxOut >> g slots of 8 dwords (level g has at most
+// half the outputs of level g - 1 per strip; host-checked)
+__host__ __device__ constexpr int walk_rec_cap(int g) { return (kWalkMaxOut >> g) > 4 ? (kWalkMaxOut >> g) : 4; }
 
 // tables of the in-walk pyramid (device memory owned by the plan)
 struct WalkPyr {
     int G;                        // general levels (<= template G; the rest are inert)
-    int waves_x;                  // 120-column wave tiles per row = strips_x * 4
-    const int* row_prog;          // [out_h + 8][kStreamProgRow(Gp)]: record of stream row y at index y + 4
-    const int* col_hdr;           // [G][waves_x][2]: first output column, number of outputs (<= 64)
-    const int* col_rec;           // [G][waves_x][64][8]: index of tap 0 in the wave's 128 columns, 6 weights, pad
+    const int* row_prog;          // [out_h + 8 (+ padding)][walk_prog_row(Gp)]: record of stream row y at index y + 4
+    const int* col_hdr;           // [G][strips_x][2]: first output column, number of outputs of the strip
+    const int* col_rec;           // [strips_x][walk_rec_total(Gp)][8]: ring index of tap 0, 6 weights, pad
     long long px_off[8];          // pixel offset of level g inside one pyramid
     int out_w[8];
 };
@@ -66,16 +83,32 @@ struct WalkTab {
 typedef __attribute__((address_space(3))) void* walk_lds_ptr;
 typedef const __attribute__((address_space(1))) void* walk_glb_ptr;
 
+// total record slots of the LDS column table for a kernel compiled for G levels
+__host__ __device__ constexpr int walk_rec_total(int g) {
+    int n = 0;
+    for (int i = 0; i < g; ++i) n += (kWalkMaxOut >> i) > 4 ? (kWalkMaxOut >> i) : 4;
+    return n;
+}
+__host__ __device__ constexpr int walk_rec_base(int g) {
+    int n = 0;
+    for (int i = 0; i < g; ++i) n += (kWalkMaxOut >> i) > 4 ? (kWalkMaxOut >> i) : 4;
+    return n;
+}
+
 template <int K, bool NT, int G>
-__global__ __launch_bounds__(kWalkThreads) void gray_walk_kernel(const float* __restrict__ frames,
-                                                                  float* __restrict__ pyr, float* __restrict__ cs_out,
-                                                                  float* __restrict__ end_out, const WalkTab tab,
-                                                                  const WalkPyr wp, const GrayW wts, float clip_hi) {
+__global__ __launch_bounds__(walk_threads(G)) void gray_walk_kernel(const float* __restrict__ frames,
+                                                                     float* __restrict__ pyr, float* __restrict__ cs_out,
+                                                                     float* __restrict__ end_out, const WalkTab tab,
+                                                                     const WalkPyr wp, const GrayW wts, float clip_hi) {
     static_assert(K == 4 || K == 8, "two-pixel store layouts exist for K = 4 and K = 8");
     static_assert(G == 0 || G == stream_pad_levels(G), "row programs are padded to 4 or 7 levels");
+    constexpr int GG = G > 0 ? G : 1;
+    constexpr int PR = G > 0 ? walk_prog_row(GG) : 4;           // dwords per row record
     __shared__ __attribute__((aligned(16))) float s_ring[kWalkSlots * kWalkCH][kWalkRowF];   // 48 KB
-    __shared__ __attribute__((aligned(16))) float s_slab[K == 8 ? kWalkNC * 1024 : 4];       // K = 8 store transpose
-    __shared__ __attribute__((aligned(16))) float s_line[G > 0 ? kWalkNC * 128 : 4];         // completed rows of other levels
+    __shared__ __attribute__((aligned(16))) float s_slab[K == 8 ? kWalkNC * 512 : 4];        // K = 8 store transpose
+    __shared__ __attribute__((aligned(16))) int s_prog[G > 0 ? kWalkSlots * kWalkCH * PR : 4];   // row records of the ring's chunks
+    __shared__ __attribute__((aligned(16))) float s_line[G > 0 ? kWalkRowF : 4];                  // a completed row of another level
+    __shared__ __attribute__((aligned(16))) int s_rec[G > 0 ? walk_rec_total(GG) * 8 : 4];        // column records of this strip
 
     const unsigned bid = blockIdx.x;
     const int strip = (int)(bid % (unsigned)tab.strips_x);
@@ -107,13 +140,20 @@ __global__ __launch_bounds__(kWalkThreads) void gray_walk_kernel(const float* __
                 __builtin_amdgcn_global_load_lds((walk_glb_ptr)(rp + c0), (walk_lds_ptr)dst, 16, 0, 0);
                 __builtin_amdgcn_global_load_lds((walk_glb_ptr)(rp + c1), (walk_lds_ptr)(dst + 256), 16, 0, 0);
             }
+            if constexpr (G > 0) {
+                // the chunk's kWalkCH row records (contiguous in the table: record of stream row s at (seg_y0 + s) * PR)
+                const int* rp = wp.row_prog + ((long long)seg_y0 + (long long)c * kWalkCH) * PR + lane * 4;
+                int* dst = s_prog + slot * (kWalkCH * PR);
+                if (lane < kWalkCH * PR / 4)
+                    __builtin_amdgcn_global_load_lds((walk_glb_ptr)rp, (walk_lds_ptr)dst, 16, 0, 0);
+            }
         };
         issue(0, 0);
         if (n_chunks > 1) issue(1, 1);
         int slot2 = 2;                                          // slot of chunk c + 2
         for (int c = 0; c < n_chunks; ++c) {
             // chunks 0 .. c + 1 have been issued: leave only the newest one in flight -> chunk c has landed
-            if (c + 1 < n_chunks) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(kWalkLoadsPerChunk) : "memory");
+            if (c + 1 < n_chunks) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(kWalkLoadsPerChunk + (G > 0 ? 1 : 0)) : "memory");
             else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __builtin_amdgcn_s_barrier();                       // barrier c: consumers are done with chunk c - 1
             if (c + 2 < n_chunks) issue(c + 2, slot2);          // ... whose slot is the one chunk c + 2 goes to
@@ -122,9 +162,124 @@ __global__ __launch_bounds__(kWalkThreads) void gray_walk_kernel(const float* __
         return;
     }
 
+    if constexpr (G > 0) {
+        if (wave == kWalkNC + 1) {
+            // -------------------------------------------------------------- pyramid wave: every other level
+            const long long frame_px0 = (long long)frame * tab.frame_px;
+            // stage this strip's column records into LDS (wave-private data: no block-level sync needed); these are the
+            // only vector loads of this wave and they precede all of its stores
+            {
+                const int4* __restrict__ src4 = reinterpret_cast<const int4*>(wp.col_rec) + (long long)strip * (walk_rec_total(G) * 2);
+                int4* dst4 = reinterpret_cast<int4*>(s_rec);
+                for (int i = lane; i < walk_rec_total(G) * 2; i += 64) dst4[i] = src4[i];
+            }
+            int gx0[G], gn[G];
+            typedef const __attribute__((address_space(4))) int* const_int_ptr;
+#pragma unroll
+            for (int g = 0; g < G; ++g) {
+                const int gg = min(g, wp.G - 1);
+                const_int_ptr h = (const_int_ptr)(wp.col_hdr + ((long long)gg * tab.strips_x + strip) * 2);
+                gx0[g] = h[0];
+                gn[g] = g < wp.G ? h[1] : 0;
+            }
+            // ring offsets of the lane's 8 columns (ring columns 8 lane .. 8 lane + 7 <-> crop columns X0 - 4 + ...)
+            const bool interior = X0 - 4 >= 0 && X0 + kWalkRowF - 4 <= tab.src_w;   // wave-uniform: no mirrored column
+            int off[8];
+#pragma unroll
+            for (int q = 0; q < 8; ++q)
+                off[q] = min(max(mirror_near(X0 - 4 + lane * 8 + q, tab.src_w) - (X0 - 4), 0), kWalkRowF - 1);
+            float vacc[G][kWalkMaxSlots][8];
+#pragma unroll
+            for (int g = 0; g < G; ++g)
+#pragma unroll
+                for (int k = 0; k < kWalkMaxSlots; ++k)
+#pragma unroll
+                    for (int q = 0; q < 8; ++q) vacc[g][k][q] = 0.0f;
+            asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");   // records staged
+            __builtin_amdgcn_wave_barrier();
+
+            int slot = 0;
+            for (int c = 0; c < n_chunks; ++c) {
+                __builtin_amdgcn_s_barrier();                   // barrier c: chunk c (rows + records) is in the ring
+                asm volatile("" ::: "memory");
+#pragma unroll 1
+                for (int r = 0; r < kWalkCH; ++r) {
+                    const int s = c * kWalkCH + r;
+                    if (s >= n_rows) break;
+                    const float* __restrict__ row = &s_ring[slot * kWalkCH + r][0];
+                    float x[8];
+                    if (interior) {
+                        typedef float nf4 __attribute__((ext_vector_type(4)));
+                        const nf4 lo = *reinterpret_cast<const nf4*>(row + lane * 8);
+                        const nf4 hi = *reinterpret_cast<const nf4*>(row + lane * 8 + 4);
+                        x[0] = lo.x; x[1] = lo.y; x[2] = lo.z; x[3] = lo.w;
+                        x[4] = hi.x; x[5] = hi.y; x[6] = hi.z; x[7] = hi.w;
+                    } else {
+#pragma unroll
+                        for (int q = 0; q < 8; ++q) x[q] = row[off[q]];
+                    }
+                    const int4* __restrict__ rec4 = reinterpret_cast<const int4*>(s_prog + (slot * kWalkCH + r) * PR);
+                    int cur[PR];
+#pragma unroll
+                    for (int e = 0; e < PR / 4; ++e) {
+                        const int4 t = rec4[e];                 // every lane reads the same record (LDS broadcast)
+                        cur[4 * e] = t.x; cur[4 * e + 1] = t.y; cur[4 * e + 2] = t.z; cur[4 * e + 3] = t.w;
+                    }
+#pragma unroll
+                    for (int g = 0; g < G; ++g) {
+                        const int meta = __builtin_amdgcn_readfirstlane(cur[g]);
+                        if (!(meta & 128)) continue;            // wave-uniform: this source row carries no tap of level g
+#pragma unroll
+                        for (int k = 0; k < walk_slots(g); ++k) {
+                            const float w = __int_as_float(cur[walk_w_off(G, g) + k]);
+                            const bool restart = (meta >> k) & 1;
+#pragma unroll
+                            for (int q = 0; q < 8; ++q)
+                                vacc[g][k][q] = __builtin_fmaf(w, x[q], restart ? 0.0f : vacc[g][k][q]);
+                        }
+                        const int done = (meta >> 4) & 7;
+                        // the row's anchor is source row y - 3 = seg_y0 + s - 7: stored by the segment that owns it
+                        const int anchor = seg_y0 + s - 7;
+                        if (done < kWalkMaxSlots && anchor >= seg_y0 && anchor < seg_y0 + seg_h) {   // wave-uniform
+                            const int oy = meta >> 8;
+                            float v[8];
+#pragma unroll
+                            for (int q = 0; q < 8; ++q) {
+                                v[q] = vacc[g][0][q];
+#pragma unroll
+                                for (int k = 1; k < walk_slots(g); ++k) v[q] = done == k ? vacc[g][k][q] : v[q];
+                            }
+                            typedef float nf4 __attribute__((ext_vector_type(4)));
+                            *reinterpret_cast<nf4*>(s_line + lane * 8) = nf4{v[0], v[1], v[2], v[3]};
+                            *reinterpret_cast<nf4*>(s_line + lane * 8 + 4) = nf4{v[4], v[5], v[6], v[7]};
+                            __builtin_amdgcn_wave_barrier();
+                            float* __restrict__ dst = pyr + frame_px0 + wp.px_off[g] + (long long)oy * wp.out_w[g] + gx0[g];
+#pragma unroll
+                            for (int q = 0; q < (walk_rec_cap(g) + 63) / 64; ++q) {
+                                const int j = q * 64 + lane;    // output j of the strip's run
+                                const int jj = min(j, walk_rec_cap(g) - 1);
+                                const int4* __restrict__ rc = reinterpret_cast<const int4*>(s_rec + (walk_rec_base(g) + jj) * 8);
+                                const int4 ra = rc[0], rb = rc[1];
+                                const float* tp = s_line + ra.x;
+                                float acc = __int_as_float(ra.y) * tp[0];
+                                acc = __builtin_fmaf(__int_as_float(ra.z), tp[1], acc);
+                                acc = __builtin_fmaf(__int_as_float(ra.w), tp[2], acc);
+                                acc = __builtin_fmaf(__int_as_float(rb.x), tp[3], acc);
+                                acc = __builtin_fmaf(__int_as_float(rb.y), tp[4], acc);
+                                acc = __builtin_fmaf(__int_as_float(rb.z), tp[5], acc);
+                                if (j < gn[g]) dst[j] = acc;
+                            }
+                            __builtin_amdgcn_wave_barrier();
+                        }
+                    }
+                }
+                slot = slot == kWalkSlots - 1 ? 0 : slot + 1;
+            }
+            return;
+        }
+    }
+
     // ---------------------------------------------------------------------- consumers
-    const FusedLevel* unused = nullptr;
-    (void)unused;
     const int xw0 = X0 + wave * kWalkCols;                      // first output column of this wave
     const bool live = xw0 < tab.out_w;                          // wave-uniform; a dead wave still meets every barrier
     const int colA = xw0 - 4 + 2 * lane, colB = colA + 1;       // the lane's two columns (level = crop coordinates)
@@ -158,51 +313,6 @@ __global__ __launch_bounds__(kWalkThreads) void gray_walk_kernel(const float* __
         }
     }
 
-    // ---- in-walk pyramid state (G > 0): column records of this lane's output per level, vertical accumulators
-    constexpr int GG = G > 0 ? G : 1;
-    constexpr int PR = G > 0 ? kStreamProgRow(GG) : 1;
-    typedef const __attribute__((address_space(4))) int* const_int_ptr;
-    int gx0[GG], gn[GG], gtap[GG];
-    float gw[GG][6];
-    float vacc[GG][kStreamSlots][2];
-    const long long frame_px0 = (long long)frame * tab.frame_px;
-    if constexpr (G > 0) {
-        const int wx_tile = strip * kWalkNC + wave;
-#pragma unroll
-        for (int g = 0; g < G; ++g) {
-            const int gg = min(g, wp.G - 1);
-            const_int_ptr h = (const_int_ptr)(wp.col_hdr + ((long long)gg * wp.waves_x + wx_tile) * 2);
-            gx0[g] = h[0];
-            gn[g] = g < wp.G ? h[1] : 0;
-            const int4* __restrict__ rec =
-                reinterpret_cast<const int4*>(wp.col_rec + (((long long)gg * wp.waves_x + wx_tile) * 64 + lane) * 8);
-            const int4 ra = rec[0], rb = rec[1];
-            gtap[g] = ra.x;
-            gw[g][0] = __int_as_float(ra.y);
-            gw[g][1] = __int_as_float(ra.z);
-            gw[g][2] = __int_as_float(ra.w);
-            gw[g][3] = __int_as_float(rb.x);
-            gw[g][4] = __int_as_float(rb.y);
-            gw[g][5] = __int_as_float(rb.z);
-#pragma unroll
-            for (int k = 0; k < kStreamSlots; ++k) vacc[g][k][0] = vacc[g][k][1] = 0.0f;
-        }
-        // retire these loads here: they are the only vector loads of a consumer, and the only thing its vmcnt queue
-        // will ever be waited for
-#pragma unroll
-        for (int g = 0; g < G; ++g) {
-            asm volatile("" ::"v"(gtap[g]));
-#pragma unroll
-            for (int j = 0; j < 6; ++j) asm volatile("" ::"v"(gw[g][j]));
-        }
-    }
-    const_int_ptr prog = (const_int_ptr)(wp.row_prog + (long long)seg_y0 * PR);   // record of stream row s at s * PR
-    int cur[PR];
-    if constexpr (G > 0) {
-#pragma unroll
-        for (int e = 0; e < PR; ++e) cur[e] = prog[e];
-    }
-
     float hA[5] = {0, 0, 0, 0, 0}, hB[5] = {0, 0, 0, 0, 0};   // horizontally smoothed rows y-4 .. y of the two columns
     float iw[3][4], cw[3][4];                                   // level-0 rows / CS rows x columns (A-1, A, B, B+1)
 #pragma unroll
@@ -221,50 +331,6 @@ __global__ __launch_bounds__(kWalkThreads) void gray_walk_kernel(const float* __
                 if (s >= n_rows) break;                         // wave-uniform (padding of the last chunk)
                 const float* __restrict__ row = &s_ring[slot * kWalkCH + r][0];
                 const float a = row[offA], b = row[offB];
-                // ---- the other levels: vertical taps of this source row, gather + store of a row that completes
-                if constexpr (G > 0) {
-                    int nxt[PR];
-                    const int sn = min(s + 1, n_rows - 1);      // record of the NEXT row, requested before this row's work
-#pragma unroll
-                    for (int e = 0; e < PR; ++e) nxt[e] = prog[sn * PR + e];
-#pragma unroll
-                    for (int g = 0; g < G; ++g) {
-                        const int meta = cur[g];
-                        if (!(meta & 128)) continue;            // wave-uniform: this source row carries no tap of level g
-#pragma unroll
-                        for (int k = 0; k < stream_slots(g); ++k) {
-                            const float w = __int_as_float(cur[stream_w_off(G, g) + k]);
-                            const bool restart = (meta >> k) & 1;
-                            vacc[g][k][0] = __builtin_fmaf(w, a, restart ? 0.0f : vacc[g][k][0]);
-                            vacc[g][k][1] = __builtin_fmaf(w, b, restart ? 0.0f : vacc[g][k][1]);
-                        }
-                        const int done = (meta >> 4) & 7;
-                        // the row's anchor is source row y - 3 = seg_y0 + s - 7: stored by the segment that owns it
-                        const int anchor = seg_y0 + s - 7;
-                        if (done < kStreamSlots && anchor >= seg_y0 && anchor < seg_y0 + seg_h) {   // wave-uniform
-                            const int oy = meta >> 8;
-                            float v0 = vacc[g][0][0], v1 = vacc[g][0][1];
-#pragma unroll
-                            for (int k = 1; k < stream_slots(g); ++k) {
-                                v0 = done == k ? vacc[g][k][0] : v0;
-                                v1 = done == k ? vacc[g][k][1] : v1;
-                            }
-                            float* line = s_line + wave * 128;
-                            typedef float nf2 __attribute__((ext_vector_type(2)));
-                            *reinterpret_cast<nf2*>(line + 2 * lane) = nf2{v0, v1};
-                            __builtin_amdgcn_wave_barrier();
-                            const float* tp = line + gtap[g];
-                            float acc = gw[g][0] * tp[0];
-#pragma unroll
-                            for (int t = 1; t < 6; ++t) acc = __builtin_fmaf(gw[g][t], tp[t], acc);
-                            __builtin_amdgcn_wave_barrier();
-                            if (lane < gn[g])
-                                pyr[frame_px0 + wp.px_off[g] + (long long)oy * wp.out_w[g] + gx0[g] + lane] = acc;
-                        }
-                    }
-#pragma unroll
-                    for (int e = 0; e < PR; ++e) cur[e] = nxt[e];
-                }
                 // ---- horizontal 5 taps (same fma order as gray_unit_fused_kernel)
                 {
                     const float La = from_lane_below(a), Lb = from_lane_below(b);
@@ -383,24 +449,28 @@ __global__ __launch_bounds__(kWalkThreads) void gray_walk_kernel(const float* __
                         } else {
                             // K = 8: the lane's two pixels are 64 contiguous bytes; four 16-byte stores per lane would each
                             // write 16-byte pieces at a 64-byte stride.  Transpose through a wave-private LDS slab instead:
-                            // store instruction q writes pieces 64 q .. 64 q + 63 of the row, 1 KiB contiguous each.
-                            nf4* slab = reinterpret_cast<nf4*>(s_slab + wave * 1024);
-                            slab[lane * 4 + 0] = nf4{e0[0], e0[1], e0[2], e0[3]};
-                            slab[lane * 4 + 1] = nf4{e0[4], e0[5], e0[6], e0[7]};
-                            slab[lane * 4 + 2] = nf4{e1[0], e1[1], e1[2], e1[3]};
-                            slab[lane * 4 + 3] = nf4{e1[4], e1[5], e1[6], e1[7]};
-                            __builtin_amdgcn_wave_barrier();
-                            nf4 piece[4];
-#pragma unroll
-                            for (int q = 0; q < 4; ++q) piece[q] = slab[q * 64 + lane];
-                            __builtin_amdgcn_wave_barrier();
-                            // piece i (16 bytes) belongs to column (xw0 - 4) + i / 2; stored columns: xw0 .. xw0 + ncols - 1
+                            // every store instruction writes 64 consecutive pieces of the row, 1 KiB contiguous,
+                            // in two halves (lanes 0-31, then 32-63), so that the slab is 2 KB per wave.
+                            nf4* slab = reinterpret_cast<nf4*>(s_slab + wave * 512);
                             const int ncols = min(kWalkCols, tab.out_w - xw0);
                             nf4* dst = reinterpret_cast<nf4*>(end_out + (base_px + (long long)yo * tab.out_w + (xw0 - 4)) * 8);
 #pragma unroll
-                            for (int q = 0; q < 4; ++q) {
-                                const int col = (q * 64 + lane) >> 1;   // column index inside the wave's 128
-                                if (col >= 4 && col < 4 + ncols) dst[q * 64 + lane] = piece[q];
+                            for (int hlf = 0; hlf < 2; ++hlf) {
+                                if ((lane >> 5) == hlf) {
+                                    const int l5 = lane & 31;
+                                    slab[l5 * 4 + 0] = nf4{e0[0], e0[1], e0[2], e0[3]};
+                                    slab[l5 * 4 + 1] = nf4{e0[4], e0[5], e0[6], e0[7]};
+                                    slab[l5 * 4 + 2] = nf4{e1[0], e1[1], e1[2], e1[3]};
+                                    slab[l5 * 4 + 3] = nf4{e1[4], e1[5], e1[6], e1[7]};
+                                }
+                                __builtin_amdgcn_wave_barrier();
+                                const nf4 p0 = slab[lane], p1 = slab[64 + lane];
+                                __builtin_amdgcn_wave_barrier();
+                                // piece i of the row (16 bytes) belongs to column (xw0 - 4) + i / 2; this half holds pieces
+                                // 128 hlf .. 128 hlf + 127; stored columns: xw0 .. xw0 + ncols - 1
+                                const int i0 = hlf * 128 + lane, i1 = i0 + 64;
+                                if ((i0 >> 1) >= 4 && (i0 >> 1) < 4 + ncols) dst[i0] = p0;
+                                if ((i1 >> 1) >= 4 && (i1 >> 1) < 4 + ncols) dst[i1] = p1;
                             }
                         }
                     }
