@@ -10,8 +10,10 @@ pipe = LineEndPipeline((1080, 1920), mode="gray", n_levels=5, n_orient=4, batch=
 frames = torch.randint(0, 256, (B, 1080, 1920, 1), device="cuda").float()
 def two_step():
     pipe.run_pyramid(frames); pipe.run_filters()
-variants = {"two-step": ("0", two_step), "walk": ("0", lambda: pipe.step(frames)),
+variants = {"two-step": ("0", two_step), "walk": (os.environ.get("SILENT_AB_WALK_OPTS", "0"), lambda: pipe.step(frames)),
             "walk plain st": ("256", lambda: pipe.step(frames)), "walk+region": ("512", lambda: pipe.step(frames)),
+            "walk+region 3/CU": (str(512 + 1024), lambda: pipe.step(frames)), "walk+region 4/CU": (str(512 + 2048), lambda: pipe.step(frames)),
+            "walk 3/CU": ("1024", lambda: pipe.step(frames)),
             "tile stream": ("64", lambda: pipe.step(frames))}
 if os.environ.get("AB_ONLY"):
     variants = {k: v for k, v in variants.items() if k in os.environ["AB_ONLY"].split(",")}
@@ -32,7 +34,7 @@ for rnd in range(12):
 byt = pipe.algorithmic_bytes_per_frame() * B
 for k in variants:
     t = np.array(times[k])
-    print("%-14s median %.4f ms  min %.4f  max %.4f   %.0f GB/s algorithmic = %.1f %% of 8 TB/s" % (k, np.median(t), t.min(), t.max(), byt / np.median(t) / 1e6, byt / np.median(t) / 1e6 / 80))
+    print("%-18s median %.4f ms  min %.4f  max %.4f   %.0f GB/s algorithmic = %.1f %% of 8 TB/s" % (k, np.median(t), t.min(), t.max(), byt / np.median(t) / 1e6, byt / np.median(t) / 1e6 / 80))
 
 # dominant kernel alone (HIP events recorded by the library around its launch) + a device copy for calibration
 pipe.ctx.set_tuning(0, int(os.environ.get("AB_BASE_OPTS", "0")))
