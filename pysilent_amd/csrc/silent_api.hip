@@ -1422,7 +1422,8 @@ SILENT_EXPORT int silent_pyramid_plan_create(silent_ctx* ctx, int frame_h, int f
             const size_t n_rec = (size_t)u.out_h + 8;                 // stream rows y = -4 .. out_h + 3 at index y + 4
             const size_t n_rec_pad = n_rec + 2 * kWalkCH;             // the loader fetches whole chunks of records
             const int rec_total = walk_rec_total(Gp);
-            std::vector<int> prog(n_rec_pad * PR, 0), hdr((size_t)G * strips_x * 2, 0), rec((size_t)strips_x * rec_total * 8, 0);
+            const int waves_x = strips_x * kWalkNC;
+            std::vector<int> prog(n_rec_pad * PR, 0), hdr((size_t)G * waves_x * 2, 0), rec((size_t)waves_x * rec_total * 8, 0);
             for (size_t r = 0; r < n_rec_pad; ++r)
                 for (int gg = 0; gg < Gp; ++gg) prog[r * PR + gg] = 7 << 4;  // inert: feeds nothing, no slot completes
             std::vector<char> used(n_rec * G * kWalkMaxSlots, 0);
@@ -1454,18 +1455,18 @@ SILENT_EXPORT int silent_pyramid_plan_create(silent_ctx* ctx, int frame_h, int f
                     }
                 }
                 int ox = 0;
-                for (int sx = 0; sx < strips_x && ok; ++sx) {
-                    const int X0 = sx * kWalkStripW;
-                    while (ox < zc && xb[ox] < X0) ++ox;
+                for (int wx = 0; wx < waves_x && ok; ++wx) {
+                    const int xw0 = wx * kWalkCols;
+                    while (ox < zc && xb[ox] < xw0) ++ox;
                     int n = 0;
-                    while (ox + n < zc && xb[ox + n] < X0 + kWalkStripW) ++n;
-                    if (n > walk_rec_cap(g)) { ok = false; break; }      // <= 4 outputs per lane at level 0, halving per level
-                    hdr[((size_t)g * strips_x + sx) * 2] = ox;
-                    hdr[((size_t)g * strips_x + sx) * 2 + 1] = n;
+                    while (ox + n < zc && xb[ox + n] < xw0 + kWalkCols) ++n;
+                    if (n > walk_rec_cap(g)) { ok = false; break; }      // one output per lane at level 0, halving per level
+                    hdr[((size_t)g * waves_x + wx) * 2] = ox;
+                    hdr[((size_t)g * waves_x + wx) * 2 + 1] = n;
                     for (int j = 0; j < n; ++j) {
-                        int* r = rec.data() + ((size_t)sx * rec_total + walk_rec_base(g) + j) * 8;
-                        r[0] = xb[ox + j] - X0 + 2;   // ring index of tap 0 (ring index 0 <-> column X0 - 4)
-                        if (r[0] < 0 || r[0] + 5 > kWalkStripW + 7) { ok = false; break; }
+                        int* r = rec.data() + ((size_t)wx * rec_total + walk_rec_base(g) + j) * 8;
+                        r[0] = xb[ox + j] - xw0 + 2;   // index of tap 0 in the wave's 128 columns (index 0 <-> column xw0 - 4)
+                        if (r[0] < 0 || r[0] + 5 > 127) { ok = false; break; }
                         std::memcpy(r + 1, &xw[(size_t)(d.xtab_off + ox + j) * 6], 24);
                     }
                     ox += n;

@@ -19,17 +19,19 @@
 // Eligibility is host-checked (silent_api.hip, walk_plan): single-channel unit level, 16-byte aligned rows and crop
 // (W, src_x0, out_w multiples of 4; even pyramid offsets), K = 4 or 8.  Everything else keeps gray_stream_kernel.
 //
-// The OTHER levels of the pyramid (template G > 0) come out of the same walk, from a sixth wave of the block (the
-// PYRAMID WAVE), with the arithmetic order of gray_stream_kernel's pass 2 and of the region kernel (vertical 6 taps in
-// the lane, then horizontal 6 taps by gather: bit-identical, tested).  It owns all 488 ring columns, 8 per lane, and
-// keeps per level up to walk_slots(g) output rows in flight; a wave-uniform ROW PROGRAM (one record per source row of
-// the level-0 crop, built by the host from the float64 tap tables) says which slot takes which weight, which restarts,
-// which completes.  The loader DMAs the records of a chunk into the ring slot beside its rows, so the pyramid wave reads
-// them from LDS (first version: scalar loads inside the consumers -- s_load shares lgkmcnt with the ring reads and the
-// records overflowed the SGPR file: 2x slower).  A completed row goes through a 512-float LDS line; the outputs
-// ANCHORED in the strip's 480 columns (<= 256 per level, host-checked: zoom steps >= 1.875) gather their 6 taps from it,
-// 4 outputs per lane, with column records (tap index + 6 weights) that the wave staged into LDS at its start.  A segment
-// stores the rows whose anchor row it owns; their taps lie inside its streamed rows (4 halo rows per side).
+// The OTHER levels of the pyramid (template G > 0) come out of the same walk, in the consumers, with the arithmetic
+// order of gray_stream_kernel's pass 2 and of the region kernel (vertical 6 taps in the lane, then horizontal 6 taps by
+// gather: bit-identical, tested).  A consumer keeps, per level, up to walk_slots(g) output rows in flight for its two
+// columns; a wave-uniform ROW PROGRAM (one record per source row of the level-0 crop, built by the host from the float64
+// tap tables) says which slot takes which weight, which restarts, which completes.  The loader DMAs the records of a
+// chunk into the ring beside its rows and the consumer reads them from LDS with the row's own values.  (Measured
+// alternatives: records by scalar loads inside the consumers -- s_load shares lgkmcnt with the ring reads and the records
+// overflowed the SGPR file, 2x slower; a sixth "pyramid wave" owning all 488 columns, 8 per lane -- one wave cannot keep
+// up: ~350 instructions and ~5 LDS round trips per row against a budget of ~3000 cycles, kernel 0.73 -> 1.05 ms.)
+// A completed row goes through a wave-private 128-float LDS line; the outputs ANCHORED in the wave's 120 columns (one per
+// lane; host-checked <= 64 >> g, i.e. zoom steps >= 1.875 per level) gather their 6 taps from it, with column records (tap
+// index + 6 weights) that the wave staged into LDS at its start.  A segment stores the rows whose anchor row it owns;
+// their taps lie inside its streamed rows (4 halo rows per side).
 #pragma once
 
 #include <type_traits>
@@ -46,8 +48,8 @@ constexpr int kWalkRowF = 512;                      // floats per ring row (488 
 constexpr int kWalkCH = 8;                          // rows per chunk
 constexpr int kWalkSlots = 3;                       // chunks in the ring
 constexpr int kWalkLoadsPerChunk = 2 * kWalkCH;     // LDS-DMA instructions the loader issues per chunk (+1 with a pyramid wave)
-constexpr int kWalkMaxOut = 256;                    // outputs of one general level anchored in a strip (4 per lane)
-__host__ __device__ constexpr int walk_threads(int g) { return (kWalkNC + 1 + (g > 0 ? 1 : 0)) * 64; }
+constexpr int kWalkMaxOut = 64;                     // outputs of general level 0 anchored in a wave's 120 columns (one per lane)
+__host__ __device__ constexpr int walk_threads(int) { return (kWalkNC + 1) * 64; }
 // output rows of general level g in flight at once in the pyramid wave.  The walk only takes zoom steps >= 1.875 per
 // level (host-checked through the slot-conflict test), so 3 / 2 / 1 rows suffice where gray_stream_kernel keeps 4 / 3 / 2.
 __host__ __device__ constexpr int walk_slots(int g) { return g == 0 ? 3 : (g == 1 ? 2 : 1); }
@@ -59,16 +61,16 @@ __host__ __device__ constexpr int walk_w_off(int gp, int g) {
     return o;
 }
 __host__ __device__ constexpr int walk_prog_row(int gp) { return gp <= 4 ? 12 : 20; }   // >= walk_w_off(gp, gp), multiple of 4
-// LDS column-record table of the pyramid wave: level g holds kWalkMaxOut >> g slots of 8 dwords (level g has at most
-// half the outputs of level g - 1 per strip; host-checked)
-__host__ __device__ constexpr int walk_rec_cap(int g) { return (kWalkMaxOut >> g) > 4 ? (kWalkMaxOut >> g) : 4; }
+// LDS column-record table of a consumer wave: level g holds max(kWalkMaxOut >> g, 1) slots of 8 dwords (level g has at
+// most half the outputs of level g - 1 per wave tile; host-checked)
+__host__ __device__ constexpr int walk_rec_cap(int g) { return (kWalkMaxOut >> g) > 1 ? (kWalkMaxOut >> g) : 1; }
 
 // tables of the in-walk pyramid (device memory owned by the plan)
 struct WalkPyr {
     int G;                        // general levels (<= template G; the rest are inert)
     const int* row_prog;          // [out_h + 8 (+ padding)][walk_prog_row(Gp)]: record of stream row y at index y + 4
-    const int* col_hdr;           // [G][strips_x][2]: first output column, number of outputs of the strip
-    const int* col_rec;           // [strips_x][walk_rec_total(Gp)][8]: ring index of tap 0, 6 weights, pad
+    const int* col_hdr;           // [G][waves_x][2]: first output column, number of outputs of the 120-column wave tile
+    const int* col_rec;           // [waves_x][walk_rec_total(Gp)][8]: index of tap 0 in the wave's 128 columns, 6 weights, pad
     long long px_off[8];          // pixel offset of level g inside one pyramid
     int out_w[8];
 };
@@ -97,12 +99,12 @@ typedef const __attribute__((address_space(1))) void* walk_glb_ptr;
 // total record slots of the LDS column table for a kernel compiled for G levels
 __host__ __device__ constexpr int walk_rec_total(int g) {
     int n = 0;
-    for (int i = 0; i < g; ++i) n += (kWalkMaxOut >> i) > 4 ? (kWalkMaxOut >> i) : 4;
+    for (int i = 0; i < g; ++i) n += (kWalkMaxOut >> i) > 1 ? (kWalkMaxOut >> i) : 1;
     return n;
 }
 __host__ __device__ constexpr int walk_rec_base(int g) {
     int n = 0;
-    for (int i = 0; i < g; ++i) n += (kWalkMaxOut >> i) > 4 ? (kWalkMaxOut >> i) : 4;
+    for (int i = 0; i < g; ++i) n += (kWalkMaxOut >> i) > 1 ? (kWalkMaxOut >> i) : 1;
     return n;
 }
 
@@ -119,8 +121,8 @@ __global__ __launch_bounds__(walk_threads(G)) __attribute__((amdgpu_waves_per_eu
     __shared__ __attribute__((aligned(16))) float s_ring[kWalkSlots * kWalkCH][kWalkRowF];   // 48 KB
     __shared__ __attribute__((aligned(16))) float s_slab[K == 8 ? kWalkNC * 512 : 4];        // K = 8 store transpose
     __shared__ __attribute__((aligned(16))) int s_prog[G > 0 ? kWalkSlots * kWalkCH * PR : 4];   // row records of the ring's chunks
-    __shared__ __attribute__((aligned(16))) float s_line[G > 0 ? kWalkRowF : 4];                  // a completed row of another level
-    __shared__ __attribute__((aligned(16))) int s_rec[G > 0 ? walk_rec_total(GG) * 8 : 4];        // column records of this strip
+    __shared__ __attribute__((aligned(16))) float s_line[G > 0 ? kWalkNC * 128 : 4];              // a completed row of another level, per wave
+    __shared__ __attribute__((aligned(16))) int s_rec[G > 0 ? kWalkNC * walk_rec_total(GG) * 8 : 4];   // column records, per wave
 
     const unsigned bid = blockIdx.x;
     const int strip = (int)(bid % (unsigned)tab.strips_x);
@@ -174,143 +176,6 @@ __global__ __launch_bounds__(walk_threads(G)) __attribute__((amdgpu_waves_per_eu
         return;
     }
 
-    if constexpr (G > 0) {
-        if (wave == kWalkNC + 1) {
-            // -------------------------------------------------------------- pyramid wave: every other level
-            const long long frame_px0 = (long long)frame * tab.frame_px;
-            // stage this strip's column records into LDS (wave-private data: no block-level sync needed); these are the
-            // only vector loads of this wave and they precede all of its stores
-            {
-                const int4* __restrict__ src4 = reinterpret_cast<const int4*>(wp.col_rec) + (long long)strip * (walk_rec_total(G) * 2);
-                int4* dst4 = reinterpret_cast<int4*>(s_rec);
-                for (int i = lane; i < walk_rec_total(G) * 2; i += 64) dst4[i] = src4[i];
-            }
-            int gx0[G], gn[G];
-            typedef const __attribute__((address_space(4))) int* const_int_ptr;
-#pragma unroll
-            for (int g = 0; g < G; ++g) {
-                const int gg = min(g, wp.G - 1);
-                const_int_ptr h = (const_int_ptr)(wp.col_hdr + ((long long)gg * tab.strips_x + strip) * 2);
-                gx0[g] = h[0];
-                gn[g] = g < wp.G ? h[1] : 0;
-            }
-            // ring offsets of the lane's 8 columns (ring columns 8 lane .. 8 lane + 7 <-> crop columns X0 - 4 + ...)
-            const bool interior = X0 - 4 >= 0 && X0 + kWalkRowF - 4 <= tab.src_w;   // wave-uniform: no mirrored column
-            int off[8];
-#pragma unroll
-            for (int q = 0; q < 8; ++q)
-                off[q] = min(max(mirror_near(X0 - 4 + lane * 8 + q, tab.src_w) - (X0 - 4), 0), kWalkRowF - 1);
-            float vacc[G][kWalkMaxSlots][8];
-#pragma unroll
-            for (int g = 0; g < G; ++g)
-#pragma unroll
-                for (int k = 0; k < kWalkMaxSlots; ++k)
-#pragma unroll
-                    for (int q = 0; q < 8; ++q) vacc[g][k][q] = 0.0f;
-            asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");   // records staged
-            __builtin_amdgcn_wave_barrier();
-
-            int slot = 0;
-            for (int c = 0; c < n_chunks; ++c) {
-                __builtin_amdgcn_s_barrier();                   // barrier c: chunk c (rows + records) is in the ring
-                asm volatile("" ::: "memory");
-#pragma unroll 1
-                for (int r = 0; r < kWalkCH; ++r) {
-                    const int s = c * kWalkCH + r;
-                    if (s >= n_rows) break;
-                    const float* __restrict__ row = &s_ring[slot * kWalkCH + r][0];
-                    float x[8];
-                    if (interior) {
-                        typedef float nf4 __attribute__((ext_vector_type(4)));
-                        const nf4 lo = *reinterpret_cast<const nf4*>(row + lane * 8);
-                        const nf4 hi = *reinterpret_cast<const nf4*>(row + lane * 8 + 4);
-                        x[0] = lo.x; x[1] = lo.y; x[2] = lo.z; x[3] = lo.w;
-                        x[4] = hi.x; x[5] = hi.y; x[6] = hi.z; x[7] = hi.w;
-                    } else {
-#pragma unroll
-                        for (int q = 0; q < 8; ++q) x[q] = row[off[q]];
-                    }
-                    const int4* __restrict__ rec4 = reinterpret_cast<const int4*>(s_prog + (slot * kWalkCH + r) * PR);
-                    int cur[PR];
-#pragma unroll
-                    for (int e = 0; e < PR / 4; ++e) {
-                        const int4 t = rec4[e];                 // every lane reads the same record (LDS broadcast)
-                        cur[4 * e] = t.x; cur[4 * e + 1] = t.y; cur[4 * e + 2] = t.z; cur[4 * e + 3] = t.w;
-                    }
-                    walk_static_for<0, G>([&](auto gc) {
-                        constexpr int g = decltype(gc)::value;
-                        const int meta = __builtin_amdgcn_readfirstlane(cur[g]);
-                        if (!(meta & 128)) return;              // wave-uniform: this source row carries no tap of level g
-#pragma unroll
-                        for (int k = 0; k < walk_slots(g); ++k) {
-                            const float w = __int_as_float(cur[walk_w_off(G, g) + k]);
-                            // a slot that restarts accumulates onto +0 (wave-uniform branch, no per-element select)
-                            if ((meta >> k) & 1) {
-#pragma unroll
-                                for (int q = 0; q < 8; ++q) vacc[g][k][q] = __builtin_fmaf(w, x[q], 0.0f);
-                            } else {
-#pragma unroll
-                                for (int q = 0; q < 8; ++q) vacc[g][k][q] = __builtin_fmaf(w, x[q], vacc[g][k][q]);
-                            }
-                        }
-                        const int done = (meta >> 4) & 7;
-                        // the row's anchor is source row y - 3 = seg_y0 + s - 7: stored by the segment that owns it
-                        const int anchor = seg_y0 + s - 7;
-                        if (done < kWalkMaxSlots && anchor >= seg_y0 && anchor < seg_y0 + seg_h) {   // wave-uniform
-                            const int oy = meta >> 8;
-                            float v[8];
-#pragma unroll
-                            for (int q = 0; q < 8; ++q) {
-                                v[q] = vacc[g][0][q];
-#pragma unroll
-                                for (int k = 1; k < walk_slots(g); ++k) v[q] = done == k ? vacc[g][k][q] : v[q];
-                            }
-                            // The gather, two outputs of the lane at a time with their LDS round trips overlapped: column
-                            // records requested together, then all taps, fma chains side by side, only the store predicated
-                            // (one output at a time = 2 dependent LDS round trips each: 0.17 ms of the 0.9 ms kernel)
-                            constexpr int NQ = (walk_rec_cap(g) + 63) / 64;   // outputs per lane
-                            constexpr int QB = NQ < 2 ? NQ : 2;               // ... gathered two at a time (registers)
-                            typedef float nf4 __attribute__((ext_vector_type(4)));
-                            *reinterpret_cast<nf4*>(s_line + lane * 8) = nf4{v[0], v[1], v[2], v[3]};
-                            *reinterpret_cast<nf4*>(s_line + lane * 8 + 4) = nf4{v[4], v[5], v[6], v[7]};
-                            __builtin_amdgcn_wave_barrier();
-                            float* __restrict__ dst = pyr + frame_px0 + wp.px_off[g] + (long long)oy * wp.out_w[g] + gx0[g];
-#pragma unroll
-                            for (int q0 = 0; q0 < NQ; q0 += QB) {
-                                int4 ra[QB], rb[QB];
-#pragma unroll
-                                for (int q = 0; q < QB; ++q) {
-                                    const int jj = min((q0 + q) * 64 + lane, walk_rec_cap(g) - 1);
-                                    const int4* __restrict__ rc = reinterpret_cast<const int4*>(s_rec + (walk_rec_base(g) + jj) * 8);
-                                    ra[q] = rc[0];
-                                    rb[q] = rc[1];
-                                }
-                                float tp[QB][6];
-#pragma unroll
-                                for (int q = 0; q < QB; ++q)
-#pragma unroll
-                                    for (int t = 0; t < 6; ++t) tp[q][t] = s_line[ra[q].x + t];
-#pragma unroll
-                                for (int q = 0; q < QB; ++q) {
-                                    float acc = __int_as_float(ra[q].y) * tp[q][0];
-                                    acc = __builtin_fmaf(__int_as_float(ra[q].z), tp[q][1], acc);
-                                    acc = __builtin_fmaf(__int_as_float(ra[q].w), tp[q][2], acc);
-                                    acc = __builtin_fmaf(__int_as_float(rb[q].x), tp[q][3], acc);
-                                    acc = __builtin_fmaf(__int_as_float(rb[q].y), tp[q][4], acc);
-                                    acc = __builtin_fmaf(__int_as_float(rb[q].z), tp[q][5], acc);
-                                    if ((q0 + q) * 64 + lane < gn[g]) dst[(q0 + q) * 64 + lane] = acc;
-                                }
-                            }
-                            __builtin_amdgcn_wave_barrier();
-                        }
-                    });
-                }
-                slot = slot == kWalkSlots - 1 ? 0 : slot + 1;
-            }
-            return;
-        }
-    }
-
     // ---------------------------------------------------------------------- consumers
     const int xw0 = X0 + wave * kWalkCols;                      // first output column of this wave
     const bool live = xw0 < tab.out_w;                          // wave-uniform; a dead wave still meets every barrier
@@ -345,6 +210,35 @@ __global__ __launch_bounds__(walk_threads(G)) __attribute__((amdgpu_waves_per_eu
         }
     }
 
+    // ---- in-walk pyramid state (G > 0)
+    float vacc[GG][kWalkMaxSlots][2];
+    int gx0[GG], gn[GG];
+    const long long frame_px0 = (long long)frame * tab.frame_px;
+    int* const my_rec = s_rec + wave * (walk_rec_total(GG) * 8);
+    float* const my_line = s_line + wave * 128;
+    if constexpr (G > 0) {
+        const int wx_tile = strip * kWalkNC + wave;
+        // stage this wave tile's column records into LDS (wave-private: no block-level sync needed); these are the only
+        // vector loads of a consumer and they precede all of its stores
+        {
+            const int4* __restrict__ src4 = reinterpret_cast<const int4*>(wp.col_rec) + (long long)wx_tile * (walk_rec_total(G) * 2);
+            int4* dst4 = reinterpret_cast<int4*>(my_rec);
+            for (int i = lane; i < walk_rec_total(G) * 2; i += 64) dst4[i] = src4[i];
+        }
+        typedef const __attribute__((address_space(4))) int* const_int_ptr;
+#pragma unroll
+        for (int g = 0; g < G; ++g) {
+            const int gg = min(g, wp.G - 1);
+            const_int_ptr h = (const_int_ptr)(wp.col_hdr + ((long long)gg * (tab.strips_x * kWalkNC) + wx_tile) * 2);
+            gx0[g] = h[0];
+            gn[g] = g < wp.G ? h[1] : 0;
+#pragma unroll
+            for (int k = 0; k < kWalkMaxSlots; ++k) vacc[g][k][0] = vacc[g][k][1] = 0.0f;
+        }
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");   // records staged
+        __builtin_amdgcn_wave_barrier();
+    }
+
     float hA[5] = {0, 0, 0, 0, 0}, hB[5] = {0, 0, 0, 0, 0};   // horizontally smoothed rows y-4 .. y of the two columns
     float iw[3][4], cw[3][4];                                   // level-0 rows / CS rows x columns (A-1, A, B, B+1)
 #pragma unroll
@@ -363,6 +257,57 @@ __global__ __launch_bounds__(walk_threads(G)) __attribute__((amdgpu_waves_per_eu
                 if (s >= n_rows) break;                         // wave-uniform (padding of the last chunk)
                 const float* __restrict__ row = &s_ring[slot * kWalkCH + r][0];
                 const float a = row[offA], b = row[offB];
+                // ---- the other levels: vertical taps of this source row, gather + store of a row that completes
+                if constexpr (G > 0) {
+                    const int4* __restrict__ rec4 = reinterpret_cast<const int4*>(s_prog + (slot * kWalkCH + r) * PR);
+                    int cur[PR];
+#pragma unroll
+                    for (int e = 0; e < PR / 4; ++e) {
+                        const int4 t = rec4[e];                 // every lane reads the same record (LDS broadcast)
+                        cur[4 * e] = t.x; cur[4 * e + 1] = t.y; cur[4 * e + 2] = t.z; cur[4 * e + 3] = t.w;
+                    }
+                    walk_static_for<0, G>([&](auto gc) {
+                        constexpr int g = decltype(gc)::value;
+                        const int meta = __builtin_amdgcn_readfirstlane(cur[g]);
+                        if (!(meta & 128)) return;              // wave-uniform: this source row carries no tap of level g
+#pragma unroll
+                        for (int k = 0; k < walk_slots(g); ++k) {
+                            const float w = __int_as_float(cur[walk_w_off(G, g) + k]);
+                            const bool restart = (meta >> k) & 1;   // a slot that restarts accumulates onto +0
+                            vacc[g][k][0] = __builtin_fmaf(w, a, restart ? 0.0f : vacc[g][k][0]);
+                            vacc[g][k][1] = __builtin_fmaf(w, b, restart ? 0.0f : vacc[g][k][1]);
+                        }
+                        const int done = (meta >> 4) & 7;
+                        // the row's anchor is source row y - 3 = seg_y0 + s - 7: stored by the segment that owns it
+                        const int anchor = seg_y0 + s - 7;
+                        if (done < kWalkMaxSlots && anchor >= seg_y0 && anchor < seg_y0 + seg_h) {   // wave-uniform
+                            const int oy = meta >> 8;
+                            // the lane's column record is requested before the row is written: one LDS round trip less
+                            const int jj = min(lane, walk_rec_cap(g) - 1);
+                            const int4* __restrict__ rc = reinterpret_cast<const int4*>(my_rec + (walk_rec_base(g) + jj) * 8);
+                            const int4 ra = rc[0], rb = rc[1];
+                            float v0 = vacc[g][0][0], v1 = vacc[g][0][1];
+#pragma unroll
+                            for (int k = 1; k < walk_slots(g); ++k) {
+                                v0 = done == k ? vacc[g][k][0] : v0;
+                                v1 = done == k ? vacc[g][k][1] : v1;
+                            }
+                            typedef float nf2 __attribute__((ext_vector_type(2)));
+                            *reinterpret_cast<nf2*>(my_line + 2 * lane) = nf2{v0, v1};
+                            __builtin_amdgcn_wave_barrier();
+                            const float* tp = my_line + ra.x;
+                            float acc = __int_as_float(ra.y) * tp[0];
+                            acc = __builtin_fmaf(__int_as_float(ra.z), tp[1], acc);
+                            acc = __builtin_fmaf(__int_as_float(ra.w), tp[2], acc);
+                            acc = __builtin_fmaf(__int_as_float(rb.x), tp[3], acc);
+                            acc = __builtin_fmaf(__int_as_float(rb.y), tp[4], acc);
+                            acc = __builtin_fmaf(__int_as_float(rb.z), tp[5], acc);
+                            __builtin_amdgcn_wave_barrier();
+                            if (lane < gn[g])
+                                pyr[frame_px0 + wp.px_off[g] + (long long)oy * wp.out_w[g] + gx0[g] + lane] = acc;
+                        }
+                    });
+                }
                 // ---- horizontal 5 taps (same fma order as gray_unit_fused_kernel)
                 {
                     const float La = from_lane_below(a), Lb = from_lane_below(b);
