@@ -614,6 +614,8 @@ SILENT_EXPORT int silent_select_peaks_dev(silent_ctx* ctx, const float* color, c
 static int region_axis(int size, int stride, int* n_win, int* nseg, int* cut, int* w_lo, int* w_hi, float* scale) {
     if (stride < 1) return -1;
     const int out = (size + stride - 1) / stride;
+    *n_win = out;
+    *scale = (float)out / (float)size;
     if (out > kMaxWin) return -2;
     const int pad_before = ((out - 1) * stride) / 2;
     int lo[kMaxWin], hi[kMaxWin];
@@ -645,19 +647,38 @@ static int region_axis(int size, int stride, int* n_win, int* nseg, int* cut, in
     return 0;
 }
 
-// Region tables of max_value_indices_region (TF1 max_pool geometry per level)
+// Region tables of max_value_indices_region (TF1 max_pool geometry per level).  *general = true when some level has more
+// than kMaxWin windows per axis: the cell tables (kernarg-resident) do not apply then and the separable prefix / suffix
+// path runs (region_rowmax_kernel / region_colmax_kernel) -- any region_shape the reference accepts
+// (slam_recognition/util/selection/top_value_points.py:32-45).
+constexpr int kRegionGeneralMaxW = 16384;   // the row pass stages one row twice in LDS
 static int build_region_tab(silent_ctx* ctx, const char* who, const silent_extent* levels, int n_levels,
-                            const silent_extent* regions, RegionTab* rt) {
+                            const silent_extent* regions, RegionTab* rt, bool* general) {
     std::memset(rt, 0, sizeof(*rt));
+    *general = false;
+    long long m1 = 0, pooled = 0;
     for (int l = 0; l < n_levels; ++l) {
         RegionLevel& r = rt->lv[l];
-        int rc = region_axis(levels[l].h, regions[l].h, &r.oh, &r.nrs, r.rcut, r.wy_lo, r.wy_hi, &r.yscale);
-        if (rc == 0) rc = region_axis(levels[l].w, regions[l].w, &r.ow, &r.ncs, r.ccut, r.wx_lo, r.wx_hi, &r.xscale);
-        if (rc == -1) return fail(ctx, SILENT_E_INVALID, std::string(who) + ": region extents must be >= 1");
-        if (rc == -2)
-            return fail(ctx, SILENT_E_UNSUPPORTED,
-                        std::string(who) + ": more than " + std::to_string(kMaxWin) + " windows per axis at level " + std::to_string(l));
+        if (regions[l].h < 1 || regions[l].w < 1) return fail(ctx, SILENT_E_INVALID, std::string(who) + ": region extents must be >= 1");
+        const int rc0 = region_axis(levels[l].h, regions[l].h, &r.oh, &r.nrs, r.rcut, r.wy_lo, r.wy_hi, &r.yscale);
+        const int rc1 = region_axis(levels[l].w, regions[l].w, &r.ow, &r.ncs, r.ccut, r.wx_lo, r.wx_hi, &r.xscale);
+        if (rc0 == -2 || rc1 == -2) *general = true;
+        r.ry = regions[l].h;
+        r.rx = regions[l].w;
+        r.pad_y = ((r.oh - 1) * r.ry) / 2;
+        r.pad_x = ((r.ow - 1) * r.rx) / 2;
+        r.m1_off = m1;
+        r.pooled_off = pooled;
+        m1 += (long long)levels[l].h * r.ow;
+        pooled += (long long)r.oh * r.ow;
     }
+    rt->m1_per_frame = m1;
+    rt->pooled_per_frame = pooled;
+    if (*general)
+        for (int l = 0; l < n_levels; ++l)
+            if (levels[l].w > kRegionGeneralMaxW)
+                return fail(ctx, SILENT_E_UNSUPPORTED, std::string(who) + ": more than " + std::to_string(kMaxWin) +
+                                                           " windows per axis on a level wider than " + std::to_string(kRegionGeneralMaxW));
     return SILENT_OK;
 }
 
@@ -667,29 +688,62 @@ struct KeypointWs {
     int* chunk_counts;
     long long* chunk_offsets;
     size_t n_cells;
+    float* m1;       // general path: row maxima over the column windows
+    float* pooled;   // general path: window maxima
 };
 
-static int keypoint_workspace(silent_ctx* ctx, int n_levels, int n_frames, long long blocks, size_t reserve, KeypointWs* w) {
+static int keypoint_workspace(silent_ctx* ctx, int n_levels, int n_frames, long long blocks, size_t reserve,
+                              const RegionTab& rt, bool general, KeypointWs* w) {
     w->n_cells = (size_t)n_frames * n_levels * kCells;
     const size_t off_cells = align_up(reserve);
     const size_t off_counts = off_cells + align_up(w->n_cells * sizeof(unsigned));
     const size_t off_offsets = off_counts + align_up((size_t)blocks * sizeof(int));
-    const size_t total = off_offsets + align_up((size_t)blocks * sizeof(long long));
+    const size_t off_m1 = off_offsets + align_up((size_t)blocks * sizeof(long long));
+    const size_t off_pooled = off_m1 + (general ? align_up((size_t)n_frames * rt.m1_per_frame * sizeof(float)) : 0);
+    const size_t total = off_pooled + (general ? align_up((size_t)n_frames * rt.pooled_per_frame * sizeof(float)) : 0);
     TRY(grow(ctx, ctx->ws, total));
     w->cells = (unsigned*)((char*)ctx->ws.p + off_cells);
     w->chunk_counts = (int*)((char*)ctx->ws.p + off_counts);
     w->chunk_offsets = (long long*)((char*)ctx->ws.p + off_offsets);
+    w->m1 = (float*)((char*)ctx->ws.p + off_m1);
+    w->pooled = (float*)((char*)ctx->ws.p + off_pooled);
     return SILENT_OK;
+}
+
+// general path: window maxima of every level into w.pooled (two launches)
+static int region_window_maxima(silent_ctx* ctx, const char* who, const float* value, const silent_extent* levels, int n_levels,
+                                int n_frames, const RegionTab& rt, const KeypointWs& w, hipStream_t s) {
+    LevelTab rowtab;
+    long long rows;
+    TRY(build_level_tab(ctx, who, levels, n_levels, n_frames, 1 << 30, 1, &rowtab, &rows));   // one tile per row
+    int maxw = 1;
+    long long cols = 0;
+    for (int l = 0; l < n_levels; ++l) {
+        maxw = std::max(maxw, levels[l].w);
+        cols += rt.lv[l].ow;
+    }
+    hipLaunchKernelGGL(region_rowmax_kernel, dim3((unsigned)rows), dim3(256), sizeof(float) * 2 * (size_t)maxw, s, value, rowtab, rt, w.m1);
+    const long long threads = cols * n_frames;
+    hipLaunchKernelGGL(region_colmax_kernel, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, s, w.m1, rowtab, rt, n_frames,
+                       cols, w.pooled);
+    return check_launch(ctx, who);
 }
 
 // count -> scan -> ordered write, given the cell maxima
 static void keypoint_passes(const float* value, const LevelTab& tab, long long blocks, const RegionTab& rt, const KeypointWs& w,
-                            int n_frames, int64_t* idx, size_t cap_per_frame, int64_t* counts, hipStream_t s) {
-    hipLaunchKernelGGL(region_count_kernel, dim3((unsigned)blocks), dim3(256), 0, s, value, tab, rt, w.cells, w.chunk_counts);
+                            bool general, int n_frames, int64_t* idx, size_t cap_per_frame, int64_t* counts, hipStream_t s) {
+    if (general)
+        hipLaunchKernelGGL(region_count_kernel<true>, dim3((unsigned)blocks), dim3(256), 0, s, value, tab, rt, w.cells, w.pooled, w.chunk_counts);
+    else
+        hipLaunchKernelGGL(region_count_kernel<false>, dim3((unsigned)blocks), dim3(256), 0, s, value, tab, rt, w.cells, w.pooled, w.chunk_counts);
     hipLaunchKernelGGL(region_scan_kernel, dim3((unsigned)n_frames), dim3(256), 0, s, w.chunk_counts, w.chunk_offsets,
                        tab.tiles_per_frame, counts);
-    if (cap_per_frame)
-        hipLaunchKernelGGL(region_write_kernel, dim3((unsigned)blocks), dim3(256), 0, s, value, tab, rt, w.cells,
+    if (!cap_per_frame) return;
+    if (general)
+        hipLaunchKernelGGL(region_write_kernel<true>, dim3((unsigned)blocks), dim3(256), 0, s, value, tab, rt, w.cells, w.pooled,
+                           w.chunk_offsets, idx, (long long)cap_per_frame);
+    else
+        hipLaunchKernelGGL(region_write_kernel<false>, dim3((unsigned)blocks), dim3(256), 0, s, value, tab, rt, w.cells, w.pooled,
                            w.chunk_offsets, idx, (long long)cap_per_frame);
 }
 
@@ -706,13 +760,18 @@ SILENT_EXPORT int silent_max_value_indices_region_dev(silent_ctx* ctx, const flo
     TRY(build_level_tab(ctx, who, levels, n_levels, n_frames, kKpChunk, 0, &tab, &blocks));   // count / write chunks
     TRY(build_level_tab(ctx, who, levels, n_levels, n_frames, kRedChunk, 0, &ctab, &cblocks));  // cell maxima
     RegionTab rt;
-    TRY(build_region_tab(ctx, who, levels, n_levels, regions, &rt));
+    bool general;
+    TRY(build_region_tab(ctx, who, levels, n_levels, regions, &rt, &general));
     KeypointWs w;
-    TRY(keypoint_workspace(ctx, n_levels, n_frames, blocks, 0, &w));
+    TRY(keypoint_workspace(ctx, n_levels, n_frames, blocks, 0, rt, general, &w));
     hipStream_t s = (hipStream_t)stream;
-    hipLaunchKernelGGL(init_cells_kernel, dim3((unsigned)((w.n_cells + 255) / 256)), dim3(256), 0, s, w.cells, (long long)w.n_cells);
-    hipLaunchKernelGGL(region_cell_max_kernel, dim3((unsigned)cblocks), dim3(256), 0, s, value, ctab, rt, w.cells);
-    keypoint_passes(value, tab, blocks, rt, w, n_frames, idx, cap_per_frame, counts, s);
+    if (general) {
+        TRY(region_window_maxima(ctx, who, value, levels, n_levels, n_frames, rt, w, s));
+    } else {
+        hipLaunchKernelGGL(init_cells_kernel, dim3((unsigned)((w.n_cells + 255) / 256)), dim3(256), 0, s, w.cells, (long long)w.n_cells);
+        hipLaunchKernelGGL(region_cell_max_kernel, dim3((unsigned)cblocks), dim3(256), 0, s, value, ctab, rt, w.cells);
+    }
+    keypoint_passes(value, tab, blocks, rt, w, general, n_frames, idx, cap_per_frame, counts, s);
     return check_launch(ctx, who);
 }
 
@@ -733,10 +792,11 @@ SILENT_EXPORT int silent_select_keypoints_dev(silent_ctx* ctx, const float* colo
     TRY(build_level_tab(ctx, who, levels, n_levels, n_frames, kSelTW, kSelTH, &stab, &sblocks));
     TRY(build_level_tab(ctx, who, levels, n_levels, n_frames, kKpChunk, 0, &tab, &blocks));
     RegionTab rt;
-    TRY(build_region_tab(ctx, who, levels, n_levels, regions, &rt));
+    bool general;
+    TRY(build_region_tab(ctx, who, levels, n_levels, regions, &rt, &general));
     const int nmm = n_frames * n_levels;
     KeypointWs w;
-    TRY(keypoint_workspace(ctx, n_levels, n_frames, blocks, sizeof(unsigned) * 2 * (size_t)nmm, &w));
+    TRY(keypoint_workspace(ctx, n_levels, n_frames, blocks, sizeof(unsigned) * 2 * (size_t)nmm, rt, general, &w));
     unsigned* mm = (unsigned*)ctx->ws.p;
     hipStream_t s = (hipStream_t)stream;
     hipLaunchKernelGGL(init_maxmin_kernel, dim3((nmm + 255) / 256), dim3(256), 0, s, mm, nmm);
@@ -744,13 +804,23 @@ SILENT_EXPORT int silent_select_keypoints_dev(silent_ctx* ctx, const float* colo
     hipLaunchKernelGGL(level_maxmin_kernel, dim3((unsigned)rblocks), dim3(256), 0, s, value, value ? nullptr : color,
                        channels, rtab, mm);
     const float a = (float)(1.0 - top_percent), b = (float)top_percent;
-    if (channels == 3)
+    if (general) {
+        // many windows: the selection pass without the folded cell maxima, then the separable window maxima
+        if (channels == 3)
+            hipLaunchKernelGGL((select_peaks_kernel<3, false>), dim3((unsigned)sblocks), dim3(256), 0, s, color, value, nullptr, nullptr,
+                               peak_value_out, stab, a, b, mm, rt, nullptr);
+        else
+            hipLaunchKernelGGL((select_peaks_kernel<1, false>), dim3((unsigned)sblocks), dim3(256), 0, s, color, value, nullptr, nullptr,
+                               peak_value_out, stab, a, b, mm, rt, nullptr);
+        TRY(region_window_maxima(ctx, who, peak_value_out, levels, n_levels, n_frames, rt, w, s));
+    } else if (channels == 3) {
         hipLaunchKernelGGL((select_peaks_kernel<3, true>), dim3((unsigned)sblocks), dim3(256), 0, s, color, value, nullptr, nullptr,
                            peak_value_out, stab, a, b, mm, rt, w.cells);
-    else
+    } else {
         hipLaunchKernelGGL((select_peaks_kernel<1, true>), dim3((unsigned)sblocks), dim3(256), 0, s, color, value, nullptr, nullptr,
                            peak_value_out, stab, a, b, mm, rt, w.cells);
-    keypoint_passes(peak_value_out, tab, blocks, rt, w, n_frames, idx, cap_per_frame, counts, s);
+    }
+    keypoint_passes(peak_value_out, tab, blocks, rt, w, general, n_frames, idx, cap_per_frame, counts, s);
     return check_launch(ctx, who);
 }
 

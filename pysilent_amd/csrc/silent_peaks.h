@@ -208,6 +208,11 @@ constexpr int kMaxWin = 4;  // windows per axis (the reference uses 2); keeps Re
 constexpr int kMaxSeg = 8;  // segments per axis (<= 2 * windows)
 
 struct RegionLevel {
+    // general path (any number of windows): TF1 geometry as arithmetic, tables in the workspace
+    int ry, rx;          // strides = region extents
+    int pad_y, pad_x;    // pad_before of max_pool SAME: window j starts at j * stride - pad_before
+    long long m1_off;    // offset of this level's [h][ow] row maxima inside one frame's M1 table
+    long long pooled_off;  // offset of this level's [oh][ow] window maxima inside one frame's pooled table
     int oh, ow;          // windows per axis
     int nrs, ncs;        // segments per axis
     int rcut[kMaxSeg + 1];  // row segment s = [rcut[s], rcut[s+1])
@@ -219,6 +224,7 @@ struct RegionLevel {
 
 struct RegionTab {
     RegionLevel lv[kMaxLevels];
+    long long m1_per_frame, pooled_per_frame;   // general path: floats per frame of the two tables
 };
 
 constexpr int kCells = kMaxSeg * kMaxSeg;
@@ -509,22 +515,117 @@ __device__ __forceinline__ void load_pooled(const unsigned* __restrict__ cells, 
     }
 }
 
-// threshold of pixel (y, x): the window maximum its cell maps back to
-__device__ __forceinline__ float region_thr(int y, int x, const RegionLevel& rl, const float* s_pooled) {
+// threshold of pixel (y, x): the window maximum its cell maps back to.  `pooled` is the LDS copy of the (<= 4 x 4)
+// window maxima with row stride kMaxWin, or (GEN) the level's [oh][ow] table in the workspace.
+template <bool GEN>
+__device__ __forceinline__ float region_thr(int y, int x, const RegionLevel& rl, const float* pooled) {
     // TF1 ResizeNearestNeighbor: min(floorf(dst * scale), in - 1), float32
     int sy = (int)floorf(__fmul_rn((float)y, rl.yscale));
     int sx = (int)floorf(__fmul_rn((float)x, rl.xscale));
     sy = sy > rl.oh - 1 ? rl.oh - 1 : sy;
     sx = sx > rl.ow - 1 ? rl.ow - 1 : sx;
-    return s_pooled[sy * kMaxWin + sx];
+    return pooled[sy * (GEN ? rl.ow : kMaxWin) + sx];
+}
+
+// ---- a-11, any region_shape (more than kMaxWin windows per axis): the windows of max_pool(k = full extent, stride = region,
+// SAME) are PREFIXES (start j * stride - pad <= 0) or SUFFIXES of the rows and of the columns, so the window maxima are
+// separable prefix / suffix maxima: pass 1 gives every row its maxima over the column windows (M1[y][i]), pass 2 walks
+// each column of M1 down (prefix windows) and up (suffix windows).  max is exact and order-free (pool_max ignores NaN),
+// so the result is bit-identical to the cell path and to the oracle.
+// One block per (frame, level, row): the row is staged into LDS, prefix and suffix maxima by chunked scans.
+__global__ __launch_bounds__(256) void region_rowmax_kernel(const float* __restrict__ value, const LevelTab tab,
+                                                            const RegionTab rt, float* __restrict__ m1) {
+    extern __shared__ float s_dyn_rows[];   // p[W] | s[W]
+    __shared__ float s_tot[2][256];
+    const TileCoord tc = locate_tile(tab, blockIdx.x);   // tile = one row: ty = y
+    const RegionLevel& rl = rt.lv[tc.level];
+    const int W = tab.w[tc.level], y = tc.ty;
+    const float* __restrict__ row = value + (long long)tc.frame * tab.frame_px + tab.px_off[tc.level] + (long long)y * W;
+    float* p = s_dyn_rows;
+    float* sfx = s_dyn_rows + W;
+    const int tid = threadIdx.x;
+    for (int x = tid; x < W; x += 256) {
+        const float v = pool_max(kPoolLowest, row[x]);
+        p[x] = v;
+        sfx[x] = v;
+    }
+    __syncthreads();
+    const int n = (W + 255) / 256, lo = min(tid * n, W), hi = min(lo + n, W);
+    float m = kPoolLowest;
+    for (int x = lo; x < hi; ++x) {
+        m = pool_max(m, p[x]);
+        p[x] = m;
+    }
+    s_tot[0][tid] = m;
+    m = kPoolLowest;
+    for (int x = hi - 1; x >= lo; --x) {
+        m = pool_max(m, sfx[x]);
+        sfx[x] = m;
+    }
+    s_tot[1][tid] = m;
+    __syncthreads();
+    float cp = kPoolLowest, cs = kPoolLowest;          // carries: maxima of the chunks before / after this one
+    for (int t = 0; t < tid; ++t) cp = pool_max(cp, s_tot[0][t]);
+    for (int t = tid + 1; t < 256; ++t) cs = pool_max(cs, s_tot[1][t]);
+    for (int x = lo; x < hi; ++x) {
+        p[x] = pool_max(cp, p[x]);
+        sfx[x] = pool_max(cs, sfx[x]);
+    }
+    __syncthreads();
+    float* __restrict__ out = m1 + (long long)tc.frame * rt.m1_per_frame + rl.m1_off + (long long)y * rl.ow;
+    for (int i = tid; i < rl.ow; i += 256) {
+        const int a = i * rl.rx - rl.pad_x;
+        out[i] = a <= 0 ? p[min(a + W, W) - 1] : sfx[a];
+    }
+}
+
+// pass 2: one thread per (frame, level, column window i)
+__global__ __launch_bounds__(256) void region_colmax_kernel(const float* __restrict__ m1, const LevelTab tab,
+                                                            const RegionTab rt, int n_frames, long long cols_per_frame,
+                                                            float* __restrict__ pooled) {
+    const long long gid = (long long)blockIdx.x * 256 + threadIdx.x;
+    const int frame = (int)(gid / cols_per_frame);
+    if (frame >= n_frames) return;
+    long long rem = gid - (long long)frame * cols_per_frame;
+    int l = 0;
+    while (l + 1 < tab.n_levels && rem >= rt.lv[l].ow) {
+        rem -= rt.lv[l].ow;
+        ++l;
+    }
+    const RegionLevel& rl = rt.lv[l];
+    const int i = (int)rem, H = tab.h[l];
+    const float* __restrict__ col = m1 + (long long)frame * rt.m1_per_frame + rl.m1_off + i;
+    float* __restrict__ out = pooled + (long long)frame * rt.pooled_per_frame + rl.pooled_off + i;
+    // prefix windows (start <= 0), ends ascending with j
+    float m = kPoolLowest;
+    int j = 0;
+    for (int y = 0; y < H; ++y) {
+        m = pool_max(m, col[(long long)y * rl.ow]);
+        while (j < rl.oh && j * rl.ry - rl.pad_y <= 0 && min(j * rl.ry - rl.pad_y + H, H) - 1 == y) {
+            out[(long long)j * rl.ow] = m;
+            ++j;
+        }
+    }
+    // suffix windows (start > 0), starts descending with j from the last window
+    m = kPoolLowest;
+    int k = rl.oh - 1;
+    for (int y = H - 1; y >= 0 && k >= j; --y) {
+        m = pool_max(m, col[(long long)y * rl.ow]);
+        while (k >= j && k * rl.ry - rl.pad_y == y) {
+            out[(long long)k * rl.ow] = m;
+            --k;
+        }
+    }
 }
 
 // pass 1: matches per chunk.  A chunk is kKpChunk pixels: wave w owns the w-th quarter, lane l the pixels
 // quarter + k * 64 + l (coalesced 256-byte loads); hits are wave ballots, so ranks stay row-major without any
 // per-thread bookkeeping.  (1024-pixel chunks with 4 consecutive pixels per thread ran at 1.7 TB/s.)
 constexpr int kKpChunk = 4096, kKpPer = kKpChunk / 256;
+template <bool GEN>
 __global__ __launch_bounds__(256) void region_count_kernel(const float* __restrict__ value, const LevelTab tab,
                                                            const RegionTab rt, const unsigned* __restrict__ cells,
+                                                           const float* __restrict__ pooled_g,
                                                            int* __restrict__ chunk_counts) {
     __shared__ float s_pooled[kMaxWin * kMaxWin];
     __shared__ int s_cnt[4];
@@ -539,14 +640,19 @@ __global__ __launch_bounds__(256) void region_count_kernel(const float* __restri
     float v[kKpPer];
 #pragma unroll
     for (int k = 0; k < kKpPer; ++k) v[k] = value[base_px + min(seg + k * 64 + lane, npx - 1)];
-    load_pooled(cells + ((long long)tc.frame * tab.n_levels + tc.level) * kCells, rl, s_pooled);
-    __syncthreads();
+    const float* pooled = s_pooled;
+    if constexpr (GEN) {
+        pooled = pooled_g + (long long)tc.frame * rt.pooled_per_frame + rl.pooled_off;
+    } else {
+        load_pooled(cells + ((long long)tc.frame * tab.n_levels + tc.level) * kCells, rl, s_pooled);
+        __syncthreads();
+    }
     int n = 0;
     int y = (seg + lane) / W, x = seg + lane - y * W;
 #pragma unroll
     for (int k = 0; k < kKpPer; ++k, advance_yx(y, x, 64, W)) {
         const int p = seg + k * 64 + lane;
-        const bool hit = p < npx && v[k] >= region_thr(y, x, rl, s_pooled);
+        const bool hit = p < npx && v[k] >= region_thr<GEN>(y, x, rl, pooled);
         n += __popcll(__ballot(hit));
     }
     if (lane == 0) s_cnt[wave] = n;
@@ -587,8 +693,10 @@ __global__ __launch_bounds__(256) void region_scan_kernel(const int* __restrict_
 
 // pass 3: ordered write of (level, y, x, 0) rows: rank = chunk offset + hits of the lower waves + hits of this wave's
 // earlier 64-pixel groups + hits of the lower lanes of this group
+template <bool GEN>
 __global__ __launch_bounds__(256) void region_write_kernel(const float* __restrict__ value, const LevelTab tab,
                                                            const RegionTab rt, const unsigned* __restrict__ cells,
+                                                           const float* __restrict__ pooled_g,
                                                            const long long* __restrict__ chunk_offsets,
                                                            int64_t* __restrict__ idx, long long cap_per_frame) {
     __shared__ float s_pooled[kMaxWin * kMaxWin];
@@ -603,8 +711,13 @@ __global__ __launch_bounds__(256) void region_write_kernel(const float* __restri
     float v[kKpPer];
 #pragma unroll
     for (int k = 0; k < kKpPer; ++k) v[k] = value[base_px + min(seg + k * 64 + lane, npx - 1)];
-    load_pooled(cells + ((long long)tc.frame * tab.n_levels + tc.level) * kCells, rl, s_pooled);
-    __syncthreads();
+    const float* pooled = s_pooled;
+    if constexpr (GEN) {
+        pooled = pooled_g + (long long)tc.frame * rt.pooled_per_frame + rl.pooled_off;
+    } else {
+        load_pooled(cells + ((long long)tc.frame * tab.n_levels + tc.level) * kCells, rl, s_pooled);
+        __syncthreads();
+    }
     unsigned long long hits[kKpPer];
     int n = 0;
     const int y0 = (seg + lane) / W, x0 = seg + lane - y0 * W;
@@ -612,7 +725,7 @@ __global__ __launch_bounds__(256) void region_write_kernel(const float* __restri
 #pragma unroll
     for (int k = 0; k < kKpPer; ++k, advance_yx(y, x, 64, W)) {
         const int p = seg + k * 64 + lane;
-        const bool hit = p < npx && v[k] >= region_thr(y, x, rl, s_pooled);
+        const bool hit = p < npx && v[k] >= region_thr<GEN>(y, x, rl, pooled);
         hits[k] = __ballot(hit);
         n += __popcll(hits[k]);
     }

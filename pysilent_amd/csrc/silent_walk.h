@@ -250,11 +250,14 @@ __global__ __launch_bounds__(walk_threads(G)) __attribute__((amdgpu_waves_per_eu
     for (int c = 0; c < n_chunks; ++c) {
         __builtin_amdgcn_s_barrier();                           // barrier c: chunk c is in the ring
         asm volatile("" ::: "memory");
-        if (live) {
-#pragma unroll
-            for (int r = 0; r < kWalkCH; ++r) {
+        // One source row.  CHECK = false is the steady state (an INTERIOR chunk: every row of it is a stream row of the
+        // segment whose level-0 / CS / output rows are all stored and inside the image): no row conditions at all, so the
+        // 8 unrolled rows are one straight-line block and the register windows rotate by renaming instead of moves.
+        auto do_row = [&](auto check_c, int r) {
+            constexpr bool CHECK = decltype(check_c)::value;
+            {
                 const int s = c * kWalkCH + r;                  // stream row index; source row y = seg_y0 - 4 + s
-                if (s >= n_rows) break;                         // wave-uniform (padding of the last chunk)
+                if (CHECK && s >= n_rows) return;               // wave-uniform (padding of the last chunk)
                 const float* __restrict__ row = &s_ring[slot * kWalkCH + r][0];
                 const float a = row[offA], b = row[offB];
                 // ---- the other levels: vertical taps of this source row, gather + store of a row that completes
@@ -280,7 +283,7 @@ __global__ __launch_bounds__(walk_threads(G)) __attribute__((amdgpu_waves_per_eu
                         const int done = (meta >> 4) & 7;
                         // the row's anchor is source row y - 3 = seg_y0 + s - 7: stored by the segment that owns it
                         const int anchor = seg_y0 + s - 7;
-                        if (done < kWalkMaxSlots && anchor >= seg_y0 && anchor < seg_y0 + seg_h) {   // wave-uniform
+                        if (done < kWalkMaxSlots && (!CHECK || (anchor >= seg_y0 && anchor < seg_y0 + seg_h))) {   // wave-uniform
                             const int oy = meta >> 8;
                             // the lane's column record is requested before the row is written: one LDS round trip less
                             const int jj = min(lane, walk_rec_cap(g) - 1);
@@ -340,10 +343,10 @@ __global__ __launch_bounds__(walk_threads(G)) __attribute__((amdgpu_waves_per_eu
                         v0 = __builtin_fmaf(wv[j], hA[j], v0);
                         v1 = __builtin_fmaf(wv[j], hB[j], v1);
                     }
-                    const bool prow = p >= 0 && p < tab.eff_h;
+                    const bool prow = !CHECK || (p >= 0 && p < tab.eff_h);
                     v0 = (prow && effA) ? v0 : 0.0f;
                     v1 = (prow && effB) ? v1 : 0.0f;
-                    if (p >= seg_y0 && p < seg_y0 + seg_h && out_lane) {
+                    if ((!CHECK || (p >= seg_y0 && p < seg_y0 + seg_h)) && out_lane) {
                         typedef float nf2 __attribute__((ext_vector_type(2)));
                         nf2* dst = reinterpret_cast<nf2*>(pyr + (lane_px + (long long)p * tab.out_w));
                         const nf2 v = {v0, v1};
@@ -371,7 +374,7 @@ __global__ __launch_bounds__(walk_threads(G)) __attribute__((amdgpu_waves_per_eu
                             a0 = __builtin_fmaf(iw[dy][dx], csw[dy * 3 + dx], a0);
                             a1 = __builtin_fmaf(iw[dy][dx + 1], csw[dy * 3 + dx], a1);
                         }
-                    const bool crow = cr >= 0 && cr < tab.out_h;
+                    const bool crow = !CHECK || (cr >= 0 && cr < tab.out_h);
                     // relu (a NaN stays a NaN) and the zero padding of the end convolution in one select
                     const float cs0 = (crow && inA && !(a0 < 0.0f)) ? a0 : 0.0f;
                     const float cs1 = (crow && inB && !(a1 < 0.0f)) ? a1 : 0.0f;
@@ -387,7 +390,7 @@ __global__ __launch_bounds__(walk_threads(G)) __attribute__((amdgpu_waves_per_eu
                 }
                 // ---- output row yo = p - 2
                 const int yo = p - 2;
-                if (yo >= seg_y0 && yo < seg_y0 + seg_h) {      // wave-uniform
+                if (!CHECK || (yo >= seg_y0 && yo < seg_y0 + seg_h)) {      // wave-uniform
                     const long long row_px = lane_px + (long long)yo * tab.out_w;
                     if (cs_out && out_lane) {
                         typedef float nf2 __attribute__((ext_vector_type(2)));
@@ -411,10 +414,28 @@ __global__ __launch_bounds__(walk_threads(G)) __attribute__((amdgpu_waves_per_eu
                                     e0[k] = __builtin_fmaf(cw[dy][dx], w, e0[k]);
                                     e1[k] = __builtin_fmaf(cw[dy][dx + 1], w, e1[k]);
                                 }
+                        // relu + clip.  The reference's forms ((x < 0) ? 0 : x, (x > hi) ? hi : x) keep a NaN a NaN; as compare +
+                        // select pairs they are 4 instructions per value, serialised through VCC with hazard nops (a quarter of
+                        // the row's issue slots).  For every non-NaN x they equal the median of (x, 0, hi) -- one v_med3_f32 --
+                        // when hi >= 0 (the chains start from +0, so x is never -0).  The 2K raw values are summed first: the sum is
+                        // a NaN iff one of them is (or +inf meets -inf), and only then the wave takes the select form.
+                        {
+                            float chk = e0[0] + e1[0];
 #pragma unroll
-                        for (int k = 0; k < K; ++k) {
-                            e0[k] = clip_hi_tf(relu_tf(e0[k]), clip_hi);
-                            e1[k] = clip_hi_tf(relu_tf(e1[k]), clip_hi);
+                            for (int k = 1; k < K; ++k) chk += e0[k] + e1[k];
+                            if (clip_hi >= 0.0f && !__any(chk != chk)) {   // wave-uniform
+#pragma unroll
+                                for (int k = 0; k < K; ++k) {
+                                    e0[k] = __builtin_amdgcn_fmed3f(e0[k], 0.0f, clip_hi);
+                                    e1[k] = __builtin_amdgcn_fmed3f(e1[k], 0.0f, clip_hi);
+                                }
+                            } else {
+#pragma unroll
+                                for (int k = 0; k < K; ++k) {
+                                    e0[k] = clip_hi_tf(relu_tf(e0[k]), clip_hi);
+                                    e1[k] = clip_hi_tf(relu_tf(e1[k]), clip_hi);
+                                }
+                            }
                         }
                         typedef float nf4 __attribute__((ext_vector_type(4)));
                         if constexpr (K == 4) {
@@ -452,6 +473,18 @@ __global__ __launch_bounds__(walk_threads(G)) __attribute__((amdgpu_waves_per_eu
                         }
                     }
                 }
+            }
+        };
+        if (live) {
+            // interior: rows s = 8c .. 8c + 7 all have s >= 8 (first stored output row reached), level-0 row p = seg_y0 + s - 6
+            // below the segment's end and inside the zoomed crop
+            const bool interior = c >= 1 && c * kWalkCH + 1 < seg_h && seg_y0 + c * kWalkCH + 1 < tab.eff_h;
+            if (interior) {
+#pragma unroll
+                for (int r = 0; r < kWalkCH; ++r) do_row(std::false_type{}, r);
+            } else {
+#pragma unroll
+                for (int r = 0; r < kWalkCH; ++r) do_row(std::true_type{}, r);
             }
         }
         slot = slot == kWalkSlots - 1 ? 0 : slot + 1;

@@ -23,14 +23,12 @@ if name == "noarith":      # loads, LDS, barriers and stores as in the product; 
     s = re.sub(r"for \(int k = 0; k < K; \+\+k\) e0\[k\] = e1\[k\] = 0.0f;.*?e1\[k\] = clip_hi_tf\(relu_tf\(e1\[k\]\), clip_hi\);\n\s*\}", "for (int k = 0; k < K; ++k) { e0[k] = cw[1][1] + k; e1[k] = cw[1][2] + k; }", s, flags=re.S)
 elif name == "nostore":    # everything but the stores of the unit level (a never-true runtime condition keeps the arithmetic alive)
     rep("const bool out_lane = lane >= 2 && lane < 62 && colA < tab.out_w;", "const bool out_lane = lane >= 2 && lane < 62 && colA < tab.out_w && clip_hi == -12345.0f;")
-elif name == "pw_nogather":   # pyramid wave: vertical accumulation only, completed rows are dropped
+elif name == "p2_nostore":     # other levels: everything but the global store of a completed row
+    rep("if (lane < gn[g])\n                                pyr[frame_px0", "if (lane < gn[g] && clip_hi == -12345.0f)\n                                pyr[frame_px0")
+elif name == "p2_nogather":    # other levels: vertical accumulation only
     rep("if (done < kWalkMaxSlots && anchor >= seg_y0 && anchor < seg_y0 + seg_h) {   // wave-uniform", "if (done < kWalkMaxSlots && anchor >= seg_y0 && anchor < seg_y0 + seg_h && clip_hi == -12345.0f) {")
-elif name == "pw_novert":     # pyramid wave: no vertical fmas (the gather runs on whatever the accumulators hold)
-    rep("vacc[g][k][q] = __builtin_fmaf(w, x[q], restart ? 0.0f : vacc[g][k][q]);", "vacc[g][k][q] = restart ? w : x[q];")
-elif name == "pw_only":       # consumers store nothing: what the pyramid wave alone allows
-    rep("const bool out_lane = lane >= 2 && lane < 62 && colA < tab.out_w;", "const bool out_lane = lane >= 2 && lane < 62 && colA < tab.out_w && clip_hi == -12345.0f;")
-elif name == "pw_idle":       # the pyramid wave meets the barriers and does nothing else
-    rep("                    if (s >= n_rows) break;\n                    const float* __restrict__ row = &s_ring[slot * kWalkCH + r][0];\n                    float x[8];", "                    if (s >= n_rows || clip_hi != -12345.0f) break;\n                    const float* __restrict__ row = &s_ring[slot * kWalkCH + r][0];\n                    float x[8];")
+elif name == "p2_norec":       # other levels: the row record is not read (all-inert): cost of the record reads + branches
+    rep("const int meta = __builtin_amdgcn_readfirstlane(cur[g]);", "const int meta = clip_hi == -12345.0f ? __builtin_amdgcn_readfirstlane(cur[g]) : 0;")
 elif name.startswith("eu"): # occupancy hint: let the scheduler spend registers on instruction-level parallelism
     n = int(name[2:])
     rep("__global__ __launch_bounds__(walk_threads(G)) void gray_walk_kernel", "__global__ __launch_bounds__(walk_threads(G)) __attribute__((amdgpu_waves_per_eu(%d, %d))) void gray_walk_kernel" % (n, n))

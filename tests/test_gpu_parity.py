@@ -1119,3 +1119,66 @@ def test_gray_walk_kernel_nan_and_inf_frames(rt, kernels):
     for a, b_ in zip(got, ref):
         np.testing.assert_array_equal(a.data, b_.data)
     assert np.isnan(got[2].data).any()
+
+
+# ----------------------------------------------------------------------------- a-11 with any region_shape
+
+@pytest.mark.parametrize("shape,region", [((2, 192, 288, 3), (1, 3, 3, 3)),        # the reference's centroid_region_shape as regions: 64 x 96 windows
+                                          ((1, 37, 53, 1), (1, 5, 7, 1)),
+                                          ((2, 40, 40, 3), (1, 1, 1, 3)),          # every pixel its own stride: 40 x 40 windows
+                                          ((1, 64, 300, 1), (1, 64, 7, 1)),        # many windows on one axis only
+                                          ((1, 135, 240, 1), (1, 9, 16, 1)),
+                                          ((3, 19, 27, 1), (1, 2, 27, 1))])
+def test_max_value_indices_region_with_many_windows(rt, shape, region):
+    """More than 4 windows per axis (the kernarg cell tables of the fast path do not apply): separable prefix / suffix
+    window maxima.  Bit-exact against the oracle, ties, zero plateaus and NaNs included, for NHWC tensors and packed levels."""
+    from pysilent_amd.util.selection import max_value_indices_region
+    x = np.floor(np.random.default_rng(12).random(shape) * 16).astype(np.float32) * 16      # many ties
+    x[0, :shape[1] // 3, :shape[2] // 3] = 0
+    x[0, shape[1] // 2, shape[2] // 2:] = np.nan
+    got = max_value_indices_region(x, region)
+    want = so.max_value_indices_region(x, region)
+    assert got.dtype == np.int64 and len(want) > 0
+    np.testing.assert_array_equal(got, want)
+    v = so.value_from_color(x)
+    np.testing.assert_array_equal(max_value_indices_region(x, region, v), co.max_value_indices_region(x, region, v))
+
+
+def test_select_keypoints_with_many_windows(rt):
+    """The config-3 composite (top-percent > NMS > value > keypoints) with 3 x 3 regions: the selection pass without folded
+    cell maxima + the general window-maxima path, equal to the separate calls and to the oracle."""
+    import ctypes as C
+    from pysilent_amd import _lib
+    from pysilent_amd.util.selection import max_value_indices_region
+    extents = [(37, 131), (70, 60), (5, 7)]
+    rng = np.random.default_rng(3)
+    levels = [np.floor(rng.random((2, h, w, 3)) * 8).astype(np.float32) * 32 for h, w in extents]
+    packed = rt.PackedPyramid.from_levels(levels)
+    fused = rt.select_peaks(packed, 0.1)
+    regions = [(3, 3)] * 3
+    kp = max_value_indices_region(packed, regions, fused["peak_value"])
+    for f in range(2):
+        rows = []
+        for l, lev in enumerate(levels):
+            pv = so.value_from_color(so.nms3x3(so.top_value_points(lev[f:f + 1], 0.1), "product"))
+            r = so.max_value_indices_region(None, (1, 3, 3, 3), pv)
+            r[:, 0] = l
+            rows.append(r)
+        np.testing.assert_array_equal(kp[f], np.concatenate(rows))
+    # the composite entry point through the C ABI (host twin)
+    ctx = rt.get_context()
+    lib = _lib.load()
+    n_levels, n_frames = 3, 2
+    lv = (_lib.Extent * n_levels)(*[_lib.Extent(h, w) for h, w in extents])
+    rg = (_lib.Extent * n_levels)(*[_lib.Extent(3, 3)] * n_levels)
+    cap = packed.frame_px
+    pv_out = np.empty(n_frames * packed.frame_px, np.float32)
+    idx = np.empty((n_frames, cap, 4), np.int64)
+    counts = np.zeros(n_frames, np.int64)
+    f32p = lambda a: a.ctypes.data_as(C.POINTER(C.c_float))
+    ctx.check(lib.silent_select_keypoints(ctx.handle, f32p(packed.data), None, lv, n_levels, n_frames, 3, C.c_double(0.1), rg,
+                                          f32p(pv_out), C.c_void_p(idx.ctypes.data), C.c_size_t(cap),
+                                          C.c_void_p(counts.ctypes.data)))
+    np.testing.assert_array_equal(pv_out, fused["peak_value"].data)
+    for f in range(2):
+        np.testing.assert_array_equal(idx[f, :counts[f]], kp[f])
