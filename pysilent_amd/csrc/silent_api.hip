@@ -1670,7 +1670,7 @@ SILENT_EXPORT int silent_profile_elapsed_ms(silent_ctx* ctx, float* ms, int64_t*
 // canvas are 16-byte aligned, the bank has 4 or 8 orientations, and the batch is large enough to give every CU two blocks
 // of at least 64 rows (small batches keep the tile kernels: they have 30x the blocks).  force: tuning bit 128.
 static bool walk_plan(const silent_ctx* ctx, const silent_pyramid_plan* plan, int n_frames, int n_orient, bool force,
-                      int blocks_per_cu, WalkTab* wt, int* unit_level) {
+                      int blocks_per_cu, int seg_rows_knob, WalkTab* wt, int* unit_level) {
     const PyrTab& pt = plan->tab;
     if (pt.C != 1 || (n_orient != 4 && n_orient != 8)) return false;
     int unit = -1, n_unit = 0;
@@ -1692,6 +1692,7 @@ static bool walk_plan(const silent_ctx* ctx, const silent_pyramid_plan* plan, in
     int segs = (int)std::min<long long>(max_segs, (want + per_seg - 1) / per_seg);
     if (per_seg * segs < 2ll * ctx->n_cus && !force) return false;
     int seg_rows = (d.out_h + segs - 1) / segs;
+    if (seg_rows_knob > 0) seg_rows = std::min(seg_rows_knob, d.out_h);   // A/B knob: rows per segment
     seg_rows = (seg_rows + kWalkCH - 1) / kWalkCH * kWalkCH;
     wt->seg_rows = seg_rows;
     wt->segs_y = (d.out_h + seg_rows - 1) / seg_rows;
@@ -1722,7 +1723,7 @@ SILENT_EXPORT int silent_gray_pass_dev(silent_ctx* ctx, const silent_pyramid_pla
     // strip-walk kernel for the unit level (bit 64: off, bit 128: also for small batches, bit 256: plain stores)
     WalkTab wt;
     int walk_unit = -1;
-    const bool walk_path = !(kopts & 64) && end_out && walk_plan(ctx, plan, n_frames, n_orient, (kopts & 128) != 0, 2 + ((kopts >> 10) & 3), &wt, &walk_unit);
+    const bool walk_path = !(kopts & 64) && end_out && walk_plan(ctx, plan, n_frames, n_orient, (kopts & 128) != 0, 2 + ((kopts >> 10) & 3), 32 * ((kopts >> 12) & 63), &wt, &walk_unit);
     const bool walk_pyr = walk_path && plan->walk_pyr_ok && !(kopts & 512);   // other levels from the same walk
     const bool stream_path = plan->stream_ok && !(kopts & 16) && !walk_path;
     // 1. non-unit levels of the pyramid: by the region kernel, unless the stream kernel of step 2 produces them

@@ -79,4 +79,23 @@ __device__ __forceinline__ int mirror_near(int i, int n) {
 __device__ __forceinline__ float relu_tf(float v) { return v < 0.0f ? 0.0f : v; }
 __device__ __forceinline__ float clip_hi_tf(float v, float hi) { return v > hi ? hi : v; }
 
+// relu + clip of N accumulators of one pixel: clip(relu(x), hi) with the reference's NaN behaviour.  The select forms
+// ((x < 0) ? 0 : x, (x > hi) ? hi : x) keep a NaN a NaN but are 4 instructions per value, serialised through VCC with hazard
+// nops.  For every non-NaN x they equal the median of (x, 0, hi) -- one v_med3_f32 -- when hi >= 0 (the fma chains start
+// from +0, so x is never -0).  The N raw values are summed first: the sum is a NaN iff one of them is (or +inf meets -inf),
+// and only then the wave takes the select form.  Wave-uniform branch; every lane of the wave must call this.
+template <int N>
+__device__ __forceinline__ void relu_clip_tf(float (&v)[N], float hi) {
+    float chk = v[0];
+#pragma unroll
+    for (int k = 1; k < N; ++k) chk += v[k];
+    if (hi >= 0.0f && !__any(chk != chk)) {
+#pragma unroll
+        for (int k = 0; k < N; ++k) v[k] = __builtin_amdgcn_fmed3f(v[k], 0.0f, hi);
+    } else {
+#pragma unroll
+        for (int k = 0; k < N; ++k) v[k] = clip_hi_tf(relu_tf(v[k]), hi);
+    }
+}
+
 }  // namespace silent

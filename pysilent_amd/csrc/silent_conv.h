@@ -315,8 +315,7 @@ __global__ __launch_bounds__(256) void gray_line_end_kernel(const float* __restr
 #pragma unroll
                             for (int k = 0; k < K; ++k)
                                 acc[k] = __builtin_fmaf(cw[dy][dx], wts.end[(dy * 3 + dx) * K + k], acc[k]);
-#pragma unroll
-                    for (int k = 0; k < K; ++k) acc[k] = clip_hi_tf(relu_tf(acc[k]), clip_hi);
+                    relu_clip_tf(acc, clip_hi);
                     if constexpr (K == 8) {
                         // lane 0's pixel is column xw0 - 2; valid pixels are lanes 2 .. 2 + ncols
                         const int ncols = min(kGrayCols, W - xw0);
@@ -480,8 +479,7 @@ __global__ __launch_bounds__(256) void gray_unit_fused_kernel(const float* __res
 #pragma unroll
                             for (int k = 0; k < K; ++k)
                                 acc[k] = __builtin_fmaf(cw[dy][dx], wts.end[(dy * 3 + dx) * K + k], acc[k]);
-#pragma unroll
-                    for (int k = 0; k < K; ++k) acc[k] = clip_hi_tf(relu_tf(acc[k]), clip_hi);
+                    relu_clip_tf(acc, clip_hi);
                     if constexpr (K == 8) {
                         const int ncols = min(kFusedCols, lv.out_w - xw0);
                         store_row_k8(end_out + (base_px + (long long)y * lv.out_w + (xw0 - 4)) * 8, acc,
@@ -789,8 +787,7 @@ __global__ __launch_bounds__(256) void gray_stream_kernel(const float* __restric
                                     if constexpr (VW) acc[k] = __builtin_fmaf(cw[dy][dx], endw[wi], acc[k]);
                                     else acc[k] = __builtin_fmaf(cw[dy][dx], wts.end[wi], acc[k]);
                                 }
-#pragma unroll
-                        for (int k = 0; k < K; ++k) acc[k] = clip_hi_tf(relu_tf(acc[k]), clip_hi);
+                        relu_clip_tf(acc, clip_hi);
                         if constexpr (K == 8) {
                             const int ncols = min(kFusedCols, lv.out_w - xw0);
                             store_row_k8(end_out + row_px * 8, acc, s_slab + wave * 512, lane, 4, ncols);

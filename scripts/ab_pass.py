@@ -14,6 +14,9 @@ variants = {"two-step": ("0", two_step), "walk": (os.environ.get("SILENT_AB_WALK
             "walk plain st": ("256", lambda: pipe.step(frames)), "walk+region": ("512", lambda: pipe.step(frames)),
             "walk+region 3/CU": (str(512 + 1024), lambda: pipe.step(frames)), "walk+region 4/CU": (str(512 + 2048), lambda: pipe.step(frames)),
             "walk 3/CU": ("1024", lambda: pipe.step(frames)),
+            "A seg64": (str(512 + (2 << 12)), lambda: pipe.step(frames)), "A seg128": (str(512 + (4 << 12)), lambda: pipe.step(frames)),
+            "A seg272": (str(512 + (9 << 12)), lambda: pipe.step(frames)), "A seg544": (str(512 + (17 << 12)), lambda: pipe.step(frames)),
+            "A seg1088": (str(512 + (34 << 12)), lambda: pipe.step(frames)),
             "tile stream": ("64", lambda: pipe.step(frames))}
 if os.environ.get("AB_ONLY"):
     variants = {k: v for k, v in variants.items() if k in os.environ["AB_ONLY"].split(",")}
