@@ -1720,10 +1720,13 @@ SILENT_EXPORT int silent_gray_pass_dev(silent_ctx* ctx, const silent_pyramid_pla
     hipStream_t s = (hipStream_t)stream;
     const PyrTab& pt = plan->tab;
     const int kopts = (int)ctx->tune[SILENT_TUNE_GRAY];  // A/B knobs: bit3 32-row fused tiles, bit4 disable the stream path
-    // strip-walk kernel for the unit level (bit 64: off, bit 128: also for small batches, bit 256: plain stores)
+    // strip-walk kernel for the unit level: OFF by default -- measured on 64 x 1080p (profiles/r02/walk_kernel.txt) it
+    // moves 15 % fewer bytes than the tile kernel but at a lower HBM efficiency, 0.73-0.79 ms for the unit level alone
+    // against 0.78-0.85 ms for the tile kernel's whole job.  Bit 128 selects it (bit 256: plain instead of non-temporal
+    // stores, bit 512: other levels by the region kernel, bits 10-11 / 12-17: blocks per CU / rows per segment).
     WalkTab wt;
     int walk_unit = -1;
-    const bool walk_path = !(kopts & 64) && end_out && walk_plan(ctx, plan, n_frames, n_orient, (kopts & 128) != 0, 2 + ((kopts >> 10) & 3), 32 * ((kopts >> 12) & 63), &wt, &walk_unit);
+    const bool walk_path = (kopts & 128) && end_out && walk_plan(ctx, plan, n_frames, n_orient, true, 2 + ((kopts >> 10) & 3), 32 * ((kopts >> 12) & 63), &wt, &walk_unit);
     const bool walk_pyr = walk_path && plan->walk_pyr_ok && !(kopts & 512);   // other levels from the same walk
     const bool stream_path = plan->stream_ok && !(kopts & 16) && !walk_path;
     // 1. non-unit levels of the pyramid: by the region kernel, unless the stream kernel of step 2 produces them

@@ -190,7 +190,7 @@ __global__ __launch_bounds__(walk_threads(G)) __attribute__((amdgpu_waves_per_eu
     const long long lane_px = base_px + colA;                   // + row * out_w
 
     // conv weights in VGPRs (all-VGPR fmas issue at ~2.7 cycles, SGPR-operand ones at ~4.2: profiles/r01b/valu_rate.txt)
-    constexpr bool VW = K <= 4;
+    constexpr bool VW = K <= 4 && G == 0;   // (with the in-walk pyramid state the 36 end weights would push the wave past 168 VGPRs)
     float wv[5], csw[9], endw[VW ? 9 * K : 1];
 #pragma unroll
     for (int j = 0; j < 5; ++j) {

@@ -10,14 +10,14 @@ pipe = LineEndPipeline((1080, 1920), mode="gray", n_levels=5, n_orient=4, batch=
 frames = torch.randint(0, 256, (B, 1080, 1920, 1), device="cuda").float()
 def two_step():
     pipe.run_pyramid(frames); pipe.run_filters()
-variants = {"two-step": ("0", two_step), "walk": (os.environ.get("SILENT_AB_WALK_OPTS", "0"), lambda: pipe.step(frames)),
-            "walk plain st": ("256", lambda: pipe.step(frames)), "walk+region": ("512", lambda: pipe.step(frames)),
-            "walk+region 3/CU": (str(512 + 1024), lambda: pipe.step(frames)), "walk+region 4/CU": (str(512 + 2048), lambda: pipe.step(frames)),
-            "walk 3/CU": ("1024", lambda: pipe.step(frames)),
-            "A seg64": (str(512 + (2 << 12)), lambda: pipe.step(frames)), "A seg128": (str(512 + (4 << 12)), lambda: pipe.step(frames)),
-            "A seg272": (str(512 + (9 << 12)), lambda: pipe.step(frames)), "A seg544": (str(512 + (17 << 12)), lambda: pipe.step(frames)),
-            "A seg1088": (str(512 + (34 << 12)), lambda: pipe.step(frames)),
-            "tile stream": ("64", lambda: pipe.step(frames))}
+variants = {"two-step": ("0", two_step), "walk": (os.environ.get("SILENT_AB_WALK_OPTS", "128"), lambda: pipe.step(frames)),
+            "walk plain st": ("384", lambda: pipe.step(frames)), "walk+region": ("640", lambda: pipe.step(frames)),
+            "walk+region 3/CU": (str(640 + 1024), lambda: pipe.step(frames)), "walk+region 4/CU": (str(640 + 2048), lambda: pipe.step(frames)),
+            "walk 3/CU": ("1152", lambda: pipe.step(frames)),
+            "A seg64": (str(640 + (2 << 12)), lambda: pipe.step(frames)), "A seg128": (str(640 + (4 << 12)), lambda: pipe.step(frames)),
+            "A seg272": (str(640 + (9 << 12)), lambda: pipe.step(frames)), "A seg544": (str(640 + (17 << 12)), lambda: pipe.step(frames)),
+            "A seg1088": (str(640 + (34 << 12)), lambda: pipe.step(frames)),
+            "tile stream": ("0", lambda: pipe.step(frames))}
 if os.environ.get("AB_ONLY"):
     variants = {k: v for k, v in variants.items() if k in os.environ["AB_ONLY"].split(",")}
 if os.environ.get("AB_QUICK"):

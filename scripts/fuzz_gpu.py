@@ -49,7 +49,7 @@ def case_gray_pass(rng, k):
     K = int(rng.choice([3, 4, 8]))
     B = int(rng.integers(1, 4))
     # development knobs select other (bit-identical) code paths: tile order, 32-row tiles, no stream path, unit + region pyramid
-    kg, kp = int(rng.choice([0, 0, 1, 2, 3, 8, 16, 24, 64, 80])), int(rng.choice([0, 0, 1]))
+    kg, kp = int(rng.choice([0, 0, 1, 2, 3, 8, 16, 24, 128, 128 + 512, 128 + 256])), int(rng.choice([0, 0, 1]))
     rt.get_context().set_tuning(_lib.TUNE_GRAY, kg)
     rt.get_context().set_tuning(_lib.TUNE_PYRAMID, kp)
     desc = "gray_pass h=%d w=%d scale=%.3f n=%d K=%d B=%d knobs=%s/%s" % (h, w, scale, n, K, B, kg, kp)

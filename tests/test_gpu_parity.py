@@ -1081,8 +1081,8 @@ def test_entry_points_leave_the_callers_device_alone(rt):
                                                ((540, 960, 1), 2.0, 8, 8, 2),          # 7 general levels (config 5 shape / 4)
                                                ((300, 480, 1), 2.5, 4, 4, 1)])         # zoom step 2.5
 def test_gray_walk_kernel_is_bit_identical_to_the_tile_kernels(rt, kernels, shape, scale, n, K, B):
-    """The strip-walk kernel (loader wave + two pixels per lane, tuning bit 128 forces it on small batches) against the
-    round-1 path (bit 64 switches it off): the same arithmetic in the same order, so every map is equal bit for bit --
+    """The strip-walk kernel (loader wave + two pixels per lane, tuning bit 128 selects it) against the
+    tile kernels (the default path): the same arithmetic in the same order, so every map is equal bit for bit --
     across segment seams, strip seams, ragged right edges and both store layouts."""
     from pysilent_amd.util.zoom.from_image import classic_levels
     frames = np.stack([structured_frame(20 + s, *shape, n_lines=60) + noise_frame(s, *shape) * np.float32(0.25) for s in range(B)])
@@ -1092,7 +1092,7 @@ def test_gray_walk_kernel_is_bit_identical_to_the_tile_kernels(rt, kernels, shap
         pyr, cs, end = plan.gray_pass(frames, kernels["cs_gray"], bank)
     with rt.tuning(TUNE_GRAY, 128 | 256 | 512):                 # plain instead of non-temporal stores; other levels by
         pyr_p, cs_p, end_p = plan.gray_pass(frames, kernels["cs_gray"], bank)   # the region kernel instead of the walk
-    with rt.tuning(TUNE_GRAY, 64):
+    with rt.tuning(TUNE_GRAY, 0):
         pyr2, cs2, end2 = plan.gray_pass(frames, kernels["cs_gray"], bank)
     for a, b_, c_ in ((pyr, pyr_p, pyr2), (cs, cs_p, cs2), (end, end_p, end2)):
         np.testing.assert_array_equal(a.data, c_.data)
@@ -1114,7 +1114,7 @@ def test_gray_walk_kernel_nan_and_inf_frames(rt, kernels):
     plan = rt.PyramidPlan(150, 488, 1, classic_levels((150, 488), 2.0, 3))
     with rt.tuning(TUNE_GRAY, 128):
         got = plan.gray_pass(frames, kernels["cs_gray"], kernels["end4"])
-    with rt.tuning(TUNE_GRAY, 64):
+    with rt.tuning(TUNE_GRAY, 0):
         ref = plan.gray_pass(frames, kernels["cs_gray"], kernels["end4"])
     for a, b_ in zip(got, ref):
         np.testing.assert_array_equal(a.data, b_.data)
