@@ -354,6 +354,12 @@ def run_rank(args):
     elapsed = timed_steps(torch, D, pipe, frames, args.steps, args.warmup, dev)
 
     # ---- everything below is outside the timed region ----
+    # Steady state, reported beside `value`, never instead of it: after an idle period the first ~20 back-to-back launches
+    # of the pass run up to 20 % slower than the rate the chip then settles at (profiles/r02/launch_drift.txt: 864 -> 1040
+    # -> 848 us for the dominant kernel; flat with 20 ms idle gaps; a plain device copy does the same) -- a power-management
+    # transient, and with --warmup 5 the K timed steps sit inside it.  60 more steps, timed the same way, show the settled rate.
+    settle_steps = 60
+    steady = timed_steps(torch, D, pipe, frames, settle_steps, 0, dev)
     dom = dominant_kernel(torch, pipe, frames, wl, B, dev)
     gray = wl["mode"] == "gray"
     if rank != 0:
@@ -388,6 +394,11 @@ def run_rank(args):
                    "sharding": "frame i -> rank i mod N; one RCCL broadcast of constants at init",
                    "csrc_revision": csrc_revision()},
         "roofline": roofline_of(dom, B),
+        "steady_state": {"ms_per_step": round(steady / settle_steps * 1e3, 4), "steps": settle_steps,
+                         "value": round(B * world * settle_steps * h * w / steady / 1e6, 2),
+                         "whole_pass_frac_of_hbm_peak": round(pipe.algorithmic_bytes_per_frame() * B * settle_steps / steady / 1e9 / HBM_PEAK_GBS, 4),
+                         "note": "the same steps timed again right after the K timed ones: the first ~20 launches after an idle "
+                                 "period run inside a power-management transient (profiles/r02/launch_drift.txt)"},
     }
     del pipe, frames
     torch.cuda.empty_cache()

@@ -103,6 +103,34 @@ def assert_close(got, want, rtol=1e-5, scale=None, what="", rel_floor=0.1):
     WORST_REL[what] = (max(old[0], worst[0]), max(old[1], worst[1]))
 
 
+def assert_regulated_close(got, stripe, blur, want, rtol=1e-5, what=""):
+    """The regulator's output y = x * rv / pow(min(b, 1), root) under flat_policy "ieee" (0 * inf = NaN where the stripe
+    value AND its whole 7 x 7 x 3 blur window are 0), compared by a DETERMINISTIC rule in three zones of the ORACLE's blur b
+    (float64 accumulation), tau = 1e-5 * max(1, max stripe response of the level):
+      b == 0   every stripe value of the window is exactly 0 (black input: every product is exactly 0 in any summation
+               order): the GPU must show NaN exactly where the oracle does, and be close elsewhere;
+      b > tau  ordinary response: finite on both sides, within the response tolerance;
+      0 < b <= tau   rounding residue of cancelling taps on flat, non-black regions -- whether it is an exact 0 depends on
+               the summation order (TF's own CPU and GPU kernels would disagree there): the GPU value must be NaN or a
+               residue itself, 0 <= y <= 2 * tau ** 0.9 (x <= b because the blur's centre tap is 1, so y = x / b ** 0.1)."""
+    got, stripe, blur, want = (np.asarray(a) for a in (got, stripe, blur, want))
+    tau = 1e-5 * max(1.0, float(np.nanmax(stripe)))
+    zero, resid = blur == 0, (blur > 0) & (blur <= tau)
+    normal = ~zero & ~resid
+    gn, wn = np.isnan(got), np.isnan(want)
+    assert np.array_equal(gn[zero], wn[zero]), "%s: NaN pattern differs on exactly-zero windows (%d vs %d)" % (
+        what, gn[zero].sum(), wn[zero].sum())
+    assert not gn[normal].any() and not wn[normal].any(), "%s: NaN on an ordinary response" % what
+    firm = (zero & ~wn) | normal
+    if firm.any():
+        assert_close(got[firm], want[firm], rtol, scale=float(np.nanmax(np.abs(want[firm]))) or 1.0, what=what + " (firm zones)")
+    r = got[resid]
+    ok = np.isnan(r) | ((r >= 0) & (r <= 2.0 * tau ** 0.9))
+    assert ok.all(), "%s: %d residue-band values are neither NaN nor residue (max %.3g, bound %.3g)" % (
+        what, (~ok).sum(), np.nanmax(r), 2.0 * tau ** 0.9)
+    return int(resid.sum()), int((gn != wn)[resid].sum())
+
+
 def pytest_terminal_summary(terminalreporter):
     if WORST_REL:
         worst = sorted(WORST_REL.items(), key=lambda kv: -kv[1][1])[:10]

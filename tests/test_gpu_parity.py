@@ -10,7 +10,7 @@ import pytest
 
 import silent_oracle as so
 import c_oracle as co
-from conftest import assert_close, noise_frame, structured_frame
+from conftest import assert_close, assert_regulated_close, noise_frame, structured_frame
 from pysilent_amd._lib import TUNE_GRAY, TUNE_PYRAMID, TUNE_RGB  # noqa: F401
 
 pytestmark = pytest.mark.gpu
@@ -1182,3 +1182,28 @@ def test_select_keypoints_with_many_windows(rt):
     np.testing.assert_array_equal(pv_out, fused["peak_value"].data)
     for f in range(2):
         np.testing.assert_array_equal(idx[f, :counts[f]], kp[f])
+
+
+def test_rgb_chain_on_plateau_frames_under_ieee_by_the_three_zone_rule(rt, kernels):
+    """Plateau frames (flat coloured regions whose stencil taps cancel to rounding residue, black regions whose taps are
+    exactly 0, and edges between them) under the reference's default flat policy: the regulator's NaN pattern must equal
+    the oracle's wherever it is decidable (exactly-zero windows, ordinary responses) and be {NaN, residue} in the band where
+    the summation order decides -- the deterministic rule of conftest.assert_regulated_close (this replaces the ad-hoc
+    "residue criterion" of round 1's fuzz script).  The stages after the regulator are compared against the oracle applied
+    to the GPU's own orient map."""
+    rng = np.random.default_rng(21)
+    frames = np.floor(rng.random((2, 96, 150, 3)) * 4).astype(np.float32) * 64          # 4-level plateaus, random per pixel
+    frames = np.repeat(np.repeat(frames[:, ::6, ::6], 6, axis=1), 6, axis=2)[:, :96, :150]   # 6 x 6 flat blocks
+    frames[0, 20:60, 30:90] = 0.0                                                        # a black region
+    frames[1, :, 100:] = 128.0                                                           # a large flat grey region
+    ks = {x: kernels[x] for x in ("rgc", "rgby", "stripe", "blur", "end")}
+    got = rt.rgb_line_end(frames, ks, flat_policy="ieee")
+    want = so.rgb_line_end_chain(frames, ks, "ieee")
+    b = so.conv2d_same(want["stripe"], ks["blur"])
+    n_resid, n_flip = assert_regulated_close(got["orient"], want["stripe"], b, want["orient"], RTOL, what="plateau orient")
+    assert np.isnan(want["orient"]).sum() > 1000                 # the black region really produces the 0 * inf case
+    le = so.pad_inwards(so.conv2d_same(np.ascontiguousarray(got["orient"]), ks["end"], relu=True, clip_hi=255.0),
+                        [[0, 0], [2, 2], [2, 2], [0, 0]])
+    assert_close(got["line_end"], le, RTOL, scale=255.0, what="plateau line_end from the GPU's orient")
+    np.testing.assert_array_equal(got["value"], so.value_from_color(np.ascontiguousarray(got["line_end"])))
+    print("plateau frames: %d residue-band values, NaN-or-residue differs from the oracle at %d of them" % (n_resid, n_flip))
