@@ -24,7 +24,7 @@ def init(backend=None, device=None):
     rank, size, local = world()
     if device is not None:
         local = int(device)
-    if size > 1:
+    if size > 1 or os.environ.get("SILENT_DIST_FORCE") == "1":   # FORCE: a 1-rank group (exercises the RCCL calls on one GPU)
         import torch
         import torch.distributed as dist
         if not dist.is_initialized():
@@ -56,7 +56,7 @@ def broadcast_constants(mode, n_orient=4, device=None):
     import torch.distributed as dist
     local = default_constants(mode, n_orient)
     blob, layout = pack_constants(local)
-    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+    if not (dist.is_available() and dist.is_initialized()):
         return unpack_constants(blob, layout)
     on_gpu = dist.get_backend() == "nccl"
     dev = torch.device("cuda", int(os.environ.get("LOCAL_RANK", "0")) if device is None else device) if on_gpu else "cpu"
@@ -72,7 +72,7 @@ def max_over_ranks(value):
     """MAX all-reduce of a Python float (step time of the slowest rank)."""
     import torch
     import torch.distributed as dist
-    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+    if not (dist.is_available() and dist.is_initialized()):
         return float(value)
     on_gpu = dist.get_backend() == "nccl"
     t = torch.tensor([float(value)], dtype=torch.float64,
@@ -83,7 +83,7 @@ def max_over_ranks(value):
 
 def barrier():
     import torch.distributed as dist
-    if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+    if dist.is_available() and dist.is_initialized():
         if dist.get_backend() == "nccl":
             import torch
             dist.barrier(device_ids=[torch.cuda.current_device()])      # this rank's GPU, not a guess from the rank

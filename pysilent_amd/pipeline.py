@@ -217,7 +217,10 @@ class LineEndPipeline(object):
         self.run_keypoints(s)
 
     # -- results as PackedPyramids over the pipeline's buffers ---------------------------------------
-    def outputs(self):
+    def outputs(self, allow_truncated=False):
+        """Views over the pipeline's buffers (maps) and host copies of the keypoints.  Raises ValueError when a frame
+        produced more keypoints than ``max_keypoints_per_frame`` (like the host entry point's SILENT_E_CAPACITY) unless
+        ``allow_truncated``; ``keypoint_counts`` always holds the true counts."""
         P = _runtime.PackedPyramid
         out = {"pyramid": P(self.pyr, self.extents, self.channels, self.batch)}
         if self.mode == "gray":
@@ -233,6 +236,12 @@ class LineEndPipeline(object):
                     out["peaks"] = P(self.peaks, self.extents, 3, self.batch)
                 out["peak_value"] = P(self.peak_value, self.extents, 1, self.batch)
             counts = self.kp_counts.cpu().numpy()
+            if not allow_truncated and (counts > self.kp_cap).any():
+                # the asynchronous *_dev entry points cannot return SILENT_E_CAPACITY: counts[f] > cap IS the overflow flag
+                raise ValueError("keypoint capacity exceeded: frame %d produced %d rows, max_keypoints_per_frame is %d "
+                                 "(only the first %d were written; pass allow_truncated=True to take them)"
+                                 % (int(np.argmax(counts)), int(counts.max()), self.kp_cap, self.kp_cap))
             idx = self.kp_idx.cpu().numpy()
             out["keypoints"] = [idx[f, :min(int(counts[f]), self.kp_cap)].copy() for f in range(self.batch)]
+            out["keypoint_counts"] = counts
         return out

@@ -1207,3 +1207,50 @@ def test_rgb_chain_on_plateau_frames_under_ieee_by_the_three_zone_rule(rt, kerne
     assert_close(got["line_end"], le, RTOL, scale=255.0, what="plateau line_end from the GPU's orient")
     np.testing.assert_array_equal(got["value"], so.value_from_color(np.ascontiguousarray(got["line_end"])))
     print("plateau frames: %d residue-band values, NaN-or-residue differs from the oracle at %d of them" % (n_resid, n_flip))
+
+
+def test_rccl_calls_execute_on_one_gpu(tmp_path):
+    """The RCCL branches of pysilent_amd.distributed (broadcast of the constants, MAX all-reduce, barrier with device_ids)
+    in a 1-rank "nccl" process group: RCCL refuses two ranks on one device, so this is as much of the real backend as a
+    one-GPU box can run; the 2-rank logic is covered by the gloo tests on CPU."""
+    import json, subprocess, sys, textwrap
+    from conftest import ROOT
+    script = tmp_path / "one_rank.py"
+    script.write_text(textwrap.dedent("""
+        import json, sys
+        sys.path.insert(0, %r)
+        import numpy as np, torch, torch.distributed as dist
+        from pysilent_amd import distributed as D
+        from pysilent_amd.pipeline import default_constants
+        rank, world, local = D.init(backend="nccl")
+        assert dist.is_initialized() and dist.get_backend() == "nccl" and world == 1
+        c = D.broadcast_constants("gray", 4, device=local)
+        ok = all(np.array_equal(c[k], default_constants("gray", 4)[k]) for k in c)
+        r = D.broadcast_constants("rgb", device=local)
+        D.barrier()
+        slow = D.max_over_ranks(2.5)
+        print(json.dumps({"ok": bool(ok), "slow": slow, "n_rgb": len(r)}))
+        D.finalize()
+    """) % ROOT)
+    import os, socket
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    env = dict(os.environ, RANK="0", WORLD_SIZE="1", LOCAL_RANK="0", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+               SILENT_DIST_FORCE="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    p = subprocess.run([sys.executable, str(script)], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=300)
+    assert p.returncode == 0, p.stderr[-2000:]
+    out = json.loads(p.stdout.strip().splitlines()[-1])
+    assert out == {"ok": True, "slow": 2.5, "n_rgb": 5}
+
+
+def test_pipeline_flags_keypoint_overflow(rt, kernels):
+    """The device entry points are asynchronous and cannot return SILENT_E_CAPACITY; counts > cap is the flag, and
+    LineEndPipeline.outputs() turns it into the same ValueError as the host path."""
+    import torch
+    from pysilent_amd.pipeline import LineEndPipeline
+    pipe = LineEndPipeline((64, 96), mode="rgb", n_levels=2, batch=1, max_keypoints_per_frame=5, flat_policy="zero")
+    pipe.step(torch.zeros((1, 64, 96, 3), device="cuda"))          # an all-zero frame (zero policy): every pixel is a keypoint
+    torch.cuda.synchronize()
+    with pytest.raises(ValueError, match="keypoint capacity exceeded"):
+        pipe.outputs()
+    out = pipe.outputs(allow_truncated=True)
+    assert len(out["keypoints"][0]) == 5 and int(out["keypoint_counts"][0]) == 64 * 96 + 32 * 48
