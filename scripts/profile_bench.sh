@@ -8,7 +8,9 @@ OUT=$REPO/gpurun_out/prof_$TAG
 mkdir -p $OUT
 export TMPDIR=/tmp
 cd /tmp
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -o trace -- python3 $REPO/bench.py --steps 5 --warmup 2 --no-cpu-baseline "$@" > $OUT/bench_trace.log 2>&1 || exit 1
-rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch -o fetch -- python3 $REPO/bench.py --steps 2 --warmup 1 --no-cpu-baseline "$@" > $OUT/bench_fetch.log 2>&1 || exit 1
-rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_write -o write -- python3 $REPO/bench.py --steps 2 --warmup 1 --no-cpu-baseline "$@" > $OUT/bench_write.log 2>&1 || exit 1
+# 60 timed steps: the first ~20 launches after an idle period sit in a power-management transient (profiles/r02/launch_drift.txt);
+# a 5-step trace would average only that transient
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -o trace -- python3 $REPO/bench.py --steps 60 --warmup 10 --no-cpu-baseline --no-side-workloads "$@" > $OUT/bench_trace.log 2>&1 || exit 1
+rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch -o fetch -- python3 $REPO/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-side-workloads "$@" > $OUT/bench_fetch.log 2>&1 || exit 1
+rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_write -o write -- python3 $REPO/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-side-workloads "$@" > $OUT/bench_write.log 2>&1 || exit 1
 find $OUT -name "*.csv" | head -20
