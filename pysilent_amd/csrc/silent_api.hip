@@ -17,6 +17,7 @@
 #include "silent_pyramid.h"
 #include "silent_rgb.h"
 #include "silent_walk.h"
+#include "silent_walk_rgb.h"
 
 using namespace silent;
 
@@ -87,6 +88,7 @@ struct silent_pyramid_plan {
     // in-walk pyramid of gray_walk_kernel (silent_walk.h): row program over the whole crop + column records per
     // 120-column wave tile, when every general level resamples the unit level's crop with <= 64 outputs per tile
     bool walk_pyr_ok = false;
+    int walk_unit_level = -1;
     void* walk_tables = nullptr;
     WalkPyr walk{};
 };
@@ -1469,12 +1471,13 @@ SILENT_EXPORT int silent_pyramid_plan_create(silent_ctx* ctx, int frame_h, int f
             }
         }
     }
-    // ---- in-walk pyramid tables (see gray_walk_kernel): same eligibility as the stream path plus the walk's own
+    // ---- in-walk pyramid tables (gray_walk_kernel for 1 channel, pyramid_walk3_kernel for 3): one unit level, every
+    // other level resamples the unit level's crop, and the walk's own limits (slots, outputs per wave tile)
     {
         int unit = -1, n_unit = 0;
         for (int l = 0; l < n_levels; ++l)
             if (tab.lv[l].kind == kPyrUnit) { unit = l; ++n_unit; }
-        bool ok = channels == 1 && n_unit == 1 && tab.n_general >= 1 && tab.n_general <= 7;
+        bool ok = n_unit == 1 && tab.n_general >= 1 && tab.n_general <= 7;
         if (ok) {
             const PyrLevelDev& u = tab.lv[unit];
             ok = u.out_h >= u.src_h && u.out_w >= u.src_w;
@@ -1487,12 +1490,19 @@ SILENT_EXPORT int silent_pyramid_plan_create(silent_ctx* ctx, int frame_h, int f
         if (ok) {
             const PyrLevelDev& u = tab.lv[unit];
             const int G = tab.n_general;
-            const int strips_x = (u.out_w + kWalkStripW - 1) / kWalkStripW;
             const int Gp = stream_pad_levels(G), PR = walk_prog_row(Gp);
+            // geometry of a wave tile: pixels per tile, tiles per row, record slots, and the tap index of an output anchored
+            // at pixel xb of the tile that starts at pixel xw0 (1 channel: index into the wave's 128 columns, first column
+            // xw0 - 4; 3 channels: FLOAT index into the wave's line, first pixel xw0 - 2)
+            const bool rgb = channels == 3;
+            const int tile_px = rgb ? kW3Px : kWalkCols;
+            const int strip_px = rgb ? kW3StripPx : kWalkStripW;
+            const int waves_x = ((u.out_w + strip_px - 1) / strip_px) * (rgb ? kW3NC : kWalkNC);
+            const int rec_total = rgb ? w3_rec_total(Gp) : walk_rec_total(Gp);
+            auto cap = [&](int g) { return rgb ? w3_rec_cap(g) : walk_rec_cap(g); };
+            auto base = [&](int g) { return rgb ? w3_rec_base(g) : walk_rec_base(g); };
             const size_t n_rec = (size_t)u.out_h + 8;                 // stream rows y = -4 .. out_h + 3 at index y + 4
             const size_t n_rec_pad = n_rec + 2 * kWalkCH;             // the loader fetches whole chunks of records
-            const int rec_total = walk_rec_total(Gp);
-            const int waves_x = strips_x * kWalkNC;
             std::vector<int> prog(n_rec_pad * PR, 0), hdr((size_t)G * waves_x * 2, 0), rec((size_t)waves_x * rec_total * 8, 0);
             for (size_t r = 0; r < n_rec_pad; ++r)
                 for (int gg = 0; gg < Gp; ++gg) prog[r * PR + gg] = 7 << 4;  // inert: feeds nothing, no slot completes
@@ -1526,17 +1536,22 @@ SILENT_EXPORT int silent_pyramid_plan_create(silent_ctx* ctx, int frame_h, int f
                 }
                 int ox = 0;
                 for (int wx = 0; wx < waves_x && ok; ++wx) {
-                    const int xw0 = wx * kWalkCols;
+                    const int xw0 = wx * tile_px;
                     while (ox < zc && xb[ox] < xw0) ++ox;
                     int n = 0;
-                    while (ox + n < zc && xb[ox + n] < xw0 + kWalkCols) ++n;
-                    if (n > walk_rec_cap(g)) { ok = false; break; }      // one output per lane at level 0, halving per level
+                    while (ox + n < zc && xb[ox + n] < xw0 + tile_px) ++n;
+                    if (n > cap(g)) { ok = false; break; }               // one output (pixel) per lane (triple), halving per level
                     hdr[((size_t)g * waves_x + wx) * 2] = ox;
                     hdr[((size_t)g * waves_x + wx) * 2 + 1] = n;
                     for (int j = 0; j < n; ++j) {
-                        int* r = rec.data() + ((size_t)wx * rec_total + walk_rec_base(g) + j) * 8;
-                        r[0] = xb[ox + j] - xw0 + 2;   // index of tap 0 in the wave's 128 columns (index 0 <-> column xw0 - 4)
-                        if (r[0] < 0 || r[0] + 5 > 127) { ok = false; break; }
+                        int* r = rec.data() + ((size_t)wx * rec_total + base(g) + j) * 8;
+                        if (rgb) {
+                            r[0] = (xb[ox + j] - xw0) * 3;               // float index of tap 0, channel 0 (line starts at pixel xw0 - 2)
+                            if (r[0] < 0 || r[0] + 2 + 15 > kW3TileF - 1) { ok = false; break; }
+                        } else {
+                            r[0] = xb[ox + j] - xw0 + 2;                 // index of tap 0 in the wave's 128 columns (index 0 <-> column xw0 - 4)
+                            if (r[0] < 0 || r[0] + 5 > 127) { ok = false; break; }
+                        }
                         std::memcpy(r + 1, &xw[(size_t)(d.xtab_off + ox + j) * 6], 24);
                     }
                     ox += n;
@@ -1561,6 +1576,7 @@ SILENT_EXPORT int silent_pyramid_plan_create(silent_ctx* ctx, int frame_h, int f
                     plan->walk.col_hdr = (const int*)((char*)plan->walk_tables + b0);
                     plan->walk.col_rec = (const int*)((char*)plan->walk_tables + b0 + b1);
                     plan->walk_pyr_ok = true;
+                    plan->walk_unit_level = unit;
                 }
             }
         }
@@ -1578,6 +1594,33 @@ SILENT_EXPORT void silent_pyramid_plan_destroy(silent_pyramid_plan* plan) {
     delete plan;
 }
 
+// Geometry of the single-read RGB pyramid walk: eligible when the plan has walk tables (3 channels), rows / crop are
+// 16-byte aligned and the canvas offsets even.  Any batch size: the segment height adapts so that the grid fills the chip.
+static bool walk3_plan(const silent_ctx* ctx, const silent_pyramid_plan* plan, int n_frames, WalkTab* wt) {
+    const PyrTab& pt = plan->tab;
+    if (pt.C != 3 || !plan->walk_pyr_ok || plan->walk_unit_level < 0) return false;
+    const PyrLevelDev& d = pt.lv[plan->walk_unit_level];
+    if (pt.W % 4 || d.src_x0 % 4 || d.src_w % 4 || d.out_w % 2 || pt.frame_px_out % 2 || pt.px_off[plan->walk_unit_level] % 2) return false;
+    if (d.src_w < 8) return false;
+    std::memset(wt, 0, sizeof(*wt));
+    wt->H = pt.H; wt->W = pt.W;
+    wt->src_y0 = d.src_y0; wt->src_x0 = d.src_x0; wt->src_h = d.src_h; wt->src_w = d.src_w;
+    wt->out_h = d.out_h; wt->out_w = d.out_w;
+    wt->eff_h = std::min(d.zoom_h, d.out_h); wt->eff_w = std::min(d.zoom_w, d.out_w);
+    wt->strips_x = (d.out_w + kW3StripPx - 1) / kW3StripPx;
+    const long long per_seg = (long long)n_frames * wt->strips_x;
+    const int max_segs = std::max(1, d.out_h / 32);
+    const int segs = (int)std::min<long long>(max_segs, (3ll * ctx->n_cus + per_seg - 1) / per_seg);
+    int seg_rows = (d.out_h + segs - 1) / segs;
+    seg_rows = (seg_rows + kWalkCH - 1) / kWalkCH * kWalkCH;
+    wt->seg_rows = seg_rows;
+    wt->segs_y = (d.out_h + seg_rows - 1) / seg_rows;
+    wt->frame_px = pt.frame_px_out;
+    wt->px_off = pt.px_off[plan->walk_unit_level];
+    for (int j = 0; j < 5; ++j) wt->wx[j] = plan->unit_w[j];
+    return true;
+}
+
 static int launch_pyramid(silent_ctx* ctx, const char* who, const silent_pyramid_plan* plan, const float* frames,
                           int n_frames, float* pyr, hipStream_t s, bool with_unit, bool with_region = true) {
     if (!plan || !frames || !pyr) return fail(ctx, SILENT_E_INVALID, std::string(who) + ": NULL pointer");
@@ -1590,6 +1633,7 @@ static int launch_pyramid(silent_ctx* ctx, const char* who, const silent_pyramid
     if (b_unit > 0x7fffffffll || b_region > 0x7fffffffll || b_zero > 0x7fffffffll)
         return fail(ctx, SILENT_E_INVALID, std::string(who) + ": too many tiles for one launch");
     const unsigned kopts = ctx->tune[SILENT_TUNE_PYRAMID];  // 1: no stream kernel
+    WalkTab w3t;
     if (plan->stream_ok && with_unit && with_region && !(kopts & 1u)) {
         // single-read pyramid: frame -> every level in one kernel (pyramid_stream_kernel; single-channel plans only:
         // on interleaved RGB the stride-3 accesses of the same kernel made it 1.5x SLOWER than unit + region kernels)
@@ -1614,6 +1658,13 @@ static int launch_pyramid(silent_ctx* ctx, const char* who, const silent_pyramid
         if (plan->stream.G <= 4) PYR_STREAM(4);
         else PYR_STREAM(7);
 #undef PYR_STREAM
+    } else if (tab.C == 3 && plan->walk_pyr_ok && with_unit && with_region && !(kopts & 3u) && walk3_plan(ctx, plan, n_frames, &w3t)) {
+        // single-read RGB pyramid (pyramid_walk3_kernel, silent_walk_rgb.h); PYRAMID knob bits 1 / 2: unit + region kernels
+        const long long wblocks = (long long)n_frames * w3t.segs_y * w3t.strips_x;
+        if (plan->walk.G <= 4)
+            hipLaunchKernelGGL(pyramid_walk3_kernel<4>, dim3((unsigned)wblocks), dim3(kW3Threads), 0, s, frames, pyr, w3t, plan->walk);
+        else
+            hipLaunchKernelGGL(pyramid_walk3_kernel<7>, dim3((unsigned)wblocks), dim3(kW3Threads), 0, s, frames, pyr, w3t, plan->walk);
     } else if (tab.C == 1) {
         if (b_unit) hipLaunchKernelGGL(pyramid_unit_kernel<1>, dim3((unsigned)b_unit), dim3(256), 0, s, frames, pyr, tab);
         if (b_region) hipLaunchKernelGGL(pyramid_region_kernel<1>, dim3((unsigned)b_region), dim3(256), 0, s, frames, pyr, tab);
@@ -1727,7 +1778,7 @@ SILENT_EXPORT int silent_gray_pass_dev(silent_ctx* ctx, const silent_pyramid_pla
     WalkTab wt;
     int walk_unit = -1;
     const bool walk_path = (kopts & 128) && end_out && walk_plan(ctx, plan, n_frames, n_orient, true, 2 + ((kopts >> 10) & 3), 32 * ((kopts >> 12) & 63), &wt, &walk_unit);
-    const bool walk_pyr = walk_path && plan->walk_pyr_ok && !(kopts & 512);   // other levels from the same walk
+    const bool walk_pyr = walk_path && plan->walk_pyr_ok && pt.C == 1 && !(kopts & 512);   // other levels from the same walk
     const bool stream_path = plan->stream_ok && !(kopts & 16) && !walk_path;
     // 1. non-unit levels of the pyramid: by the region kernel, unless the stream kernel of step 2 produces them
     //    from the same single read of the frame; plus the zero fill of canvases larger than their zoomed crop

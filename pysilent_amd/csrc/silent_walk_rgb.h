@@ -1,0 +1,248 @@
+// pyramid_walk3_kernel: the whole zoom pyramid of a 3-channel (interleaved RGB) frame from ONE read of the frame, as a
+// strip walk with a dedicated loader wave -- the structure of gray_walk_kernel (silent_walk.h) applied to the pyramid of
+// BASELINE config 3, where round 1 ran two kernels (pyramid_unit_kernel<3> + pyramid_region_kernel<3>: the frame is fetched
+// 2.95x, the region kernel moves 1.64x its algorithmic bytes and is latency-bound at 1.9 TB/s).
+//
+// Everything is indexed in FLOATS of the interleaved row (pixel p, channel c <-> float 3p + c):
+//   * a block owns a strip of 144 pixels of one frame segment; wave 4 (the loader) LDS-DMAs the strip's rows (+ 4 / 3 halo
+//     pixels) into a ring of 3 chunks x 8 rows, two chunks ahead, together with the chunk's row records;
+//   * waves 0-3 (consumers) own 36 pixels each = 108 floats, two floats per lane, plus a halo of 2 / 3 pixels that only
+//     the gather of the other levels needs: the unit level's 5 horizontal taps sit 3 floats apart and are read straight
+//     from the ring (no DPP, hence no halo lanes for the smoother), the 5 vertical taps are a register window;
+//   * the other levels: vertical 6 taps in the lane (walk_slots(g) output rows in flight, row program from the ring), a
+//     completed row goes through a wave-private LDS line, and lane 3j + c gathers the 6 taps of channel c of output pixel
+//     j (3 floats apart) with column records staged in LDS -- the arithmetic order of the region kernel, bit-identical.
+// Same protocol as the gray walk: one raw s_barrier per chunk, uniform trip counts, the consumers' vmcnt queue holds
+// stores only.  Eligibility (host): one unit level, every other level resamples its crop with a zoom step >= 1.875,
+// W, src_x0, src_w multiples of 4, out_w even, even pyramid offsets.
+#pragma once
+
+#include <type_traits>
+
+#include "silent_common.h"
+#include "silent_walk.h"
+
+namespace silent {
+
+constexpr int kW3NC = 4;                        // consumer waves per block
+constexpr int kW3Px = 36;                       // pixels per consumer wave
+constexpr int kW3StripPx = kW3NC * kW3Px;       // 144 pixels per block
+constexpr int kW3HaloL = 4, kW3HaloR = 3;       // ring halo in pixels (left one keeps the ring row 16-byte aligned)
+constexpr int kW3TileL = 2;                     // a wave's line starts 2 pixels left of its first pixel ...
+constexpr int kW3TileF = 124;                   // ... and holds 124 floats (41 pixels + 1 float): taps -2 .. +3 of its anchors
+constexpr int kW3RowF = 456;                    // floats per ring row ((144 + 7) * 3 = 453 used)
+constexpr int kW3Threads = (kW3NC + 1) * 64;
+// column records per wave tile and level (output PIXELS anchored in a wave's 36 pixels at zoom step >= 1.875 ^ (g + 1))
+__host__ __device__ constexpr int w3_rec_cap(int g) { return g == 0 ? 21 : (g == 1 ? 11 : (g == 2 ? 6 : (g == 3 ? 4 : (g <= 5 ? 2 : 1)))); }
+__host__ __device__ constexpr int w3_rec_base(int g) {
+    int n = 0;
+    for (int i = 0; i < g; ++i) n += w3_rec_cap(i);
+    return n;
+}
+__host__ __device__ constexpr int w3_rec_total(int g) { return w3_rec_base(g); }
+
+template <int G>
+__global__ __launch_bounds__(kW3Threads) void pyramid_walk3_kernel(const float* __restrict__ frames, float* __restrict__ pyr,
+                                                                    const WalkTab tab, const WalkPyr wp) {
+    static_assert(G == stream_pad_levels(G), "row programs are padded to 4 or 7 levels");
+    constexpr int PR = walk_prog_row(G);
+    __shared__ __attribute__((aligned(16))) float s_ring[kWalkSlots * kWalkCH][kW3RowF];          // 43.8 KB
+    __shared__ __attribute__((aligned(16))) int s_prog[kWalkSlots * kWalkCH * PR];                // row records of the ring's chunks
+    __shared__ __attribute__((aligned(16))) float s_line[kW3NC * 128];                            // a completed row, per wave
+    __shared__ __attribute__((aligned(16))) int s_rec[kW3NC * w3_rec_total(G) * 8];               // column records, per wave
+
+    const unsigned bid = blockIdx.x;
+    const int strip = (int)(bid % (unsigned)tab.strips_x);
+    const unsigned rest = bid / (unsigned)tab.strips_x;
+    const int seg = (int)(rest % (unsigned)tab.segs_y);
+    const int frame = (int)(rest / (unsigned)tab.segs_y);
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int seg_y0 = seg * tab.seg_rows;
+    const int seg_h = min(tab.seg_rows, tab.out_h - seg_y0);
+    const int n_rows = seg_h + 8;                              // stream rows seg_y0 - 4 .. seg_y0 + seg_h + 3
+    const int n_chunks = (n_rows + kWalkCH - 1) / kWalkCH;
+    const int X0 = strip * kW3StripPx;                         // first pixel of the strip; the ring row starts at pixel X0 - 4
+    const int R0 = X0 - kW3HaloL;
+
+    if (wave == kW3NC) {
+        // ------------------------------------------------------------------ loader: LDS-DMA only
+        const float* __restrict__ src = frames + (long long)frame * tab.H * tab.W * 3;
+        const int rowf = tab.src_w * 3;                        // floats of a crop row (multiple of 4: host-checked)
+        // 4-float groups are aligned in the row, so a group lies wholly inside the crop or wholly outside; outside groups are
+        // clamped to a valid address and never read (the consumers read mirrored pixels instead)
+        const int f0 = min(max(R0 * 3 + lane * 4, 0), rowf - 4) + tab.src_x0 * 3;
+        const int f1 = min(max(R0 * 3 + 256 + lane * 4, 0), rowf - 4) + tab.src_x0 * 3;
+        auto issue = [&](int c, int slot) {
+#pragma unroll
+            for (int r = 0; r < kWalkCH; ++r) {
+                const int y = seg_y0 - 4 + c * kWalkCH + r;
+                const float* rp = src + (long long)(mirror_near(y, tab.src_h) + tab.src_y0) * tab.W * 3;
+                float* dst = &s_ring[slot * kWalkCH + r][0];
+                __builtin_amdgcn_global_load_lds((walk_glb_ptr)(rp + f0), (walk_lds_ptr)dst, 16, 0, 0);
+                if (lane < (kW3RowF - 256) / 4)
+                    __builtin_amdgcn_global_load_lds((walk_glb_ptr)(rp + f1), (walk_lds_ptr)(dst + 256), 16, 0, 0);
+            }
+            const int* rp = wp.row_prog + ((long long)seg_y0 + (long long)c * kWalkCH) * PR + lane * 4;
+            int* dst = s_prog + slot * (kWalkCH * PR);
+            if (lane < kWalkCH * PR / 4) __builtin_amdgcn_global_load_lds((walk_glb_ptr)rp, (walk_lds_ptr)dst, 16, 0, 0);
+        };
+        issue(0, 0);
+        if (n_chunks > 1) issue(1, 1);
+        int slot2 = 2;
+        for (int c = 0; c < n_chunks; ++c) {
+            if (c + 1 < n_chunks) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * kWalkCH + 1) : "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            if (c + 2 < n_chunks) issue(c + 2, slot2);
+            slot2 = slot2 == kWalkSlots - 1 ? 0 : slot2 + 1;
+        }
+        return;
+    }
+
+    // ---------------------------------------------------------------------- consumers
+    const int wx0 = X0 + wave * kW3Px;                          // first pixel of this wave
+    const bool live = wx0 < tab.out_w;                          // wave-uniform; a dead wave still meets every barrier
+    // the lane's two floats: line floats 2 lane, 2 lane + 1 <-> pixel wx0 - 2 + (2 lane + k) / 3, channel (2 lane + k) % 3
+    int off[2][5];                                              // ring offsets of the 5 horizontal taps (pixel - 2 .. + 2) of each float
+    int px[2];
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+        const int i = 2 * lane + k;
+        const int p = wx0 - kW3TileL + i / 3, c = i % 3;
+        px[k] = p;
+#pragma unroll
+        for (int d = 0; d < 5; ++d)
+            off[k][d] = min(max((mirror_near(p + d - 2, tab.src_w) - R0) * 3 + c, 0), kW3RowF - 1);
+    }
+    const bool out_lane = px[0] >= wx0 && px[1] < wx0 + kW3Px && px[1] < tab.out_w && lane < 62;   // both floats or neither
+    const bool eff0 = px[0] < tab.eff_w, eff1 = px[1] < tab.eff_w;
+    const long long base_f = ((long long)frame * tab.frame_px + tab.px_off) * 3 + (long long)(wx0 - kW3TileL) * 3 + 2 * lane;
+
+    float vacc[G][kWalkMaxSlots][2];
+    int gx0[G], gn[G];
+    const long long frame_px0 = (long long)frame * tab.frame_px;
+    int* const my_rec = s_rec + wave * (w3_rec_total(G) * 8);
+    float* const my_line = s_line + wave * 128;
+    {
+        const int wx_tile = strip * kW3NC + wave;
+        const int4* __restrict__ src4 = reinterpret_cast<const int4*>(wp.col_rec) + (long long)wx_tile * (w3_rec_total(G) * 2);
+        int4* dst4 = reinterpret_cast<int4*>(my_rec);
+        for (int i = lane; i < w3_rec_total(G) * 2; i += 64) dst4[i] = src4[i];
+        typedef const __attribute__((address_space(4))) int* const_int_ptr;
+#pragma unroll
+        for (int g = 0; g < G; ++g) {
+            const int gg = min(g, wp.G - 1);
+            const_int_ptr h = (const_int_ptr)(wp.col_hdr + ((long long)gg * (tab.strips_x * kW3NC) + wx_tile) * 2);
+            gx0[g] = h[0];
+            gn[g] = g < wp.G ? h[1] : 0;
+#pragma unroll
+            for (int k = 0; k < kWalkMaxSlots; ++k) vacc[g][k][0] = vacc[g][k][1] = 0.0f;
+        }
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");   // records staged (the only vector loads of a consumer)
+        __builtin_amdgcn_wave_barrier();
+    }
+    const int gj = lane / 3, gc = lane - 3 * gj;               // gather role: output pixel gj, channel gc
+
+    float hw[5][2];                                             // horizontally smoothed rows y-4 .. y of the two floats
+#pragma unroll
+    for (int j = 0; j < 5; ++j) hw[j][0] = hw[j][1] = 0.0f;
+
+    int slot = 0;
+    for (int c = 0; c < n_chunks; ++c) {
+        __builtin_amdgcn_s_barrier();                           // barrier c: chunk c (rows + records) is in the ring
+        asm volatile("" ::: "memory");
+        if (live) {
+#pragma unroll
+            for (int r = 0; r < kWalkCH; ++r) {
+                const int s = c * kWalkCH + r;                  // stream row; source row y = seg_y0 - 4 + s
+                if (s >= n_rows) break;                         // wave-uniform
+                const float* __restrict__ row = &s_ring[slot * kWalkCH + r][0];
+                float t[2][5];
+#pragma unroll
+                for (int k = 0; k < 2; ++k)
+#pragma unroll
+                    for (int d = 0; d < 5; ++d) t[k][d] = row[off[k][d]];
+                const int4* __restrict__ rec4 = reinterpret_cast<const int4*>(s_prog + (slot * kWalkCH + r) * PR);
+                int cur[PR];
+#pragma unroll
+                for (int e = 0; e < PR / 4; ++e) {
+                    const int4 q = rec4[e];                     // every lane reads the same record (LDS broadcast)
+                    cur[4 * e] = q.x; cur[4 * e + 1] = q.y; cur[4 * e + 2] = q.z; cur[4 * e + 3] = q.w;
+                }
+                // ---- unit level: horizontal 5 taps (same fma order as pyramid_unit_kernel), then the vertical window
+#pragma unroll
+                for (int k = 0; k < 2; ++k) {
+                    float h = tab.wx[0] * t[k][0];
+                    h = __builtin_fmaf(tab.wx[1], t[k][1], h);
+                    h = __builtin_fmaf(tab.wx[2], t[k][2], h);
+                    h = __builtin_fmaf(tab.wx[3], t[k][3], h);
+                    h = __builtin_fmaf(tab.wx[4], t[k][4], h);
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) hw[j][k] = hw[j + 1][k];
+                    hw[4][k] = h;
+                }
+                const int p = seg_y0 + s - 6;                   // level-0 row that completes with source row y = p + 2
+                if (p >= seg_y0 && p < seg_y0 + seg_h) {        // wave-uniform (rows above are warm-up)
+                    float v0 = tab.wx[0] * hw[0][0], v1 = tab.wx[0] * hw[0][1];
+#pragma unroll
+                    for (int j = 1; j < 5; ++j) {
+                        v0 = __builtin_fmaf(tab.wx[j], hw[j][0], v0);
+                        v1 = __builtin_fmaf(tab.wx[j], hw[j][1], v1);
+                    }
+                    const bool prow = p < tab.eff_h;
+                    v0 = (prow && eff0) ? v0 : 0.0f;            // canvas beyond the zoomed crop
+                    v1 = (prow && eff1) ? v1 : 0.0f;
+                    if (out_lane) {
+                        typedef float nf2 __attribute__((ext_vector_type(2)));
+                        *reinterpret_cast<nf2*>(pyr + base_f + (long long)p * tab.out_w * 3) = nf2{v0, v1};
+                    }
+                }
+                // ---- the other levels: vertical taps of this source row on the lane's own floats (taps d = 0)
+                const float a = t[0][2], b = t[1][2];
+                walk_static_for<0, G>([&](auto gcst) {
+                    constexpr int g = decltype(gcst)::value;
+                    const int meta = __builtin_amdgcn_readfirstlane(cur[g]);
+                    if (!(meta & 128)) return;                  // wave-uniform: this source row carries no tap of level g
+#pragma unroll
+                    for (int k = 0; k < walk_slots(g); ++k) {
+                        const float w = __int_as_float(cur[walk_w_off(G, g) + k]);
+                        const bool restart = (meta >> k) & 1;   // a slot that restarts accumulates onto +0
+                        vacc[g][k][0] = __builtin_fmaf(w, a, restart ? 0.0f : vacc[g][k][0]);
+                        vacc[g][k][1] = __builtin_fmaf(w, b, restart ? 0.0f : vacc[g][k][1]);
+                    }
+                    const int done = (meta >> 4) & 7;
+                    const int anchor = seg_y0 + s - 7;          // the completing row's anchor: stored by the segment that owns it
+                    if (done < kWalkMaxSlots && anchor >= seg_y0 && anchor < seg_y0 + seg_h) {   // wave-uniform
+                        const int oy = meta >> 8;
+                        const int jj = min(gj, w3_rec_cap(g) - 1);
+                        const int4* __restrict__ rc = reinterpret_cast<const int4*>(my_rec + (w3_rec_base(g) + jj) * 8);
+                        const int4 ra = rc[0], rb = rc[1];
+                        float v0 = vacc[g][0][0], v1 = vacc[g][0][1];
+#pragma unroll
+                        for (int k = 1; k < walk_slots(g); ++k) {
+                            v0 = done == k ? vacc[g][k][0] : v0;
+                            v1 = done == k ? vacc[g][k][1] : v1;
+                        }
+                        typedef float nf2 __attribute__((ext_vector_type(2)));
+                        *reinterpret_cast<nf2*>(my_line + 2 * lane) = nf2{v0, v1};
+                        __builtin_amdgcn_wave_barrier();
+                        const float* tp = my_line + min(ra.x + gc, kW3TileF - 16);   // taps 3 floats apart (clamped: idle lanes)
+                        float acc = __int_as_float(ra.y) * tp[0];
+                        acc = __builtin_fmaf(__int_as_float(ra.z), tp[3], acc);
+                        acc = __builtin_fmaf(__int_as_float(ra.w), tp[6], acc);
+                        acc = __builtin_fmaf(__int_as_float(rb.x), tp[9], acc);
+                        acc = __builtin_fmaf(__int_as_float(rb.y), tp[12], acc);
+                        acc = __builtin_fmaf(__int_as_float(rb.z), tp[15], acc);
+                        __builtin_amdgcn_wave_barrier();
+                        if (gj < gn[g])
+                            pyr[(frame_px0 + wp.px_off[g] + (long long)oy * wp.out_w[g] + gx0[g]) * 3 + lane] = acc;
+                    }
+                });
+            }
+        }
+        slot = slot == kWalkSlots - 1 ? 0 : slot + 1;
+    }
+}
+
+}  // namespace silent

@@ -1254,3 +1254,32 @@ def test_pipeline_flags_keypoint_overflow(rt, kernels):
         pipe.outputs()
     out = pipe.outputs(allow_truncated=True)
     assert len(out["keypoints"][0]) == 5 and int(out["keypoint_counts"][0]) == 64 * 96 + 32 * 48
+
+
+# ----------------------------------------------------------------------------- single-read RGB pyramid (silent_walk_rgb.h)
+
+@pytest.mark.parametrize("shape,scale,n,B", [((135, 240, 3), 2.0, 4, 2),        # one strip + a ragged one (240 = 144 + 96)
+                                             ((64, 64, 3), 2.0, 3, 3),
+                                             ((270, 480, 3), 2.0, 8, 1),         # 7 general levels
+                                             ((97, 1000, 3), 2.0, 4, 2),         # 7 strips, the last holds 136 pixels
+                                             ((200, 148, 3), 2.5, 3, 2),         # second strip holds 4 pixels
+                                             ((40, 8, 3), 2.0, 2, 1),            # narrower than a wave tile
+                                             ((1080, 1920, 3), 2.0, 6, 1)])      # config 3 geometry
+def test_rgb_pyramid_walk_is_bit_identical_to_unit_plus_region_kernels(rt, shape, scale, n, B):
+    """pyramid_walk3_kernel (one read of the frame: loader wave + ring, two floats per lane, other levels gathered from a
+    wave-private line) against pyramid_unit_kernel<3> + pyramid_region_kernel<3> (PYRAMID knob 2): same taps, same order,
+    every level equal bit for bit -- across strips, segments, ragged edges, NaN / inf pixels -- and both match the oracle."""
+    from pysilent_amd.util.zoom.from_image import classic_levels
+    frames = np.stack([noise_frame(70 + s_, *shape) for s_ in range(B)])
+    frames[0, shape[0] // 2, shape[1] // 3, 1] = np.nan
+    frames[B - 1, 0, 0, 2] = np.inf
+    plan = rt.PyramidPlan(shape[0], shape[1], 3, classic_levels(shape[:2], scale, n))
+    got = plan.run(frames)
+    with rt.tuning(TUNE_PYRAMID, 2):
+        two = plan.run(frames)
+    np.testing.assert_array_equal(got.data, two.data)
+    clean = noise_frame(99, *shape)
+    want = so.classic_pyramid(clean, scale, n)
+    res = plan.run(clean[None])
+    for l in range(n):
+        assert_close(res.level(l), want[l], RTOL, scale=255.0, what="rgb walk level %d" % l)
