@@ -1490,11 +1490,11 @@ SILENT_EXPORT int silent_pyramid_plan_create(silent_ctx* ctx, int frame_h, int f
         if (ok) {
             const PyrLevelDev& u = tab.lv[unit];
             const int G = tab.n_general;
-            const int Gp = stream_pad_levels(G), PR = walk_prog_row(Gp);
+            const bool rgb = channels == 3;
+            const int Gp = stream_pad_levels(G), PR = rgb ? w3_prog_row(Gp) : walk_prog_row(Gp);
             // geometry of a wave tile: pixels per tile, tiles per row, record slots, and the tap index of an output anchored
             // at pixel xb of the tile that starts at pixel xw0 (1 channel: index into the wave's 128 columns, first column
             // xw0 - 4; 3 channels: FLOAT index into the wave's line, first pixel xw0 - 2)
-            const bool rgb = channels == 3;
             const int tile_px = rgb ? kW3Px : kWalkCols;
             const int strip_px = rgb ? kW3StripPx : kWalkStripW;
             const int waves_x = ((u.out_w + strip_px - 1) / strip_px) * (rgb ? kW3NC : kWalkNC);
@@ -1504,8 +1504,9 @@ SILENT_EXPORT int silent_pyramid_plan_create(silent_ctx* ctx, int frame_h, int f
             const size_t n_rec = (size_t)u.out_h + 8;                 // stream rows y = -4 .. out_h + 3 at index y + 4
             const size_t n_rec_pad = n_rec + 2 * kWalkCH;             // the loader fetches whole chunks of records
             std::vector<int> prog(n_rec_pad * PR, 0), hdr((size_t)G * waves_x * 2, 0), rec((size_t)waves_x * rec_total * 8, 0);
-            for (size_t r = 0; r < n_rec_pad; ++r)
-                for (int gg = 0; gg < Gp; ++gg) prog[r * PR + gg] = 7 << 4;  // inert: feeds nothing, no slot completes
+            if (!rgb)
+                for (size_t r = 0; r < n_rec_pad; ++r)
+                    for (int gg = 0; gg < Gp; ++gg) prog[r * PR + gg] = 7 << 4;  // inert: feeds nothing, no slot completes
             std::vector<char> used(n_rec * G * kWalkMaxSlots, 0);
             int g = 0;
             for (int l = 0; l < n_levels && ok; ++l) {
@@ -1514,7 +1515,17 @@ SILENT_EXPORT int silent_pyramid_plan_create(silent_ctx* ctx, int frame_h, int f
                 const int zc = std::min(d.zoom_w, d.out_w), zr = std::min(d.zoom_h, d.out_h);
                 const int* yb = ybase.data() + d.ytab_off;
                 const int* xb = xbase.data() + d.xtab_off;
-                for (int oy = 0; oy < zr && ok; ++oy) {
+                for (int oy = 0; oy < zr && ok && rgb; ++oy) {
+                    // 3 channels (silent_walk_rgb.h): one record entry per COMPLETING row: flag + output row, 6 weights
+                    if (yb[oy] < 0 || yb[oy] >= u.out_h) { ok = false; break; }
+                    const size_t r = (size_t)(yb[oy] + 7);              // the last tap sits on stream row y = yb + 3, index y + 4
+                    if (r >= n_rec) { ok = false; break; }
+                    int* pr = prog.data() + r * PR;
+                    if (pr[g] & 1) { ok = false; break; }                // two rows of one level completing together: step < 1
+                    pr[g] = 1 | (oy << 8);
+                    std::memcpy(pr + Gp + 6 * g, &yw[(size_t)(d.ytab_off + oy) * 6], 24);
+                }
+                for (int oy = 0; oy < zr && ok && !rgb; ++oy) {
                     if (yb[oy] < 0 || yb[oy] >= u.out_h) { ok = false; break; }
                     const int slot = oy % walk_slots(g);
                     for (int j = 0; j < 6; ++j) {
@@ -1608,11 +1619,24 @@ static bool walk3_plan(const silent_ctx* ctx, const silent_pyramid_plan* plan, i
     wt->out_h = d.out_h; wt->out_w = d.out_w;
     wt->eff_h = std::min(d.zoom_h, d.out_h); wt->eff_w = std::min(d.zoom_w, d.out_w);
     wt->strips_x = (d.out_w + kW3StripPx - 1) / kW3StripPx;
+    // Segments per frame: all blocks take the same time, so the launch lasts ceil(blocks / resident blocks) rounds of
+    // (segment rows + 8 halo rows) row steps -- pick the segment count that minimises that product (896 blocks on a chip
+    // that holds 768 run TWO rounds: measured 1.07 ms against 0.66 ms for 5 segments per frame).
     const long long per_seg = (long long)n_frames * wt->strips_x;
+    const long long resident = 3ll * ctx->n_cus;              // 51 KB of LDS per block: 3 blocks per CU
     const int max_segs = std::max(1, d.out_h / 32);
-    const int segs = (int)std::min<long long>(max_segs, (3ll * ctx->n_cus + per_seg - 1) / per_seg);
-    int seg_rows = (d.out_h + segs - 1) / segs;
-    seg_rows = (seg_rows + kWalkCH - 1) / kWalkCH * kWalkCH;
+    long long best_cost = -1;
+    int seg_rows = d.out_h;
+    for (int segs = 1; segs <= max_segs; ++segs) {
+        int rows = (d.out_h + segs - 1) / segs;
+        rows = (rows + kWalkCH - 1) / kWalkCH * kWalkCH;
+        const long long n_seg = (d.out_h + rows - 1) / rows;
+        const long long cost = ((per_seg * n_seg + resident - 1) / resident) * (rows + 8);
+        if (best_cost < 0 || cost < best_cost) {
+            best_cost = cost;
+            seg_rows = rows;
+        }
+    }
     wt->seg_rows = seg_rows;
     wt->segs_y = (d.out_h + seg_rows - 1) / seg_rows;
     wt->frame_px = pt.frame_px_out;

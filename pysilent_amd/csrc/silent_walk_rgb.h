@@ -9,9 +9,13 @@
 //   * waves 0-3 (consumers) own 36 pixels each = 108 floats, two floats per lane, plus a halo of 2 / 3 pixels that only
 //     the gather of the other levels needs: the unit level's 5 horizontal taps sit 3 floats apart and are read straight
 //     from the ring (no DPP, hence no halo lanes for the smoother), the 5 vertical taps are a register window;
-//   * the other levels: vertical 6 taps in the lane (walk_slots(g) output rows in flight, row program from the ring), a
-//     completed row goes through a wave-private LDS line, and lane 3j + c gathers the 6 taps of channel c of output pixel
-//     j (3 floats apart) with column records staged in LDS -- the arithmetic order of the region kernel, bit-identical.
+//   * the other levels: every output row of every level is a 6-tap combination of 6 CONSECUTIVE source rows (the spline's
+//     support; the zoom step only says how often a row completes), so the lane keeps a window of its last 6 source rows and
+//     evaluates a row when the row program (one record per source row, DMA'd into the ring with the rows) says it completes:
+//     6 weights from the record, 6 fmas per float, taps ascending.  No rolling accumulators, no slots, no restart logic --
+//     the first version carried gray_walk_kernel's accumulate-every-row scheme and spent 0.32 of its 0.87 ms there.  The
+//     completed row goes through a wave-private LDS line, and lane 3j + c gathers the 6 taps of channel c of output pixel j
+//     (3 floats apart) with column records staged in LDS -- the arithmetic order of the region kernel, bit-identical.
 // Same protocol as the gray walk: one raw s_barrier per chunk, uniform trip counts, the consumers' vmcnt queue holds
 // stores only.  Eligibility (host): one unit level, every other level resamples its crop with a zoom step >= 1.875,
 // W, src_x0, src_w multiples of 4, out_w even, even pyramid offsets.
@@ -40,12 +44,15 @@ __host__ __device__ constexpr int w3_rec_base(int g) {
     return n;
 }
 __host__ __device__ constexpr int w3_rec_total(int g) { return w3_rec_base(g); }
+// row record of the walk: [meta(0) .. meta(Gp-1)] [6 weights of level 0] ... [6 weights of level Gp-1], padded to a multiple
+// of 4 dwords.  meta: bit 0 "an output row of this level completes with this source row", bits 8.. that output row.
+__host__ __device__ constexpr int w3_prog_row(int gp) { return (gp * 7 + 3) / 4 * 4; }
 
 template <int G>
 __global__ __launch_bounds__(kW3Threads) void pyramid_walk3_kernel(const float* __restrict__ frames, float* __restrict__ pyr,
                                                                     const WalkTab tab, const WalkPyr wp) {
     static_assert(G == stream_pad_levels(G), "row programs are padded to 4 or 7 levels");
-    constexpr int PR = walk_prog_row(G);
+    constexpr int PR = w3_prog_row(G);
     __shared__ __attribute__((aligned(16))) float s_ring[kWalkSlots * kWalkCH][kW3RowF];          // 43.8 KB
     __shared__ __attribute__((aligned(16))) int s_prog[kWalkSlots * kWalkCH * PR];                // row records of the ring's chunks
     __shared__ __attribute__((aligned(16))) float s_line[kW3NC * 128];                            // a completed row, per wave
@@ -85,13 +92,17 @@ __global__ __launch_bounds__(kW3Threads) void pyramid_walk3_kernel(const float* 
             }
             const int* rp = wp.row_prog + ((long long)seg_y0 + (long long)c * kWalkCH) * PR + lane * 4;
             int* dst = s_prog + slot * (kWalkCH * PR);
-            if (lane < kWalkCH * PR / 4) __builtin_amdgcn_global_load_lds((walk_glb_ptr)rp, (walk_lds_ptr)dst, 16, 0, 0);
+            constexpr int NV = kWalkCH * PR / 4;               // 16-byte pieces of a chunk's records
+            if (lane < NV) __builtin_amdgcn_global_load_lds((walk_glb_ptr)rp, (walk_lds_ptr)dst, 16, 0, 0);
+            if constexpr (NV > 64) {
+                if (lane < NV - 64) __builtin_amdgcn_global_load_lds((walk_glb_ptr)(rp + 256), (walk_lds_ptr)(dst + 256), 16, 0, 0);
+            }
         };
         issue(0, 0);
         if (n_chunks > 1) issue(1, 1);
         int slot2 = 2;
         for (int c = 0; c < n_chunks; ++c) {
-            if (c + 1 < n_chunks) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * kWalkCH + 1) : "memory");
+            if (c + 1 < n_chunks) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * kWalkCH + (kWalkCH * PR / 4 > 64 ? 2 : 1)) : "memory");
             else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __builtin_amdgcn_s_barrier();
             if (c + 2 < n_chunks) issue(c + 2, slot2);
@@ -119,7 +130,9 @@ __global__ __launch_bounds__(kW3Threads) void pyramid_walk3_kernel(const float* 
     const bool eff0 = px[0] < tab.eff_w, eff1 = px[1] < tab.eff_w;
     const long long base_f = ((long long)frame * tab.frame_px + tab.px_off) * 3 + (long long)(wx0 - kW3TileL) * 3 + 2 * lane;
 
-    float vacc[G][kWalkMaxSlots][2];
+    float hist[6][2];                                           // the lane's two floats on the last 6 source rows
+#pragma unroll
+    for (int j = 0; j < 6; ++j) hist[j][0] = hist[j][1] = 0.0f;
     int gx0[G], gn[G];
     const long long frame_px0 = (long long)frame * tab.frame_px;
     int* const my_rec = s_rec + wave * (w3_rec_total(G) * 8);
@@ -136,8 +149,6 @@ __global__ __launch_bounds__(kW3Threads) void pyramid_walk3_kernel(const float* 
             const_int_ptr h = (const_int_ptr)(wp.col_hdr + ((long long)gg * (tab.strips_x * kW3NC) + wx_tile) * 2);
             gx0[g] = h[0];
             gn[g] = g < wp.G ? h[1] : 0;
-#pragma unroll
-            for (int k = 0; k < kWalkMaxSlots; ++k) vacc[g][k][0] = vacc[g][k][1] = 0.0f;
         }
         asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");   // records staged (the only vector loads of a consumer)
         __builtin_amdgcn_wave_barrier();
@@ -163,12 +174,12 @@ __global__ __launch_bounds__(kW3Threads) void pyramid_walk3_kernel(const float* 
                 for (int k = 0; k < 2; ++k)
 #pragma unroll
                     for (int d = 0; d < 5; ++d) t[k][d] = row[off[k][d]];
-                const int4* __restrict__ rec4 = reinterpret_cast<const int4*>(s_prog + (slot * kWalkCH + r) * PR);
-                int cur[PR];
+                const int* __restrict__ prow = s_prog + (slot * kWalkCH + r) * PR;
+                int meta_v[(G + 3) / 4 * 4];
 #pragma unroll
-                for (int e = 0; e < PR / 4; ++e) {
-                    const int4 q = rec4[e];                     // every lane reads the same record (LDS broadcast)
-                    cur[4 * e] = q.x; cur[4 * e + 1] = q.y; cur[4 * e + 2] = q.z; cur[4 * e + 3] = q.w;
+                for (int e = 0; e < (G + 3) / 4; ++e) {
+                    const int4 q = reinterpret_cast<const int4*>(prow)[e];   // every lane reads the same record (LDS broadcast)
+                    meta_v[4 * e] = q.x; meta_v[4 * e + 1] = q.y; meta_v[4 * e + 2] = q.z; meta_v[4 * e + 3] = q.w;
                 }
                 // ---- unit level: horizontal 5 taps (same fma order as pyramid_unit_kernel), then the vertical window
 #pragma unroll
@@ -198,31 +209,30 @@ __global__ __launch_bounds__(kW3Threads) void pyramid_walk3_kernel(const float* 
                         *reinterpret_cast<nf2*>(pyr + base_f + (long long)p * tab.out_w * 3) = nf2{v0, v1};
                     }
                 }
-                // ---- the other levels: vertical taps of this source row on the lane's own floats (taps d = 0)
-                const float a = t[0][2], b = t[1][2];
-                walk_static_for<0, G>([&](auto gcst) {
-                    constexpr int g = decltype(gcst)::value;
-                    const int meta = __builtin_amdgcn_readfirstlane(cur[g]);
-                    if (!(meta & 128)) return;                  // wave-uniform: this source row carries no tap of level g
+                // ---- the other levels: the window of the last 6 source rows, and a row of level g when the record says so
 #pragma unroll
-                    for (int k = 0; k < walk_slots(g); ++k) {
-                        const float w = __int_as_float(cur[walk_w_off(G, g) + k]);
-                        const bool restart = (meta >> k) & 1;   // a slot that restarts accumulates onto +0
-                        vacc[g][k][0] = __builtin_fmaf(w, a, restart ? 0.0f : vacc[g][k][0]);
-                        vacc[g][k][1] = __builtin_fmaf(w, b, restart ? 0.0f : vacc[g][k][1]);
-                    }
-                    const int done = (meta >> 4) & 7;
-                    const int anchor = seg_y0 + s - 7;          // the completing row's anchor: stored by the segment that owns it
-                    if (done < kWalkMaxSlots && anchor >= seg_y0 && anchor < seg_y0 + seg_h) {   // wave-uniform
+                for (int j = 0; j < 5; ++j) {
+                    hist[j][0] = hist[j + 1][0];
+                    hist[j][1] = hist[j + 1][1];
+                }
+                hist[5][0] = t[0][2];                           // the lane's own floats (horizontal tap d = 0)
+                hist[5][1] = t[1][2];
+                const int anchor = seg_y0 + s - 7;              // anchor row of a row completing now: stored by the segment that owns it
+                if (anchor >= seg_y0 && anchor < seg_y0 + seg_h) {   // wave-uniform
+                    walk_static_for<0, G>([&](auto gcst) {
+                        constexpr int g = decltype(gcst)::value;
+                        const int meta = __builtin_amdgcn_readfirstlane(meta_v[g]);
+                        if (!(meta & 1)) return;                // wave-uniform: no row of level g completes here
                         const int oy = meta >> 8;
                         const int jj = min(gj, w3_rec_cap(g) - 1);
                         const int4* __restrict__ rc = reinterpret_cast<const int4*>(my_rec + (w3_rec_base(g) + jj) * 8);
                         const int4 ra = rc[0], rb = rc[1];
-                        float v0 = vacc[g][0][0], v1 = vacc[g][0][1];
+                        const float* __restrict__ wv = reinterpret_cast<const float*>(prow + G + 6 * g);   // 6 vertical weights (broadcast)
+                        float v0 = __builtin_fmaf(wv[0], hist[0][0], 0.0f), v1 = __builtin_fmaf(wv[0], hist[0][1], 0.0f);
 #pragma unroll
-                        for (int k = 1; k < walk_slots(g); ++k) {
-                            v0 = done == k ? vacc[g][k][0] : v0;
-                            v1 = done == k ? vacc[g][k][1] : v1;
+                        for (int j = 1; j < 6; ++j) {
+                            v0 = __builtin_fmaf(wv[j], hist[j][0], v0);
+                            v1 = __builtin_fmaf(wv[j], hist[j][1], v1);
                         }
                         typedef float nf2 __attribute__((ext_vector_type(2)));
                         *reinterpret_cast<nf2*>(my_line + 2 * lane) = nf2{v0, v1};
@@ -237,8 +247,8 @@ __global__ __launch_bounds__(kW3Threads) void pyramid_walk3_kernel(const float* 
                         __builtin_amdgcn_wave_barrier();
                         if (gj < gn[g])
                             pyr[(frame_px0 + wp.px_off[g] + (long long)oy * wp.out_w[g] + gx0[g]) * 3 + lane] = acc;
-                    }
-                });
+                    });
+                }
             }
         }
         slot = slot == kWalkSlots - 1 ? 0 : slot + 1;
