@@ -1623,7 +1623,11 @@ static bool walk3_plan(const silent_ctx* ctx, const silent_pyramid_plan* plan, i
     // (segment rows + 8 halo rows) row steps -- pick the segment count that minimises that product (896 blocks on a chip
     // that holds 768 run TWO rounds: measured 1.07 ms against 0.66 ms for 5 segments per frame).
     const long long per_seg = (long long)n_frames * wt->strips_x;
-    const long long resident = 3ll * ctx->n_cus;              // 51 KB of LDS per block: 3 blocks per CU
+    int per_cu = 0;                                           // resident blocks per CU (LDS- and register-limited)
+    if (plan->walk.G <= 4) (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, pyramid_walk3_kernel<4>, kW3Threads, 0);
+    else (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, pyramid_walk3_kernel<7>, kW3Threads, 0);
+    (void)hipGetLastError();
+    const long long resident = (long long)std::max(per_cu, 1) * ctx->n_cus;
     const int max_segs = std::max(1, d.out_h / 32);
     long long best_cost = -1;
     int seg_rows = d.out_h;

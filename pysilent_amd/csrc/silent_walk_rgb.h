@@ -36,6 +36,9 @@ constexpr int kW3TileL = 2;                     // a wave's line starts 2 pixels
 constexpr int kW3TileF = 124;                   // ... and holds 124 floats (41 pixels + 1 float): taps -2 .. +3 of its anchors
 constexpr int kW3RowF = 456;                    // floats per ring row ((144 + 7) * 3 = 453 used)
 constexpr int kW3Threads = (kW3NC + 1) * 64;
+constexpr int kW3CH = 4;                        // rows per chunk: a 12-row ring (22 KB) instead of 24 rows -- the loader is far from
+                                                // being the limit (all loads alone: 0.14 ms), the consumers are latency-bound and
+                                                // want waves: 31 KB of LDS per block = 4 blocks (16 consumer waves) per CU instead of 3
 // column records per wave tile and level (output PIXELS anchored in a wave's 36 pixels at zoom step >= 1.875 ^ (g + 1))
 __host__ __device__ constexpr int w3_rec_cap(int g) { return g == 0 ? 21 : (g == 1 ? 11 : (g == 2 ? 6 : (g == 3 ? 4 : (g <= 5 ? 2 : 1)))); }
 __host__ __device__ constexpr int w3_rec_base(int g) {
@@ -53,8 +56,8 @@ __global__ __launch_bounds__(kW3Threads) void pyramid_walk3_kernel(const float* 
                                                                     const WalkTab tab, const WalkPyr wp) {
     static_assert(G == stream_pad_levels(G), "row programs are padded to 4 or 7 levels");
     constexpr int PR = w3_prog_row(G);
-    __shared__ __attribute__((aligned(16))) float s_ring[kWalkSlots * kWalkCH][kW3RowF];          // 43.8 KB
-    __shared__ __attribute__((aligned(16))) int s_prog[kWalkSlots * kWalkCH * PR];                // row records of the ring's chunks
+    __shared__ __attribute__((aligned(16))) float s_ring[kWalkSlots * kW3CH][kW3RowF];          // 43.8 KB
+    __shared__ __attribute__((aligned(16))) int s_prog[kWalkSlots * kW3CH * PR];                // row records of the ring's chunks
     __shared__ __attribute__((aligned(16))) float s_line[kW3NC * 128];                            // a completed row, per wave
     __shared__ __attribute__((aligned(16))) int s_rec[kW3NC * w3_rec_total(G) * 8];               // column records, per wave
 
@@ -68,7 +71,7 @@ __global__ __launch_bounds__(kW3Threads) void pyramid_walk3_kernel(const float* 
     const int seg_y0 = seg * tab.seg_rows;
     const int seg_h = min(tab.seg_rows, tab.out_h - seg_y0);
     const int n_rows = seg_h + 8;                              // stream rows seg_y0 - 4 .. seg_y0 + seg_h + 3
-    const int n_chunks = (n_rows + kWalkCH - 1) / kWalkCH;
+    const int n_chunks = (n_rows + kW3CH - 1) / kW3CH;
     const int X0 = strip * kW3StripPx;                         // first pixel of the strip; the ring row starts at pixel X0 - 4
     const int R0 = X0 - kW3HaloL;
 
@@ -82,17 +85,17 @@ __global__ __launch_bounds__(kW3Threads) void pyramid_walk3_kernel(const float* 
         const int f1 = min(max(R0 * 3 + 256 + lane * 4, 0), rowf - 4) + tab.src_x0 * 3;
         auto issue = [&](int c, int slot) {
 #pragma unroll
-            for (int r = 0; r < kWalkCH; ++r) {
-                const int y = seg_y0 - 4 + c * kWalkCH + r;
+            for (int r = 0; r < kW3CH; ++r) {
+                const int y = seg_y0 - 4 + c * kW3CH + r;
                 const float* rp = src + (long long)(mirror_near(y, tab.src_h) + tab.src_y0) * tab.W * 3;
-                float* dst = &s_ring[slot * kWalkCH + r][0];
+                float* dst = &s_ring[slot * kW3CH + r][0];
                 __builtin_amdgcn_global_load_lds((walk_glb_ptr)(rp + f0), (walk_lds_ptr)dst, 16, 0, 0);
                 if (lane < (kW3RowF - 256) / 4)
                     __builtin_amdgcn_global_load_lds((walk_glb_ptr)(rp + f1), (walk_lds_ptr)(dst + 256), 16, 0, 0);
             }
-            const int* rp = wp.row_prog + ((long long)seg_y0 + (long long)c * kWalkCH) * PR + lane * 4;
-            int* dst = s_prog + slot * (kWalkCH * PR);
-            constexpr int NV = kWalkCH * PR / 4;               // 16-byte pieces of a chunk's records
+            const int* rp = wp.row_prog + ((long long)seg_y0 + (long long)c * kW3CH) * PR + lane * 4;
+            int* dst = s_prog + slot * (kW3CH * PR);
+            constexpr int NV = kW3CH * PR / 4;               // 16-byte pieces of a chunk's records
             if (lane < NV) __builtin_amdgcn_global_load_lds((walk_glb_ptr)rp, (walk_lds_ptr)dst, 16, 0, 0);
             if constexpr (NV > 64) {
                 if (lane < NV - 64) __builtin_amdgcn_global_load_lds((walk_glb_ptr)(rp + 256), (walk_lds_ptr)(dst + 256), 16, 0, 0);
@@ -102,7 +105,7 @@ __global__ __launch_bounds__(kW3Threads) void pyramid_walk3_kernel(const float* 
         if (n_chunks > 1) issue(1, 1);
         int slot2 = 2;
         for (int c = 0; c < n_chunks; ++c) {
-            if (c + 1 < n_chunks) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * kWalkCH + (kWalkCH * PR / 4 > 64 ? 2 : 1)) : "memory");
+            if (c + 1 < n_chunks) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * kW3CH + (kW3CH * PR / 4 > 64 ? 2 : 1)) : "memory");
             else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __builtin_amdgcn_s_barrier();
             if (c + 2 < n_chunks) issue(c + 2, slot2);
@@ -165,16 +168,16 @@ __global__ __launch_bounds__(kW3Threads) void pyramid_walk3_kernel(const float* 
         asm volatile("" ::: "memory");
         if (live) {
 #pragma unroll
-            for (int r = 0; r < kWalkCH; ++r) {
-                const int s = c * kWalkCH + r;                  // stream row; source row y = seg_y0 - 4 + s
+            for (int r = 0; r < kW3CH; ++r) {
+                const int s = c * kW3CH + r;                  // stream row; source row y = seg_y0 - 4 + s
                 if (s >= n_rows) break;                         // wave-uniform
-                const float* __restrict__ row = &s_ring[slot * kWalkCH + r][0];
+                const float* __restrict__ row = &s_ring[slot * kW3CH + r][0];
                 float t[2][5];
 #pragma unroll
                 for (int k = 0; k < 2; ++k)
 #pragma unroll
                     for (int d = 0; d < 5; ++d) t[k][d] = row[off[k][d]];
-                const int* __restrict__ prow = s_prog + (slot * kWalkCH + r) * PR;
+                const int* __restrict__ prow = s_prog + (slot * kW3CH + r) * PR;
                 int meta_v[(G + 3) / 4 * 4];
 #pragma unroll
                 for (int e = 0; e < (G + 3) / 4; ++e) {
