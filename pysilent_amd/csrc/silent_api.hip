@@ -18,6 +18,7 @@
 #include "silent_rgb.h"
 #include "silent_walk.h"
 #include "silent_walk_rgb.h"
+#include "silent_walk1.h"
 
 using namespace silent;
 
@@ -91,6 +92,10 @@ struct silent_pyramid_plan {
     int walk_unit_level = -1;
     void* walk_tables = nullptr;
     WalkPyr walk{};
+    // the same for gray_walk1_kernel (one pixel per lane, completion records)
+    bool walk1_ok = false;
+    void* walk1_tables = nullptr;
+    WalkPyr walk1{};
 };
 
 static thread_local std::string g_create_err;
@@ -1471,43 +1476,43 @@ SILENT_EXPORT int silent_pyramid_plan_create(silent_ctx* ctx, int frame_h, int f
             }
         }
     }
-    // ---- in-walk pyramid tables (gray_walk_kernel for 1 channel, pyramid_walk3_kernel for 3): one unit level, every
-    // other level resamples the unit level's crop, and the walk's own limits (slots, outputs per wave tile)
+    // ---- in-walk pyramid tables: one unit level, every other level resamples the unit level's crop, and the walk's own
+    // limits (outputs per wave tile; slots for the rolling format).  mode 0: gray_walk_kernel (two pixels per lane, rolling
+    // accumulators), 1: pyramid_walk3_kernel (RGB, completion records), 2: gray_walk1_kernel (one pixel per lane, completion
+    // records).  1-channel plans get modes 0 and 2, 3-channel plans mode 1.
     {
         int unit = -1, n_unit = 0;
         for (int l = 0; l < n_levels; ++l)
             if (tab.lv[l].kind == kPyrUnit) { unit = l; ++n_unit; }
-        bool ok = n_unit == 1 && tab.n_general >= 1 && tab.n_general <= 7;
-        if (ok) {
+        bool same_crop = n_unit == 1 && tab.n_general >= 1 && tab.n_general <= 7;
+        if (same_crop) {
             const PyrLevelDev& u = tab.lv[unit];
-            ok = u.out_h >= u.src_h && u.out_w >= u.src_w;
-            for (int l = 0; l < n_levels && ok; ++l) {
+            same_crop = u.out_h >= u.src_h && u.out_w >= u.src_w;
+            for (int l = 0; l < n_levels && same_crop; ++l) {
                 const PyrLevelDev& d = tab.lv[l];
                 if (d.kind != kPyrGeneral) continue;
-                ok = d.src_y0 == u.src_y0 && d.src_x0 == u.src_x0 && d.src_h == u.src_h && d.src_w == u.src_w;
+                same_crop = d.src_y0 == u.src_y0 && d.src_x0 == u.src_x0 && d.src_h == u.src_h && d.src_w == u.src_w;
             }
         }
-        if (ok) {
+        auto build_walk = [&](int mode, WalkPyr& wout, void*& tables_out, bool& ok_out) {
+            bool ok = true;
             const PyrLevelDev& u = tab.lv[unit];
             const int G = tab.n_general;
-            const bool rgb = channels == 3;
-            const int Gp = stream_pad_levels(G), PR = rgb ? w3_prog_row(Gp) : walk_prog_row(Gp);
-            // geometry of a wave tile: pixels per tile, tiles per row, record slots, and the tap index of an output anchored
-            // at pixel xb of the tile that starts at pixel xw0 (1 channel: index into the wave's 128 columns, first column
-            // xw0 - 4; 3 channels: FLOAT index into the wave's line, first pixel xw0 - 2)
-            const int tile_px = rgb ? kW3Px : kWalkCols;
-            const int strip_px = rgb ? kW3StripPx : kWalkStripW;
-            const int waves_x = ((u.out_w + strip_px - 1) / strip_px) * (rgb ? kW3NC : kWalkNC);
-            const int rec_total = rgb ? w3_rec_total(Gp) : walk_rec_total(Gp);
-            auto cap = [&](int g) { return rgb ? w3_rec_cap(g) : walk_rec_cap(g); };
-            auto base = [&](int g) { return rgb ? w3_rec_base(g) : walk_rec_base(g); };
+            const bool completion = mode != 0;                       // record format
+            const int Gp = stream_pad_levels(G), PR = completion ? w3_prog_row(Gp) : walk_prog_row(Gp);
+            const int tile_px = mode == 1 ? kW3Px : (mode == 2 ? kW1Cols : kWalkCols);
+            const int strip_px = mode == 1 ? kW3StripPx : (mode == 2 ? kW1StripW : kWalkStripW);
+            const int waves_x = ((u.out_w + strip_px - 1) / strip_px) * (strip_px / tile_px);
+            const int rec_total = mode == 1 ? w3_rec_total(Gp) : (mode == 2 ? w1_rec_total(Gp) : walk_rec_total(Gp));
+            auto cap = [&](int g) { return mode == 1 ? w3_rec_cap(g) : (mode == 2 ? w1_rec_cap(g) : walk_rec_cap(g)); };
+            auto base = [&](int g) { return mode == 1 ? w3_rec_base(g) : (mode == 2 ? w1_rec_base(g) : walk_rec_base(g)); };
             const size_t n_rec = (size_t)u.out_h + 8;                 // stream rows y = -4 .. out_h + 3 at index y + 4
             const size_t n_rec_pad = n_rec + 2 * kWalkCH;             // the loader fetches whole chunks of records
             std::vector<int> prog(n_rec_pad * PR, 0), hdr((size_t)G * waves_x * 2, 0), rec((size_t)waves_x * rec_total * 8, 0);
-            if (!rgb)
+            if (!completion)
                 for (size_t r = 0; r < n_rec_pad; ++r)
                     for (int gg = 0; gg < Gp; ++gg) prog[r * PR + gg] = 7 << 4;  // inert: feeds nothing, no slot completes
-            std::vector<char> used(n_rec * G * kWalkMaxSlots, 0);
+            std::vector<char> used(completion ? 1 : n_rec * G * kWalkMaxSlots, 0);
             int g = 0;
             for (int l = 0; l < n_levels && ok; ++l) {
                 const PyrLevelDev& d = tab.lv[l];
@@ -1515,8 +1520,8 @@ SILENT_EXPORT int silent_pyramid_plan_create(silent_ctx* ctx, int frame_h, int f
                 const int zc = std::min(d.zoom_w, d.out_w), zr = std::min(d.zoom_h, d.out_h);
                 const int* yb = ybase.data() + d.ytab_off;
                 const int* xb = xbase.data() + d.xtab_off;
-                for (int oy = 0; oy < zr && ok && rgb; ++oy) {
-                    // 3 channels (silent_walk_rgb.h): one record entry per COMPLETING row: flag + output row, 6 weights
+                for (int oy = 0; oy < zr && ok && completion; ++oy) {
+                    // one record entry per COMPLETING row: flag + output row, 6 weights
                     if (yb[oy] < 0 || yb[oy] >= u.out_h) { ok = false; break; }
                     const size_t r = (size_t)(yb[oy] + 7);              // the last tap sits on stream row y = yb + 3, index y + 4
                     if (r >= n_rec) { ok = false; break; }
@@ -1525,7 +1530,7 @@ SILENT_EXPORT int silent_pyramid_plan_create(silent_ctx* ctx, int frame_h, int f
                     pr[g] = 1 | (oy << 8);
                     std::memcpy(pr + Gp + 6 * g, &yw[(size_t)(d.ytab_off + oy) * 6], 24);
                 }
-                for (int oy = 0; oy < zr && ok && !rgb; ++oy) {
+                for (int oy = 0; oy < zr && ok && !completion; ++oy) {
                     if (yb[oy] < 0 || yb[oy] >= u.out_h) { ok = false; break; }
                     const int slot = oy % walk_slots(g);
                     for (int j = 0; j < 6; ++j) {
@@ -1551,44 +1556,50 @@ SILENT_EXPORT int silent_pyramid_plan_create(silent_ctx* ctx, int frame_h, int f
                     while (ox < zc && xb[ox] < xw0) ++ox;
                     int n = 0;
                     while (ox + n < zc && xb[ox + n] < xw0 + tile_px) ++n;
-                    if (n > cap(g)) { ok = false; break; }               // one output (pixel) per lane (triple), halving per level
+                    if (n > cap(g)) { ok = false; break; }               // outputs per wave tile: zoom steps >= 1.875 per level
                     hdr[((size_t)g * waves_x + wx) * 2] = ox;
                     hdr[((size_t)g * waves_x + wx) * 2 + 1] = n;
                     for (int j = 0; j < n; ++j) {
                         int* r = rec.data() + ((size_t)wx * rec_total + base(g) + j) * 8;
-                        if (rgb) {
-                            r[0] = (xb[ox + j] - xw0) * 3;               // float index of tap 0, channel 0 (line starts at pixel xw0 - 2)
+                        if (mode == 1) {
+                            r[0] = (xb[ox + j] - xw0) * 3;               // FLOAT index of tap 0, channel 0 (line starts at pixel xw0 - 2)
                             if (r[0] < 0 || r[0] + 2 + 15 > kW3TileF - 1) { ok = false; break; }
                         } else {
-                            r[0] = xb[ox + j] - xw0 + 2;                 // index of tap 0 in the wave's 128 columns (index 0 <-> column xw0 - 4)
-                            if (r[0] < 0 || r[0] + 5 > 127) { ok = false; break; }
+                            r[0] = xb[ox + j] - xw0 + 2;                 // lane / column of tap 0 (index 0 <-> column xw0 - 4)
+                            if (r[0] < 0 || r[0] + 5 > (mode == 2 ? 63 : 127)) { ok = false; break; }
                         }
                         std::memcpy(r + 1, &xw[(size_t)(d.xtab_off + ox + j) * 6], 24);
                     }
                     ox += n;
                 }
-                plan->walk.px_off[g] = tab.px_off[l];
-                plan->walk.out_w[g] = d.out_w;
+                wout.px_off[g] = tab.px_off[l];
+                wout.out_w[g] = d.out_w;
                 ++g;
             }
-            if (ok) {
-                const size_t b0 = align_up(prog.size() * 4), b1 = align_up(hdr.size() * 4), b2 = align_up(rec.size() * 4);
-                hipError_t se = hipMalloc(&plan->walk_tables, b0 + b1 + b2);
-                if (se == hipSuccess) se = hipMemcpy(plan->walk_tables, prog.data(), prog.size() * 4, hipMemcpyHostToDevice);
-                if (se == hipSuccess) se = hipMemcpy((char*)plan->walk_tables + b0, hdr.data(), hdr.size() * 4, hipMemcpyHostToDevice);
-                if (se == hipSuccess) se = hipMemcpy((char*)plan->walk_tables + b0 + b1, rec.data(), rec.size() * 4, hipMemcpyHostToDevice);
-                if (se != hipSuccess) {
-                    (void)hipGetLastError();
-                    if (plan->walk_tables) (void)hipFree(plan->walk_tables);
-                    plan->walk_tables = nullptr;
-                } else {
-                    plan->walk.G = G;
-                    plan->walk.row_prog = (const int*)plan->walk_tables;
-                    plan->walk.col_hdr = (const int*)((char*)plan->walk_tables + b0);
-                    plan->walk.col_rec = (const int*)((char*)plan->walk_tables + b0 + b1);
-                    plan->walk_pyr_ok = true;
-                    plan->walk_unit_level = unit;
-                }
+            if (!ok) return;
+            const size_t b0 = align_up(prog.size() * 4), b1 = align_up(hdr.size() * 4), b2 = align_up(rec.size() * 4);
+            hipError_t se = hipMalloc(&tables_out, b0 + b1 + b2);
+            if (se == hipSuccess) se = hipMemcpy(tables_out, prog.data(), prog.size() * 4, hipMemcpyHostToDevice);
+            if (se == hipSuccess) se = hipMemcpy((char*)tables_out + b0, hdr.data(), hdr.size() * 4, hipMemcpyHostToDevice);
+            if (se == hipSuccess) se = hipMemcpy((char*)tables_out + b0 + b1, rec.data(), rec.size() * 4, hipMemcpyHostToDevice);
+            if (se != hipSuccess) {
+                (void)hipGetLastError();
+                if (tables_out) (void)hipFree(tables_out);
+                tables_out = nullptr;
+                return;
+            }
+            wout.G = G;
+            wout.row_prog = (const int*)tables_out;
+            wout.col_hdr = (const int*)((char*)tables_out + b0);
+            wout.col_rec = (const int*)((char*)tables_out + b0 + b1);
+            ok_out = true;
+        };
+        plan->walk_unit_level = n_unit == 1 ? unit : -1;
+        if (same_crop) {
+            if (channels == 3) build_walk(1, plan->walk, plan->walk_tables, plan->walk_pyr_ok);
+            else {
+                build_walk(0, plan->walk, plan->walk_tables, plan->walk_pyr_ok);
+                build_walk(2, plan->walk1, plan->walk1_tables, plan->walk1_ok);
             }
         }
     }
@@ -1602,6 +1613,7 @@ SILENT_EXPORT void silent_pyramid_plan_destroy(silent_pyramid_plan* plan) {
     if (plan->tables) (void)hipFree(plan->tables);
     if (plan->stream_tables) (void)hipFree(plan->stream_tables);
     if (plan->walk_tables) (void)hipFree(plan->walk_tables);
+    if (plan->walk1_tables) (void)hipFree(plan->walk1_tables);
     delete plan;
 }
 
@@ -1782,6 +1794,62 @@ static bool walk_plan(const silent_ctx* ctx, const silent_pyramid_plan* plan, in
     return true;
 }
 
+// Geometry of gray_walk1_kernel (silent_walk1.h): one unit level + walk tables, 16-byte aligned rows and crop.
+template <class Kern>
+static bool walk1_plan(const silent_ctx* ctx, const silent_pyramid_plan* plan, int n_frames, Kern kern, WalkTab* wt) {
+    const PyrTab& pt = plan->tab;
+    if (pt.C != 1 || !plan->walk1_ok || plan->walk_unit_level < 0) return false;
+    const PyrLevelDev& d = pt.lv[plan->walk_unit_level];
+    if (pt.W % 4 || d.src_x0 % 4 || d.src_w % 4 || d.src_w < 8) return false;
+    std::memset(wt, 0, sizeof(*wt));
+    wt->H = pt.H; wt->W = pt.W;
+    wt->src_y0 = d.src_y0; wt->src_x0 = d.src_x0; wt->src_h = d.src_h; wt->src_w = d.src_w;
+    wt->out_h = d.out_h; wt->out_w = d.out_w;
+    wt->eff_h = std::min(d.zoom_h, d.out_h); wt->eff_w = std::min(d.zoom_w, d.out_w);
+    wt->strips_x = (d.out_w + kW1StripW - 1) / kW1StripW;
+    int per_cu = 0;
+    (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kern, kW1Threads, 0);
+    (void)hipGetLastError();
+    // all blocks take the same time: the launch lasts ceil(blocks / resident blocks) rounds of (segment rows + 8) row steps
+    const long long per_seg = (long long)n_frames * wt->strips_x;
+    const long long resident = (long long)std::max(per_cu, 1) * ctx->n_cus;
+    const int max_segs = std::max(1, d.out_h / 32);
+    long long best_cost = -1;
+    int seg_rows = d.out_h;
+    for (int segs = 1; segs <= max_segs; ++segs) {
+        int rows = (d.out_h + segs - 1) / segs;
+        rows = (rows + kWalkCH - 1) / kWalkCH * kWalkCH;
+        const long long n_seg = (d.out_h + rows - 1) / rows;
+        const long long cost = ((per_seg * n_seg + resident - 1) / resident) * (rows + 8);
+        if (best_cost < 0 || cost < best_cost) {
+            best_cost = cost;
+            seg_rows = rows;
+        }
+    }
+    wt->seg_rows = seg_rows;
+    wt->segs_y = (d.out_h + seg_rows - 1) / seg_rows;
+    wt->frame_px = pt.frame_px_out;
+    wt->px_off = pt.px_off[plan->walk_unit_level];
+    for (int j = 0; j < 5; ++j) wt->wx[j] = plan->unit_w[j];
+    return true;
+}
+
+template <int K>
+static bool launch_walk1(silent_ctx* ctx, const silent_pyramid_plan* plan, const float* frames, int n_frames, float* pyr,
+                         float* cs_out, float* end_out, const GrayW& w, float clip_hi, hipStream_t s) {
+    WalkTab wt;
+    if (plan->walk1.G <= 4) {
+        if (!walk1_plan(ctx, plan, n_frames, gray_walk1_kernel<K, 4>, &wt)) return false;
+        hipLaunchKernelGGL((gray_walk1_kernel<K, 4>), dim3((unsigned)((long long)n_frames * wt.segs_y * wt.strips_x)), dim3(kW1Threads), 0, s,
+                           frames, pyr, cs_out, end_out, wt, plan->walk1, w, clip_hi);
+    } else {
+        if (!walk1_plan(ctx, plan, n_frames, gray_walk1_kernel<K, 7>, &wt)) return false;
+        hipLaunchKernelGGL((gray_walk1_kernel<K, 7>), dim3((unsigned)((long long)n_frames * wt.segs_y * wt.strips_x)), dim3(kW1Threads), 0, s,
+                           frames, pyr, cs_out, end_out, wt, plan->walk1, w, clip_hi);
+    }
+    return true;
+}
+
 SILENT_EXPORT int silent_gray_pass_dev(silent_ctx* ctx, const silent_pyramid_plan* plan, const float* frames,
                                        int n_frames, const float* cs_kernel, const float* end_bank, int n_orient,
                                        float clip_hi, float* pyr, float* cs_out, float* end_out,
@@ -1807,10 +1875,14 @@ SILENT_EXPORT int silent_gray_pass_dev(silent_ctx* ctx, const silent_pyramid_pla
     int walk_unit = -1;
     const bool walk_path = (kopts & 128) && end_out && walk_plan(ctx, plan, n_frames, n_orient, true, 2 + ((kopts >> 10) & 3), 32 * ((kopts >> 12) & 63), &wt, &walk_unit);
     const bool walk_pyr = walk_path && plan->walk_pyr_ok && pt.C == 1 && !(kopts & 512);   // other levels from the same walk
-    const bool stream_path = plan->stream_ok && !(kopts & 16) && !walk_path;
+    // one-pixel-per-lane strip walk (silent_walk1.h): pyramid of all levels + unit-level filters, bit 18 selects it
+    const bool walk1_path = (kopts & (1 << 18)) && !walk_path && end_out && plan->walk1_ok && pt.C == 1 &&
+                            plan->walk_unit_level >= 0 && !(pt.W % 4) && !(pt.lv[plan->walk_unit_level].src_x0 % 4) &&
+                            !(pt.lv[plan->walk_unit_level].src_w % 4) && pt.lv[plan->walk_unit_level].src_w >= 8;
+    const bool stream_path = plan->stream_ok && !(kopts & 16) && !walk_path && !walk1_path;
     // 1. non-unit levels of the pyramid: by the region kernel, unless the stream kernel of step 2 produces them
     //    from the same single read of the frame; plus the zero fill of canvases larger than their zoomed crop
-    TRY(launch_pyramid(ctx, who, plan, frames, n_frames, pyr, s, false, !stream_path && !walk_pyr));
+    TRY(launch_pyramid(ctx, who, plan, frames, n_frames, pyr, s, false, !stream_path && !walk_pyr && !walk1_path));
     // 2. unit levels: pyramid + CS + end in one kernel
     const int fth = (!stream_path && (kopts & 8)) ? 32 : kFusedTH;
     FusedTab ft;
@@ -1849,7 +1921,13 @@ SILENT_EXPORT int silent_gray_pass_dev(silent_ctx* ctx, const silent_pyramid_pla
         ctx->prof_sample = ctx->profiling && (ctx->prof_calls++ % ctx->prof_period) == 0;
         const int prof_slot = ctx->prof_recorded % silent_ctx::kProfPairs;
         if (ctx->prof_sample) HIP_TRY(ctx, hipEventRecord(ctx->prof_ev[prof_slot][0], s));
-        if (walk_path) {
+        if (walk1_path) {
+            bool ok1 = false;
+            if (n_orient == 3) ok1 = launch_walk1<3>(ctx, plan, frames, n_frames, pyr, cs_out, end_out, w, clip_hi, s);
+            else if (n_orient == 4) ok1 = launch_walk1<4>(ctx, plan, frames, n_frames, pyr, cs_out, end_out, w, clip_hi, s);
+            else ok1 = launch_walk1<8>(ctx, plan, frames, n_frames, pyr, cs_out, end_out, w, clip_hi, s);
+            if (!ok1) return fail(ctx, SILENT_E_HIP, std::string(who) + ": internal error: walk1 plan rejected after eligibility check");
+        } else if (walk_path) {
             const long long wblocks = (long long)n_frames * wt.segs_y * wt.strips_x;
 #define WALK_LAUNCH(K_, NT_, G_) \
     hipLaunchKernelGGL((gray_walk_kernel<K_, NT_, G_>), dim3((unsigned)wblocks), dim3(walk_threads(G_)), 0, s, frames, pyr, cs_out, end_out, wt, wpyr, w, clip_hi)

@@ -1283,3 +1283,36 @@ def test_rgb_pyramid_walk_is_bit_identical_to_unit_plus_region_kernels(rt, shape
     res = plan.run(clean[None])
     for l in range(n):
         assert_close(res.level(l), want[l], RTOL, scale=255.0, what="rgb walk level %d" % l)
+
+
+# ----------------------------------------------------------------------------- one-pixel-per-lane strip walk (silent_walk1.h)
+
+WALK1 = 1 << 18
+
+
+@pytest.mark.parametrize("shape,scale,n,K,B", [((135, 240, 1), 2.0, 5, 4, 2),         # one strip (224) + a ragged one
+                                               ((97, 132, 1), 2.0, 4, 8, 3),           # K = 8 store transpose
+                                               ((64, 300, 1), 2.0, 3, 3, 1),           # K = 3
+                                               ((200, 1000, 1), 2.0, 4, 4, 2),         # five strips
+                                               ((200, 228, 1), 2.0, 2, 8, 1),          # second strip holds 4 columns
+                                               ((270, 480, 1), 2.5, 4, 4, 2),
+                                               ((8, 8, 1), 2.0, 2, 4, 2),
+                                               ((540, 960, 1), 2.0, 8, 8, 2),          # 7 general levels
+                                               ((1080, 1920, 1), 2.0, 5, 4, 2)])       # config 2 geometry
+def test_gray_walk1_kernel_is_bit_identical_to_the_tile_kernels(rt, kernels, shape, scale, n, K, B):
+    """gray_walk1_kernel (loader wave + 12-row ring, one pixel per lane, other levels from a 6-row window at completion,
+    tuning bit 18) against the tile kernels: every map equal bit for bit across segment and strip seams, ragged edges,
+    K = 3 / 4 / 8, NaN / inf pixels."""
+    from pysilent_amd.util.zoom.from_image import classic_levels
+    frames = np.stack([structured_frame(20 + s, *shape, n_lines=60) + noise_frame(s, *shape) * np.float32(0.25) for s in range(B)])
+    if shape[0] > 20:
+        frames[0, shape[0] // 2, shape[1] // 3] = np.nan
+        frames[B - 1, 3, shape[1] - 2] = np.inf
+    plan = rt.PyramidPlan(shape[0], shape[1], 1, classic_levels(shape[:2], scale, n))
+    bank = kernels["end%d" % K]
+    with rt.tuning(TUNE_GRAY, WALK1):
+        got = plan.gray_pass(frames, kernels["cs_gray"], bank)
+    with rt.tuning(TUNE_GRAY, 0):
+        ref = plan.gray_pass(frames, kernels["cs_gray"], bank)
+    for a, b_ in zip(got, ref):
+        np.testing.assert_array_equal(a.data, b_.data)
