@@ -134,8 +134,8 @@ class LineEndPipeline(object):
         if self.mode == "gray":
             return ("gray_stream_kernel (whole pyramid + level-0 CS/line-end, frame read once) + "
                     "gray_line_end_kernel (levels >= 1)")
-        return ("unit + region pyramid, fused RGB chain, max/min + fused selection (top 10 % > NMS > value), "
-                "cell-max / count / scan / write keypoint kernels")
+        return ("single-read RGB pyramid (pyramid_walk3_kernel), fused RGB chain, max/min + fused selection "
+                "(top 10 % > NMS > value), cell-max / count / scan / write keypoint kernels")
 
     # -- launches --------------------------------------------------------------------------------------
     def _stream(self):

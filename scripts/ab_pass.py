@@ -14,6 +14,7 @@ variants = {"two-step": ("0", two_step), "walk": (os.environ.get("SILENT_AB_WALK
             "walk plain st": ("384", lambda: pipe.step(frames)), "walk+region": ("640", lambda: pipe.step(frames)),
             "walk+region 3/CU": (str(640 + 1024), lambda: pipe.step(frames)), "walk+region 4/CU": (str(640 + 2048), lambda: pipe.step(frames)),
             "walk 3/CU": ("1152", lambda: pipe.step(frames)),
+            "walk1": (str(1 << 18), lambda: pipe.step(frames)),
             "A seg64": (str(640 + (2 << 12)), lambda: pipe.step(frames)), "A seg128": (str(640 + (4 << 12)), lambda: pipe.step(frames)),
             "A seg272": (str(640 + (9 << 12)), lambda: pipe.step(frames)), "A seg544": (str(640 + (17 << 12)), lambda: pipe.step(frames)),
             "A seg1088": (str(640 + (34 << 12)), lambda: pipe.step(frames)),
