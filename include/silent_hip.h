@@ -19,9 +19,10 @@
  *   - Ownership: the caller owns every buffer; the library never keeps a caller pointer past
  *     return.  silent_ctx / silent_pyramid_plan are library-owned handles.
  *   - Threading: a silent_ctx is not thread-safe; use one per (host thread, GPU).  Several entry points keep
- *     temporaries (reduction slots, chunk counts, staged intermediates) in ONE workspace owned by the context, so all
- *     *_dev calls on a context must be issued to the same stream (or be ordered by the caller); independent streams
- *     need their own context.
+ *     temporaries (reduction slots, chunk counts, staged intermediates) in ONE workspace owned by the context.  The
+ *     library enforces the ordering this needs: when a workspace-using *_dev call arrives on another stream than the
+ *     previous one, that previous stream is drained first (correct, but serialising: streams that should overlap need
+ *     a context each).  The entry points run on the context's device and restore the caller's current HIP device.
  *   - Entry points without suffix take HOST pointers and are synchronous (they stage through the
  *     context's device arena).  The *_dev twins take DEVICE pointers plus a hipStream_t (passed as
  *     void*; NULL = the legacy default stream), are stream-ordered and do not synchronise.

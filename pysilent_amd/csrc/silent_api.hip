@@ -38,6 +38,8 @@ struct silent_ctx {
     int n_cus = 256;
     DevBuf arena;  // staging for the host-pointer entry points
     DevBuf ws;     // scratch for reductions / compaction / the RGB chain temporaries
+    hipStream_t ws_stream = nullptr;   // the stream whose work last used ws (see workspace())
+    bool ws_used = false;
     bool profiling = false;
     // HIP-event sampling of the dominant kernel of silent_gray_pass_dev: every prof_period-th call records a pair
     // into a ring of kProfPairs, silent_profile_elapsed_ms averages the recorded ones
@@ -138,6 +140,15 @@ static int grow(silent_ctx* ctx, DevBuf& b, size_t bytes) {
 }
 
 static inline size_t align_up(size_t v, size_t a = 256) { return (v + a - 1) / a * a; }
+
+// The context has ONE workspace, so its users are ordered by the stream they run on.  A caller that moves to another
+// stream is not an error: the previous stream is drained first (rare path), then the workspace belongs to the new one.
+static int workspace(silent_ctx* ctx, hipStream_t s, size_t bytes) {
+    if (ctx->ws_used && ctx->ws_stream != s) HIP_TRY(ctx, hipStreamSynchronize(ctx->ws_stream));
+    ctx->ws_stream = s;
+    ctx->ws_used = true;
+    return grow(ctx, ctx->ws, bytes);
+}
 
 SILENT_EXPORT int silent_abi_version(void) { return SILENT_ABI_VERSION; }
 
@@ -570,7 +581,7 @@ SILENT_EXPORT int silent_top_value_points_dev(silent_ctx* ctx, const float* colo
     long long rblocks;
     TRY(build_level_tab(ctx, who, levels, n_levels, n_frames, kRedChunk, 0, &rtab, &rblocks));
     const int nmm = n_frames * n_levels;
-    TRY(grow(ctx, ctx->ws, sizeof(unsigned) * 2 * (size_t)nmm));
+    TRY(workspace(ctx, (hipStream_t)stream, sizeof(unsigned) * 2 * (size_t)nmm));
     unsigned* mm = (unsigned*)ctx->ws.p;
     hipStream_t s = (hipStream_t)stream;
     hipLaunchKernelGGL(init_maxmin_kernel, dim3((nmm + 255) / 256), dim3(256), 0, s, mm, nmm);
@@ -597,7 +608,7 @@ SILENT_EXPORT int silent_select_peaks_dev(silent_ctx* ctx, const float* color, c
     TRY(build_level_tab(ctx, who, levels, n_levels, n_frames, kRedChunk, 0, &rtab, &rblocks));
     TRY(build_level_tab(ctx, who, levels, n_levels, n_frames, kSelTW, kSelTH, &tab, &blocks));
     const int nmm = n_frames * n_levels;
-    TRY(grow(ctx, ctx->ws, sizeof(unsigned) * 2 * (size_t)nmm));
+    TRY(workspace(ctx, (hipStream_t)stream, sizeof(unsigned) * 2 * (size_t)nmm));
     unsigned* mm = (unsigned*)ctx->ws.p;
     hipStream_t s = (hipStream_t)stream;
     hipLaunchKernelGGL(init_maxmin_kernel, dim3((nmm + 255) / 256), dim3(256), 0, s, mm, nmm);
@@ -699,7 +710,7 @@ struct KeypointWs {
     float* pooled;   // general path: window maxima
 };
 
-static int keypoint_workspace(silent_ctx* ctx, int n_levels, int n_frames, long long blocks, size_t reserve,
+static int keypoint_workspace(silent_ctx* ctx, hipStream_t stream, int n_levels, int n_frames, long long blocks, size_t reserve,
                               const RegionTab& rt, bool general, KeypointWs* w) {
     w->n_cells = (size_t)n_frames * n_levels * kCells;
     const size_t off_cells = align_up(reserve);
@@ -708,7 +719,7 @@ static int keypoint_workspace(silent_ctx* ctx, int n_levels, int n_frames, long 
     const size_t off_m1 = off_offsets + align_up((size_t)blocks * sizeof(long long));
     const size_t off_pooled = off_m1 + (general ? align_up((size_t)n_frames * rt.m1_per_frame * sizeof(float)) : 0);
     const size_t total = off_pooled + (general ? align_up((size_t)n_frames * rt.pooled_per_frame * sizeof(float)) : 0);
-    TRY(grow(ctx, ctx->ws, total));
+    TRY(workspace(ctx, (hipStream_t)stream, total));
     w->cells = (unsigned*)((char*)ctx->ws.p + off_cells);
     w->chunk_counts = (int*)((char*)ctx->ws.p + off_counts);
     w->chunk_offsets = (long long*)((char*)ctx->ws.p + off_offsets);
@@ -770,7 +781,7 @@ SILENT_EXPORT int silent_max_value_indices_region_dev(silent_ctx* ctx, const flo
     bool general;
     TRY(build_region_tab(ctx, who, levels, n_levels, regions, &rt, &general));
     KeypointWs w;
-    TRY(keypoint_workspace(ctx, n_levels, n_frames, blocks, 0, rt, general, &w));
+    TRY(keypoint_workspace(ctx, (hipStream_t)stream, n_levels, n_frames, blocks, 0, rt, general, &w));
     hipStream_t s = (hipStream_t)stream;
     if (general) {
         TRY(region_window_maxima(ctx, who, value, levels, n_levels, n_frames, rt, w, s));
@@ -803,7 +814,7 @@ SILENT_EXPORT int silent_select_keypoints_dev(silent_ctx* ctx, const float* colo
     TRY(build_region_tab(ctx, who, levels, n_levels, regions, &rt, &general));
     const int nmm = n_frames * n_levels;
     KeypointWs w;
-    TRY(keypoint_workspace(ctx, n_levels, n_frames, blocks, sizeof(unsigned) * 2 * (size_t)nmm, rt, general, &w));
+    TRY(keypoint_workspace(ctx, (hipStream_t)stream, n_levels, n_frames, blocks, sizeof(unsigned) * 2 * (size_t)nmm, rt, general, &w));
     unsigned* mm = (unsigned*)ctx->ws.p;
     hipStream_t s = (hipStream_t)stream;
     hipLaunchKernelGGL(init_maxmin_kernel, dim3((nmm + 255) / 256), dim3(256), 0, s, mm, nmm);
@@ -868,7 +879,7 @@ SILENT_EXPORT int silent_centroids_dev(silent_ctx* ctx, const float* value, cons
     TRY(build_cell_tab(ctx, who, levels, n_levels, region_h, region_w, &ct));
     const long long cells = ct.frame_cells * n_frames;
     if ((cells + 255) / 256 > 0x7fffffffll) return fail(ctx, SILENT_E_INVALID, std::string(who) + ": too many cells");
-    TRY(grow(ctx, ctx->ws, (size_t)cells * 2 * sizeof(float)));
+    TRY(workspace(ctx, (hipStream_t)stream, (size_t)cells * 2 * sizeof(float)));
     float* cxy = (float*)ctx->ws.p;
     hipStream_t s = (hipStream_t)stream;
     hipLaunchKernelGGL(centroid_cells_kernel, dim3((unsigned)((cells + 255) / 256)), dim3(256), 0, s, value, tab, ct, n_frames,
@@ -908,7 +919,7 @@ SILENT_EXPORT int silent_boosting_step_dev(silent_ctx* ctx, const float* input, 
     TRY(build_level_tab(ctx, who, levels, n_levels, n_frames, 0, 0, &tab, &blocks));
     const long long n = tab.frame_px * n_frames;
     if ((n + 255) / 256 > 0x7fffffffll) return fail(ctx, SILENT_E_INVALID, std::string(who) + ": too many pixels");
-    TRY(grow(ctx, ctx->ws, (size_t)n * sizeof(float)));
+    TRY(workspace(ctx, (hipStream_t)stream, (size_t)n * sizeof(float)));
     float* m = (float*)ctx->ws.p;
     hipStream_t s = (hipStream_t)stream;
     hipLaunchKernelGGL(boost_power_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, input, energy, m, n);
@@ -1157,7 +1168,7 @@ SILENT_EXPORT int silent_rgb_line_end_dev(silent_ctx* ctx, const float* pyr, con
     // General blur: stage-per-launch composition through ping-pong temporaries in the context workspace.
     const size_t n = (size_t)pyramid_px(levels, n_levels) * n_frames * 3;
     const size_t bytes = align_up(n * sizeof(float));
-    TRY(grow(ctx, ctx->ws, 3 * bytes));
+    TRY(workspace(ctx, (hipStream_t)stream, 3 * bytes));
     float* t0 = (float*)ctx->ws.p;
     float* t1 = (float*)((char*)ctx->ws.p + bytes);
     float* t2 = (float*)((char*)ctx->ws.p + 2 * bytes);

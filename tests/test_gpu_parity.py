@@ -1316,3 +1316,21 @@ def test_gray_walk1_kernel_is_bit_identical_to_the_tile_kernels(rt, kernels, sha
         ref = plan.gray_pass(frames, kernels["cs_gray"], bank)
     for a, b_ in zip(got, ref):
         np.testing.assert_array_equal(a.data, b_.data)
+
+
+def test_workspace_follows_the_callers_stream(rt):
+    """One workspace per context: a caller that alternates between two streams gets correct results (the library drains
+    the previous stream before the workspace changes hands)."""
+    import torch
+    from pysilent_amd.util.selection import top_value_points
+    x = torch.from_numpy(np.stack([noise_frame(s, 64, 96, 3) for s in range(4)])).cuda()
+    want = so.top_value_points(x.cpu().numpy(), 0.3)
+    s1, s2 = torch.cuda.Stream(), torch.cuda.Stream()
+    torch.cuda.synchronize()
+    outs = []
+    for i in range(6):
+        with torch.cuda.stream(s1 if i % 2 == 0 else s2):
+            outs.append(top_value_points(x, 0.3))
+    torch.cuda.synchronize()
+    for o in outs:
+        np.testing.assert_array_equal(o.cpu().numpy(), want)
