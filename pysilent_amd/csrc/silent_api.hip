@@ -144,7 +144,13 @@ static inline size_t align_up(size_t v, size_t a = 256) { return (v + a - 1) / a
 // The context has ONE workspace, so its users are ordered by the stream they run on.  A caller that moves to another
 // stream is not an error: the previous stream is drained first (rare path), then the workspace belongs to the new one.
 static int workspace(silent_ctx* ctx, hipStream_t s, size_t bytes) {
-    if (ctx->ws_used && ctx->ws_stream != s) HIP_TRY(ctx, hipStreamSynchronize(ctx->ws_stream));
+    if (ctx->ws_used && ctx->ws_stream != s) {
+        // (not while `s` is capturing a HIP graph: a host synchronisation is illegal there, and a caller that captures has
+        // ordered its warm-up stream against the capture stream itself -- pysilent_amd.recognition_testing does)
+        hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+        if (hipStreamIsCapturing(s, &cap) != hipSuccess) (void)hipGetLastError();
+        if (cap != hipStreamCaptureStatusActive) HIP_TRY(ctx, hipStreamSynchronize(ctx->ws_stream));
+    }
     ctx->ws_stream = s;
     ctx->ws_used = true;
     return grow(ctx, ctx->ws, bytes);
