@@ -714,6 +714,7 @@ struct KeypointWs {
     size_t n_cells;
     float* m1;       // general path: row maxima over the column windows
     float* pooled;   // general path: window maxima
+    unsigned long long* hit_masks;   // 1 bit per pixel: the count pass's ballots, read by the write pass
 };
 
 static int keypoint_workspace(silent_ctx* ctx, hipStream_t stream, int n_levels, int n_frames, long long blocks, size_t reserve,
@@ -724,13 +725,15 @@ static int keypoint_workspace(silent_ctx* ctx, hipStream_t stream, int n_levels,
     const size_t off_offsets = off_counts + align_up((size_t)blocks * sizeof(int));
     const size_t off_m1 = off_offsets + align_up((size_t)blocks * sizeof(long long));
     const size_t off_pooled = off_m1 + (general ? align_up((size_t)n_frames * rt.m1_per_frame * sizeof(float)) : 0);
-    const size_t total = off_pooled + (general ? align_up((size_t)n_frames * rt.pooled_per_frame * sizeof(float)) : 0);
+    const size_t off_masks = off_pooled + (general ? align_up((size_t)n_frames * rt.pooled_per_frame * sizeof(float)) : 0);
+    const size_t total = off_masks + align_up((size_t)blocks * 4 * kKpPer * sizeof(unsigned long long));
     TRY(workspace(ctx, (hipStream_t)stream, total));
     w->cells = (unsigned*)((char*)ctx->ws.p + off_cells);
     w->chunk_counts = (int*)((char*)ctx->ws.p + off_counts);
     w->chunk_offsets = (long long*)((char*)ctx->ws.p + off_offsets);
     w->m1 = (float*)((char*)ctx->ws.p + off_m1);
     w->pooled = (float*)((char*)ctx->ws.p + off_pooled);
+    w->hit_masks = (unsigned long long*)((char*)ctx->ws.p + off_masks);
     return SILENT_OK;
 }
 
@@ -757,18 +760,14 @@ static int region_window_maxima(silent_ctx* ctx, const char* who, const float* v
 static void keypoint_passes(const float* value, const LevelTab& tab, long long blocks, const RegionTab& rt, const KeypointWs& w,
                             bool general, int n_frames, int64_t* idx, size_t cap_per_frame, int64_t* counts, hipStream_t s) {
     if (general)
-        hipLaunchKernelGGL(region_count_kernel<true>, dim3((unsigned)blocks), dim3(256), 0, s, value, tab, rt, w.cells, w.pooled, w.chunk_counts);
+        hipLaunchKernelGGL(region_count_kernel<true>, dim3((unsigned)blocks), dim3(256), 0, s, value, tab, rt, w.cells, w.pooled, w.chunk_counts, w.hit_masks);
     else
-        hipLaunchKernelGGL(region_count_kernel<false>, dim3((unsigned)blocks), dim3(256), 0, s, value, tab, rt, w.cells, w.pooled, w.chunk_counts);
+        hipLaunchKernelGGL(region_count_kernel<false>, dim3((unsigned)blocks), dim3(256), 0, s, value, tab, rt, w.cells, w.pooled, w.chunk_counts, w.hit_masks);
     hipLaunchKernelGGL(region_scan_kernel, dim3((unsigned)n_frames), dim3(256), 0, s, w.chunk_counts, w.chunk_offsets,
                        tab.tiles_per_frame, counts);
     if (!cap_per_frame) return;
-    if (general)
-        hipLaunchKernelGGL(region_write_kernel<true>, dim3((unsigned)blocks), dim3(256), 0, s, value, tab, rt, w.cells, w.pooled,
-                           w.chunk_offsets, idx, (long long)cap_per_frame);
-    else
-        hipLaunchKernelGGL(region_write_kernel<false>, dim3((unsigned)blocks), dim3(256), 0, s, value, tab, rt, w.cells, w.pooled,
-                           w.chunk_offsets, idx, (long long)cap_per_frame);
+    hipLaunchKernelGGL(region_write_kernel, dim3((unsigned)blocks), dim3(256), 0, s, tab, w.hit_masks, w.chunk_offsets, idx,
+                       (long long)cap_per_frame);
 }
 
 SILENT_EXPORT int silent_max_value_indices_region_dev(silent_ctx* ctx, const float* value, const silent_extent* levels,

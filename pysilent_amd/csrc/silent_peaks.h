@@ -626,7 +626,8 @@ template <bool GEN>
 __global__ __launch_bounds__(256) void region_count_kernel(const float* __restrict__ value, const LevelTab tab,
                                                            const RegionTab rt, const unsigned* __restrict__ cells,
                                                            const float* __restrict__ pooled_g,
-                                                           int* __restrict__ chunk_counts) {
+                                                           int* __restrict__ chunk_counts,
+                                                           unsigned long long* __restrict__ hit_masks) {
     __shared__ float s_pooled[kMaxWin * kMaxWin];
     __shared__ int s_cnt[4];
     const TileCoord tc = locate_tile(tab, blockIdx.x);
@@ -653,7 +654,11 @@ __global__ __launch_bounds__(256) void region_count_kernel(const float* __restri
     for (int k = 0; k < kKpPer; ++k, advance_yx(y, x, 64, W)) {
         const int p = seg + k * 64 + lane;
         const bool hit = p < npx && v[k] >= region_thr<GEN>(y, x, rl, pooled);
-        n += __popcll(__ballot(hit));
+        const unsigned long long m = __ballot(hit);
+        n += __popcll(m);
+        // the 64 hit bits of this group, kept for the write pass (1 bit per pixel instead of a second read of the value map
+        // and a second evaluation of the thresholds)
+        if (lane == 0) hit_masks[((long long)blockIdx.x * 4 + wave) * kKpPer + k] = m;
     }
     if (lane == 0) s_cnt[wave] = n;
     __syncthreads();
@@ -693,50 +698,31 @@ __global__ __launch_bounds__(256) void region_scan_kernel(const int* __restrict_
 
 // pass 3: ordered write of (level, y, x, 0) rows: rank = chunk offset + hits of the lower waves + hits of this wave's
 // earlier 64-pixel groups + hits of the lower lanes of this group
-template <bool GEN>
-__global__ __launch_bounds__(256) void region_write_kernel(const float* __restrict__ value, const LevelTab tab,
-                                                           const RegionTab rt, const unsigned* __restrict__ cells,
-                                                           const float* __restrict__ pooled_g,
+__global__ __launch_bounds__(256) void region_write_kernel(const LevelTab tab, const unsigned long long* __restrict__ hit_masks,
                                                            const long long* __restrict__ chunk_offsets,
                                                            int64_t* __restrict__ idx, long long cap_per_frame) {
-    __shared__ float s_pooled[kMaxWin * kMaxWin];
     __shared__ int s_wave[4];
     const TileCoord tc = locate_tile(tab, blockIdx.x);
-    const RegionLevel& rl = rt.lv[tc.level];
     const int W = tab.w[tc.level];
-    const int npx = tab.h[tc.level] * W;
-    const long long base_px = (long long)tc.frame * tab.frame_px + tab.px_off[tc.level];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int seg = tc.tx * kKpChunk + wave * (kKpChunk / 4);
-    float v[kKpPer];
-#pragma unroll
-    for (int k = 0; k < kKpPer; ++k) v[k] = value[base_px + min(seg + k * 64 + lane, npx - 1)];
-    const float* pooled = s_pooled;
-    if constexpr (GEN) {
-        pooled = pooled_g + (long long)tc.frame * rt.pooled_per_frame + rl.pooled_off;
-    } else {
-        load_pooled(cells + ((long long)tc.frame * tab.n_levels + tc.level) * kCells, rl, s_pooled);
-        __syncthreads();
-    }
+    // the hit bits the count pass left: kKpPer 64-bit masks per wave (wave-uniform loads)
+    const unsigned long long* __restrict__ mk = hit_masks + ((long long)blockIdx.x * 4 + wave) * kKpPer;
     unsigned long long hits[kKpPer];
     int n = 0;
-    const int y0 = (seg + lane) / W, x0 = seg + lane - y0 * W;
-    int y = y0, x = x0;
 #pragma unroll
-    for (int k = 0; k < kKpPer; ++k, advance_yx(y, x, 64, W)) {
-        const int p = seg + k * 64 + lane;
-        const bool hit = p < npx && v[k] >= region_thr<GEN>(y, x, rl, pooled);
-        hits[k] = __ballot(hit);
+    for (int k = 0; k < kKpPer; ++k) {
+        hits[k] = mk[k];
         n += __popcll(hits[k]);
     }
     if (lane == 0) s_wave[wave] = n;
     __syncthreads();
+    if (s_wave[0] + s_wave[1] + s_wave[2] + s_wave[3] == 0) return;   // block-uniform: nothing to write in this chunk
     long long pos = chunk_offsets[blockIdx.x];
     for (int i = 0; i < wave; ++i) pos += s_wave[i];
     int64_t* dst = idx + (long long)tc.frame * cap_per_frame * 4;
     const unsigned long long below = (1ull << lane) - 1ull;
-    y = y0;
-    x = x0;
+    int y = (seg + lane) / W, x = seg + lane - y * W;
 #pragma unroll
     for (int k = 0; k < kKpPer; ++k, advance_yx(y, x, 64, W)) {
         const unsigned long long m = hits[k];
