@@ -1110,11 +1110,35 @@ SILENT_EXPORT int silent_rgb_line_end_dev(silent_ctx* ctx, const float* pyr, con
     if (uniform_blur) {
         LevelTab tab;
         long long blocks;
-        TRY(build_level_tab(ctx, who, levels, n_levels, n_frames, kRgbTW, kRgbTH, &tab, &blocks));
-        const unsigned kopts = ctx->tune[SILENT_TUNE_RGB];  // 1: dense, 2: no two-group, 8: no short tiles
-        // few tiles: latency of one wave's row walk, not throughput, sets the time -> short tiles (silent_rgb.h)
-        const bool small = blocks < kRgbSmallBlocks && !(kopts & 8u);
-        if (small) TRY(build_level_tab(ctx, who, levels, n_levels, n_frames, kRgbTW, kRgbTHSmall, &tab, &blocks));
+        const unsigned kopts = ctx->tune[SILENT_TUNE_RGB];  // 1: dense, 2: no two-group, 8: 90-row tiles, bits 8-15: tile height / 2
+        // tile height: the one that minimises ceil(tiles / resident tiles) x (th + 14) row steps (silent_rgb.h)
+        int th = kRgbTH;
+        if ((kopts >> 8) & 0xffu) {
+            th = std::min(std::max((int)((kopts >> 8) & 0xffu) * 2, 2), 400);
+        } else if (!(kopts & 8u)) {
+            const long long resident = 5ll * ctx->n_cus;     // 94 VGPRs, 256 threads: 5 tiles per CU
+            long long best = -1;
+            // Launches that fill the chip several times over keep round 1's 90 rows: a sweep on config 3 (scripts/sweep_rgb_th.py:
+            // 50 ... 156 rows = 1.40 1.32 1.30 1.37 1.35 1.40 1.32 1.36 1.30 1.37 ms) shows +-4 % with no trend the rounds
+            // model predicts (tiles are not equal: ragged edges, small levels).  The model decides where it is sharp: launches
+            // of about one round or less, where it picks short tiles (the latency of one wave's row walk sets the time).
+            long long tiles90 = 0;
+            for (int l = 0; l < n_levels; ++l)
+                tiles90 += (long long)((levels[l].w + kRgbTW - 1) / kRgbTW) * ((levels[l].h + kRgbTH - 1) / kRgbTH);
+            const bool model = tiles90 * n_frames < 2 * resident;
+            for (int cand = kRgbTHMin; model && cand <= kRgbTHMax; cand += 2) {
+                long long tiles = 0;
+                for (int l = 0; l < n_levels; ++l)
+                    tiles += (long long)((levels[l].w + kRgbTW - 1) / kRgbTW) * ((levels[l].h + cand - 1) / cand);
+                tiles *= n_frames;
+                const long long cost = ((tiles + resident - 1) / resident) * (cand + 2 * kRgbHalo);
+                if (best < 0 || cost < best) {
+                    best = cost;
+                    th = cand;
+                }
+            }
+        }
+        TRY(build_level_tab(ctx, who, levels, n_levels, n_frames, kRgbTW, th, &tab, &blocks));
         if (p->flat_policy != SILENT_FLAT_IEEE && p->flat_policy != SILENT_FLAT_ZERO)
             return fail(ctx, SILENT_E_INVALID, std::string(who) + ": flat_policy must be SILENT_FLAT_IEEE or SILENT_FLAT_ZERO");
         RgbArgs a;
@@ -1123,6 +1147,7 @@ SILENT_EXPORT int silent_rgb_line_end_dev(silent_ctx* ctx, const float* pyr, con
         a.line_out = line_end_out;
         a.value_out = value_out;
         a.tab = tab;
+        a.th = th;
         auto repack = [](const float* hwio, float* dst) {  // HWIO [dy][dx][i][o] -> [o][dy][dx][i]
             for (int o = 0; o < 3; ++o)
                 for (int dy = 0; dy < 3; ++dy)
@@ -1147,26 +1172,11 @@ SILENT_EXPORT int silent_rgb_line_end_dev(silent_ctx* ctx, const float* pyr, con
         if (two) {
             std::memcpy(a.w.rgby, rs.rgby_w, sizeof(rs.rgby_w));
             std::memcpy(a.w.end, rs.end_w, sizeof(rs.end_w));
-            if (small)
-                hipLaunchKernelGGL((rgb_line_end_kernel<0x111u, true, kRgbyA, kEndA0, kEndA1, kEndA2, kRgbTHSmall>),
-                                   dim3((unsigned)blocks), dim3(256), 0, s, a);
-            else
-                hipLaunchKernelGGL((rgb_line_end_kernel<0x111u, true, kRgbyA, kEndA0, kEndA1, kEndA2>),
-                                   dim3((unsigned)blocks), dim3(256), 0, s, a);
+            hipLaunchKernelGGL((rgb_line_end_kernel<0x111u, true, kRgbyA, kEndA0, kEndA1, kEndA2>), dim3((unsigned)blocks), dim3(256), 0, s, a);
         } else if (basic) {
-            if (small)
-                hipLaunchKernelGGL((rgb_line_end_kernel<0x111u, true, kDense, kDense, kDense, kDense, kRgbTHSmall>),
-                                   dim3((unsigned)blocks), dim3(256), 0, s, a);
-            else
-                hipLaunchKernelGGL((rgb_line_end_kernel<0x111u, true, kDense, kDense, kDense, kDense>),
-                                   dim3((unsigned)blocks), dim3(256), 0, s, a);
+            hipLaunchKernelGGL((rgb_line_end_kernel<0x111u, true, kDense, kDense, kDense, kDense>), dim3((unsigned)blocks), dim3(256), 0, s, a);
         } else {
-            if (small)
-                hipLaunchKernelGGL((rgb_line_end_kernel<0x1ffu, false, kDense, kDense, kDense, kDense, kRgbTHSmall>),
-                                   dim3((unsigned)blocks), dim3(256), 0, s, a);
-            else
-                hipLaunchKernelGGL((rgb_line_end_kernel<0x1ffu, false, kDense, kDense, kDense, kDense>),
-                                   dim3((unsigned)blocks), dim3(256), 0, s, a);
+            hipLaunchKernelGGL((rgb_line_end_kernel<0x1ffu, false, kDense, kDense, kDense, kDense>), dim3((unsigned)blocks), dim3(256), 0, s, a);
         }
         return check_launch(ctx, who);
     }

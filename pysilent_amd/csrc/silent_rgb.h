@@ -51,15 +51,18 @@ struct RgbP {
 constexpr int kRgbHalo = 7;
 constexpr int kRgbCols = 64 - 2 * kRgbHalo;  // 50 output columns per wave
 constexpr int kRgbTW = 4 * kRgbCols;         // 4 waves side by side
-constexpr int kRgbTH = 90;                   // output rows per tile (50 / 72 / 90 / 108 / 120 measured: 1.44 / 1.36 / 1.33 / 1.34 / 1.40 ms)
+constexpr int kRgbTH = 90;                   // round 1's fixed tile height (50 / 72 / 90 / 108 / 120 measured: 1.44 / 1.36 / 1.33 / 1.34 / 1.40 ms)
+// Round 2: the tile height is a launch parameter (RgbArgs::th, even, kRgbTHMin .. kRgbTHMax).  Launches of about one round of
+// resident tiles or less get the height that minimises ceil(tiles / resident tiles) x (th + 14) row steps -- short tiles, the
+// generalisation of round 1's 18-row instantiation; launches that fill the chip several times keep 90 rows (the sweep in
+// silent_api.hip: +-4 % without a trend).
+constexpr int kRgbTHMin = 18, kRgbTHMax = 160;
 constexpr int kRgbChunk = 2;                 // input rows per prefetch chunk; (TH + 14) % chunk == 0
 // A wave walks its TH + 14 rows one after the other (~1.8 us per row when it has a SIMD to itself), so a launch with
 // few tiles -- one 480p frame of the reference application has 36 waves' worth -- takes 104 row steps = 190 us whatever
 // its size.  Such launches use 18-row tiles: 5x as many waves, 32 row steps each (1.78x the rows of work instead of 1.16x,
 // which only matters once the chip is full).
-constexpr int kRgbTHSmall = 18;
-constexpr long long kRgbSmallBlocks = 512;   // use the short tiles while the 90-row grid has fewer blocks than this
-static_assert((kRgbTH + 2 * kRgbHalo) % kRgbChunk == 0 && (kRgbTHSmall + 2 * kRgbHalo) % kRgbChunk == 0,
+static_assert((kRgbTH + 2 * kRgbHalo) % kRgbChunk == 0 && (kRgbTHMin + 2 * kRgbHalo) % kRgbChunk == 0,
               "row pipeline works in whole chunks");
 
 
@@ -220,6 +223,7 @@ struct RgbArgs {
     LevelTab tab;
     RgbW w;
     RgbP prm;
+    int th;   // output rows per tile (even)
 };
 
 // RGC_PAIRS: (o, i) pairs of the rgc kernel that are not identically zero; STRIPE_SUM: the stripe kernel does not
@@ -227,10 +231,10 @@ struct RgbArgs {
 // RGBY_A: group-A tap mask of the two-group form of rgby (same for the three inputs), END_A0..2: of the end bank per
 // input channel; kDense = the dense 81-fma form.
 constexpr unsigned kDense = 0xffffffffu;
-template <unsigned RGC_PAIRS, bool STRIPE_SUM, unsigned RGBY_A, unsigned END_A0, unsigned END_A1, unsigned END_A2,
-          int TH = kRgbTH>
+template <unsigned RGC_PAIRS, bool STRIPE_SUM, unsigned RGBY_A, unsigned END_A0, unsigned END_A1, unsigned END_A2>
 __global__ __launch_bounds__(256) void rgb_line_end_kernel(const RgbArgs args) {
-    constexpr int R = TH, D = kRgbChunk, NCH = (R + 2 * kRgbHalo) / D;
+    constexpr int D = kRgbChunk;
+    const int R = args.th, NCH = (R + 2 * kRgbHalo) / D;       // th is even: whole chunks
     const float* __restrict__ pyr = args.pyr;
     float* __restrict__ orient_out = args.orient_out;
     float* __restrict__ line_out = args.line_out;
