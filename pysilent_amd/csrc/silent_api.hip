@@ -274,13 +274,26 @@ SILENT_EXPORT int silent_gather_d2h(silent_ctx* ctx, void* dst_host, const void*
                                     int n, silent_stream stream) {
     NEED_CTX(ctx);
     if (n < 0 || (n && (!dst_host || !src_dev || !bytes))) return fail(ctx, SILENT_E_INVALID, "silent_gather_d2h: NULL pointer");
-    char* dst = (char*)dst_host;
+    size_t total = 0;
     for (int i = 0; i < n; ++i) {
         if (bytes[i] && !src_dev[i]) return fail(ctx, SILENT_E_INVALID, "silent_gather_d2h: NULL source");
-        HIP_TRY(ctx, hipMemcpyAsync(dst, src_dev[i], bytes[i], hipMemcpyDeviceToHost, (hipStream_t)stream));
-        dst += bytes[i];
+        total += bytes[i];
     }
-    HIP_TRY(ctx, hipStreamSynchronize((hipStream_t)stream));
+    hipStream_t s = (hipStream_t)stream;
+    if (n == 1) {
+        HIP_TRY(ctx, hipMemcpyAsync(dst_host, src_dev[0], bytes[0], hipMemcpyDeviceToHost, s));
+    } else if (n > 1 && total) {
+        // device-to-device into the context's staging arena (asynchronous, no host round trip each), then ONE copy to the
+        // host: n separate copies into pageable memory cost a staging synchronisation each
+        TRY(grow(ctx, ctx->arena, total));
+        char* d = (char*)ctx->arena.p;
+        for (int i = 0; i < n; ++i) {
+            if (bytes[i]) HIP_TRY(ctx, hipMemcpyAsync(d, src_dev[i], bytes[i], hipMemcpyDeviceToDevice, s));
+            d += bytes[i];
+        }
+        HIP_TRY(ctx, hipMemcpyAsync(dst_host, ctx->arena.p, total, hipMemcpyDeviceToHost, s));
+    }
+    HIP_TRY(ctx, hipStreamSynchronize(s));
     return SILENT_OK;
 }
 
