@@ -16,6 +16,7 @@
 #include "silent_peaks.h"
 #include "silent_pyramid.h"
 #include "silent_rgb.h"
+#include "silent_rgb2.h"
 #include "silent_walk.h"
 #include "silent_walk_rgb.h"
 #include "silent_walk1.h"
@@ -1151,7 +1152,8 @@ SILENT_EXPORT int silent_rgb_line_end_dev(silent_ctx* ctx, const float* pyr, con
                 }
             }
         }
-        TRY(build_level_tab(ctx, who, levels, n_levels, n_frames, kRgbTW, th, &tab, &blocks));
+        const bool pair_kernel = !(kopts & 16u);  // two pixels per lane on packed f32 (silent_rgb2.h); 16: one pixel per lane
+        TRY(build_level_tab(ctx, who, levels, n_levels, n_frames, pair_kernel ? kRgb2TW : kRgbTW, th, &tab, &blocks));
         if (p->flat_policy != SILENT_FLAT_IEEE && p->flat_policy != SILENT_FLAT_ZERO)
             return fail(ctx, SILENT_E_INVALID, std::string(who) + ": flat_policy must be SILENT_FLAT_IEEE or SILENT_FLAT_ZERO");
         RgbArgs a;
@@ -1185,6 +1187,22 @@ SILENT_EXPORT int silent_rgb_line_end_dev(silent_ctx* ctx, const float* pyr, con
         if (two) {
             std::memcpy(a.w.rgby, rs.rgby_w, sizeof(rs.rgby_w));
             std::memcpy(a.w.end, rs.end_w, sizeof(rs.end_w));
+        }
+        if (pair_kernel) {
+            Rgb2Args a2;
+            a2.pyr = a.pyr;
+            a2.orient_out = a.orient_out;
+            a2.line_out = a.line_out;
+            a2.value_out = a.value_out;
+            a2.tab = a.tab;
+            a2.prm = a.prm;
+            a2.th = a.th;
+            std::memset(a2.ws, 0, sizeof(a2.ws));
+            rgb2_fill_stream(a.w, basic ? 0x111u : 0x1ffu, basic, two, two, a2.ws);
+            if (two) hipLaunchKernelGGL((rgb_line_end2_kernel<0x111u, true, kRgbyA, kEndA0, kEndA1, kEndA2>), dim3((unsigned)blocks), dim3(256), 0, s, a2);
+            else if (basic) hipLaunchKernelGGL((rgb_line_end2_kernel<0x111u, true, kDense, kDense, kDense, kDense>), dim3((unsigned)blocks), dim3(256), 0, s, a2);
+            else hipLaunchKernelGGL((rgb_line_end2_kernel<0x1ffu, false, kDense, kDense, kDense, kDense>), dim3((unsigned)blocks), dim3(256), 0, s, a2);
+        } else if (two) {
             hipLaunchKernelGGL((rgb_line_end_kernel<0x111u, true, kRgbyA, kEndA0, kEndA1, kEndA2>), dim3((unsigned)blocks), dim3(256), 0, s, a);
         } else if (basic) {
             hipLaunchKernelGGL((rgb_line_end_kernel<0x111u, true, kDense, kDense, kDense, kDense>), dim3((unsigned)blocks), dim3(256), 0, s, a);

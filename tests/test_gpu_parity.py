@@ -583,6 +583,39 @@ def test_rgb_chain_structured_and_dense_kernels_agree(rt, kernels):
     assert_close(fast["orient"], want["orient"], RTOL, what="orient vs oracle")
 
 
+@pytest.mark.parametrize("shape", [(2, 70, 131, 3), (1, 33, 448, 3), (1, 211, 449, 3), (3, 19, 5, 3), (1, 1, 1, 3),
+                                   (1, 100, 113, 3), (1, 95, 912, 3)])
+@pytest.mark.parametrize("variant", [0, 1, 2])
+def test_rgb_pair_kernel_is_bit_identical_to_the_one_pixel_kernel(rt, kernels, shape, variant):
+    """rgb_line_end2_kernel (two adjacent pixels per lane, v_pk_fma_f32 with the SGPR weight for both halves; default) against
+    rgb_line_end_kernel (TUNE_RGB bit 16): each half of a packed fma chain is the fmaf chain of its pixel in the same order,
+    so every output bit must agree -- for the structured, the basic and the dense instantiation, on odd widths, widths
+    around the 112 / 448-column wave / tile boundaries, single pixels, NaN / inf pixels, both flat policies and 18 / 90-row
+    tiles."""
+    rng = np.random.default_rng(shape[1] * 1000 + shape[2])
+    frames = np.stack([noise_frame(50 + i, shape[1], shape[2], 3) for i in range(shape[0])])
+    if shape[1] > 8:
+        frames[0, 3:9, : max(1, shape[2] // 3)] = 0.0            # a flat region: 0 * inf under 'ieee'
+    if shape[1] * shape[2] > 64:
+        ys = rng.integers(0, shape[1], 5)
+        xs = rng.integers(0, shape[2], 5)
+        frames[0, ys[0], xs[0], 1] = np.nan
+        frames[0, ys[1], xs[1], 0] = -np.nan
+        frames[0, ys[2], xs[2], 2] = np.inf
+        frames[0, ys[3], xs[3], 0] = -np.inf
+    for policy in ("ieee", "zero"):
+        for tall in (0, 8):
+            with rt.tuning(TUNE_RGB, variant | tall):
+                pair = rt.rgb_line_end(frames, kernels, flat_policy=policy)
+            with rt.tuning(TUNE_RGB, variant | tall | 16):
+                one = rt.rgb_line_end(frames, kernels, flat_policy=policy)
+            for name in ("orient", "line_end", "value"):
+                a, b = pair[name], one[name]
+                assert a.shape == b.shape
+                assert np.array_equal(np.isnan(a), np.isnan(b)), (name, policy, tall)
+                np.testing.assert_array_equal(np.nan_to_num(a, nan=7.0), np.nan_to_num(b, nan=7.0), err_msg="%s %s %d" % (name, policy, tall))
+
+
 @pytest.mark.parametrize("root", [0.0, 0.5, 1.0])
 def test_rgb_chain_regulation_roots(rt, kernels, root):
     """The fused chain's regulator power (exp2(root * log2 m), powf for root = 0 and denormal m) against the oracle for
