@@ -367,9 +367,10 @@ __global__ __launch_bounds__(256) void rgb_line_end2_kernel(const Rgb2Args args)
 #pragma unroll
         for (int c = 0; c < 3; ++c) hist[k][c] = zero2;
 
-    // raw: the current row's pixels (masked), nraw: the next row's as loaded -- the zero fill outside the image is applied
-    // when the row is taken over, not at the load, so that nothing consumes the load early
-    float raw[6], nraw[6];
+    // raw: the current row's pixels (masked); nb[r & 1]: row r as loaded, fetched TWO steps ahead (the row loop is unrolled by
+    // two so that the two buffers alternate without a move -- a move would consume the load) -- the zero fill outside the
+    // image is applied when a row is taken over, not at the load, so that nothing consumes a load early
+    float raw[6], nb0[6], nb1[6];
     auto fetch = [&](float (&buf)[6], int row) {
         const int y = y0 - kRgb2RowHalo + row;
         const float* __restrict__ p = src + (long long)min(max(y, 0), H - 1) * W * 3;
@@ -379,21 +380,22 @@ __global__ __launch_bounds__(256) void rgb_line_end2_kernel(const Rgb2Args args)
             buf[3 + c] = p[xoff1 + c];
         }
     };
-    auto take = [&](int row) {
+    auto take = [&](const float (&buf)[6], int row) {
         const int y = y0 - kRgb2RowHalo + row;
         const bool rok = y >= 0 && y < H;
 #pragma unroll
         for (int c = 0; c < 3; ++c) {
-            raw[c] = (rok && col0) ? nraw[c] : 0.0f;
-            raw[3 + c] = (rok && col1) ? nraw[3 + c] : 0.0f;
+            raw[c] = (rok && col0) ? buf[c] : 0.0f;
+            raw[3 + c] = (rok && col1) ? buf[3 + c] : 0.0f;
         }
     };
-    fetch(nraw, 0);
-    take(0);
+    fetch(nb0, 0);
+    fetch(nb1, 1);
+    take(nb0, 0);
 
-#pragma unroll 1
-    for (int row = 0; row < NROWS; ++row) {
-        if (row + 1 < NROWS) fetch(nraw, row + 1);
+    // one row step: `mine` held this row (free now: row + 2 is fetched into it), `next` holds row + 1
+    auto step = [&](int row, float (&mine)[6], float (&next)[6]) {
+        fetch(mine, min(row + 2, NROWS - 1));   // (clamped: the last two fetches are not used)
         const int yin = y0 - kRgb2RowHalo + row;  // input row of this step
         f2 v[3][3], g[3];
         // ---- rgc: completes row yin - 1
@@ -506,7 +508,7 @@ __global__ __launch_bounds__(256) void rgb_line_end2_kernel(const Rgb2Args args)
         // The next row's pixels are taken over BEFORE this step's stores are issued: vmcnt counts loads and stores in one
         // in-order queue, so a wait for the loads placed after the stores waits for the stores' completion as well
         // (leave-one-out: 1.43 ms with that wait, 1.02 without the stores, 0.94 without the loads).
-        take(row + 1);
+        take(next, row + 1);
         asm volatile("" : "+v"(raw[0]), "+v"(raw[1]), "+v"(raw[2]), "+v"(raw[3]), "+v"(raw[4]), "+v"(raw[5]) : : "memory");
         if (orient_out && t >= y0 && t < y0 + R && t < H) {
             float* __restrict__ po = orient_out + (base_px + (long long)t * W + x0) * 3;
@@ -559,6 +561,11 @@ __global__ __launch_bounds__(256) void rgb_line_end2_kernel(const Rgb2Args args)
             }
         }
         ws.template skip<L::total, L::blocks * kRgb2Blk>();
+    };
+#pragma unroll 1
+    for (int row = 0; row < NROWS; row += 2) {   // th is even: whole pairs of rows
+        step(row, nb0, nb1);
+        step(row + 1, nb1, nb0);
     }
 }
 
