@@ -1152,7 +1152,10 @@ SILENT_EXPORT int silent_rgb_line_end_dev(silent_ctx* ctx, const float* pyr, con
                 }
             }
         }
-        const bool pair_kernel = !(kopts & 16u);  // two pixels per lane on packed f32 (silent_rgb2.h); 16: one pixel per lane
+        // two pixels per lane on packed f32 (silent_rgb2.h; its buffer addressing wants levels below 2^30 bytes per map); 16: one pixel per lane
+        bool pair_kernel = !(kopts & 16u);
+        for (int l = 0; l < n_levels; ++l)
+            if ((long long)levels[l].h * levels[l].w * 12 >= (long long)kRgb2Out) pair_kernel = false;
         TRY(build_level_tab(ctx, who, levels, n_levels, n_frames, pair_kernel ? kRgb2TW : kRgbTW, th, &tab, &blocks));
         if (p->flat_policy != SILENT_FLAT_IEEE && p->flat_policy != SILENT_FLAT_ZERO)
             return fail(ctx, SILENT_E_INVALID, std::string(who) + ": flat_policy must be SILENT_FLAT_IEEE or SILENT_FLAT_ZERO");

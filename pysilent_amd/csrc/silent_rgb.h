@@ -204,6 +204,17 @@ __device__ __forceinline__ void conv3_roll_sum(const float (&s)[3], kfloat_p wst
     }
 }
 
+// The regulator's factor rv / min(b, 1) ** root, evaluated as rv * exp2(-root * log2(m)) on the transcendental unit
+// (v_log_f32, v_exp_f32: 1 ulp each; <= 3 ulp in all since |root * log2 m| stays small) -- no powf (~100 instructions) and no
+// IEEE division (~10).  m = 0 gives exp2(+inf) = inf like rv / 0.  v_log_f32 treats denormal inputs as 0: below 2^-100 the
+// accurate powf and a true division run (a lane-divergent branch that no lane takes in practice), and for root = 0
+// (0 * -inf; pow(0, 0) = 1).  silent_regulate / conv2d_same_kernel keep powf.
+__device__ __forceinline__ float regulator_ratio(float bd, float rv, float root) {
+    const float m = bd > 1.0f ? 1.0f : bd;
+    if ((m > 0.0f && m < 7.8886e-31f) || root == 0.0f) return rv / powf(m, root);
+    return rv * __builtin_amdgcn_exp2f(-root * __builtin_amdgcn_logf(m));
+}
+
 __device__ __forceinline__ void with_neighbours(const float (&c)[3], float (&v)[3][3]) {
 #pragma unroll
     for (int i = 0; i < 3; ++i) {
@@ -371,15 +382,7 @@ __global__ __launch_bounds__(256) void rgb_line_end_kernel(const RgbArgs args) {
             const int t = yin - 6;
             float o3[3];
             {
-                const float m = bdone > 1.0f ? 1.0f : bdone;
-                // m ** root as exp2(root * log2(m)) on the transcendental unit (v_log_f32 / v_exp_f32, 1 ulp each: <= 3 ulp
-                // here since |root * log2 m| stays small) instead of the ~100-instruction powf; m is in (0, 1] or 0.
-                // v_log_f32 treats denormal inputs as 0: below 2^-100 the accurate powf runs (a lane-divergent branch that no
-                // lane takes in practice).  silent_regulate / conv2d_same_kernel keep powf.
-                float pw;
-                if ((m > 0.0f && m < 7.8886e-31f) || prm.root == 0.0f) pw = powf(m, prm.root);  // (0 * -inf: pow(0, 0) = 1)
-                else pw = __builtin_amdgcn_exp2f(prm.root * __builtin_amdgcn_logf(m));
-                const float r = prm.rv / pw;
+                const float r = regulator_ratio(bdone, prm.rv, prm.root);
                 const bool ok = t >= 0 && t < H && col_ok;
 #pragma unroll
                 for (int c = 0; c < 3; ++c) {

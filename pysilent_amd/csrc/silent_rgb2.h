@@ -29,6 +29,7 @@ constexpr int kRgb2Halo = 8;                     // pixels per side (4 lanes); 7
 constexpr int kRgb2Cols = 128 - 2 * kRgb2Halo;   // 112 output columns per wave
 constexpr int kRgb2TW = 4 * kRgb2Cols;           // 4 waves side by side
 constexpr int kRgb2RowHalo = 7;                  // rows above / below a tile (same as silent_rgb.h)
+constexpr int kRgb2Out = 0x40000000;             // byte offset of "outside": lane + row parts add up to >= this; levels are smaller
 
 // ---- the weight stream -------------------------------------------------------------------------------------------
 // The kernel consumes its weights in ONE fixed order per row step, so the host lays them out in that order
@@ -321,7 +322,7 @@ __device__ __forceinline__ void conv3_roll2_sum(const f2 (&s)[3], WS& ws, f2 (&p
 __device__ __forceinline__ float relu_ok(float v, bool ok) { return ok ? relu_tf(v) : 0.0f; }
 
 template <unsigned RGC_PAIRS, bool STRIPE_SUM, unsigned RGBY_A, unsigned END_A0, unsigned END_A1, unsigned END_A2>
-__global__ __launch_bounds__(256) void rgb_line_end2_kernel(const Rgb2Args args) {
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 8))) void rgb_line_end2_kernel(const Rgb2Args args) {
     typedef Rgb2Layout<RGC_PAIRS, STRIPE_SUM, RGBY_A != kDense, END_A0 != kDense> L;
     static_assert(L::blocks * kRgb2Blk <= kRgb2StreamMax, "stream fits its kernarg array");
     const int R = args.th, NROWS = R + 2 * kRgb2RowHalo;
@@ -348,11 +349,30 @@ __global__ __launch_bounds__(256) void rgb_line_end2_kernel(const Rgb2Args args)
     const int y0 = tc.ty * R;
     const int x0 = xw0 + 2 * lane - kRgb2Halo, x1 = x0 + 1;  // the lane's pixel pair
     const bool col0 = x0 >= 0 && x0 < W, col1 = x1 >= 0 && x1 < W;
-    const long long xoff0 = (long long)min(max(x0, 0), W - 1) * 3, xoff1 = (long long)min(max(x1, 0), W - 1) * 3;
     const bool out_lane = lane >= kRgb2Halo / 2 && lane < 64 - kRgb2Halo / 2;
     const bool out0 = out_lane && x0 < W, out1 = out_lane && x1 < W;
+    // All pixel traffic goes through RAW BUFFER instructions on per-level resources (base = this frame's level, num_records =
+    // its bytes): a lane or row outside the image gets an offset >= kRgb2Out, which the range check turns into a load of 0 --
+    // the zero padding of the SAME convolutions -- or into a dropped store.  So there is no clamping, no select and, above
+    // all, NO BRANCH around a store: every step issues the same 2 loads + 6 stores, the compiler knows the in-order vmcnt
+    // distance exactly, and the wait for a row fetched two steps ago does not wait for the stores issued since (with
+    // exec-masked store blocks it cannot know how many were issued and waits for all of them: 1.06 ms, 0.83 without stores).
+    const unsigned lvl_bytes = (unsigned)H * (unsigned)W * 12u;   // < kRgb2Out (host-checked)
+    const __amdgpu_buffer_rsrc_t r_src = __builtin_amdgcn_make_buffer_rsrc((void*)src, 0, lvl_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t r_orient = __builtin_amdgcn_make_buffer_rsrc((void*)(orient_out + base_px * 3), 0, orient_out ? lvl_bytes : 0u, 0x00020000);
+    const __amdgpu_buffer_rsrc_t r_line = __builtin_amdgcn_make_buffer_rsrc((void*)(line_out + base_px * 3), 0, line_out ? lvl_bytes : 0u, 0x00020000);
+    const __amdgpu_buffer_rsrc_t r_value = __builtin_amdgcn_make_buffer_rsrc((void*)(value_out + base_px), 0, value_out ? lvl_bytes / 3u : 0u, 0x00020000);
+    const int in0 = col0 ? x0 * 12 : kRgb2Out, in1 = col1 ? x1 * 12 : kRgb2Out;     // byte offsets inside a row, or out of range
+    // Stores: a lane's own pixel pair would make every x3 store instruction write 12 of every 24 bytes (its partner instruction
+    // the other 12) -- measured 15 % slower than runs of whole pixels per instruction (profiles/r02/rgb_pair_kernel.txt).  So an
+    // output row goes through a per-wave LDS row (s_tr: written as the lanes hold it, read back pixel-major): store A writes
+    // pixels 0..63 of the wave's 128 columns (768 contiguous bytes), store B pixels 64..127.
+    const int xa = xw0 - kRgb2Halo + lane, xb = xa + 64;
+    const int sta = (lane >= kRgb2Halo && xa < W) ? xa * 12 : kRgb2Out, stb = (lane < 64 - kRgb2Halo && xb < W) ? xb * 12 : kRgb2Out;
+    // value: the lane's two floats are adjacent in memory: one 8-byte store where both pixels exist, a 4-byte one for a last odd column
+    const int sv2 = (out0 && out1) ? x0 * 4 : kRgb2Out, sv1 = (out0 && !out1) ? x0 * 4 : kRgb2Out;
     const bool padc0 = x0 >= prm.pad && x0 < W - prm.pad, padc1 = x1 >= prm.pad && x1 < W - prm.pad;
-    const float inv3 = 1.0f / 3.0f;
+    const f2 inv3p = {1.0f / 3.0f, 1.0f / 3.0f};
     const f2 zero2 = {0.0f, 0.0f};
 
     // rolling state (pairs)
@@ -361,49 +381,58 @@ __global__ __launch_bounds__(256) void rgb_line_end2_kernel(const Rgb2Args args)
     f2 a3[3] = {zero2, zero2, zero2}, b3[3] = {zero2, zero2, zero2};
     f2 a5[6] = {zero2, zero2, zero2, zero2, zero2, zero2}, b5[6] = {zero2, zero2, zero2, zero2, zero2, zero2};
     f2 pb[7] = {zero2, zero2, zero2, zero2, zero2, zero2, zero2};
-    f2 hist[4][3];
+    // The stripe rows wait three steps for their blur row: a 4-slot delay line per wave in LDS (each lane reads back what it
+    // wrote itself: no barrier) instead of 24 VGPRs -- with them the kernel is over 128 registers, i.e. 3 instead of 4 waves/SIMD.
+    __shared__ f2 s_hist[4][4][3][64];   // [wave][slot = row & 3][channel][lane]
+    __shared__ float s_tr[4][128 * 3];   // [wave][one output row of the wave's 128 columns x 3 channels]
+    float* const tr = s_tr[wave];
+    // lane-major in (as held), pixel-major out; LDS operations of one wave execute in order, so no wait / barrier in between
+    typedef int i3 __attribute__((ext_vector_type(3)));
+    auto store_row3 = [&](const f2 (&val)[3], __amdgpu_buffer_rsrc_t rsrc, int ro) {
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            tr[lane * 6 + c] = val[c].x;
+            tr[lane * 6 + 3 + c] = val[c].y;
+        }
+        const i3 da = {__float_as_int(tr[lane * 3 + 0]), __float_as_int(tr[lane * 3 + 1]), __float_as_int(tr[lane * 3 + 2])};
+        const i3 db = {__float_as_int(tr[192 + lane * 3 + 0]), __float_as_int(tr[192 + lane * 3 + 1]), __float_as_int(tr[192 + lane * 3 + 2])};
+        __builtin_amdgcn_raw_buffer_store_b96(da, rsrc, sta + ro, 0, 0);
+        __builtin_amdgcn_raw_buffer_store_b96(db, rsrc, stb + ro, 0, 0);
+    };
 #pragma unroll
     for (int k = 0; k < 4; ++k)
 #pragma unroll
-        for (int c = 0; c < 3; ++c) hist[k][c] = zero2;
+        for (int c = 0; c < 3; ++c) s_hist[wave][k][c][lane] = zero2;
 
-    // raw: the current row's pixels (masked); nb[r & 1]: row r as loaded, fetched TWO steps ahead (the row loop is unrolled by
-    // two so that the two buffers alternate without a move -- a move would consume the load) -- the zero fill outside the
-    // image is applied when a row is taken over, not at the load, so that nothing consumes a load early
-    float raw[6], nb0[6], nb1[6];
-    auto fetch = [&](float (&buf)[6], int row) {
+    // nb[r & 1]: input row r, fetched TWO steps ahead; the row loop is unrolled by two so that the two buffers alternate without
+    // a move (a move would consume the load early)
+    i3 nb0[2], nb1[2];
+    auto fetch = [&](i3 (&buf)[2], int row) {
         const int y = y0 - kRgb2RowHalo + row;
-        const float* __restrict__ p = src + (long long)min(max(y, 0), H - 1) * W * 3;
-#pragma unroll
-        for (int c = 0; c < 3; ++c) {
-            buf[c] = p[xoff0 + c];
-            buf[3 + c] = p[xoff1 + c];
-        }
-    };
-    auto take = [&](const float (&buf)[6], int row) {
-        const int y = y0 - kRgb2RowHalo + row;
-        const bool rok = y >= 0 && y < H;
-#pragma unroll
-        for (int c = 0; c < 3; ++c) {
-            raw[c] = (rok && col0) ? buf[c] : 0.0f;
-            raw[3 + c] = (rok && col1) ? buf[3 + c] : 0.0f;
-        }
+        const int ro = (y >= 0 && y < H) ? y * W * 12 : kRgb2Out;
+        buf[0] = __builtin_amdgcn_raw_buffer_load_b96(r_src, in0 + ro, 0, 0);
+        buf[1] = __builtin_amdgcn_raw_buffer_load_b96(r_src, in1 + ro, 0, 0);
     };
     fetch(nb0, 0);
     fetch(nb1, 1);
-    take(nb0, 0);
+    // The wait at the head of the row loop merges two paths: the back edge (14 younger operations behind the loads it waits for:
+    // 6 + 6 stores and 2 loads) and this prologue (2: the second fetch) -- the compiler takes the minimum, vmcnt(2), which on
+    // the back edge waits for the previous iteration's 12 stores.  Twelve out-of-range (dropped) stores make both paths 14.
+#pragma unroll
+    for (int k = 0; k < 12; ++k) __builtin_amdgcn_raw_buffer_store_b32(k, r_value, kRgb2Out + 64 * k, 0, 0);   // (distinct: identical ones are merged)
 
-    // one row step: `mine` held this row (free now: row + 2 is fetched into it), `next` holds row + 1
-    auto step = [&](int row, float (&mine)[6], float (&next)[6]) {
-        fetch(mine, min(row + 2, NROWS - 1));   // (clamped: the last two fetches are not used)
+    // one row step: `mine` holds this row; row + 2 is fetched into it as soon as the row has been taken
+    auto step = [&](int row, i3 (&mine)[2]) {
         const int yin = y0 - kRgb2RowHalo + row;  // input row of this step
         f2 v[3][3], g[3];
         // ---- rgc: completes row yin - 1
 #pragma unroll
         for (int c = 0; c < 3; ++c) {
-            v[1][c] = f2{raw[c], raw[3 + c]};
+            v[1][c] = f2{__int_as_float(mine[0][c]), __int_as_float(mine[1][c])};
             neighbours2(v[1][c], v[0][c], v[2][c]);
         }
+        asm volatile("" : "+v"(v[1][0]), "+v"(v[1][1]), "+v"(v[1][2]));   // taken: the buffer is free
+        fetch(mine, row + 2);   // (rows past the tile's last input row are fetched and not used)
         conv3_roll2<RGC_PAIRS & 0x1ffu, L::b_rgc>(v, ws, a1, b1, g);
         {
             const bool rok = yin - 1 >= 0 && yin - 1 < H;
@@ -442,12 +471,12 @@ __global__ __launch_bounds__(256) void rgb_line_end2_kernel(const Rgb2Args args)
 #pragma unroll
             for (int c = 0; c < 3; ++c) g[c] = f2{relu_ok(g[c].x, rok && col0), relu_ok(g[c].y, rok && col1)};
         }
+        f2 xs3[3];   // the stripe row of three steps ago
 #pragma unroll
-        for (int k = 3; k > 0; --k)
-#pragma unroll
-            for (int c = 0; c < 3; ++c) hist[k][c] = hist[k - 1][c];
-#pragma unroll
-        for (int c = 0; c < 3; ++c) hist[0][c] = g[c];
+        for (int c = 0; c < 3; ++c) {
+            s_hist[wave][row & 3][c][lane] = g[c];
+            xs3[c] = s_hist[wave][(row + 1) & 3][c][lane];
+        }
         // ---- blur of the channel sum: stripe row q feeds blur rows q-3 .. q+3; row t = q - 3 completes
         f2 bdone;
         {
@@ -486,42 +515,21 @@ __global__ __launch_bounds__(256) void rgb_line_end2_kernel(const Rgb2Args args)
         f2 o3[3];
         {
             const bool rok = t >= 0 && t < H;
-            auto ratio = [&](float bd) {
-                const float m = bd > 1.0f ? 1.0f : bd;
-                float pw;
-                if ((m > 0.0f && m < 7.8886e-31f) || prm.root == 0.0f) pw = powf(m, prm.root);
-                else pw = __builtin_amdgcn_exp2f(prm.root * __builtin_amdgcn_logf(m));
-                return prm.rv / pw;
-            };
-            const float r0 = ratio(bdone.x), r1 = ratio(bdone.y);
+            const f2 rr = {regulator_ratio(bdone.x, prm.rv, prm.root), regulator_ratio(bdone.y, prm.rv, prm.root)};
 #pragma unroll
             for (int c = 0; c < 3; ++c) {
-                const f2 xs = hist[3][c];
-                float ya = xs.x * r0, yb = xs.y * r1;
+                const f2 xs = xs3[c];
+                f2 y = xs * rr;
                 if (prm.flat_policy == SILENT_FLAT_ZERO) {
-                    if (xs.x == 0.0f) ya = 0.0f;
-                    if (xs.y == 0.0f) yb = 0.0f;
+                    if (xs.x == 0.0f) y.x = 0.0f;
+                    if (xs.y == 0.0f) y.y = 0.0f;
                 }
-                o3[c] = f2{(rok && col0) ? ya : 0.0f, (rok && col1) ? yb : 0.0f};
+                o3[c] = f2{(rok && col0) ? y.x : 0.0f, (rok && col1) ? y.y : 0.0f};
             }
         }
-        // The next row's pixels are taken over BEFORE this step's stores are issued: vmcnt counts loads and stores in one
-        // in-order queue, so a wait for the loads placed after the stores waits for the stores' completion as well
-        // (leave-one-out: 1.43 ms with that wait, 1.02 without the stores, 0.94 without the loads).
-        take(next, row + 1);
-        asm volatile("" : "+v"(raw[0]), "+v"(raw[1]), "+v"(raw[2]), "+v"(raw[3]), "+v"(raw[4]), "+v"(raw[5]) : : "memory");
-        if (orient_out && t >= y0 && t < y0 + R && t < H) {
-            float* __restrict__ po = orient_out + (base_px + (long long)t * W + x0) * 3;
-            if (out0) {
-                po[0] = o3[0].x;
-                po[1] = o3[1].x;
-                po[2] = o3[2].x;
-            }
-            if (out1) {
-                po[3] = o3[0].y;
-                po[4] = o3[1].y;
-                po[5] = o3[2].y;
-            }
+        {
+            const int ro = (t >= y0 && t < y0 + R && t < H) ? t * W * 12 : kRgb2Out;
+            store_row3(o3, r_orient, ro);
         }
         // ---- end bank: completes row yout = yin - 7
 #pragma unroll
@@ -532,40 +540,27 @@ __global__ __launch_bounds__(256) void rgb_line_end2_kernel(const Rgb2Args args)
         if constexpr (END_A0 != kDense) conv3_roll2_struct<END_A0, END_A1, END_A2, L::b_end>(v, ws, a5, b5, g);
         else conv3_roll2<0x1ffu, L::b_end>(v, ws, reinterpret_cast<f2 (&)[3]>(a5), reinterpret_cast<f2 (&)[3]>(b5), g);
         const int yout = yin - 7;
-        if (yout >= y0 && yout < H) {
+        {
+            const bool rows = yout >= y0 && yout < H;
             const bool padr = yout >= prm.pad && yout < H - prm.pad;
-            const float mk0 = (padc0 && padr) ? 1.0f : 0.0f, mk1 = (padc1 && padr) ? 1.0f : 0.0f;
-            float le0[3], le1[3];
+            const f2 mk = {(padc0 && padr) ? 1.0f : 0.0f, (padc1 && padr) ? 1.0f : 0.0f};
+            f2 le[3];
 #pragma unroll
-            for (int c = 0; c < 3; ++c) {
-                le0[c] = mk0 * clip_hi_tf(relu_tf(g[c].x), prm.clip_hi);
-                le1[c] = mk1 * clip_hi_tf(relu_tf(g[c].y), prm.clip_hi);
-            }
-            const long long px = base_px + (long long)yout * W + x0;
-            if (line_out) {
-                float* __restrict__ pl = line_out + px * 3;
-                if (out0) {
-                    pl[0] = le0[0];
-                    pl[1] = le0[1];
-                    pl[2] = le0[2];
-                }
-                if (out1) {
-                    pl[3] = le1[0];
-                    pl[4] = le1[1];
-                    pl[5] = le1[2];
-                }
-            }
-            if (value_out) {
-                if (out0) value_out[px] = __fmul_rn(__fadd_rn(__fadd_rn(le0[0], le0[1]), le0[2]), inv3);
-                if (out1) value_out[px + 1] = __fmul_rn(__fadd_rn(__fadd_rn(le1[0], le1[1]), le1[2]), inv3);
-            }
+            for (int c = 0; c < 3; ++c)
+                le[c] = mk * f2{clip_hi_tf(relu_tf(g[c].x), prm.clip_hi), clip_hi_tf(relu_tf(g[c].y), prm.clip_hi)};
+            const int ro = rows ? yout * W * 12 : kRgb2Out, rv = rows ? yout * W * 4 : kRgb2Out;
+            store_row3(le, r_line, ro);
+            const f2 val = ((le[0] + le[1]) + le[2]) * inv3p;
+            typedef int i2 __attribute__((ext_vector_type(2)));
+            __builtin_amdgcn_raw_buffer_store_b64(i2{__float_as_int(val.x), __float_as_int(val.y)}, r_value, sv2 + rv, 0, 0);
+            __builtin_amdgcn_raw_buffer_store_b32(__float_as_int(val.x), r_value, sv1 + rv, 0, 0);
         }
         ws.template skip<L::total, L::blocks * kRgb2Blk>();
     };
 #pragma unroll 1
     for (int row = 0; row < NROWS; row += 2) {   // th is even: whole pairs of rows
-        step(row, nb0, nb1);
-        step(row + 1, nb1, nb0);
+        step(row, nb0);
+        step(row + 1, nb1);
     }
 }
 

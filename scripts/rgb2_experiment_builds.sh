@@ -18,14 +18,55 @@ def rep(a, b):
 if name == "noweights":     # the weight stream is never refilled: blocks 0 / 1 requested once, no waits
     rep("            wait_weights();\n            request<(blk + 1) % NB>();", "")
     rep("    ws.template request<0>();", "    ws.template request<0>();\n    ws.template request<1>();")
-elif name == "nostore":
-    rep("if (orient_out && t >= y0", "if (orient_out && prm.pad == -12345 && t >= y0")
-    rep("        if (yout >= y0 && yout < H) {", "        if (yout >= y0 && yout < H && prm.pad == -12345) {")
-elif name == "noload":      # pixel rows are not fetched
-    rep("        if (row + 1 < NROWS) fetch(nraw, row + 1);", "        if (row + 1 < NROWS && prm.pad == -12345) fetch(nraw, row + 1);")
+elif name == "nostore":     # stores are issued but dropped by the range check (num_records = 0)
+    rep("orient_out ? lvl_bytes : 0u", "0u")
+    rep("line_out ? lvl_bytes : 0u", "0u")
+    rep("value_out ? lvl_bytes / 3u : 0u", "0u")
+elif name == "noload":      # pixel rows are not fetched inside the loop
+    rep("        fetch(mine, row + 2);", "        if (prm.pad == -12345) fetch(mine, row + 2);")
+elif name == "norelu":      # the three inner relu / zero-fill selects become plain copies
+    rep("g[c] = f2{relu_ok(g[c].x, rok && col0), relu_ok(g[c].y, rok && col1)};", "g[c] = g[c];")
+elif name == "storesame":   # every store goes to the first rows of the level (same instructions, L2-resident lines: no DRAM write stream)
+    rep("const int ro = (t >= y0 && t < y0 + R && t < H) ? t * W * 12 : kRgb2Out;", "const int ro = (t >= y0 && t < y0 + R && t < H) ? (t & 1) * W * 12 : kRgb2Out;")
+    rep("const int ro = rows ? yout * W * 12 : kRgb2Out, rv = rows ? yout * W * 4 : kRgb2Out;", "const int ro = rows ? (yout & 1) * W * 12 : kRgb2Out, rv = rows ? (yout & 1) * W * 4 : kRgb2Out;")
+elif name == "loadsame":    # every fetch reads one of the first two rows of the level (L2 hits)
+    rep("const int ro = (y >= 0 && y < H) ? y * W * 12 : kRgb2Out;", "const int ro = (y >= 0 && y < H) ? (y & 1) * W * 12 : kRgb2Out;")
+elif name == "ntall":       # nt bit on all six stores
+    rep("r_orient, st0 + ro, 0, 0);", "r_orient, st0 + ro, 0, 2);")
+    rep("r_orient, st1 + ro, 0, 0);", "r_orient, st1 + ro, 0, 2);")
+    rep("r_line, st0 + ro, 0, 0);", "r_line, st0 + ro, 0, 2);")
+    rep("r_line, st1 + ro, 0, 0);", "r_line, st1 + ro, 0, 2);")
+    rep("r_value, sv0 + rv, 0, 0);", "r_value, sv0 + rv, 0, 2);")
+    rep("r_value, sv1 + rv, 0, 0);", "r_value, sv1 + rv, 0, 2);")
+elif name == "ntol":        # nt bit on the orient / line_end stores
+    rep("r_orient, st0 + ro, 0, 0);", "r_orient, st0 + ro, 0, 2);")
+    rep("r_orient, st1 + ro, 0, 0);", "r_orient, st1 + ro, 0, 2);")
+    rep("r_line, st0 + ro, 0, 0);", "r_line, st0 + ro, 0, 2);")
+    rep("r_line, st1 + ro, 0, 0);", "r_line, st1 + ro, 0, 2);")
+elif name == "ntld":        # nt bit on the loads too
+    rep("r_src, in0 + ro, 0, 0);", "r_src, in0 + ro, 0, 2);")
+    rep("r_src, in1 + ro, 0, 0);", "r_src, in1 + ro, 0, 2);")
+    rep("r_orient, st0 + ro, 0, 0);", "r_orient, st0 + ro, 0, 2);")
+    rep("r_orient, st1 + ro, 0, 0);", "r_orient, st1 + ro, 0, 2);")
+    rep("r_line, st0 + ro, 0, 0);", "r_line, st0 + ro, 0, 2);")
+    rep("r_line, st1 + ro, 0, 0);", "r_line, st1 + ro, 0, 2);")
+elif name == "contig":      # ntol + each x3 store instruction writes one contiguous run (pixels land in the wrong place)
+    rep("const int st0 = out0 ? x0 * 12 : kRgb2Out, st1 = out1 ? x1 * 12 : kRgb2Out;", "const int st0 = out0 ? (xw0 + lane - 4) * 12 : kRgb2Out, st1 = out1 ? (xw0 + 56 + lane - 4) * 12 : kRgb2Out;")
+    rep("r_orient, st0 + ro, 0, 0);", "r_orient, st0 + ro, 0, 2);")
+    rep("r_orient, st1 + ro, 0, 0);", "r_orient, st1 + ro, 0, 2);")
+    rep("r_line, st0 + ro, 0, 0);", "r_line, st0 + ro, 0, 2);")
+    rep("r_line, st1 + ro, 0, 0);", "r_line, st1 + ro, 0, 2);")
+elif name == "contigv":     # contig + the two value stores contiguous as well, nt
+    rep("const int st0 = out0 ? x0 * 12 : kRgb2Out, st1 = out1 ? x1 * 12 : kRgb2Out;", "const int st0 = out0 ? (xw0 + lane - 4) * 12 : kRgb2Out, st1 = out1 ? (xw0 + 56 + lane - 4) * 12 : kRgb2Out;")
+    rep("const int sv0 = out0 ? x0 * 4 : kRgb2Out, sv1 = out1 ? x1 * 4 : kRgb2Out;", "const int sv0 = out0 ? (xw0 + lane - 4) * 4 : kRgb2Out, sv1 = out1 ? (xw0 + 56 + lane - 4) * 4 : kRgb2Out;")
+    rep("r_orient, st0 + ro, 0, 0);", "r_orient, st0 + ro, 0, 2);")
+    rep("r_orient, st1 + ro, 0, 0);", "r_orient, st1 + ro, 0, 2);")
+    rep("r_line, st0 + ro, 0, 0);", "r_line, st0 + ro, 0, 2);")
+    rep("r_line, st1 + ro, 0, 0);", "r_line, st1 + ro, 0, 2);")
+    rep("r_value, sv0 + rv, 0, 0);", "r_value, sv0 + rv, 0, 2);")
+    rep("r_value, sv1 + rv, 0, 0);", "r_value, sv1 + rv, 0, 2);")
 elif name == "nopow":       # regulator ratio without log / exp / division
-    rep("                return prm.rv / pw;", "                return prm.rv * m;")
-    rep("                if ((m > 0.0f && m < 7.8886e-31f) || prm.root == 0.0f) pw = powf(m, prm.root);\n                else pw", "                pw")
+    rep("const f2 rr = {regulator_ratio(bdone.x, prm.rv, prm.root), regulator_ratio(bdone.y, prm.rv, prm.root)};", "const f2 rr = bdone;")
 elif name == "base":
     pass
 open(p, "w").write(s)
