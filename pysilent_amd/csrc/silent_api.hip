@@ -1125,12 +1125,17 @@ SILENT_EXPORT int silent_rgb_line_end_dev(silent_ctx* ctx, const float* pyr, con
         LevelTab tab;
         long long blocks;
         const unsigned kopts = ctx->tune[SILENT_TUNE_RGB];  // 1: dense, 2: no two-group, 8: 90-row tiles, bits 8-15: tile height / 2
+        // two pixels per lane on packed f32 (silent_rgb2.h; its buffer addressing wants levels below 2^30 bytes per map); 16: one pixel per lane
+        bool pair_kernel = !(kopts & 16u);
+        for (int l = 0; l < n_levels; ++l)
+            if ((long long)levels[l].h * levels[l].w * 12 >= (long long)kRgb2Out) pair_kernel = false;
         // tile height: the one that minimises ceil(tiles / resident tiles) x (th + 14) row steps (silent_rgb.h)
         int th = kRgbTH;
         if ((kopts >> 8) & 0xffu) {
             th = std::min(std::max((int)((kopts >> 8) & 0xffu) * 2, 2), 400);
         } else if (!(kopts & 8u)) {
-            const long long resident = 5ll * ctx->n_cus;     // 94 VGPRs, 256 threads: 5 tiles per CU
+            const long long resident = (pair_kernel ? 4ll : 5ll) * ctx->n_cus;   // 128 / 94 VGPRs, 256 threads: 4 / 5 tiles per CU
+            const int tw = pair_kernel ? kRgb2TW : kRgbTW;
             long long best = -1;
             // Launches that fill the chip several times over keep round 1's 90 rows: a sweep on config 3 (scripts/sweep_rgb_th.py:
             // 50 ... 156 rows = 1.40 1.32 1.30 1.37 1.35 1.40 1.32 1.36 1.30 1.37 ms) shows +-4 % with no trend the rounds
@@ -1138,12 +1143,12 @@ SILENT_EXPORT int silent_rgb_line_end_dev(silent_ctx* ctx, const float* pyr, con
             // of about one round or less, where it picks short tiles (the latency of one wave's row walk sets the time).
             long long tiles90 = 0;
             for (int l = 0; l < n_levels; ++l)
-                tiles90 += (long long)((levels[l].w + kRgbTW - 1) / kRgbTW) * ((levels[l].h + kRgbTH - 1) / kRgbTH);
+                tiles90 += (long long)((levels[l].w + tw - 1) / tw) * ((levels[l].h + kRgbTH - 1) / kRgbTH);
             const bool model = tiles90 * n_frames < 2 * resident;
             for (int cand = kRgbTHMin; model && cand <= kRgbTHMax; cand += 2) {
                 long long tiles = 0;
                 for (int l = 0; l < n_levels; ++l)
-                    tiles += (long long)((levels[l].w + kRgbTW - 1) / kRgbTW) * ((levels[l].h + cand - 1) / cand);
+                    tiles += (long long)((levels[l].w + tw - 1) / tw) * ((levels[l].h + cand - 1) / cand);
                 tiles *= n_frames;
                 const long long cost = ((tiles + resident - 1) / resident) * (cand + 2 * kRgbHalo);
                 if (best < 0 || cost < best) {
@@ -1152,10 +1157,6 @@ SILENT_EXPORT int silent_rgb_line_end_dev(silent_ctx* ctx, const float* pyr, con
                 }
             }
         }
-        // two pixels per lane on packed f32 (silent_rgb2.h; its buffer addressing wants levels below 2^30 bytes per map); 16: one pixel per lane
-        bool pair_kernel = !(kopts & 16u);
-        for (int l = 0; l < n_levels; ++l)
-            if ((long long)levels[l].h * levels[l].w * 12 >= (long long)kRgb2Out) pair_kernel = false;
         TRY(build_level_tab(ctx, who, levels, n_levels, n_frames, pair_kernel ? kRgb2TW : kRgbTW, th, &tab, &blocks));
         if (p->flat_policy != SILENT_FLAT_IEEE && p->flat_policy != SILENT_FLAT_ZERO)
             return fail(ctx, SILENT_E_INVALID, std::string(who) + ": flat_policy must be SILENT_FLAT_IEEE or SILENT_FLAT_ZERO");

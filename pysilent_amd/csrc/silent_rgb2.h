@@ -29,6 +29,10 @@ constexpr int kRgb2Halo = 8;                     // pixels per side (4 lanes); 7
 constexpr int kRgb2Cols = 128 - 2 * kRgb2Halo;   // 112 output columns per wave
 constexpr int kRgb2TW = 4 * kRgb2Cols;           // 4 waves side by side
 constexpr int kRgb2RowHalo = 7;                  // rows above / below a tile (same as silent_rgb.h)
+#ifndef RGB2_STORE_AUX
+#define RGB2_STORE_AUX 2
+#endif
+constexpr int kRgb2StoreAux = RGB2_STORE_AUX;      // 2 = nt: orient / line_end are results nobody on the GPU reads back
 constexpr int kRgb2Out = 0x40000000;             // byte offset of "outside": lane + row parts add up to >= this; levels are smaller
 
 // ---- the weight stream -------------------------------------------------------------------------------------------
@@ -396,8 +400,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 8))) voi
         }
         const i3 da = {__float_as_int(tr[lane * 3 + 0]), __float_as_int(tr[lane * 3 + 1]), __float_as_int(tr[lane * 3 + 2])};
         const i3 db = {__float_as_int(tr[192 + lane * 3 + 0]), __float_as_int(tr[192 + lane * 3 + 1]), __float_as_int(tr[192 + lane * 3 + 2])};
-        __builtin_amdgcn_raw_buffer_store_b96(da, rsrc, sta + ro, 0, 0);
-        __builtin_amdgcn_raw_buffer_store_b96(db, rsrc, stb + ro, 0, 0);
+        __builtin_amdgcn_raw_buffer_store_b96(da, rsrc, sta + ro, 0, kRgb2StoreAux);
+        __builtin_amdgcn_raw_buffer_store_b96(db, rsrc, stb + ro, 0, kRgb2StoreAux);
     };
 #pragma unroll
     for (int k = 0; k < 4; ++k)
