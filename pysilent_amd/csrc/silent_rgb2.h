@@ -27,7 +27,11 @@ typedef const __attribute__((address_space(4))) u64* ku64_p;
 
 constexpr int kRgb2Halo = 8;                     // pixels per side (4 lanes); 7 are consumed by the five stages
 constexpr int kRgb2Cols = 128 - 2 * kRgb2Halo;   // 112 output columns per wave
-constexpr int kRgb2TW = 4 * kRgb2Cols;           // 4 waves side by side
+#ifndef RGB2_WAVES
+#define RGB2_WAVES 2
+#endif
+constexpr int kRgb2Waves = RGB2_WAVES;          // waves side by side in a block
+constexpr int kRgb2TW = kRgb2Waves * kRgb2Cols;
 constexpr int kRgb2RowHalo = 7;                  // rows above / below a tile (same as silent_rgb.h)
 #ifndef RGB2_STORE_AUX
 #define RGB2_STORE_AUX 2
@@ -326,7 +330,7 @@ __device__ __forceinline__ void conv3_roll2_sum(const f2 (&s)[3], WS& ws, f2 (&p
 __device__ __forceinline__ float relu_ok(float v, bool ok) { return ok ? relu_tf(v) : 0.0f; }
 
 template <unsigned RGC_PAIRS, bool STRIPE_SUM, unsigned RGBY_A, unsigned END_A0, unsigned END_A1, unsigned END_A2>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 8))) void rgb_line_end2_kernel(const Rgb2Args args) {
+__global__ __launch_bounds__(64 * kRgb2Waves) __attribute__((amdgpu_waves_per_eu(4, 8))) void rgb_line_end2_kernel(const Rgb2Args args) {
     typedef Rgb2Layout<RGC_PAIRS, STRIPE_SUM, RGBY_A != kDense, END_A0 != kDense> L;
     static_assert(L::blocks * kRgb2Blk <= kRgb2StreamMax, "stream fits its kernarg array");
     const int R = args.th, NROWS = R + 2 * kRgb2RowHalo;
@@ -387,8 +391,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 8))) voi
     f2 pb[7] = {zero2, zero2, zero2, zero2, zero2, zero2, zero2};
     // The stripe rows wait three steps for their blur row: a 4-slot delay line per wave in LDS (each lane reads back what it
     // wrote itself: no barrier) instead of 24 VGPRs -- with them the kernel is over 128 registers, i.e. 3 instead of 4 waves/SIMD.
-    __shared__ f2 s_hist[4][4][3][64];   // [wave][slot = row & 3][channel][lane]
-    __shared__ float s_tr[4][128 * 3];   // [wave][one output row of the wave's 128 columns x 3 channels]
+    __shared__ f2 s_hist[kRgb2Waves][4][3][64];   // [wave][slot = row & 3][channel][lane]
+    __shared__ float s_tr[kRgb2Waves][128 * 3];   // [wave][one output row of the wave's 128 columns x 3 channels]
     float* const tr = s_tr[wave];
     // lane-major in (as held), pixel-major out; LDS operations of one wave execute in order, so no wait / barrier in between
     typedef int i3 __attribute__((ext_vector_type(3)));

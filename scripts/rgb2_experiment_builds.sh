@@ -65,6 +65,8 @@ elif name == "contigv":     # contig + the two value stores contiguous as well, 
     rep("r_line, st1 + ro, 0, 0);", "r_line, st1 + ro, 0, 2);")
     rep("r_value, sv0 + rv, 0, 0);", "r_value, sv0 + rv, 0, 2);")
     rep("r_value, sv1 + rv, 0, 0);", "r_value, sv1 + rv, 0, 2);")
+elif name == "swz":         # XCD-aware block order
+    rep("const TileCoord tc = locate_tile(tab, blockIdx.x);", "const TileCoord tc = locate_tile(tab, xcd_swizzle(blockIdx.x, gridDim.x));")
 elif name == "nopow":       # regulator ratio without log / exp / division
     rep("const f2 rr = {regulator_ratio(bdone.x, prm.rv, prm.root), regulator_ratio(bdone.y, prm.rv, prm.root)};", "const f2 rr = bdone;")
 elif name == "base":
