@@ -2,19 +2,23 @@
 //
 // Why (profiles/r02/pk_rate.txt): rgb_line_end_kernel is VALU-issue bound on fmas whose weight is an SGPR operand,
 // 4.2 cycles per wave instruction.  v_pk_fma_f32 takes the same SGPR weight for BOTH halves (op_sel / op_sel_hi pick the
-// low or the high dword of an aligned SGPR pair) at 4.4 cycles per instruction = 2.2 cycles per fma.  So a lane owns the
-// pixel pair (x, x + 1) and every quantity of the chain is a register pair (lo = pixel x, hi = pixel x + 1):
-//   * every fma chain of silent_rgb.h becomes the same chain of v_pk_fma_f32, term by term in the same (dy, dx, i) order:
-//     each half is the fmaf chain of its pixel, so the result is BIT-IDENTICAL to rgb_line_end_kernel (tested);
+// low or the high dword of an aligned SGPR pair) at 4.4-4.7 cycles per instruction = 2.2-2.35 cycles per fma.  So a lane owns
+// the pixel pair (x, x + 1) and every quantity of the chain is a register pair (lo = pixel x, hi = pixel x + 1):
+//   * every fma chain of silent_rgb.h becomes the same chain of v_pk_fma_f32, each accumulator seeing its terms in the same
+//     (dx, i) order: each half is the fmaf chain of its pixel, so the result is BIT-IDENTICAL to rgb_line_end_kernel
+//     (tested on NaN / inf inputs, odd widths, both flat policies); pending rows of one output advance side by side
+//     (independent accumulators back to back: a dependent packed fma costs a wait state);
 //   * left / right neighbours: (below(hi), lo) and (hi, above(lo)) -- one DPP shift + one move per pair instead of two
 //     DPP shifts per pixel; the wave covers 128 columns of which 112 produce outputs (halo 8 px = 4 lanes per side;
 //     7 are needed): column redundancy 1.14x instead of 1.28x;
-//   * weights: unchanged kernarg layout (RgbW); a chain's 7..27 weights are fetched as the aligned 8-byte pairs that
-//     cover them (s_load_dwordx2..x16 through a laundered pointer, as before) and the fma picks its half by op_sel.
+//   * weights: a STREAM in consumption order (below), read in 16-float blocks with one block of prefetch;
+//   * memory: raw buffer loads / stores (range check = zero padding / dropped store, no branch around a store so that the
+//     in-order vmcnt distance is static), input rows fetched two steps ahead, output rows transposed through LDS so that
+//     every store instruction writes a run of whole pixels, nt on the maps nobody on the GPU reads back;
+//   * the three stripe rows that wait for their blur row live in LDS: 128 VGPRs, 4 waves / SIMD.
 // All packed fmas are `asm volatile`: they stay in program order between the scalar loads around them, which is what the
-// result-laundering did in silent_rgb.h.  Before a chain's fmas the wave waits for ITS weights (lgkmcnt(0)) and only then
-// requests the next chain's, so that request is in flight during the fmas (scalar loads return out of order: any later
-// wait is lgkmcnt(0) and would otherwise wait for the prefetch too).
+// result-laundering did in silent_rgb.h.
+// History and leave-one-out measurements: profiles/r02/rgb_pair_kernel.txt, DESIGN.md 4.5.
 #pragma once
 
 #include "silent_rgb.h"
@@ -41,7 +45,7 @@ constexpr int kRgb2Out = 0x40000000;             // byte offset of "outside": la
 
 // ---- the weight stream -------------------------------------------------------------------------------------------
 // The kernel consumes its weights in ONE fixed order per row step, so the host lays them out in that order
-// (rgb2_stream_offset below maps stream position -> float of RgbW) and the kernel reads the stream in 16-float blocks
+// (rgb2_fill_stream below) and the kernel reads the stream in 16-float blocks
 // (s_load_dwordx16 = 8 aligned SGPR pairs) into two alternating buffers: at the first use of block b the wave waits for it
 // (lgkmcnt(0)) and only then requests block b + 1 into the other buffer, which is dead by then -- the request is in flight
 // during the 16 packed fmas of block b (scalar loads return out of order: any later wait is lgkmcnt(0) and would otherwise
