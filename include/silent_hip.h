@@ -176,7 +176,8 @@ int silent_profile_elapsed_ms(silent_ctx* ctx, float* ms, int64_t* pixels);
  * Every context starts from the environment variables SILENT_GRAY_OPTS / SILENT_RGB_OPTS / SILENT_PYRAMID_OPTS, read
  * once in silent_create; silent_set_tuning changes a knob of one context afterwards.  Bits -- GRAY: 1 XCD-aware tile
  * order, 2 32-row filter tiles, 8 32-row fused tiles, 16 no single-read stream kernel, 32 XCD order in the stream
- * kernel, 128 strip-walk kernel for the unit level (256 / 512: its store policy / pyramid source); RGB: 1 dense weights, 2 no two-group form, 8 no short tiles; PYRAMID: 1 no
+ * kernel, 128 strip-walk kernel for the unit level (256 / 512: its store policy / pyramid source); RGB: 1 dense weights, 2 no two-group form, 8 no short tiles,
+ * 16 the one-pixel-per-lane chain kernel (default: two pixels per lane on packed f32, same bits), bits 8-15 tile height / 2; GRAY bit 18: one-pixel strip walk; PYRAMID: 1 no
  * single-read pyramid (gray stream kernel, RGB strip walk), 2 no RGB strip walk.  All variants give the same results (bit-identical, or within the re-association tolerance
  * for the RGB forms); the defaults are the fastest measured. */
 #define SILENT_TUNE_GRAY 0

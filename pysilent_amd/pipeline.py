@@ -128,7 +128,7 @@ class LineEndPipeline(object):
 
     def dominant_kernel_name(self):
         """Substring of the rocprofv3 kernel name of the launch that moves most bytes (bench.py matches PMC rows by it)."""
-        return ("gray_stream_kernel<%d," % self.n_orient) if self.mode == "gray" else "rgb_line_end_kernel"
+        return ("gray_stream_kernel<%d," % self.n_orient) if self.mode == "gray" else "rgb_line_end2_kernel"
 
     def launch_summary(self):
         if self.mode == "gray":
