@@ -1457,7 +1457,7 @@ SILENT_EXPORT int silent_pyramid_plan_create(silent_ctx* ctx, int frame_h, int f
             const PyrLevelDev& u = tab.lv[unit];
             const int G = tab.n_general;
             const int tiles_y = (u.out_h + kFusedTH - 1) / kFusedTH;
-            const int waves_x = ((u.out_w + kFusedTW - 1) / kFusedTW) * 4;
+            const int waves_x = ((u.out_w + kFusedTW - 1) / kFusedTW) * kFusedWaves;
             const int Gp = stream_pad_levels(G), PR = kStreamProgRow(Gp);
             const size_t n_rec = (size_t)tiles_y * kStreamRows;
             std::vector<int> prog(n_rec * PR, 0), hdr((size_t)G * waves_x * 2, 0), rec((size_t)G * waves_x * 64 * 8, 0);
@@ -1755,7 +1755,7 @@ static int launch_pyramid(silent_ctx* ctx, const char* who, const silent_pyramid
         const long long blocks = (long long)ft.tiles_per_frame * n_frames;
         if (blocks > 0x7fffffffll) return fail(ctx, SILENT_E_INVALID, std::string(who) + ": too many tiles for one launch");
 #define PYR_STREAM(G_) \
-    hipLaunchKernelGGL((pyramid_stream_kernel<1, G_>), dim3((unsigned)blocks), dim3(256), 0, s, frames, pyr, ft, plan->stream)
+    hipLaunchKernelGGL((pyramid_stream_kernel<1, G_>), dim3((unsigned)blocks), dim3(64 * kFusedWaves), 0, s, frames, pyr, ft, plan->stream)
         if (plan->stream.G <= 4) PYR_STREAM(4);
         else PYR_STREAM(7);
 #undef PYR_STREAM
@@ -2008,7 +2008,7 @@ SILENT_EXPORT int silent_gray_pass_dev(silent_ctx* ctx, const silent_pyramid_pla
         } else if (stream_path) {
             const StreamTab& st = plan->stream;
 #define STREAM_LAUNCH(K_, G_) \
-    hipLaunchKernelGGL((gray_stream_kernel<K_, G_>), dim3((unsigned)blocks), dim3(256), 0, s, frames, pyr, cs_out, end_out, ft, st, w, clip_hi, (unsigned)((kopts >> 5) & 1))
+    hipLaunchKernelGGL((gray_stream_kernel<K_, G_>), dim3((unsigned)blocks), dim3(64 * kFusedWaves), 0, s, frames, pyr, cs_out, end_out, ft, st, w, clip_hi, (unsigned)((kopts >> 5) & 1))
             if (st.G <= 4) {
                 if (n_orient == 3) STREAM_LAUNCH(3, 4);
                 else if (n_orient == 4) STREAM_LAUNCH(4, 4);
@@ -2021,7 +2021,7 @@ SILENT_EXPORT int silent_gray_pass_dev(silent_ctx* ctx, const silent_pyramid_pla
 #undef STREAM_LAUNCH
         } else {
 #define FUSED_LAUNCH(K_, R_) \
-    hipLaunchKernelGGL((gray_unit_fused_kernel<K_, R_>), dim3((unsigned)blocks), dim3(256), 0, s, frames, pyr, cs_out, end_out, ft, w, clip_hi)
+    hipLaunchKernelGGL((gray_unit_fused_kernel<K_, R_>), dim3((unsigned)blocks), dim3(64 * kFusedWaves), 0, s, frames, pyr, cs_out, end_out, ft, w, clip_hi)
             if (fth == 32) {
                 if (n_orient == 3) FUSED_LAUNCH(3, 32);
                 else if (n_orient == 4) FUSED_LAUNCH(4, 32);

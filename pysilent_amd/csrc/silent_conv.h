@@ -347,7 +347,11 @@ __global__ __launch_bounds__(256) void gray_line_end_kernel(const float* __restr
 // level is never re-read from HBM by the filter pass.  Each stage costs halo lanes (2 + 1 + 1 per side):
 // 56 of the 64 lanes produce outputs; a tile is 224 columns x 16 rows and streams 24 source rows.
 constexpr int kFusedCols = 56;
-constexpr int kFusedTW = 4 * kFusedCols;
+#ifndef SILENT_FUSED_WAVES
+#define SILENT_FUSED_WAVES 4
+#endif
+constexpr int kFusedWaves = SILENT_FUSED_WAVES;   // waves side by side in a block of the fused / stream kernels (autonomous: no barrier)
+constexpr int kFusedTW = kFusedWaves * kFusedCols;
 constexpr int kFusedTH = 16;
 
 struct FusedLevel {  // the unit levels of a pyramid plan, as the kernel needs them
@@ -365,11 +369,11 @@ struct FusedTab {
 };
 
 template <int K, int R>
-__global__ __launch_bounds__(256) void gray_unit_fused_kernel(const float* __restrict__ frames,
+__global__ __launch_bounds__(64 * kFusedWaves) void gray_unit_fused_kernel(const float* __restrict__ frames,
                                                               float* __restrict__ pyr, float* __restrict__ cs_out,
                                                               float* __restrict__ end_out, const FusedTab tab,
                                                               const GrayW wts, float clip_hi) {
-    __shared__ __attribute__((aligned(16))) float s_slab[K == 8 ? 4 * 512 : 4];  // K = 8 store transpose, per wave
+    __shared__ __attribute__((aligned(16))) float s_slab[K == 8 ? kFusedWaves * 512 : 4];  // K = 8 store transpose, per wave
     const unsigned bid = blockIdx.x;
     const int frame = (int)(bid / (unsigned)tab.tiles_per_frame);
     int rem = (int)(bid - (unsigned)frame * (unsigned)tab.tiles_per_frame);
@@ -544,13 +548,13 @@ struct StreamTab {
 };
 
 template <int K, int G>
-__global__ __launch_bounds__(256) void gray_stream_kernel(const float* __restrict__ frames, float* __restrict__ pyr,
+__global__ __launch_bounds__(64 * kFusedWaves) void gray_stream_kernel(const float* __restrict__ frames, float* __restrict__ pyr,
                                                           float* __restrict__ cs_out, float* __restrict__ end_out,
                                                           const FusedTab tab, const StreamTab st, const GrayW wts,
                                                           float clip_hi, unsigned opts) {
     constexpr int R = kFusedTH, NR = kStreamRows;
-    __shared__ __attribute__((aligned(16))) float s_slab[K == 8 ? 4 * 512 : 4];
-    __shared__ __attribute__((aligned(16))) float s_rows[4][NR][64];  // the streamed rows of each wave (wave private)
+    __shared__ __attribute__((aligned(16))) float s_slab[K == 8 ? kFusedWaves * 512 : 4];
+    __shared__ __attribute__((aligned(16))) float s_rows[kFusedWaves][NR][64];  // the streamed rows of each wave (wave private)
     const unsigned bid = (opts & 1u) ? xcd_swizzle(blockIdx.x, gridDim.x) : blockIdx.x;
     const int frame = (int)(bid / (unsigned)tab.tiles_per_frame);
     const int rem = (int)(bid - (unsigned)frame * (unsigned)tab.tiles_per_frame);
@@ -561,7 +565,7 @@ __global__ __launch_bounds__(256) void gray_stream_kernel(const float* __restric
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int xw0 = tx * kFusedTW + wave * kFusedCols;
     const bool live = xw0 < lv.out_w;  // wave-uniform: this wave has columns of the level
-    const int wx_tile = tx * 4 + wave;
+    const int wx_tile = tx * kFusedWaves + wave;
     const int y0 = ty * R;
     const int ox = xw0 + lane - 4;
     const int W = tab.W;
@@ -818,10 +822,10 @@ __global__ __launch_bounds__(256) void gray_stream_kernel(const float* __restric
 // frames; with C = 3 the stride-3 loads and partial-line stores made it 1.5 ms against 1.0 ms for unit + region
 // kernels on 32 RGB frames (measured, bit-identical either way), so RGB plans are not marked streamable.
 template <int C, int G>
-__global__ __launch_bounds__(256) void pyramid_stream_kernel(const float* __restrict__ frames, float* __restrict__ pyr,
+__global__ __launch_bounds__(64 * kFusedWaves) void pyramid_stream_kernel(const float* __restrict__ frames, float* __restrict__ pyr,
                                                              const FusedTab tab, const StreamTab st) {
     constexpr int R = kFusedTH, NR = kStreamRows;
-    __shared__ float s_rows[4][NR][64];
+    __shared__ float s_rows[kFusedWaves][NR][64];
     const unsigned bid = blockIdx.x;
     const int frame = (int)(bid / (unsigned)tab.tiles_per_frame);
     const int rem = (int)(bid - (unsigned)frame * (unsigned)tab.tiles_per_frame);
@@ -831,7 +835,7 @@ __global__ __launch_bounds__(256) void pyramid_stream_kernel(const float* __rest
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int xw0 = tx * kFusedTW + wave * kFusedCols;
     if (xw0 >= lv.out_w) return;  // wave-uniform (no barrier in this kernel)
-    const int wx_tile = tx * 4 + wave;
+    const int wx_tile = tx * kFusedWaves + wave;
     const int y0 = ty * R;
     const int ox = xw0 + lane - 4;
     const long long WC = (long long)tab.W * C;

@@ -87,8 +87,11 @@ def case_rgb(rng, k):
     scale = float(rng.choice([1.5, 2.0, 2.0, 2.5, math.e ** .5]))
     n = int(rng.integers(1, 5))
     B = int(rng.integers(1, 3))
-    # 0: specialised kernel, 18-row tiles; 8: 90-row tiles; 1 / 2: dense / no two-group forms; 9, 10: combinations
-    kr = int(rng.choice([0, 0, 8, 1, 2, 9, 10]))
+    # 0: specialised kernel, short tiles; 8: 90-row tiles; 1 / 2: dense / no two-group forms; 9, 10: combinations;
+    # + 16: the one-pixel-per-lane kernel instead of the pair kernel; widths around its 112 / 224-column wave / tile boundaries
+    kr = int(rng.choice([0, 0, 8, 1, 2, 9, 10])) | (16 if rng.integers(0, 4) == 0 else 0)
+    if rng.integers(0, 6) == 0:
+        w = int(rng.choice([111, 112, 113, 223, 224, 225, 336, 337, 449])) + int(rng.integers(-1, 2))
     rt.get_context().set_tuning(_lib.TUNE_RGB, kr)
     desc = "rgb h=%d w=%d scale=%.3f n=%d B=%d knob=%s" % (h, w, scale, n, B, kr)
     try:
