@@ -350,7 +350,10 @@ constexpr int kFusedCols = 56;
 #ifndef SILENT_FUSED_WAVES
 #define SILENT_FUSED_WAVES 4
 #endif
-constexpr int kFusedWaves = SILENT_FUSED_WAVES;   // waves side by side in a block of the fused / stream kernels (autonomous: no barrier)
+// waves side by side in a block of the fused / stream kernels (autonomous: no barrier).  4 x 56 columns = 896 bytes = 7 whole
+// 128-byte lines per tile row; measured on config 2 (gray_stream_kernel alone): 1 wave 1.06 ms, 2 waves 0.93, 4 waves 0.85,
+// 5 waves (1120 bytes: tile edges off the line grid) 1.03, 8 waves 0.89
+constexpr int kFusedWaves = SILENT_FUSED_WAVES;
 constexpr int kFusedTW = kFusedWaves * kFusedCols;
 constexpr int kFusedTH = 16;
 
