@@ -616,6 +616,20 @@ def test_rgb_pair_kernel_is_bit_identical_to_the_one_pixel_kernel(rt, kernels, s
                 np.testing.assert_array_equal(np.nan_to_num(a, nan=7.0), np.nan_to_num(b, nan=7.0), err_msg="%s %s %d" % (name, policy, tall))
 
 
+def test_rgb_chain_output_subsets(rt, kernels):
+    """NULL output pointers: the pair kernel gives an absent map a buffer resource of 0 records (every store of it is dropped
+    by the range check); the maps that ARE requested must not change, and asking for nothing is an error."""
+    frames = np.stack([noise_frame(70 + i, 45, 230, 3) for i in range(2)])
+    full = rt.rgb_line_end(frames, kernels)
+    for want in (("orient",), ("line_end",), ("value",), ("orient", "value"), ("line_end", "value")):
+        part = rt.rgb_line_end(frames, kernels, want=want)
+        assert set(part) == set(want)
+        for name in want:
+            np.testing.assert_array_equal(part[name], full[name], err_msg=str(want))
+    with pytest.raises(Exception):
+        rt.rgb_line_end(frames, kernels, want=())
+
+
 @pytest.mark.parametrize("root", [0.0, 0.5, 1.0])
 def test_rgb_chain_regulation_roots(rt, kernels, root):
     """The fused chain's regulator power (exp2(root * log2 m), powf for root = 0 and denormal m) against the oracle for
