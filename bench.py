@@ -30,6 +30,9 @@ import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
+# the pool's host driver only supports dmabuf IPC: without this RCCL fails with `hipIpcGetMemHandle: invalid argument`
+# (already exported on the GPU boxes; set here too so that a rank started under plain torchrun has it before HIP loads)
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
 
 import numpy as np  # noqa: E402
 
