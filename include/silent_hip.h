@@ -369,6 +369,12 @@ typedef struct silent_rgb_chain_params {
  * (bit dy * 3 + dx) of rgby and end per input channel. */
 int silent_rgb_chain_structure(const silent_rgb_chain_params* params, unsigned* flags, unsigned* masks);
 
+/* Host-only (no GPU needed): the weight STREAM silent_rgb_line_end hands to its pair kernel for these weights -- the
+ * weights in the order the kernel consumes them (csrc/silent_rgb2.h), zero-padded to whole pairs of 16-float blocks.
+ * knobs: SILENT_TUNE_RGB bits 0 / 1.  variant: 2 two-group, 1 basic (diagonal rgc + channel-sum stripe), 0 dense;
+ * n_used = 193 / 265 / 373.  stream must hold SILENT_RGB_STREAM_MAX floats.  For tests of the host logic. */
+#define SILENT_RGB_STREAM_MAX 384
+int silent_rgb_chain_stream(const silent_rgb_chain_params* params, unsigned knobs, float* stream, int* n_used, int* variant);
 int silent_rgb_line_end(silent_ctx* ctx, const float* pyr, const silent_extent* levels, int n_levels, int n_frames,
                         const silent_rgb_chain_params* params, float* orient_out, float* line_end_out,
                         float* value_out);

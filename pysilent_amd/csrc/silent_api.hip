@@ -1086,6 +1086,47 @@ static void analyze_rgb_chain(const silent_rgb_chain_params* p, RgbStructure* r)
     r->end_two = two(p->end, r->end_mask, r->end_w);
 }
 
+// The RGB chain's weights as the fused kernels take them: HWIO -> [o][dy][dx][i], the blur's profile, and -- where the
+// host FINDS the structure in the actual weights (what the reference's generators produce, but checked, not assumed) --
+// the two-group blocks: rgc channel-diagonal (27 fmas), stripe a filter of the channel sum (27), rgby and the end bank
+// two-group (27 + 18 each): 193 instead of 373 fmas per pixel.  Anything else runs the dense instantiation.
+// kopts: SILENT_TUNE_RGB bits 0 (dense) and 1 (no two-group form).
+static void pack_rgb_weights(const silent_rgb_chain_params* p, unsigned kopts, RgbW* w, bool* basic, bool* two) {
+    auto repack = [](const float* hwio, float* dst) {  // HWIO [dy][dx][i][o] -> [o][dy][dx][i]
+        for (int o = 0; o < 3; ++o)
+            for (int dy = 0; dy < 3; ++dy)
+                for (int dx = 0; dx < 3; ++dx)
+                    for (int i = 0; i < 3; ++i) dst[((o * 3 + dy) * 3 + dx) * 3 + i] = hwio[((dy * 3 + dx) * 3 + i) * 3 + o];
+    };
+    repack(p->rgc, w->rgc);
+    repack(p->rgby, w->rgby);
+    repack(p->stripe, w->stripe);
+    repack(p->end, w->end);
+    for (int t = 0; t < 49; ++t) w->blur[t] = p->blur[t * 9];
+    RgbStructure rs;
+    analyze_rgb_chain(p, &rs);
+    *basic = rs.rgc_diag && rs.stripe_sum && !(kopts & 1u);
+    *two = *basic && !(kopts & 2u) && rs.rgby_two && rs.end_two && rs.rgby_mask[0] == kRgbyA && rs.rgby_mask[1] == kRgbyA &&
+           rs.rgby_mask[2] == kRgbyA && rs.end_mask[0] == kEndA0 && rs.end_mask[1] == kEndA1 && rs.end_mask[2] == kEndA2;
+    if (*two) {
+        std::memcpy(w->rgby, rs.rgby_w, sizeof(rs.rgby_w));
+        std::memcpy(w->end, rs.end_w, sizeof(rs.end_w));
+    }
+}
+
+SILENT_EXPORT int silent_rgb_chain_stream(const silent_rgb_chain_params* params, unsigned knobs, float* stream, int* n_used,
+                                          int* variant) {
+    if (!params || !stream || !n_used || !variant || !params->rgc || !params->rgby || !params->stripe || !params->blur || !params->end)
+        return SILENT_E_INVALID;
+    RgbW w;
+    bool basic, two;
+    pack_rgb_weights(params, knobs, &w, &basic, &two);
+    std::memset(stream, 0, sizeof(float) * SILENT_RGB_STREAM_MAX);
+    *n_used = rgb2_fill_stream(w, basic ? 0x111u : 0x1ffu, basic, two, two, stream);
+    *variant = two ? 2 : basic ? 1 : 0;
+    return SILENT_OK;
+}
+
 SILENT_EXPORT int silent_rgb_chain_structure(const silent_rgb_chain_params* params, unsigned* flags, unsigned* masks) {
     if (!params || !flags || !params->rgc || !params->rgby || !params->stripe || !params->end) return SILENT_E_INVALID;
     RgbStructure r;
@@ -1167,31 +1208,9 @@ SILENT_EXPORT int silent_rgb_line_end_dev(silent_ctx* ctx, const float* pyr, con
         a.value_out = value_out;
         a.tab = tab;
         a.th = th;
-        auto repack = [](const float* hwio, float* dst) {  // HWIO [dy][dx][i][o] -> [o][dy][dx][i]
-            for (int o = 0; o < 3; ++o)
-                for (int dy = 0; dy < 3; ++dy)
-                    for (int dx = 0; dx < 3; ++dx)
-                        for (int i = 0; i < 3; ++i) dst[((o * 3 + dy) * 3 + dx) * 3 + i] = hwio[((dy * 3 + dx) * 3 + i) * 3 + o];
-        };
-        repack(p->rgc, a.w.rgc);
-        repack(p->rgby, a.w.rgby);
-        repack(p->stripe, a.w.stripe);
-        repack(p->end, a.w.end);
-        for (int t = 0; t < 49; ++t) a.w.blur[t] = p->blur[t * 9];
         a.prm = RgbP{p->regulation_value, p->regulation_root, p->flat_policy, p->clip_hi, p->pad};
-        // structure of the actual weights (what the reference's generators produce, but checked, not assumed):
-        // rgc channel-diagonal (27 fmas), stripe a filter of the channel sum (27), rgby and the end bank two-group
-        // (27 + 18 each): 189 instead of 373 fmas per pixel.  Anything else runs the dense instantiation.
-        RgbStructure rs;
-        analyze_rgb_chain(p, &rs);
-        const bool basic = rs.rgc_diag && rs.stripe_sum && !(kopts & 1u);
-        const bool two = basic && !(kopts & 2u) && rs.rgby_two && rs.end_two && rs.rgby_mask[0] == kRgbyA &&
-                         rs.rgby_mask[1] == kRgbyA && rs.rgby_mask[2] == kRgbyA && rs.end_mask[0] == kEndA0 &&
-                         rs.end_mask[1] == kEndA1 && rs.end_mask[2] == kEndA2;
-        if (two) {
-            std::memcpy(a.w.rgby, rs.rgby_w, sizeof(rs.rgby_w));
-            std::memcpy(a.w.end, rs.end_w, sizeof(rs.end_w));
-        }
+        bool basic, two;
+        pack_rgb_weights(p, kopts, &a.w, &basic, &two);
         if (pair_kernel) {
             Rgb2Args a2;
             a2.pyr = a.pyr;

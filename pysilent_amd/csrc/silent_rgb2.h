@@ -52,7 +52,7 @@ constexpr int kRgb2Out = 0x40000000;             // byte offset of "outside": la
 // wait for the prefetch too).  The stream is cyclic (the last block's first use requests block 0 of the next row step);
 // the block count is even so that the buffer parity survives the wrap.
 constexpr int kRgb2Blk = 16;
-constexpr int kRgb2StreamMax = 384;  // 4 x 81 + 49 = 373 floats for the dense instantiation, padded to whole block pairs
+constexpr int kRgb2StreamMax = SILENT_RGB_STREAM_MAX;  // 4 x 81 + 49 = 373 floats for the dense instantiation, padded to whole block pairs
 
 constexpr int rgb2_popc(unsigned v) { return v ? (int)(v & 1u) + rgb2_popc(v >> 1) : 0; }
 

@@ -138,6 +138,111 @@ def _chain_structure(consts):
     return flags.value, list(masks)
 
 
+def _chain_stream(consts, knobs=0):
+    import ctypes as C
+    from pysilent_amd import _lib
+    lib = _lib.load()
+    fp = C.POINTER(C.c_float)
+    arrs = {k: np.ascontiguousarray(consts[k], np.float32) for k in ("rgc", "rgby", "stripe", "blur", "end")}
+    params = _lib.RgbChainParams(*[arrs[k].ctypes.data_as(fp) for k in ("rgc", "rgby", "stripe", "blur", "end")],
+                                 1.0, 0.1, 0, 255.0, 2)
+    stream = np.full(384, np.nan, np.float32)
+    n, variant = C.c_int(-1), C.c_int(-1)
+    assert lib.silent_rgb_chain_stream(C.byref(params), knobs, stream.ctypes.data_as(fp), C.byref(n), C.byref(variant)) == 0
+    return stream, n.value, variant.value, arrs
+
+
+def test_rgb_weight_stream_is_the_kernels_consumption_order():
+    """The pair kernel (csrc/silent_rgb2.h) reads its weights as a stream in the order it consumes them.  This walks the
+    stream the way the kernel does -- stage by stage, pending rows of one output side by side -- and rebuilds from it the
+    3 x 3 (x 3 x 3) kernels the stages apply; they must be the kernels that went in.  Dense form: every one of the 373
+    weights, in place; basic form: the diagonal of rgc and the channel-0 slice of the stripe bank; two-group form: the
+    scale x mix products reproduce rgby and the end bank."""
+    from pysilent_amd.pipeline import default_constants
+    consts = default_constants("rgb")
+
+    def take_conv(it, pairs):          # for o: for active (dx, i): for dy = 2, 1, 0   ->  K[dy, dx, i, o]
+        k = np.zeros((3, 3, 3, 3), np.float32)
+        for o in range(3):
+            for dx in range(3):
+                for i in range(3):
+                    if pairs >> (o * 3 + i) & 1:
+                        for dy in (2, 1, 0):
+                            k[dy, dx, i, o] = next(it)
+        return k
+
+    def take_two(it, masks):           # for (dx, i): for dy = 2, 1, 0 (scale); then for term (group, i): for o (mix)
+        scale = np.zeros((3, 3, 3), np.float32)
+        for dx in range(3):
+            for i in range(3):
+                for dy in (2, 1, 0):
+                    scale[dy, dx, i] = next(it)
+        mix = np.array([next(it) for _ in range(18)], np.float32).reshape(2, 3, 3)     # [group][i][o]
+        k = np.zeros((3, 3, 3, 3), np.float64)
+        for dy in range(3):
+            for dx in range(3):
+                for i in range(3):
+                    grp = 0 if masks[i] >> (dy * 3 + dx) & 1 else 1
+                    k[dy, dx, i, :] = np.float64(scale[dy, dx, i]) * mix[grp, i, :]
+        return k
+
+    def take_sum(it):                  # for o: for dx: for dy = 2, 1, 0
+        k = np.zeros((3, 3, 3), np.float32)
+        for o in range(3):
+            for dx in range(3):
+                for dy in (2, 1, 0):
+                    k[dy, dx, o] = next(it)
+        return k
+
+    def take_blur(it):                 # for dx: for k = 0..6 (pending row k takes kernel row 6 - k)
+        b = np.zeros((7, 7), np.float32)
+        for dx in range(7):
+            for k in range(7):
+                b[6 - k, dx] = next(it)
+        return b
+
+    # dense
+    stream, n, variant, a = _chain_stream(consts, knobs=1)
+    assert (n, variant) == (373, 0) and not np.isnan(stream).any() and not stream[n:].any()
+    it = iter(stream[:n])
+    np.testing.assert_array_equal(take_conv(it, 0x1ff), a["rgc"])
+    np.testing.assert_array_equal(take_conv(it, 0x1ff), a["rgby"])
+    np.testing.assert_array_equal(take_conv(it, 0x1ff), a["stripe"])
+    np.testing.assert_array_equal(take_blur(it), a["blur"][:, :, 0, 0])
+    np.testing.assert_array_equal(take_conv(it, 0x1ff), a["end"])
+    assert next(it, None) is None
+    # basic: diagonal rgc, stripe as a filter of the channel sum
+    stream, n, variant, a = _chain_stream(consts, knobs=2)
+    assert (n, variant) == (27 + 81 + 27 + 49 + 81, 1) and not stream[n:].any()
+    it = iter(stream[:n])
+    np.testing.assert_array_equal(take_conv(it, 0x111), a["rgc"] * np.eye(3, dtype=np.float32))
+    np.testing.assert_array_equal(take_conv(it, 0x1ff), a["rgby"])
+    np.testing.assert_array_equal(take_sum(it), a["stripe"][:, :, 0, :])
+    np.testing.assert_array_equal(take_blur(it), a["blur"][:, :, 0, 0])
+    np.testing.assert_array_equal(take_conv(it, 0x1ff), a["end"])
+    assert next(it, None) is None
+    # two-group (what the reference's kernels get)
+    stream, n, variant, a = _chain_stream(consts)
+    assert (n, variant) == (193, 2) and len(stream) % 32 == 0 and not stream[n:].any()
+    _, masks = _chain_structure(consts)
+    it = iter(stream[:n])
+    np.testing.assert_array_equal(take_conv(it, 0x111), a["rgc"] * np.eye(3, dtype=np.float32))
+    np.testing.assert_allclose(take_two(it, masks[:3]), a["rgby"], rtol=2e-6, atol=1e-9)
+    np.testing.assert_array_equal(take_sum(it), a["stripe"][:, :, 0, :])
+    np.testing.assert_array_equal(take_blur(it), a["blur"][:, :, 0, 0])
+    np.testing.assert_allclose(take_two(it, masks[3:]), a["end"], rtol=2e-6, atol=1e-9)
+    assert next(it, None) is None
+    # generic weights: the dense stream whatever the knobs say
+    rng = np.random.default_rng(3)
+    noise = {k: rng.standard_normal(np.shape(v)).astype(np.float32) for k, v in consts.items()}
+    noise["blur"] = np.repeat(np.repeat(noise["blur"][:, :, :1, :1], 3, axis=2), 3, axis=3)
+    stream, n, variant, a = _chain_stream(noise)
+    assert (n, variant) == (373, 0)
+    it = iter(stream[:n])
+    for name in ("rgc", "rgby", "stripe"):
+        np.testing.assert_array_equal(take_conv(it, 0x1ff), a[name])
+
+
 def test_rgb_chain_structure_of_the_reference_kernels():
     """The structure the fused RGB kernel exploits is DETECTED in the weights, and the reference's generators have it:
     diagonal rgc, channel-sum stripe, two-group rgby (centre tap | 8 surround taps) and end bank (per orientation the
