@@ -205,7 +205,9 @@ def make_pipeline(wl, B, local, consts):
     h, w = wl["hw"]
     return LineEndPipeline((h, w), mode=wl["mode"], n_levels=wl["n_levels"], n_orient=wl["n_orient"], batch=B,
                            device=local, constants=consts, max_keypoints_per_frame=1 << 16,
-                           **({"selection": True} if wl["mode"] == "rgb" else {}))
+                           # config 3 returns line_end + keypoints (+ orient): the value map is an intermediate the fused step
+                           # never writes (silent_rgb_keypoints)
+                           **({"selection": True, "value_map": False} if wl["mode"] == "rgb" else {}))
 
 
 def make_frames(torch, D, wl, B, rank, world, dev):

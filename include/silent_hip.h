@@ -369,6 +369,21 @@ typedef struct silent_rgb_chain_params {
  * (bit dy * 3 + dx) of rgby and end per input channel. */
 int silent_rgb_chain_structure(const silent_rgb_chain_params* params, unsigned* flags, unsigned* masks);
 
+/* Config 3 from the pyramid on in ONE call (recognition_testing.py:69-77 followed by a-10 -> a-9 -> a-8 -> a-11 on its result):
+ * = silent_rgb_line_end, then silent_select_keypoints(color = line_end, value = its value map, channels = 3).  Same outputs,
+ * bit for bit, as those two calls.  The fused chain kernel accumulates the per-level max / min of the value map that a-10's
+ * threshold needs (top_value_points.py:16-27) while it writes line_end, so the separate reduction pass and -- unless value_out
+ * is given -- the value map itself are never moved through memory.  orient_out / value_out may be NULL; the host form also
+ * accepts NULL line_end_out / peak_value_out; idx / cap_per_frame / counts as silent_max_value_indices_region. */
+int silent_rgb_keypoints(silent_ctx* ctx, const float* pyr, const silent_extent* levels, int n_levels, int n_frames,
+                         const silent_rgb_chain_params* params, double top_percent, const silent_extent* regions,
+                         float* orient_out, float* line_end_out, float* value_out, float* peak_value_out, int64_t* idx,
+                         size_t cap_per_frame, int64_t* counts);
+int silent_rgb_keypoints_dev(silent_ctx* ctx, const float* pyr, const silent_extent* levels, int n_levels, int n_frames,
+                             const silent_rgb_chain_params* params, double top_percent, const silent_extent* regions,
+                             float* orient_out, float* line_end_out, float* value_out, float* peak_value_out, int64_t* idx,
+                             size_t cap_per_frame, int64_t* counts, silent_stream stream);
+
 /* Host-only (no GPU needed): the weight STREAM silent_rgb_line_end hands to its pair kernel for these weights -- the
  * weights in the order the kernel consumes them (csrc/silent_rgb2.h), zero-padded to whole pairs of 16-float blocks.
  * knobs: SILENT_TUNE_RGB bits 0 / 1.  variant: 2 two-group, 1 basic (diagonal rgc + channel-sum stripe), 0 dense;

@@ -814,6 +814,63 @@ SILENT_EXPORT int silent_max_value_indices_region_dev(silent_ctx* ctx, const flo
 
 // SURVEY 8d config 3 as one call: top-percent -> NMS -> value -> per-region keypoint indices of the peak value.
 // = silent_select_peaks + silent_max_value_indices_region, with the cell maxima folded into the selection pass.
+// Two halves so that silent_rgb_keypoints can run the chain kernel in between (it fills the per-level extrema itself).
+struct SelectPlan {
+    LevelTab rtab, stab, tab;
+    long long rblocks, sblocks, blocks;
+    RegionTab rt;
+    bool general;
+    KeypointWs w;
+    unsigned* mm;   // [n_frames][n_levels][2] ordered-uint extrema, at the head of the context workspace
+    int nmm;
+};
+
+// tables, workspace, and the two init kernels
+static int select_prepare(silent_ctx* ctx, const char* who, const silent_extent* levels, int n_levels, int n_frames,
+                          const silent_extent* regions, hipStream_t s, SelectPlan* sp) {
+    TRY(build_level_tab(ctx, who, levels, n_levels, n_frames, kRedChunk, 0, &sp->rtab, &sp->rblocks));
+    TRY(build_level_tab(ctx, who, levels, n_levels, n_frames, kSelTW, kSelTH, &sp->stab, &sp->sblocks));
+    TRY(build_level_tab(ctx, who, levels, n_levels, n_frames, kKpChunk, 0, &sp->tab, &sp->blocks));
+    TRY(build_region_tab(ctx, who, levels, n_levels, regions, &sp->rt, &sp->general));
+    sp->nmm = n_frames * n_levels;
+    TRY(keypoint_workspace(ctx, s, n_levels, n_frames, sp->blocks, sizeof(unsigned) * 2 * (size_t)sp->nmm, sp->rt, sp->general, &sp->w));
+    sp->mm = (unsigned*)ctx->ws.p;
+    hipLaunchKernelGGL(init_maxmin_kernel, dim3((sp->nmm + 255) / 256), dim3(256), 0, s, sp->mm, sp->nmm);
+    hipLaunchKernelGGL(init_cells_kernel, dim3((unsigned)((sp->w.n_cells + 255) / 256)), dim3(256), 0, s, sp->w.cells, (long long)sp->w.n_cells);
+    return SILENT_OK;
+}
+
+// have_mm: the extrema are already in sp.mm (no reduction pass)
+static int select_run(silent_ctx* ctx, const char* who, const float* color, const float* value, const silent_extent* levels,
+                      int n_levels, int n_frames, int channels, double top_percent, const SelectPlan& sp, bool have_mm,
+                      float* peak_value_out, int64_t* idx, size_t cap_per_frame, int64_t* counts, hipStream_t s) {
+    unsigned* mm = sp.mm;
+    const RegionTab& rt = sp.rt;
+    const KeypointWs& w = sp.w;
+    if (!have_mm)
+        hipLaunchKernelGGL(level_maxmin_kernel, dim3((unsigned)sp.rblocks), dim3(256), 0, s, value, value ? nullptr : color,
+                           channels, sp.rtab, mm);
+    const float a = (float)(1.0 - top_percent), b = (float)top_percent;
+    if (sp.general) {
+        // many windows: the selection pass without the folded cell maxima, then the separable window maxima
+        if (channels == 3)
+            hipLaunchKernelGGL((select_peaks_kernel<3, false>), dim3((unsigned)sp.sblocks), dim3(256), 0, s, color, value, nullptr, nullptr,
+                               peak_value_out, sp.stab, a, b, mm, rt, nullptr);
+        else
+            hipLaunchKernelGGL((select_peaks_kernel<1, false>), dim3((unsigned)sp.sblocks), dim3(256), 0, s, color, value, nullptr, nullptr,
+                               peak_value_out, sp.stab, a, b, mm, rt, nullptr);
+        TRY(region_window_maxima(ctx, who, peak_value_out, levels, n_levels, n_frames, rt, w, s));
+    } else if (channels == 3) {
+        hipLaunchKernelGGL((select_peaks_kernel<3, true>), dim3((unsigned)sp.sblocks), dim3(256), 0, s, color, value, nullptr, nullptr,
+                           peak_value_out, sp.stab, a, b, mm, rt, w.cells);
+    } else {
+        hipLaunchKernelGGL((select_peaks_kernel<1, true>), dim3((unsigned)sp.sblocks), dim3(256), 0, s, color, value, nullptr, nullptr,
+                           peak_value_out, sp.stab, a, b, mm, rt, w.cells);
+    }
+    keypoint_passes(peak_value_out, sp.tab, sp.blocks, rt, w, sp.general, n_frames, idx, cap_per_frame, counts, s);
+    return check_launch(ctx, who);
+}
+
 SILENT_EXPORT int silent_select_keypoints_dev(silent_ctx* ctx, const float* color, const float* value,
                                               const silent_extent* levels, int n_levels, int n_frames, int channels,
                                               double top_percent, const silent_extent* regions, float* peak_value_out,
@@ -823,42 +880,10 @@ SILENT_EXPORT int silent_select_keypoints_dev(silent_ctx* ctx, const float* colo
     if (!color || !regions || !peak_value_out || !counts || (!idx && cap_per_frame))
         return fail(ctx, SILENT_E_INVALID, std::string(who) + ": NULL pointer");
     if (channels != 1 && channels != 3) return fail(ctx, SILENT_E_UNSUPPORTED, std::string(who) + ": channels must be 1 or 3");
-    LevelTab rtab, stab, tab;
-    long long rblocks, sblocks, blocks;
-    TRY(build_level_tab(ctx, who, levels, n_levels, n_frames, kRedChunk, 0, &rtab, &rblocks));
-    TRY(build_level_tab(ctx, who, levels, n_levels, n_frames, kSelTW, kSelTH, &stab, &sblocks));
-    TRY(build_level_tab(ctx, who, levels, n_levels, n_frames, kKpChunk, 0, &tab, &blocks));
-    RegionTab rt;
-    bool general;
-    TRY(build_region_tab(ctx, who, levels, n_levels, regions, &rt, &general));
-    const int nmm = n_frames * n_levels;
-    KeypointWs w;
-    TRY(keypoint_workspace(ctx, (hipStream_t)stream, n_levels, n_frames, blocks, sizeof(unsigned) * 2 * (size_t)nmm, rt, general, &w));
-    unsigned* mm = (unsigned*)ctx->ws.p;
-    hipStream_t s = (hipStream_t)stream;
-    hipLaunchKernelGGL(init_maxmin_kernel, dim3((nmm + 255) / 256), dim3(256), 0, s, mm, nmm);
-    hipLaunchKernelGGL(init_cells_kernel, dim3((unsigned)((w.n_cells + 255) / 256)), dim3(256), 0, s, w.cells, (long long)w.n_cells);
-    hipLaunchKernelGGL(level_maxmin_kernel, dim3((unsigned)rblocks), dim3(256), 0, s, value, value ? nullptr : color,
-                       channels, rtab, mm);
-    const float a = (float)(1.0 - top_percent), b = (float)top_percent;
-    if (general) {
-        // many windows: the selection pass without the folded cell maxima, then the separable window maxima
-        if (channels == 3)
-            hipLaunchKernelGGL((select_peaks_kernel<3, false>), dim3((unsigned)sblocks), dim3(256), 0, s, color, value, nullptr, nullptr,
-                               peak_value_out, stab, a, b, mm, rt, nullptr);
-        else
-            hipLaunchKernelGGL((select_peaks_kernel<1, false>), dim3((unsigned)sblocks), dim3(256), 0, s, color, value, nullptr, nullptr,
-                               peak_value_out, stab, a, b, mm, rt, nullptr);
-        TRY(region_window_maxima(ctx, who, peak_value_out, levels, n_levels, n_frames, rt, w, s));
-    } else if (channels == 3) {
-        hipLaunchKernelGGL((select_peaks_kernel<3, true>), dim3((unsigned)sblocks), dim3(256), 0, s, color, value, nullptr, nullptr,
-                           peak_value_out, stab, a, b, mm, rt, w.cells);
-    } else {
-        hipLaunchKernelGGL((select_peaks_kernel<1, true>), dim3((unsigned)sblocks), dim3(256), 0, s, color, value, nullptr, nullptr,
-                           peak_value_out, stab, a, b, mm, rt, w.cells);
-    }
-    keypoint_passes(peak_value_out, tab, blocks, rt, w, general, n_frames, idx, cap_per_frame, counts, s);
-    return check_launch(ctx, who);
+    SelectPlan sp;
+    TRY(select_prepare(ctx, who, levels, n_levels, n_frames, regions, (hipStream_t)stream, &sp));
+    return select_run(ctx, who, color, value, levels, n_levels, n_frames, channels, top_percent, sp, false, peak_value_out, idx,
+                      cap_per_frame, counts, (hipStream_t)stream);
 }
 
 // ------------------------------------------------------------------------------------------ centroids
@@ -1141,11 +1166,12 @@ SILENT_EXPORT int silent_rgb_chain_structure(const silent_rgb_chain_params* para
 }
 
 
-SILENT_EXPORT int silent_rgb_line_end_dev(silent_ctx* ctx, const float* pyr, const silent_extent* levels, int n_levels,
-                                          int n_frames, const silent_rgb_chain_params* p, float* orient_out,
-                                          float* line_end_out, float* value_out, silent_stream stream) {
-    NEED_CTX(ctx);
-    const char* who = "silent_rgb_line_end";
+// mm: optional per-level extrema slots (already initialised); *mm_done tells whether the launch filled them (only the pair
+// kernel's two-group instantiation does -- everything else leaves them to level_maxmin_kernel)
+static int rgb_chain_launch(silent_ctx* ctx, const char* who, const float* pyr, const silent_extent* levels, int n_levels,
+                            int n_frames, const silent_rgb_chain_params* p, float* orient_out, float* line_end_out,
+                            float* value_out, unsigned* mm, bool* mm_done, silent_stream stream) {
+    if (mm_done) *mm_done = false;
     if (!pyr || !p) return fail(ctx, SILENT_E_INVALID, std::string(who) + ": NULL pointer");
     if (!p->rgc || !p->rgby || !p->stripe || !p->blur || !p->end)
         return fail(ctx, SILENT_E_INVALID, std::string(who) + ": a kernel pointer in params is NULL");
@@ -1220,8 +1246,14 @@ SILENT_EXPORT int silent_rgb_line_end_dev(silent_ctx* ctx, const float* pyr, con
             a2.tab = a.tab;
             a2.prm = a.prm;
             a2.th = a.th;
+            a2.mm = nullptr;
             std::memset(a2.ws, 0, sizeof(a2.ws));
             rgb2_fill_stream(a.w, basic ? 0x111u : 0x1ffu, basic, two, two, a2.ws);
+            if (two && mm) {
+                a2.mm = mm;
+                hipLaunchKernelGGL((rgb_line_end2_kernel<0x111u, true, kRgbyA, kEndA0, kEndA1, kEndA2, true>), dim3((unsigned)blocks), dim3(64 * kRgb2Waves), 0, s, a2);
+                if (mm_done) *mm_done = true;
+            } else
             if (two) hipLaunchKernelGGL((rgb_line_end2_kernel<0x111u, true, kRgbyA, kEndA0, kEndA1, kEndA2>), dim3((unsigned)blocks), dim3(64 * kRgb2Waves), 0, s, a2);
             else if (basic) hipLaunchKernelGGL((rgb_line_end2_kernel<0x111u, true, kDense, kDense, kDense, kDense>), dim3((unsigned)blocks), dim3(64 * kRgb2Waves), 0, s, a2);
             else hipLaunchKernelGGL((rgb_line_end2_kernel<0x1ffu, false, kDense, kDense, kDense, kDense>), dim3((unsigned)blocks), dim3(64 * kRgb2Waves), 0, s, a2);
@@ -1264,6 +1296,48 @@ SILENT_EXPORT int silent_rgb_line_end_dev(silent_ctx* ctx, const float* pyr, con
     }
     return check_launch(ctx, who);
 }
+
+SILENT_EXPORT int silent_rgb_line_end_dev(silent_ctx* ctx, const float* pyr, const silent_extent* levels, int n_levels,
+                                          int n_frames, const silent_rgb_chain_params* p, float* orient_out,
+                                          float* line_end_out, float* value_out, silent_stream stream) {
+    NEED_CTX(ctx);
+    return rgb_chain_launch(ctx, "silent_rgb_line_end", pyr, levels, n_levels, n_frames, p, orient_out, line_end_out, value_out,
+                            nullptr, nullptr, stream);
+}
+
+// Config 3 from the pyramid on in one call: silent_rgb_line_end + silent_select_keypoints on its line_end / value maps.
+// When the chain runs as the pair kernel's two-group instantiation, that kernel also accumulates the per-level extrema of the
+// value map (a-10's max / min), so the reduction pass is skipped and nobody needs the value map in memory: the selection pass
+// takes the value from line_end (same three operations, same bits) and the map is written only if the caller asks for it.
+SILENT_EXPORT int silent_rgb_keypoints_dev(silent_ctx* ctx, const float* pyr, const silent_extent* levels, int n_levels,
+                                           int n_frames, const silent_rgb_chain_params* p, double top_percent,
+                                           const silent_extent* regions, float* orient_out, float* line_end_out,
+                                           float* value_out, float* peak_value_out, int64_t* idx, size_t cap_per_frame,
+                                           int64_t* counts, silent_stream stream) {
+    NEED_CTX(ctx);
+    const char* who = "silent_rgb_keypoints";
+    if (!pyr || !p || !regions || !line_end_out || !peak_value_out || !counts || (!idx && cap_per_frame))
+        return fail(ctx, SILENT_E_INVALID, std::string(who) + ": NULL pointer");
+    if (!p->rgc || !p->rgby || !p->stripe || !p->blur || !p->end)
+        return fail(ctx, SILENT_E_INVALID, std::string(who) + ": a kernel pointer in params is NULL");
+    bool uniform_blur = true;   // anything else makes the chain use the context workspace itself: plain sequence then
+    for (int t = 0; t < 49 && uniform_blur; ++t)
+        for (int io = 1; io < 9; ++io)
+            if (p->blur[t * 9 + io] != p->blur[t * 9]) uniform_blur = false;
+    hipStream_t s = (hipStream_t)stream;
+    if (!uniform_blur) {
+        TRY(rgb_chain_launch(ctx, who, pyr, levels, n_levels, n_frames, p, orient_out, line_end_out, value_out, nullptr, nullptr, stream));
+        return silent_select_keypoints_dev(ctx, line_end_out, value_out, levels, n_levels, n_frames, 3, top_percent, regions,
+                                           peak_value_out, idx, cap_per_frame, counts, stream);
+    }
+    SelectPlan sp;
+    TRY(select_prepare(ctx, who, levels, n_levels, n_frames, regions, s, &sp));
+    bool mm_done = false;
+    TRY(rgb_chain_launch(ctx, who, pyr, levels, n_levels, n_frames, p, orient_out, line_end_out, value_out, sp.mm, &mm_done, stream));
+    return select_run(ctx, who, line_end_out, mm_done ? nullptr : value_out, levels, n_levels, n_frames, 3, top_percent, sp, mm_done,
+                      peak_value_out, idx, cap_per_frame, counts, s);
+}
+
 
 // ------------------------------------------------------------------------------------------ pyramid plan
 
@@ -2305,6 +2379,35 @@ SILENT_EXPORT int silent_rgb_line_end(silent_ctx* ctx, const float* pyr, const s
     if (line_end_out) TRY(d2h(ctx, line_end_out, st.ptr<float>(i_l), b3));
     if (value_out) TRY(d2h(ctx, value_out, st.ptr<float>(i_v), b1));
     return SILENT_OK;
+}
+
+SILENT_EXPORT int silent_rgb_keypoints(silent_ctx* ctx, const float* pyr, const silent_extent* levels, int n_levels,
+                                       int n_frames, const silent_rgb_chain_params* p, double top_percent,
+                                       const silent_extent* regions, float* orient_out, float* line_end_out, float* value_out,
+                                       float* peak_value_out, int64_t* idx, size_t cap_per_frame, int64_t* counts) {
+    NEED_CTX(ctx);
+    if (!pyr || !p || !regions || !counts || (!idx && cap_per_frame))
+        return fail(ctx, SILENT_E_INVALID, "silent_rgb_keypoints: NULL pointer");
+    long long px;
+    TRY(check_levels(ctx, "silent_rgb_keypoints", levels, n_levels, n_frames, &px));
+    Stage st(ctx);
+    const size_t b3 = (size_t)px * 3 * 4, b1 = (size_t)px * 4;
+    const size_t bi = (size_t)n_frames * cap_per_frame * 4 * sizeof(int64_t), bn = (size_t)n_frames * sizeof(int64_t);
+    const size_t i_in = st.add(b3), i_o = st.add(b3), i_l = st.add(b3), i_v = st.add(b1), i_p = st.add(b1), i_i = st.add(bi),
+                 i_n = st.add(bn);
+    TRY(st.commit());
+    TRY(h2d(ctx, st.ptr<float>(i_in), pyr, b3));
+    TRY(silent_rgb_keypoints_dev(ctx, st.ptr<float>(i_in), levels, n_levels, n_frames, p, top_percent, regions,
+                                 orient_out ? st.ptr<float>(i_o) : nullptr, st.ptr<float>(i_l),
+                                 value_out ? st.ptr<float>(i_v) : nullptr, st.ptr<float>(i_p), st.ptr<int64_t>(i_i), cap_per_frame,
+                                 st.ptr<int64_t>(i_n), nullptr));
+    TRY(sync0(ctx));
+    if (orient_out) TRY(d2h(ctx, orient_out, st.ptr<float>(i_o), b3));
+    if (line_end_out) TRY(d2h(ctx, line_end_out, st.ptr<float>(i_l), b3));
+    if (value_out) TRY(d2h(ctx, value_out, st.ptr<float>(i_v), b1));
+    if (peak_value_out) TRY(d2h(ctx, peak_value_out, st.ptr<float>(i_p), b1));
+    if (cap_per_frame) TRY(d2h(ctx, idx, st.ptr<int64_t>(i_i), bi));
+    return d2h(ctx, counts, st.ptr<int64_t>(i_n), bn);
 }
 
 SILENT_EXPORT int silent_pyramid(silent_ctx* ctx, const silent_pyramid_plan* plan, const float* frames, int n_frames,

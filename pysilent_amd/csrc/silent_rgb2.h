@@ -21,6 +21,7 @@
 // History and leave-one-out measurements: profiles/r02/rgb_pair_kernel.txt, DESIGN.md 4.5.
 #pragma once
 
+#include "silent_peaks.h"
 #include "silent_rgb.h"
 
 namespace silent {
@@ -125,6 +126,7 @@ struct Rgb2Args {
     LevelTab tab;
     RgbP prm;
     int th;   // output rows per tile (even)
+    unsigned* mm;   // optional [n_frames][n_levels][2] ordered-uint slots (silent_peaks.h): max_pool(value), max_pool(-value) per level
     alignas(64) float ws[kRgb2StreamMax];
 };
 static_assert(offsetof(Rgb2Args, ws) % 64 == 0, "weight blocks are whole 64-byte lines of the kernarg segment");
@@ -333,8 +335,10 @@ __device__ __forceinline__ void conv3_roll2_sum(const f2 (&s)[3], WS& ws, f2 (&p
 
 __device__ __forceinline__ float relu_ok(float v, bool ok) { return ok ? relu_tf(v) : 0.0f; }
 
-template <unsigned RGC_PAIRS, bool STRIPE_SUM, unsigned RGBY_A, unsigned END_A0, unsigned END_A1, unsigned END_A2>
-__global__ __launch_bounds__(64 * kRgb2Waves) __attribute__((amdgpu_waves_per_eu(4, 8))) void rgb_line_end2_kernel(const Rgb2Args args) {
+// MM: also accumulate the per-level extrema of the value map (args.mm) -- compiled separately because the kernel sits at the
+// 128-VGPR edge (the extra pointer and masks cost SGPR spills that the plain instantiation should not pay)
+template <unsigned RGC_PAIRS, bool STRIPE_SUM, unsigned RGBY_A, unsigned END_A0, unsigned END_A1, unsigned END_A2, bool MM = false>
+__global__ __launch_bounds__(64 * kRgb2Waves) __attribute__((amdgpu_waves_per_eu(MM ? 3 : 4, 8))) void rgb_line_end2_kernel(const Rgb2Args args) {
     typedef Rgb2Layout<RGC_PAIRS, STRIPE_SUM, RGBY_A != kDense, END_A0 != kDense> L;
     static_assert(L::blocks * kRgb2Blk <= kRgb2StreamMax, "stream fits its kernarg array");
     const int R = args.th, NROWS = R + 2 * kRgb2RowHalo;
@@ -396,6 +400,13 @@ __global__ __launch_bounds__(64 * kRgb2Waves) __attribute__((amdgpu_waves_per_eu
     // The stripe rows wait three steps for their blur row: a 4-slot delay line per wave in LDS (each lane reads back what it
     // wrote itself: no barrier) instead of 24 VGPRs -- with them the kernel is over 128 registers, i.e. 3 instead of 4 waves/SIMD.
     __shared__ f2 s_hist[kRgb2Waves][4][3][64];   // [wave][slot = row & 3][channel][lane]
+    // per-lane running max_pool(value) / max_pool(-value) of this tile when the caller wants the per-level extrema of a-10
+    // (args.mm): in LDS, not in registers -- the kernel sits at 128 VGPRs
+    __shared__ float s_mm[MM ? kRgb2Waves : 1][2][64];
+    if constexpr (MM) {
+        s_mm[wave][0][lane] = kPoolLowest;
+        s_mm[wave][1][lane] = kPoolLowest;
+    }
     __shared__ float s_tr[kRgb2Waves][128 * 3];   // [wave][one output row of the wave's 128 columns x 3 channels]
     float* const tr = s_tr[wave];
     // lane-major in (as held), pixel-major out; LDS operations of one wave execute in order, so no wait / barrier in between
@@ -564,6 +575,15 @@ __global__ __launch_bounds__(64 * kRgb2Waves) __attribute__((amdgpu_waves_per_eu
             store_row3(le, r_line, ro);
             const f2 val = ((le[0] + le[1]) + le[2]) * inv3p;
             typedef int i2 __attribute__((ext_vector_type(2)));
+            if (MM && rows) {   // wave-uniform.  v_max3_f32 drops NaN operands like pool_max does (max_pool semantics, silent_peaks.h)
+                const float a = out0 ? val.x : kPoolLowest, b = out1 ? val.y : kPoolLowest;
+                const float na = out0 ? -val.x : kPoolLowest, nb = out1 ? -val.y : kPoolLowest;
+                float mx = s_mm[wave][0][lane], nmn = s_mm[wave][1][lane];
+                asm("v_max3_f32 %0, %1, %2, %3" : "=v"(mx) : "v"(mx), "v"(a), "v"(b));
+                asm("v_max3_f32 %0, %1, %2, %3" : "=v"(nmn) : "v"(nmn), "v"(na), "v"(nb));
+                s_mm[wave][0][lane] = mx;
+                s_mm[wave][1][lane] = nmn;
+            }
             __builtin_amdgcn_raw_buffer_store_b64(i2{__float_as_int(val.x), __float_as_int(val.y)}, r_value, sv2 + rv, 0, 0);
             __builtin_amdgcn_raw_buffer_store_b32(__float_as_int(val.x), r_value, sv1 + rv, 0, 0);
         }
@@ -573,6 +593,14 @@ __global__ __launch_bounds__(64 * kRgb2Waves) __attribute__((amdgpu_waves_per_eu
     for (int row = 0; row < NROWS; row += 2) {   // th is even: whole pairs of rows
         step(row, nb0);
         step(row + 1, nb1);
+    }
+    if constexpr (MM) {
+        const float mx = wave_max(s_mm[wave][0][lane]), nmn = wave_max(s_mm[wave][1][lane]);
+        if (lane == 0) {
+            unsigned* slot = args.mm + ((long long)tc.frame * tab.n_levels + tc.level) * 2;
+            atomicMax(slot, f2ord(mx));
+            atomicMax(slot + 1, f2ord(nmn));
+        }
     }
 }
 

@@ -56,7 +56,7 @@ def unpack_constants(blob, layout):
 class LineEndPipeline(object):
     def __init__(self, frame_hw, mode="gray", n_levels=5, scale=2.0, n_orient=4, batch=1, device=None,
                  constants=None, center_dimensions=None, clip_hi=255.0, flat_policy="ieee", pad=2,
-                 max_keypoints_per_frame=None, selection=False, top_percent=0.1, keep_selection_maps=False):
+                 max_keypoints_per_frame=None, selection=False, top_percent=0.1, keep_selection_maps=False, value_map=True):
         import torch
         self.torch = torch
         self.mode = mode
@@ -87,7 +87,10 @@ class LineEndPipeline(object):
         else:
             self.orient = torch.empty(n * 3, **f32)
             self.line_end = torch.empty(n * 3, **f32)
-            self.value = torch.empty(n, **f32)
+            # value_map=False: the value map (a-8 of the line-end map) is not kept -- with selection the fused step needs it
+            # nowhere (silent_rgb_keypoints), and BASELINE config 3 returns line_end + keypoints (+ orient) only
+            self.value_map = bool(value_map) or not selection or bool(keep_selection_maps)
+            self.value = torch.empty(n, **f32) if self.value_map else None
             self.regions = (_lib.Extent * self.n_levels)(*[_lib.Extent(max(eh // 2, 1), max(ew // 2, 1))
                                                            for eh, ew in self.extents])
             # selection=True: SURVEY.md section 8d config 3 -- top-percent threshold (a-10, p = 0.1), 3x3 NMS (a-9),
@@ -113,13 +116,13 @@ class LineEndPipeline(object):
     def algorithmic_bytes_per_frame(self):
         """4*[H*W*C (frame read) + P*C (pyramid written) + P*C (pyramid read) + P*sum(C_out returned)]"""
         h, w, c = self.frame_shape
-        outs = (1 + self.n_orient) if self.mode == "gray" else (3 + 3 + 1)
+        outs = (1 + self.n_orient) if self.mode == "gray" else (3 + 3 + (1 if self.value_map else 0))
         return 4 * (h * w * c + 2 * self.frame_px * c + self.frame_px * outs)
 
     def filter_bytes_per_frame(self):
         """The filter pass alone: pyramid read once + every returned map written once."""
         c = self.channels
-        outs = (1 + self.n_orient) if self.mode == "gray" else (3 + 3 + 1)
+        outs = (1 + self.n_orient) if self.mode == "gray" else (3 + 3 + (1 if self.value_map else 0))
         return 4 * self.frame_px * (c + outs)
 
     def pyramid_bytes_per_frame(self):
@@ -164,11 +167,21 @@ class LineEndPipeline(object):
             self.ctx.check(self._lib.silent_rgb_line_end_dev(
                 self.ctx.handle, C.c_void_p(self.pyr.data_ptr()), self.levels_c, self.n_levels, self.batch,
                 C.byref(self._params), C.c_void_p(self.orient.data_ptr()), C.c_void_p(self.line_end.data_ptr()),
-                C.c_void_p(self.value.data_ptr()), s))
+                C.c_void_p(self.value.data_ptr()) if self.value is not None else None, s))
+
+    def run_filters_keypoints(self, stream=None):
+        """rgb, selection without the intermediate colour maps: chain + a-10 -> a-9 -> a-8 -> a-11 in one C-ABI call
+        (silent_rgb_keypoints_dev): the chain kernel accumulates the per-level extrema of a-10 itself."""
+        s = stream or self._stream()
+        p = lambda t: C.c_void_p(t.data_ptr()) if t is not None else None
+        self.ctx.check(self._lib.silent_rgb_keypoints_dev(
+            self.ctx.handle, p(self.pyr), self.levels_c, self.n_levels, self.batch, C.byref(self._params), self.top_percent,
+            self.regions, p(self.orient), p(self.line_end), p(self.value), p(self.peak_value), p(self.kp_idx), self.kp_cap,
+            p(self.kp_counts), s))
 
     def run_keypoints(self, stream=None):
         s = stream or self._stream()
-        p = lambda t: C.c_void_p(t.data_ptr())
+        p = lambda t: C.c_void_p(t.data_ptr()) if t is not None else None   # (no value map: the selection takes it from line_end)
         geom = (self.levels_c, self.n_levels, self.batch)
         if self.selection and not self.keep_selection_maps:
             # a-10 -> a-9 -> a-8 -> a-11 as one composite: the keypoint search's cell maxima come out of the selection pass
@@ -213,6 +226,9 @@ class LineEndPipeline(object):
             self.run_gray_pass(frames, s)
             return
         self.run_pyramid(frames, s)
+        if self.selection and not self.keep_selection_maps:
+            self.run_filters_keypoints(s)
+            return
         self.run_filters(s)
         self.run_keypoints(s)
 
@@ -229,7 +245,8 @@ class LineEndPipeline(object):
         else:
             out["orient"] = P(self.orient, self.extents, 3, self.batch)
             out["line_end"] = P(self.line_end, self.extents, 3, self.batch)
-            out["value"] = P(self.value, self.extents, 1, self.batch)
+            if self.value_map:
+                out["value"] = P(self.value, self.extents, 1, self.batch)
             if self.selection:
                 if self.keep_selection_maps:
                     out["top"] = P(self.top, self.extents, 3, self.batch)

@@ -13,7 +13,7 @@ kw = dict(mode=wl["mode"], n_levels=wl["n_levels"], batch=B, device=0)
 if wl["mode"] == "gray":
     kw["n_orient"] = wl["n_orient"]
 else:
-    kw.update(max_keypoints_per_frame=1 << 16, selection=True)
+    kw.update(max_keypoints_per_frame=1 << 16, selection=True, value_map=False)
 pipe = LineEndPipeline(wl["hw"], **kw)
 c = 1 if wl["mode"] == "gray" else 3
 shape = (B,) + wl["hw"] + (c,)

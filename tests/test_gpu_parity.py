@@ -712,6 +712,42 @@ def test_rgb_pipeline_composite_selection_equals_separate_calls(rt, kernels, kee
         np.testing.assert_array_equal(out["keypoints"][f], np.concatenate(rows))
 
 
+@pytest.mark.parametrize("knob", [0, 8, 16, 1])
+@pytest.mark.parametrize("value_map", [True, False])
+def test_rgb_keypoints_composite_equals_chain_then_selection(rt, kernels, knob, value_map):
+    """silent_rgb_keypoints (chain + a-10 -> a-9 -> a-8 -> a-11 in one call; the pair kernel's two-group instantiation
+    accumulates the per-level extrema itself and the selection reads the value from line_end) against
+    silent_rgb_line_end followed by silent_select_keypoints: every output bit for bit -- with the extrema fused (knobs 0, 8),
+    with the one-pixel kernel and with dense weights (16, 1: the composite falls back to the reduction pass), with and
+    without the value map, on noise, on line drawings under the 'ieee' policy (NaN regions) and with NaN / inf pixels."""
+    import torch
+    from pysilent_amd.pipeline import LineEndPipeline
+    frames = np.stack([noise_frame(31, 150, 260, 3), structured_frame(32, 150, 260, 3), noise_frame(33, 150, 260, 3)])
+    frames[2, 40:60, 100:140] = 0.0
+    frames[2, 70, 30, 1] = np.nan
+    frames[2, 90, 200, 0] = np.inf
+    fused = LineEndPipeline((150, 260), mode="rgb", n_levels=4, batch=3, selection=True, value_map=value_map,
+                            max_keypoints_per_frame=1 << 16)
+    plain = LineEndPipeline((150, 260), mode="rgb", n_levels=4, batch=3, selection=True, max_keypoints_per_frame=1 << 16)
+    t = torch.from_numpy(frames).cuda()
+    with rt.tuning(TUNE_RGB, knob):
+        fused.step(t)                       # run_pyramid + silent_rgb_keypoints_dev
+        plain.run_pyramid(t)
+        plain.run_filters()                 # silent_rgb_line_end_dev
+        plain.run_keypoints()               # silent_select_keypoints_dev
+        torch.cuda.synchronize()
+    a, b = fused.outputs(), plain.outputs()
+    assert ("value" in a) == value_map
+    for name in ("orient", "line_end", "peak_value") + (("value",) if value_map else ()):
+        x, y = a[name].data.cpu().numpy(), b[name].data.cpu().numpy()
+        assert np.array_equal(np.isnan(x), np.isnan(y)), name
+        np.testing.assert_array_equal(np.nan_to_num(x, nan=7.0), np.nan_to_num(y, nan=7.0), err_msg=name)
+    np.testing.assert_array_equal(a["keypoint_counts"], b["keypoint_counts"])
+    for f in range(3):
+        np.testing.assert_array_equal(a["keypoints"][f], b["keypoints"][f])
+    assert sum(len(k) for k in a["keypoints"]) > 0
+
+
 def test_rgb_pipeline_with_selection_stage(rt, kernels):
     """chain -> top-percent (a-10, p = 0.1) -> NMS (a-9) -> value -> keypoints (a-11); every stage
     after the chain is index-like and compared bit for bit with the oracle applied to the GPU's own line-end map."""
