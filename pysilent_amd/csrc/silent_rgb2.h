@@ -335,8 +335,9 @@ __device__ __forceinline__ void conv3_roll2_sum(const f2 (&s)[3], WS& ws, f2 (&p
 
 __device__ __forceinline__ float relu_ok(float v, bool ok) { return ok ? relu_tf(v) : 0.0f; }
 
-// MM: also accumulate the per-level extrema of the value map (args.mm) -- compiled separately because the kernel sits at the
-// 128-VGPR edge (the extra pointer and masks cost SGPR spills that the plain instantiation should not pay)
+// MM: also accumulate the per-level extrema of the value map (args.mm) -- a separate instantiation with a 3-waves/SIMD register
+// budget: the plain kernel sits at the 128-VGPR edge, and forced into that budget the extra pointer, masks and accumulators
+// spill to scratch (+16 %; with 3 waves +4 %)
 template <unsigned RGC_PAIRS, bool STRIPE_SUM, unsigned RGBY_A, unsigned END_A0, unsigned END_A1, unsigned END_A2, bool MM = false>
 __global__ __launch_bounds__(64 * kRgb2Waves) __attribute__((amdgpu_waves_per_eu(MM ? 3 : 4, 8))) void rgb_line_end2_kernel(const Rgb2Args args) {
     typedef Rgb2Layout<RGC_PAIRS, STRIPE_SUM, RGBY_A != kDense, END_A0 != kDense> L;
@@ -400,13 +401,8 @@ __global__ __launch_bounds__(64 * kRgb2Waves) __attribute__((amdgpu_waves_per_eu
     // The stripe rows wait three steps for their blur row: a 4-slot delay line per wave in LDS (each lane reads back what it
     // wrote itself: no barrier) instead of 24 VGPRs -- with them the kernel is over 128 registers, i.e. 3 instead of 4 waves/SIMD.
     __shared__ f2 s_hist[kRgb2Waves][4][3][64];   // [wave][slot = row & 3][channel][lane]
-    // per-lane running max_pool(value) / max_pool(-value) of this tile when the caller wants the per-level extrema of a-10
-    // (args.mm): in LDS, not in registers -- the kernel sits at 128 VGPRs
-    __shared__ float s_mm[MM ? kRgb2Waves : 1][2][64];
-    if constexpr (MM) {
-        s_mm[wave][0][lane] = kPoolLowest;
-        s_mm[wave][1][lane] = kPoolLowest;
-    }
+    // MM: per-lane running max_pool(value) / max_pool(-value) of this tile, for the per-level extrema of a-10 (args.mm)
+    float mm_mx = kPoolLowest, mm_nmn = kPoolLowest;
     __shared__ float s_tr[kRgb2Waves][128 * 3];   // [wave][one output row of the wave's 128 columns x 3 channels]
     float* const tr = s_tr[wave];
     // lane-major in (as held), pixel-major out; LDS operations of one wave execute in order, so no wait / barrier in between
@@ -578,11 +574,8 @@ __global__ __launch_bounds__(64 * kRgb2Waves) __attribute__((amdgpu_waves_per_eu
             if (MM && rows) {   // wave-uniform.  v_max3_f32 drops NaN operands like pool_max does (max_pool semantics, silent_peaks.h)
                 const float a = out0 ? val.x : kPoolLowest, b = out1 ? val.y : kPoolLowest;
                 const float na = out0 ? -val.x : kPoolLowest, nb = out1 ? -val.y : kPoolLowest;
-                float mx = s_mm[wave][0][lane], nmn = s_mm[wave][1][lane];
-                asm("v_max3_f32 %0, %1, %2, %3" : "=v"(mx) : "v"(mx), "v"(a), "v"(b));
-                asm("v_max3_f32 %0, %1, %2, %3" : "=v"(nmn) : "v"(nmn), "v"(na), "v"(nb));
-                s_mm[wave][0][lane] = mx;
-                s_mm[wave][1][lane] = nmn;
+                asm("v_max3_f32 %0, %1, %2, %3" : "=v"(mm_mx) : "v"(mm_mx), "v"(a), "v"(b));
+                asm("v_max3_f32 %0, %1, %2, %3" : "=v"(mm_nmn) : "v"(mm_nmn), "v"(na), "v"(nb));
             }
             __builtin_amdgcn_raw_buffer_store_b64(i2{__float_as_int(val.x), __float_as_int(val.y)}, r_value, sv2 + rv, 0, 0);
             __builtin_amdgcn_raw_buffer_store_b32(__float_as_int(val.x), r_value, sv1 + rv, 0, 0);
@@ -595,7 +588,7 @@ __global__ __launch_bounds__(64 * kRgb2Waves) __attribute__((amdgpu_waves_per_eu
         step(row + 1, nb1);
     }
     if constexpr (MM) {
-        const float mx = wave_max(s_mm[wave][0][lane]), nmn = wave_max(s_mm[wave][1][lane]);
+        const float mx = wave_max(mm_mx), nmn = wave_max(mm_nmn);
         if (lane == 0) {
             unsigned* slot = args.mm + ((long long)tc.frame * tab.n_levels + tc.level) * 2;
             atomicMax(slot, f2ord(mx));
