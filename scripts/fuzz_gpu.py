@@ -255,7 +255,51 @@ def case_big(rng, k):
     return desc
 
 
-CASES = {"gray_pass": case_gray_pass, "rgb": case_rgb, "select": case_select, "ops": case_ops}
+def case_rgb_keypoints(rng, k):
+    """silent_rgb_keypoints (chain + selection + keypoints in one call, extrema from the chain kernel) against
+    silent_rgb_line_end followed by silent_select_keypoints on the same pyramid: every output bit for bit."""
+    import torch
+    from pysilent_amd.pipeline import LineEndPipeline
+    h, w = int(rng.integers(8, 180)), int(rng.integers(8, 300))
+    if rng.integers(0, 5) == 0:
+        w = int(rng.choice([111, 112, 113, 223, 224, 225, 337])) + int(rng.integers(-1, 2))
+    n, B = int(rng.integers(1, 5)), int(rng.integers(1, 3))
+    kr = int(rng.choice([0, 0, 0, 8, 16, 1, 2]))
+    policy = "zero" if rng.integers(0, 2) else "ieee"
+    vm = bool(rng.integers(0, 2))
+    p = float(rng.choice([0.0, 0.1, 0.1, 0.37, 1.0]))
+    desc = "rgb_keypoints h=%d w=%d n=%d B=%d knob=%d %s value_map=%s p=%g" % (h, w, n, B, kr, policy, vm, p)
+    try:
+        consts = {x: k[x] for x in ("rgc", "rgby", "stripe", "blur", "end")}
+        kw = dict(mode="rgb", n_levels=n, batch=B, selection=True, top_percent=p, flat_policy=policy, constants=consts,
+                  max_keypoints_per_frame=h * w * 2)
+        fused = LineEndPipeline((h, w), value_map=vm, **kw)
+        plain = LineEndPipeline((h, w), **kw)
+    except ValueError as e:
+        return desc + " (no such pyramid)" if "pyramid" in str(e) or "level" in str(e) else desc + " (plan refused: %s)" % str(e)[:60]
+    frames = np.stack([frame(rng, h, w, 3) for _ in range(B)])
+    if rng.integers(0, 4) == 0:
+        frames[0, int(rng.integers(0, h)), int(rng.integers(0, w)), int(rng.integers(0, 3))] = rng.choice([np.nan, np.inf, -np.inf])
+    t = torch.from_numpy(frames).cuda()
+    rt.get_context().set_tuning(_lib.TUNE_RGB, kr)
+    fused.step(t)
+    plain.run_pyramid(t)
+    plain.run_filters()
+    plain.run_keypoints()
+    torch.cuda.synchronize()
+    rt.get_context().set_tuning(_lib.TUNE_RGB, 0)
+    a, b = fused.outputs(allow_truncated=True), plain.outputs(allow_truncated=True)
+    for name in ("orient", "line_end", "peak_value") + (("value",) if vm else ()):
+        x, y = a[name].data.cpu().numpy(), b[name].data.cpu().numpy()
+        assert np.array_equal(np.isnan(x), np.isnan(y)), desc + " NaN pattern of " + name
+        np.testing.assert_array_equal(np.nan_to_num(x, nan=7.0), np.nan_to_num(y, nan=7.0), err_msg=desc + " " + name)
+    np.testing.assert_array_equal(a["keypoint_counts"], b["keypoint_counts"], err_msg=desc)
+    for f in range(B):
+        np.testing.assert_array_equal(a["keypoints"][f], b["keypoints"][f], err_msg=desc)
+    return desc
+
+
+CASES = {"gray_pass": case_gray_pass, "rgb": case_rgb, "select": case_select, "ops": case_ops, "rgb_keypoints": case_rgb_keypoints}
 BIG = {"big": case_big}
 
 
