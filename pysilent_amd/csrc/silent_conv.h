@@ -210,6 +210,9 @@ constexpr int kGrayTH = 16;              // rows per tile (R)
 // row through a wave-private LDS slab: lane l then stores the l-th 16-byte piece of the row, so that each of
 // the two store instructions covers 1 KiB of contiguous memory.  first / count: the lanes (= pixels of the
 // wave's 64 columns) that may be written.  Every lane of the wave must call this (LDS exchange).
+// NT: non-temporal stores (gray_stream_kernel: the map is a result nobody on the GPU reads back, and keeping it out of
+// the caches leaves the Infinity Cache to the pyramid levels that gray_line_end_kernel reads next).
+template <bool NT = false>
 __device__ __forceinline__ void store_row_k8(float* __restrict__ row_base /* address of pixel of lane 0 */,
                                              const float (&acc)[8], float* s_slab /* 512 floats, wave private */,
                                              int lane, int first, int count) {
@@ -223,8 +226,13 @@ __device__ __forceinline__ void store_row_k8(float* __restrict__ row_base /* add
     // piece q (16 bytes) belongs to pixel q / 2
     const int pa = lane >> 1, pb = 32 + (lane >> 1);
     nf4* out4 = reinterpret_cast<nf4*>(row_base);
-    if (pa >= first && pa < first + count) out4[lane] = a;
-    if (pb >= first && pb < first + count) out4[64 + lane] = b;
+    if constexpr (NT) {
+        if (pa >= first && pa < first + count) __builtin_nontemporal_store(a, out4 + lane);
+        if (pb >= first && pb < first + count) __builtin_nontemporal_store(b, out4 + 64 + lane);
+    } else {
+        if (pa >= first && pa < first + count) out4[lane] = a;
+        if (pb >= first && pb < first + count) out4[64 + lane] = b;
+    }
 }
 
 template <int K, int R>
@@ -797,12 +805,13 @@ __global__ __launch_bounds__(64 * kFusedWaves) void gray_stream_kernel(const flo
                         relu_clip_tf(acc, clip_hi);
                         if constexpr (K == 8) {
                             const int ncols = min(kFusedCols, lv.out_w - xw0);
-                            store_row_k8(end_out + row_px * 8, acc, s_slab + wave * 512, lane, 4, ncols);
+                            store_row_k8<true>(end_out + row_px * 8, acc, s_slab + wave * 512, lane, 4, ncols);
                         } else if constexpr (K == 4) {
-                            float4* __restrict__ erow = reinterpret_cast<float4*>(end_out + row_px * 4);
-                            if (out_lane) {
-                                erow[lane] = make_float4(acc[0], acc[1], acc[2], acc[3]);
-                            }
+                            // non-temporal like the two 4-byte maps: whole pass -1.6 % (the kernel alone -0.7 %: the rest is
+                            // gray_line_end_kernel finding more of the pyramid's levels >= 1 in the Infinity Cache)
+                            typedef float nf4 __attribute__((ext_vector_type(4)));
+                            nf4* __restrict__ erow = reinterpret_cast<nf4*>(end_out + row_px * 4);
+                            if (out_lane) __builtin_nontemporal_store(nf4{acc[0], acc[1], acc[2], acc[3]}, erow + lane);
                         } else {
                             float* __restrict__ po = end_out + row_px * K;
                             if (out_lane) {
