@@ -309,3 +309,55 @@ def test_centroid_box_sums_against_torch(h, w, r):
     cyr = F.interpolate(cy, size=(h, w), mode="nearest")
     want = ((cxr - xs).abs() + (cyr - ys).abs())[0, 0].numpy()
     npt.assert_allclose(cent[0, :, :, 0], want, rtol=1e-5, atol=1e-4)
+
+
+@pytest.mark.parametrize("policy", ["zero", "ieee"])
+def test_rgb_chain_composition_against_torch(kernels, policy):
+    """Second opinion for the oracle's WHOLE reference graph (recognition_testing.py:69-77, a-2 ... a-8), stage by stage in
+    torch float32 ops composed independently of oracle/silent_oracle.py: conv2d (cross-correlation, zero padding), relu,
+    the regulator x * (rv / min(conv7x7(x), 1) ** root), relu + clip, the 2-pixel border mask and the channel mean as
+    sum * float32(1/3).  The oracle accumulates its convolutions in float64 and rounds once, torch in float32: agreement
+    within 2e-5 of each map's range, and the NaN pattern of the 'ieee' policy (0 * inf on flat regions) must be the same
+    wherever the blur is exactly 0."""
+    torch = pytest.importorskip("torch")
+    F = torch.nn.functional
+    x = np.stack([noise_frame(3, 40, 56, 3), structured_frame(4, 40, 56, 3, 12)])
+    want = so.rgb_line_end_chain(x, kernels, flat_policy=policy)
+
+    def conv(t, k):
+        kt = torch.from_numpy(np.asarray(k, np.float64).astype(np.float32)).permute(3, 2, 0, 1)
+        p = (kt.shape[-1] - 1) // 2
+        return F.conv2d(F.pad(t, (p, p, p, p)), kt)
+
+    t = torch.from_numpy(x).permute(0, 3, 1, 2)
+    rgc = torch.relu(conv(t, kernels["rgc"]))
+    rgby = torch.relu(conv(rgc, kernels["rgby"]))
+    stripe = torch.relu(conv(rgby, kernels["stripe"]))
+    blur = conv(stripe, kernels["blur"])
+    orient = stripe * (1.0 / torch.pow(torch.clamp(blur, max=1.0), 0.1))
+    if policy == "zero":
+        orient = torch.where(stripe == 0, torch.zeros_like(orient), orient)
+    line = torch.clamp(torch.relu(conv(orient, kernels["end"])), max=255.0)
+    mask = torch.zeros_like(line)
+    mask[:, :, 2:-2, 2:-2] = 1.0
+    padded = line * mask
+    value = padded.sum(1, keepdim=True) * np.float32(1.0 / 3.0)
+    nhwc = lambda a: a.permute(0, 2, 3, 1).numpy()
+    for name, got in (("rgc", rgc), ("rgby", rgby), ("stripe", stripe)):
+        g, w = nhwc(got), want[name]
+        assert np.abs(g - w).max() <= 2e-5 * max(np.abs(w).max(), 1.0), name
+    b = nhwc(blur)
+    sure = (b == 0) | (b > 1e-4 * b.max())          # away from float32 rounding residue of the blur around 0
+    for name, got in (("orient", orient), ("padded", padded), ("value", value)):
+        g, w = nhwc(got), want[name]
+        s = sure if g.shape[-1] == 3 else sure.all(axis=-1, keepdims=True)
+        if name != "orient":                         # one erosion: a line-end value reads a 3x3 neighbourhood of orient
+            e = torch.from_numpy((~sure).astype(np.float32)).permute(0, 3, 1, 2).sum(1, keepdim=True)
+            grown = F.max_pool2d(e, 3, 1, 1).permute(0, 2, 3, 1).numpy() > 0
+            s = ~grown if g.shape[-1] == 1 else np.broadcast_to(~grown, g.shape)
+        assert np.array_equal(np.isnan(g)[s], np.isnan(w)[s]), name + " NaN pattern"
+        ok = s & ~np.isnan(w)
+        scale = max(np.abs(w[ok]).max(), 1.0) if ok.any() else 1.0
+        assert np.abs(g[ok] - w[ok]).max() <= 2e-5 * scale, name
+    if policy == "ieee":
+        assert np.isnan(want["orient"]).any()       # the line drawing has flat regions: the policy was exercised
