@@ -83,6 +83,16 @@ def image_to_zoom_tensor(image, num_colors, center_dimensions, scale):
     frames, dev = _frames(image, num_colors)
     if frames.shape[0] != 1:
         raise ValueError("from_image takes one [H, W, C] image; use classic_pyramid / PyramidPlan for batches")
+    if int(num_colors) not in (1, 3):
+        # the kernels take 1 or 3 interleaved channels; the reference zooms every colour plane on its own
+        # (from_image.py:54-64), so any other count is that many single-channel pyramids side by side
+        planes = [image_to_zoom_tensor(frames[0][..., c:c + 1].contiguous() if _runtime.is_torch_tensor(frames)
+                                       else np.ascontiguousarray(frames[0][..., c:c + 1]), 1, center_dimensions, scale)
+                  for c in range(int(num_colors))]
+        if _runtime.is_torch_tensor(planes[0]):
+            import torch
+            return torch.cat(planes, dim=-1)
+        return np.concatenate(planes, axis=-1)
     levels = reference_levels(tuple(frames.shape[1:3]), center_dimensions, scale)
     packed = _plan(tuple(frames.shape[1:]), levels, dev).run(frames)
     h, w = packed.extents[0]

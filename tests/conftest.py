@@ -24,6 +24,15 @@ def golden():
 
 
 @pytest.fixture(scope="session")
+def golden_pyramid():
+    """Outputs of the reference's own image_to_zoom_tensor (tests/golden/make_golden_pyramid.py): name -> (image f32,
+    pyramid f64 [L, h, w, C], (center_w, center_h, scale))."""
+    z = np.load(os.path.join(GOLDEN, "pyramid.npz"))
+    names = sorted(k[:-3] for k in z.files if k.endswith("_in"))
+    return {n: (z[n + "_in"], z[n + "_out"], z[n + "_par"]) for n in names}
+
+
+@pytest.fixture(scope="session")
 def kernels(golden):
     """The constant kernels of the chain, from the PRODUCT generators (checked against the goldens in
     test_generators.py), HWIO float64."""

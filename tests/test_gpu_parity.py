@@ -245,6 +245,18 @@ def test_from_image_reference_layout(rt, shape, center, scale):
     assert_close(got, want, RTOL, scale=255.0, what="from_image")
 
 
+def test_from_image_against_the_reference_wrappers_own_outputs(rt, golden_pyramid):
+    """zoom.from_image (HIP pyramid kernels) against pyramids produced by the reference's own image_to_zoom_tensor
+    (tests/golden/pyramid.npz, generated by tests/golden/make_golden_pyramid.py): same level count and extents, values within
+    the float32 tolerance (the GPU accumulates the 6 x 6 spline taps in float32 fmas, SciPy in float64)."""
+    from pysilent_amd.util import zoom
+    for name, (img, want, par) in golden_pyramid.items():
+        center, scale = [int(par[0]), int(par[1])], float(par[2])
+        got = zoom.from_image(img, img.shape[2], center, scale)
+        assert got.shape == want.shape and got.dtype == np.float32, name
+        assert_close(got, want.astype(np.float32), RTOL, scale=255.0, what="from_image vs reference " + name)
+
+
 @pytest.mark.parametrize("shape,scale,n", [((135, 240, 1), 2.0, 5), ((135, 240, 3), 2.0, 4), ((270, 480, 1), math.e ** .5, 6),
                                            ((48, 64, 1), 2.0, 2), ((100, 37, 1), 1.3, 7)])
 def test_classic_pyramid(rt, shape, scale, n):

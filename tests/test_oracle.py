@@ -132,6 +132,22 @@ def test_spline_restatement_is_scipy(golden):
     npt.assert_allclose(so.spline5_zoom(p, 11, 11)[5, 3:8] * 120, [66, 1716, 4356, 1716, 66], rtol=1e-6)
 
 
+def test_zoom_from_image_equals_the_reference_wrapper(golden_pyramid):
+    """a-1 pinned on the reference ITSELF: the pyramids its own image_to_zoom_tensor (from_image.py:10-69) produced when
+    executed unmodified under NumPy < 1.23's list-of-slices indexing (tests/golden/make_golden_pyramid.py) -- level count,
+    centre crops clipped to the image, zoom factors, canvas placement -- against the oracle's restatement, bit for bit,
+    with SciPy's zoom and with the oracle's own spline (the form the C port and the HIP kernels implement)."""
+    assert len(golden_pyramid) >= 5
+    for name, (img, want, par) in golden_pyramid.items():
+        center, scale = [int(par[0]), int(par[1])], float(par[2])
+        for use_scipy in (True, False):
+            got = so.zoom_from_image(img, img.shape[2], center, scale, use_scipy=use_scipy)
+            assert got.shape == want.shape, name
+            assert want.dtype == np.float64 and np.array_equal(want, want.astype(np.float32)), name   # f64 holding f32 values
+            npt.assert_array_equal(got, want.astype(np.float32), err_msg=name)
+        assert so.ref_num_scales(img.shape[:2], [center[1], center[0]], scale) == want.shape[0]
+
+
 def test_zoom_from_image_matches_reference_geometry():
     # reference default: 480x640x3 -> [2,192,288,3]; SURVEY 8a-1 level counts
     img = noise_frame(0, 480, 640, 3)
