@@ -29,7 +29,9 @@ def golden_pyramid():
     pyramid f64 [L, h, w, C], (center_w, center_h, scale))."""
     z = np.load(os.path.join(GOLDEN, "pyramid.npz"))
     names = sorted(k[:-3] for k in z.files if k.endswith("_in"))
-    return {n: (z[n + "_in"], z[n + "_out"], z[n + "_par"]) for n in names}
+    d = {n: (z[n + "_in"], z[n + "_out"], z[n + "_par"]) for n in names}
+    d["__images__"] = {k[:-7]: z[k] for k in z.files if k.endswith("_images")}
+    return d
 
 
 @pytest.fixture(scope="session")

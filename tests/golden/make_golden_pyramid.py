@@ -83,6 +83,13 @@ def main():
         out[name + "_out"] = np.asarray(z, np.float64)
         out[name + "_par"] = np.array([center[0], center[1], scale], np.float64)
         print("%-14s in %s -> %s" % (name, img.shape, z.shape))
+    # zoom_tensor_to_image_list (util/zoom/to_image_list.py:7-15), same indexing idiom, same shim: the display glue of f-3
+    tl = importlib.import_module("slam_recognition.util.zoom.to_image_list")
+    tl.np = mod.np
+    for name in ("default_small", "gray_three"):
+        imgs = tl.zoom_tensor_to_image_list(np.clip(out[name + "_out"], 0, 255).view(OldIndexing))
+        out[name + "_images"] = np.stack([np.asarray(i) for i in imgs], 0)
+        print("%-14s image list: %d x %s %s" % (name, len(imgs), imgs[0].shape, imgs[0].dtype))
     np.savez_compressed(os.path.join(HERE, "pyramid.npz"), **out)
     print("wrote", os.path.join(HERE, "pyramid.npz"), os.path.getsize(os.path.join(HERE, "pyramid.npz")), "bytes")
 

@@ -137,7 +137,16 @@ def test_zoom_from_image_equals_the_reference_wrapper(golden_pyramid):
     executed unmodified under NumPy < 1.23's list-of-slices indexing (tests/golden/make_golden_pyramid.py) -- level count,
     centre crops clipped to the image, zoom factors, canvas placement -- against the oracle's restatement, bit for bit,
     with SciPy's zoom and with the oracle's own spline (the form the C port and the HIP kernels implement)."""
-    assert len(golden_pyramid) >= 5
+    images = golden_pyramid["__images__"]
+    golden_pyramid = {k: v for k, v in golden_pyramid.items() if not k.startswith("__")}
+    assert len(golden_pyramid) >= 5 and len(images) >= 2
+    from pysilent_amd.util.zoom import to_image_list          # pure NumPy display glue (to_image_list.py:7-15)
+    for name, want_imgs in images.items():
+        got = to_image_list(np.clip(golden_pyramid[name][1], 0, 255))
+        assert len(got) == len(want_imgs)
+        for g, w in zip(got, want_imgs):
+            assert g.dtype == np.uint8 and g.shape == w.shape
+            npt.assert_array_equal(g, w, err_msg=name)
     for name, (img, want, par) in golden_pyramid.items():
         center, scale = [int(par[0]), int(par[1])], float(par[2])
         for use_scipy in (True, False):
