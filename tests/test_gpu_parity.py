@@ -250,9 +250,10 @@ def test_from_image_against_the_reference_wrappers_own_outputs(rt, golden_pyrami
     (tests/golden/pyramid.npz, generated by tests/golden/make_golden_pyramid.py): same level count and extents, values within
     the float32 tolerance (the GPU accumulates the 6 x 6 spline taps in float32 fmas, SciPy in float64)."""
     from pysilent_amd.util import zoom
-    for name, (img, want, par) in golden_pyramid.items():
+    for name, case in golden_pyramid.items():
         if name.startswith("__"):
             continue
+        img, want, par = case
         center, scale = [int(par[0]), int(par[1])], float(par[2])
         got = zoom.from_image(img, img.shape[2], center, scale)
         assert got.shape == want.shape and got.dtype == np.float32, name
