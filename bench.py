@@ -72,18 +72,39 @@ def _free_port():
     return port
 
 
+def _tail(path, n=3000):
+    try:
+        with open(path, "rb") as f:
+            f.seek(0, 2)
+            size = f.tell()
+            f.seek(max(0, size - n))
+            return f.read().decode("utf-8", "replace")
+    except OSError:
+        return ""
+
+
 def launch_ranks(n, argv, timeout_s=None):
     """Start n rank processes of this script (RANK = LOCAL_RANK = 0..n-1), relay rank 0's stdout, return the exit
-    code (0 only if every rank exited 0).  The parent has not imported torch and makes no HIP call."""
+    code (0 only if every rank exited 0).  The parent has not imported torch and makes no HIP call.  Rank r >= 1 writes
+    stdout + stderr to <log dir>/rank<r>.log (SILENT_BENCH_LOG_DIR, default a fresh temporary directory); when a rank
+    fails, the tail of ITS log is printed to stderr."""
+    import tempfile
     port = os.environ.get("MASTER_PORT") or str(_free_port())
     timeout_s = timeout_s or float(os.environ.get("SILENT_BENCH_LAUNCH_TIMEOUT", "1500"))
-    procs = []
+    logdir = os.environ.get("SILENT_BENCH_LOG_DIR") or tempfile.mkdtemp(prefix="silent_bench_")
+    os.makedirs(logdir, exist_ok=True)
+    procs, logs = [], []
     for r in range(n):
         env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1",
                    MASTER_PORT=port)
         env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        path = os.path.join(logdir, "rank%d.log" % r)
+        logs.append(path)
+        log = open(path, "wb")
+        # rank 0: stdout is the JSON line (relayed), stderr goes to its log; ranks >= 1: both to the log
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + list(argv), env=env,
-                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL, text=True))
+                                      stdout=subprocess.PIPE if r == 0 else log, stderr=log, text=(r == 0) or None))
+        log.close()
     deadline = time.time() + timeout_s
     rc, failed = 0, None
     pending = set(range(n))
@@ -105,10 +126,18 @@ def launch_ranks(n, argv, timeout_s=None):
                 procs[r].kill()
         if failed is None:
             rc = 124
-            print("bench.py launcher: ranks %s still running after %.0f s" % (sorted(pending), timeout_s), file=sys.stderr)
+            print("bench.py launcher: ranks %s still running after %.0f s (logs: %s)" % (sorted(pending), timeout_s, logdir),
+                  file=sys.stderr)
+            for r in sorted(pending):
+                print("---- rank %d, tail of %s ----\n%s" % (r, logs[r], _tail(logs[r])), file=sys.stderr)
     out = procs[0].stdout.read() if procs[0].stdout else ""
     if failed is not None:
-        print("bench.py launcher: rank %d exited with code %d" % (failed, rc), file=sys.stderr)
+        print("bench.py launcher: rank %d exited with code %d; tail of %s:\n%s" % (failed, rc, logs[failed], _tail(logs[failed])),
+              file=sys.stderr)
+    else:
+        err0 = _tail(logs[0])
+        if err0.strip():
+            sys.stderr.write(err0)
     sys.stdout.write(out)
     sys.stdout.flush()
     return rc if rc else 0
@@ -200,14 +229,18 @@ def cpu_baseline(wl, consts, budget_s=12.0):
 
 # ------------------------------------------------------------------------------------------ one rank
 
-def make_pipeline(wl, B, local, consts):
+def make_pipeline(wl, B, local, consts, **over):
     from pysilent_amd.pipeline import LineEndPipeline
     h, w = wl["hw"]
+    kw = {}
+    if wl["mode"] == "rgb":
+        # config 3 returns line_end + keypoints (+ orient, optional in SURVEY.md section 8d): the value map and the selection's
+        # peak-value map are intermediates the fused step never writes (silent_rgb_keypoints: extrema in the chain kernel,
+        # sparse keypoint tail)
+        kw = {"selection": True, "value_map": False, "peak_value_map": False}
+    kw.update(over)
     return LineEndPipeline((h, w), mode=wl["mode"], n_levels=wl["n_levels"], n_orient=wl["n_orient"], batch=B,
-                           device=local, constants=consts, max_keypoints_per_frame=1 << 16,
-                           # config 3 returns line_end + keypoints (+ orient): the value map is an intermediate the fused step
-                           # never writes (silent_rgb_keypoints)
-                           **({"selection": True, "value_map": False} if wl["mode"] == "rgb" else {}))
+                           device=local, constants=consts, max_keypoints_per_frame=1 << 16, **kw)
 
 
 def make_frames(torch, D, wl, B, rank, world, dev):
@@ -232,44 +265,35 @@ def timed_steps(torch, D, pipe, frames, steps, warmup, dev):
     torch.cuda.synchronize(dev)
     elapsed = time.perf_counter() - t0
     D.barrier()
+    timed_steps.own = elapsed                       # this rank's own time (the scaling record lists every rank's)
     return D.max_over_ranks(elapsed)
 
 
 def dominant_kernel(torch, pipe, frames, wl, B, dev, launches=24):
-    """Average launch duration of the dominant kernel from HIP events, in a loop of its own AFTER the timed region.
-    gray: the library brackets gray_stream_kernel with an event pair on the stream it launches on
-    (silent_set_profiling / silent_profile_elapsed_ms); rgb: torch events around run_filters on torch's current
-    stream, which is the stream the launch is given."""
+    """Average launch duration of the dominant kernel from HIP events, in a loop of its own AFTER the timed region: the
+    library brackets gray_stream_kernel (gray) / rgb_line_end2_kernel (rgb) with an event pair on the stream it launches on
+    (silent_set_profiling / silent_profile_elapsed_ms) while the ordinary step runs -- i.e. the very instantiation the step uses."""
+    pipe.set_profiling(1)
+    ms, px = [], 0
+    for _ in range(launches // 8):
+        for _ in range(8):                       # the library keeps a ring of 8 event pairs
+            pipe.step(frames)
+        torch.cuda.synchronize(dev)
+        t, px = pipe.profiled_kernel()
+        ms.append(float(t))
+        pipe.set_profiling(1)                    # restart the ring
+    pipe.set_profiling(0)
+    dom_ms = float(np.mean(ms))
     if wl["mode"] == "gray":
-        pipe.set_profiling(1)
-        ms = []
-        for _ in range(launches // 8):
-            for _ in range(8):                       # the library keeps a ring of 8 event pairs
-                pipe.step(frames)
-            torch.cuda.synchronize(dev)
-            t, px = pipe.profiled_kernel()
-            ms.append(float(t))
-            pipe.set_profiling(1)                    # restart the ring
-        pipe.set_profiling(0)
-        dom_ms = float(np.mean(ms))
         other_px = pipe.frame_px * B - px
         # per level-0 pixel: frame read (4 B), pyramid + CS written (4 + 4), K end maps (4K); plus the pyramid of every
         # other level written once (4 B per pixel of those levels)
         nbytes = px * (4 + 4 + 4 + 4 * wl["n_orient"]) + other_px * 4
         return {"kernel": "gray_stream_kernel<%d>" % wl["n_orient"], "ms": dom_ms, "bytes": int(nbytes),
                 "unit_level_pixels_per_launch": int(px), "pmc_name": pipe.dominant_kernel_name()}
-    evs = []
-    for _ in range(launches):
-        pipe.run_pyramid(frames)
-        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        a.record()
-        pipe.run_filters()
-        b.record()
-        pipe.run_keypoints()
-        evs.append((a, b))
-    torch.cuda.synchronize(dev)
-    return {"kernel": "rgb_line_end2_kernel", "ms": float(np.mean([a.elapsed_time(b) for a, b in evs])),
-            "bytes": int(pipe.filter_bytes_per_frame() * B), "pmc_name": "rgb_line_end2_kernel"}
+    # rgb: pyramid read once + every returned map written once (12 B/px each)
+    return {"kernel": "rgb_line_end2_kernel", "ms": dom_ms, "bytes": int(pipe.filter_bytes_per_frame() * B),
+            "pmc_name": "rgb_line_end2_kernel"}
 
 
 def roofline_of(dom, B):
@@ -283,27 +307,62 @@ def roofline_of(dom, B):
     return roof
 
 
-def side_workload(torch, D, name, local, dev, rank, world):
+def side_workload(torch, D, name, local, dev, rank, world, label=None, **over):
     """Short run of another BASELINE config on this rank (N = 1 only): ms/step, whole-pass and dominant-kernel
     fractions of the HBM peak, in the same JSON line as the headline."""
     wl = WORKLOADS[name]
     B = wl["frames"]
     consts = D.broadcast_constants(wl["mode"], wl["n_orient"], device=local)
-    pipe = make_pipeline(wl, B, local, consts)
+    pipe = make_pipeline(wl, B, local, consts, **over)
     frames = make_frames(torch, D, wl, B, rank, world, dev)
     torch.cuda.synchronize(dev)
-    steps = 10
-    elapsed = timed_steps(torch, D, pipe, frames, steps, 3, dev)
+    steps = 20
+    elapsed = timed_steps(torch, D, pipe, frames, steps, 5, dev)
     dom = dominant_kernel(torch, pipe, frames, wl, B, dev, launches=16)
     h, w = wl["hw"]
     whole = pipe.algorithmic_bytes_per_frame() * B * steps / elapsed / 1e9
-    out = {"workload": wl["name"], "frames_per_step": B, "ms_per_step": round(elapsed / steps * 1e3, 4),
+    out = {"workload": label or wl["name"], "frames_per_step": B, "ms_per_step": round(elapsed / steps * 1e3, 4),
            "mpx_in_per_s": round(B * steps * h * w / elapsed / 1e6, 1),
+           "algorithmic_bytes_per_frame": pipe.algorithmic_bytes_per_frame(),
            "whole_pass_frac_of_hbm_peak": round(whole / HBM_PEAK_GBS, 4),
            "dominant_kernel": dom["kernel"], "dominant_kernel_ms": round(dom["ms"], 4),
            "dominant_kernel_frac_of_hbm_peak": round(dom["bytes"] / (dom["ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}
+    if wl["mode"] == "rgb":
+        pipe.step(frames)
+        out["sparse_keypoint_tail"] = pipe.sparse_tail_stats()
+        out["keypoints_per_frame"] = round(float(pipe.kp_counts.float().mean().item()), 1)
     del pipe, frames
     torch.cuda.empty_cache()
+    return out
+
+
+def config3_variants(torch, D, local, dev, rank, world):
+    """Config 3 on both output sets of SURVEY.md section 8d (line_end + keypoints; the same + the optional orientation map),
+    on the bench's noise frames and -- the worst case for the sparse keypoint tail, which then hands most levels to the dense
+    kernels -- with every frame a line drawing under the default 'ieee' policy."""
+    out = {"config3": side_workload(torch, D, "config3", local, dev, rank, world),
+           "config3_line_end_only": side_workload(torch, D, "config3", local, dev, rank, world,
+                                                  label="config 3, SURVEY 8d output set: line_end + keypoints (no orientation map)",
+                                                  orient_map=False),
+           "config3_dense_tail": side_workload(torch, D, "config3", local, dev, rank, world,
+                                               label="config 3 with the selection's peak-value map returned (dense keypoint tail)",
+                                               peak_value_map=True)}
+    return out
+
+
+def dist_record(D, rank, local, ident, own_ms):
+    """all_gather of one record per rank -> the ``dist`` object of the JSON line; exits non-zero (every rank) when two
+    ranks report the same GPU: N ranks must have seen N distinct devices."""
+    rec = dict(rank=rank, local_rank=local, host=socket.gethostname(), pid=os.getpid(), ms_per_step=round(own_ms, 4), **ident)
+    recs = sorted(D.gather_records(rec), key=lambda r: r["rank"])
+    dup = D.duplicate_devices(recs) if os.environ.get("SILENT_BENCH_SHARE_GPU") != "1" else []
+    out = {"backend": D.backend_name(), "world_size": len(recs), "distinct_devices": len({r["pci_bus_id"] for r in recs}),
+           "ranks": recs}
+    if dup:
+        if rank == 0:
+            print("bench.py: ranks share a GPU: %s" % ", ".join("ranks %d and %d on %s" % d for d in dup), file=sys.stderr)
+        D.finalize()
+        sys.exit(3)
     return out
 
 
@@ -311,16 +370,22 @@ def dry_run(args):
     """SILENT_BENCH_DRY=1 (the CPU test of the launcher): everything a rank does except the GPU work."""
     from pysilent_amd import distributed as D
     wl = WORKLOADS[args.workload]
-    rank, world, _ = D.init(backend=os.environ.get("SILENT_DIST_BACKEND", "gloo"))
+    rank, world, local = D.init(backend=os.environ.get("SILENT_DIST_BACKEND", "gloo"))
     if world != args.gpus:
         raise SystemExit("--gpus %d but WORLD_SIZE is %d" % (args.gpus, world))
+    if os.environ.get("SILENT_BENCH_DRY_FAIL_RANK") == str(rank):
+        print("dry run: rank %d fails on purpose" % rank, file=sys.stderr)
+        sys.exit(7)
     consts = D.broadcast_constants(wl["mode"], wl["n_orient"])
     mine = D.shard_frame_indices(4 * world, rank, world)
     D.barrier()
     slow = D.max_over_ranks(1.0 + rank)
+    same = os.environ.get("SILENT_BENCH_DRY_SAME_BUS") == "1"
+    ident = {"device_name": "dry-run (no GPU)", "pci_bus_id": "dry:%02d" % (0 if same else rank), "uuid": "", "gcn_arch": ""}
+    dist = dist_record(D, rank, local, ident, 1.0 + rank)
     if rank == 0:
         print(json.dumps({"metric": METRIC, "value": None, "dry_run": True, "n_gpus": world, "slowest_rank_time": slow,
-                          "frames_of_rank0": mine, "constants": sorted(consts)}))
+                          "frames_of_rank0": mine, "constants": sorted(consts), "dist": dist}))
     D.finalize()
 
 
@@ -337,6 +402,12 @@ def run_rank(args):
     share = os.environ.get("SILENT_BENCH_SHARE_GPU") == "1"
     if share:
         os.environ["SILENT_DEVICE"] = "0"
+    # a short box must say so before any collective does (device_count does not initialise the GPU)
+    want = 1 if share else max(args.gpus, int(os.environ.get("LOCAL_RANK", "0")) + 1)
+    have = torch.cuda.device_count()
+    if have < want:
+        print("bench.py: --gpus %d needs %d visible GPUs, torch.cuda.device_count() is %d" % (args.gpus, want, have), file=sys.stderr)
+        sys.exit(4)
     rank, world, local = D.init(backend=os.environ.get("SILENT_DIST_BACKEND"), device=0 if share else None)
     if share:
         local = 0
@@ -357,6 +428,7 @@ def run_rank(args):
     torch.cuda.synchronize(dev)
 
     elapsed = timed_steps(torch, D, pipe, frames, args.steps, args.warmup, dev)
+    own_ms = timed_steps.own / args.steps * 1e3
 
     # ---- everything below is outside the timed region ----
     # Steady state, reported beside `value`, never instead of it: after an idle period the first ~20 back-to-back launches
@@ -366,7 +438,8 @@ def run_rank(args):
     settle_steps = 60
     steady = timed_steps(torch, D, pipe, frames, settle_steps, 0, dev)
     dom = dominant_kernel(torch, pipe, frames, wl, B, dev)
-    gray = wl["mode"] == "gray"
+    # the scaling record proves itself: backend, and per rank the device it ran on and its own step time
+    dist = dist_record(D, rank, local, D.device_identity(local), own_ms)
     if rank != 0:
         D.finalize()
         return
@@ -399,6 +472,7 @@ def run_rank(args):
                    "sharding": "frame i -> rank i mod N; one RCCL broadcast of constants at init",
                    "csrc_revision": csrc_revision()},
         "roofline": roofline_of(dom, B),
+        "dist": dist,
         "steady_state": {"ms_per_step": round(steady / settle_steps * 1e3, 4), "steps": settle_steps,
                          "value": round(B * world * settle_steps * h * w / steady / 1e6, 2),
                          "whole_pass_frac_of_hbm_peak": round(pipe.algorithmic_bytes_per_frame() * B * settle_steps / steady / 1e9 / HBM_PEAK_GBS, 4),
@@ -408,8 +482,11 @@ def run_rank(args):
     del pipe, frames
     torch.cuda.empty_cache()
     if world == 1 and not args.no_side_workloads:
-        out["other_workloads"] = {k: side_workload(torch, D, k, local, dev, rank, world)
-                                  for k in ("config3", "config5") if k != args.workload}
+        out["other_workloads"] = {}
+        if args.workload != "config3":
+            out["other_workloads"].update(config3_variants(torch, D, local, dev, rank, world))
+        if args.workload != "config5":
+            out["other_workloads"]["config5"] = side_workload(torch, D, "config5", local, dev, rank, world)
     if world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(wl, consts)
     else:

@@ -177,7 +177,7 @@ int silent_profile_elapsed_ms(silent_ctx* ctx, float* ms, int64_t* pixels);
  * once in silent_create; silent_set_tuning changes a knob of one context afterwards.  Bits -- GRAY: 1 XCD-aware tile
  * order, 2 32-row filter tiles, 8 32-row fused tiles, 16 no single-read stream kernel, 32 XCD order in the stream
  * kernel, 128 strip-walk kernel for the unit level (256 / 512: its store policy / pyramid source); RGB: 1 dense weights, 2 no two-group form, 8 no short tiles,
- * 16 the one-pixel-per-lane chain kernel (default: two pixels per lane on packed f32, same bits), bits 8-15 tile height / 2; GRAY bit 18: one-pixel strip walk; PYRAMID: 1 no
+ * 16 the one-pixel-per-lane chain kernel (default: two pixels per lane on packed f32, same bits), 32 no sparse keypoint tail, bits 8-15 tile height / 2; GRAY bit 18: one-pixel strip walk; PYRAMID: 1 no
  * single-read pyramid (gray stream kernel, RGB strip walk), 2 no RGB strip walk.  All variants give the same results (bit-identical, or within the re-association tolerance
  * for the RGB forms); the defaults are the fastest measured. */
 #define SILENT_TUNE_GRAY 0
@@ -264,8 +264,8 @@ int silent_select_peaks_dev(silent_ctx* ctx, const float* color, const float* va
 
 /* SURVEY 8d config 3 in one call: silent_select_peaks followed by silent_max_value_indices_region on its peak value
  * (a-10 -> a-9 -> a-8 -> a-11), with the cell maxima of the keypoint search folded into the selection pass (one pass
- * over the value map less).  Outputs exactly as those two calls: peak_value_out [1 ch] (required by the _dev form),
- * idx / counts as silent_max_value_indices_region. */
+ * over the value map less).  Outputs exactly as those two calls: peak_value_out [1 ch] (may be NULL: the map then lives in
+ * the context workspace), idx / counts as silent_max_value_indices_region. */
 int silent_select_keypoints(silent_ctx* ctx, const float* color, const float* value, const silent_extent* levels,
                             int n_levels, int n_frames, int channels, double top_percent,
                             const silent_extent* regions, float* peak_value_out, int64_t* idx, size_t cap_per_frame,
@@ -374,7 +374,12 @@ int silent_rgb_chain_structure(const silent_rgb_chain_params* params, unsigned* 
  * bit for bit, as those two calls.  The fused chain kernel accumulates the per-level max / min of the value map that a-10's
  * threshold needs (top_value_points.py:16-27) while it writes line_end, so the separate reduction pass and -- unless value_out
  * is given -- the value map itself are never moved through memory.  orient_out / value_out may be NULL; the host form also
- * accepts NULL line_end_out / peak_value_out; idx / cap_per_frame / counts as silent_max_value_indices_region. */
+ * accepts NULL line_end_out; idx / cap_per_frame / counts as silent_max_value_indices_region.
+ * peak_value_out may be NULL (both forms): nobody then needs the selection's value map as a MAP, and the tail runs sparse --
+ * the chain kernel leaves max_pool(value) per (pixel pair x 16 rows), and a-10 / a-9 / a-8 / a-11 are evaluated only around
+ * the pixels that reach their level's threshold (a handful per level on natural and noise frames); a (frame, level) this
+ * cannot settle exactly (a search window without a positive peak: all its pixels are keypoints; > 16384 candidates in a
+ * frame) runs the dense kernels on a map in the context workspace.  Keypoints are identical either way (tested). */
 int silent_rgb_keypoints(silent_ctx* ctx, const float* pyr, const silent_extent* levels, int n_levels, int n_frames,
                          const silent_rgb_chain_params* params, double top_percent, const silent_extent* regions,
                          float* orient_out, float* line_end_out, float* value_out, float* peak_value_out, int64_t* idx,
@@ -383,6 +388,11 @@ int silent_rgb_keypoints_dev(silent_ctx* ctx, const float* pyr, const silent_ext
                              const silent_rgb_chain_params* params, double top_percent, const silent_extent* regions,
                              float* orient_out, float* line_end_out, float* value_out, float* peak_value_out, int64_t* idx,
                              size_t cap_per_frame, int64_t* counts, silent_stream stream);
+
+/* What the sparse tail of the LAST silent_rgb_keypoints[_dev] call of this context did (synchronises that call's stream):
+ * stats[0] = 1 if it ran sparse, [1] = (frame, level) pairs, [2] = pairs it handed to the dense kernels, [3] = candidate
+ * pixels (value >= threshold) it evaluated.  For tests and the bench report; no reference counterpart. */
+int silent_sparse_tail_stats(silent_ctx* ctx, int64_t* stats);
 
 /* Host-only (no GPU needed): the weight STREAM silent_rgb_line_end hands to its pair kernel for these weights -- the
  * weights in the order the kernel consumes them (csrc/silent_rgb2.h), zero-padded to whole pairs of 16-float blocks.

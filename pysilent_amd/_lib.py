@@ -127,6 +127,7 @@ _SIGNATURES = {
     "silent_rgb_chain_structure": [C.POINTER(RgbChainParams), C.POINTER(C.c_uint), C.POINTER(C.c_uint)],
     "silent_rgb_keypoints": [_vp, _fp, _ep, _i, _i, C.POINTER(RgbChainParams), _d, _ep, _fp, _fp, _fp, _fp, _vp, _sz, _vp],
     "silent_rgb_keypoints_dev": [_vp, _fp, _ep, _i, _i, C.POINTER(RgbChainParams), _d, _ep, _fp, _fp, _fp, _fp, _vp, _sz, _vp, _vp],
+    "silent_sparse_tail_stats": [_vp, C.POINTER(C.c_int64)],
     "silent_rgb_chain_stream": [C.POINTER(RgbChainParams), C.c_uint, _fp, C.POINTER(C.c_int), C.POINTER(C.c_int)],
     "silent_rgb_line_end": [_vp, _fp, _ep, _i, _i, C.POINTER(RgbChainParams), _fp, _fp, _fp],
     "silent_rgb_line_end_dev": [_vp, _fp, _ep, _i, _i, C.POINTER(RgbChainParams), _fp, _fp, _fp, _vp],

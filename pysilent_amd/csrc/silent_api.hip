@@ -52,6 +52,11 @@ struct silent_ctx {
     // kernel-selection knobs (silent_set_tuning; initial values from SILENT_GRAY_OPTS / SILENT_RGB_OPTS /
     // SILENT_PYRAMID_OPTS read ONCE, in silent_create): tests and A/B scripts pick alternative kernels with them
     unsigned tune[SILENT_TUNE_COUNT] = {0, 0, 0};
+    // the last silent_rgb_keypoints_dev call's sparse tail (silent_sparse_tail_stats): where its flags / counters live in ws
+    bool sparse_ran = false;
+    hipStream_t sparse_stream = nullptr;
+    size_t sparse_flags_off = 0, sparse_candn_off = 0;
+    int sparse_pairs = 0, sparse_frames = 0;
 };
 
 // Entry points run on the context's device and put the caller's device back before they return: torch tracks its
@@ -639,10 +644,10 @@ SILENT_EXPORT int silent_select_peaks_dev(silent_ctx* ctx, const float* color, c
     std::memset(&no_regions, 0, sizeof(no_regions));
     if (channels == 3)
         hipLaunchKernelGGL((select_peaks_kernel<3, false>), dim3((unsigned)blocks), dim3(256), 0, s, color, value, top_out,
-                           peaks_out, peak_value_out, tab, a, b, mm, no_regions, nullptr);
+                           peaks_out, peak_value_out, tab, a, b, mm, no_regions, nullptr, nullptr);
     else
         hipLaunchKernelGGL((select_peaks_kernel<1, false>), dim3((unsigned)blocks), dim3(256), 0, s, color, value, top_out,
-                           peaks_out, peak_value_out, tab, a, b, mm, no_regions, nullptr);
+                           peaks_out, peak_value_out, tab, a, b, mm, no_regions, nullptr, nullptr);
     return check_launch(ctx, who);
 }
 
@@ -720,7 +725,8 @@ static int build_region_tab(silent_ctx* ctx, const char* who, const silent_exten
     return SILENT_OK;
 }
 
-// workspace of the keypoint passes, after `reserve` bytes the caller keeps for itself: cells | chunk_counts | offsets
+// workspace of the keypoint passes, after `reserve` bytes the caller keeps for itself:
+// cells | chunk_counts | hit_masks | cand_n | offsets | m1 | pooled | summary | candidates | dense flags | peak-value map
 struct KeypointWs {
     unsigned* cells;
     int* chunk_counts;
@@ -729,25 +735,46 @@ struct KeypointWs {
     float* m1;       // general path: row maxima over the column windows
     float* pooled;   // general path: window maxima
     unsigned long long* hit_masks;   // 1 bit per pixel: the count pass's ballots, read by the write pass
+    // sparse tail (silent_rgb_keypoints without a peak-value map; silent_peaks.h, sparse_select_kernel)
+    float* sum = nullptr;            // the chain kernel's value summary (SumTab geometry)
+    Candidate* cand = nullptr;       // [n_frames][kCandCap]
+    int* cand_n = nullptr;           // [n_frames]
+    int* dense_flags = nullptr;      // [n_frames][n_levels]
+    float* pv = nullptr;             // peak-value map of the (frame, level)s that run the dense kernels
+    void* zero_from = nullptr;       // chunk_counts | hit_masks | cand_n: one memset before a sparse tail
+    size_t zero_bytes = 0;
 };
 
 static int keypoint_workspace(silent_ctx* ctx, hipStream_t stream, int n_levels, int n_frames, long long blocks, size_t reserve,
-                              const RegionTab& rt, bool general, KeypointWs* w) {
+                              const RegionTab& rt, bool general, KeypointWs* w, long long sum_entries = 0, long long pv_px = 0) {
     w->n_cells = (size_t)n_frames * n_levels * kCells;
     const size_t off_cells = align_up(reserve);
     const size_t off_counts = off_cells + align_up(w->n_cells * sizeof(unsigned));
-    const size_t off_offsets = off_counts + align_up((size_t)blocks * sizeof(int));
+    const size_t off_masks = off_counts + align_up((size_t)blocks * sizeof(int));
+    const size_t off_candn = off_masks + align_up((size_t)blocks * 4 * kKpPer * sizeof(unsigned long long));
+    const size_t off_offsets = off_candn + align_up((size_t)n_frames * sizeof(int));
     const size_t off_m1 = off_offsets + align_up((size_t)blocks * sizeof(long long));
     const size_t off_pooled = off_m1 + (general ? align_up((size_t)n_frames * rt.m1_per_frame * sizeof(float)) : 0);
-    const size_t off_masks = off_pooled + (general ? align_up((size_t)n_frames * rt.pooled_per_frame * sizeof(float)) : 0);
-    const size_t total = off_masks + align_up((size_t)blocks * 4 * kKpPer * sizeof(unsigned long long));
+    const size_t off_sum = off_pooled + (general ? align_up((size_t)n_frames * rt.pooled_per_frame * sizeof(float)) : 0);
+    const size_t off_cand = off_sum + align_up((size_t)sum_entries * n_frames * sizeof(float));
+    const size_t off_flags = off_cand + (sum_entries ? align_up((size_t)n_frames * kCandCap * sizeof(Candidate)) : 0);
+    const size_t off_pv = off_flags + align_up((size_t)n_frames * n_levels * sizeof(int));
+    const size_t total = off_pv + align_up((size_t)pv_px * n_frames * sizeof(float));
     TRY(workspace(ctx, (hipStream_t)stream, total));
-    w->cells = (unsigned*)((char*)ctx->ws.p + off_cells);
-    w->chunk_counts = (int*)((char*)ctx->ws.p + off_counts);
-    w->chunk_offsets = (long long*)((char*)ctx->ws.p + off_offsets);
-    w->m1 = (float*)((char*)ctx->ws.p + off_m1);
-    w->pooled = (float*)((char*)ctx->ws.p + off_pooled);
-    w->hit_masks = (unsigned long long*)((char*)ctx->ws.p + off_masks);
+    char* base = (char*)ctx->ws.p;
+    w->cells = (unsigned*)(base + off_cells);
+    w->chunk_counts = (int*)(base + off_counts);
+    w->chunk_offsets = (long long*)(base + off_offsets);
+    w->m1 = (float*)(base + off_m1);
+    w->pooled = (float*)(base + off_pooled);
+    w->hit_masks = (unsigned long long*)(base + off_masks);
+    w->cand_n = (int*)(base + off_candn);
+    w->sum = sum_entries ? (float*)(base + off_sum) : nullptr;
+    w->cand = sum_entries ? (Candidate*)(base + off_cand) : nullptr;
+    w->dense_flags = (int*)(base + off_flags);
+    w->pv = pv_px ? (float*)(base + off_pv) : nullptr;
+    w->zero_from = base + off_counts;
+    w->zero_bytes = off_offsets - off_counts;
     return SILENT_OK;
 }
 
@@ -772,11 +799,12 @@ static int region_window_maxima(silent_ctx* ctx, const char* who, const float* v
 
 // count -> scan -> ordered write, given the cell maxima
 static void keypoint_passes(const float* value, const LevelTab& tab, long long blocks, const RegionTab& rt, const KeypointWs& w,
-                            bool general, int n_frames, int64_t* idx, size_t cap_per_frame, int64_t* counts, hipStream_t s) {
+                            bool general, int n_frames, int64_t* idx, size_t cap_per_frame, int64_t* counts, hipStream_t s,
+                            const int* dense_flags = nullptr) {
     if (general)
-        hipLaunchKernelGGL(region_count_kernel<true>, dim3((unsigned)blocks), dim3(256), 0, s, value, tab, rt, w.cells, w.pooled, w.chunk_counts, w.hit_masks);
+        hipLaunchKernelGGL(region_count_kernel<true>, dim3((unsigned)blocks), dim3(256), 0, s, value, tab, rt, w.cells, w.pooled, w.chunk_counts, w.hit_masks, dense_flags);
     else
-        hipLaunchKernelGGL(region_count_kernel<false>, dim3((unsigned)blocks), dim3(256), 0, s, value, tab, rt, w.cells, w.pooled, w.chunk_counts, w.hit_masks);
+        hipLaunchKernelGGL(region_count_kernel<false>, dim3((unsigned)blocks), dim3(256), 0, s, value, tab, rt, w.cells, w.pooled, w.chunk_counts, w.hit_masks, dense_flags);
     hipLaunchKernelGGL(region_scan_kernel, dim3((unsigned)n_frames), dim3(256), 0, s, w.chunk_counts, w.chunk_offsets,
                        tab.tiles_per_frame, counts);
     if (!cap_per_frame) return;
@@ -823,27 +851,49 @@ struct SelectPlan {
     KeypointWs w;
     unsigned* mm;   // [n_frames][n_levels][2] ordered-uint extrema, at the head of the context workspace
     int nmm;
+    SumTab st;      // sparse tail: geometry of the chain kernel's value summary (frame_entries = 0: none)
 };
 
-// tables, workspace, and the two init kernels
+// Geometry of the value summary a chain launch with tile height th leaves (silent_rgb2.h): per level
+// [tiles_y * gpt][ceil(w / 2)] entries, gpt = ceil(th / kSumRows).
+static void build_sum_tab(const silent_extent* levels, int n_levels, int th, SumTab* st) {
+    std::memset(st, 0, sizeof(*st));
+    st->th = th;
+    st->gpt = (th + kSumRows - 1) / kSumRows;
+    long long e = 0;
+    for (int l = 0; l < n_levels; ++l) {
+        st->off[l] = e;
+        e += (long long)((levels[l].h + th - 1) / th) * st->gpt * ((levels[l].w + 1) / 2);
+    }
+    for (int l = n_levels; l <= kMaxLevels; ++l) st->off[l] = e;
+    st->frame_entries = e;
+}
+
+// tables, workspace, and the init kernels.  sparse_th > 0: also lay out the sparse tail for a chain launch with that tile
+// height; pv_ws: keep room for a peak-value map in the workspace (the caller has none)
 static int select_prepare(silent_ctx* ctx, const char* who, const silent_extent* levels, int n_levels, int n_frames,
-                          const silent_extent* regions, hipStream_t s, SelectPlan* sp) {
+                          const silent_extent* regions, hipStream_t s, SelectPlan* sp, int sparse_th = 0, bool pv_ws = false) {
     TRY(build_level_tab(ctx, who, levels, n_levels, n_frames, kRedChunk, 0, &sp->rtab, &sp->rblocks));
     TRY(build_level_tab(ctx, who, levels, n_levels, n_frames, kSelTW, kSelTH, &sp->stab, &sp->sblocks));
     TRY(build_level_tab(ctx, who, levels, n_levels, n_frames, kKpChunk, 0, &sp->tab, &sp->blocks));
     TRY(build_region_tab(ctx, who, levels, n_levels, regions, &sp->rt, &sp->general));
     sp->nmm = n_frames * n_levels;
-    TRY(keypoint_workspace(ctx, s, n_levels, n_frames, sp->blocks, sizeof(unsigned) * 2 * (size_t)sp->nmm, sp->rt, sp->general, &sp->w));
+    std::memset(&sp->st, 0, sizeof(sp->st));
+    if (sparse_th > 0 && !sp->general) build_sum_tab(levels, n_levels, sparse_th, &sp->st);
+    TRY(keypoint_workspace(ctx, s, n_levels, n_frames, sp->blocks, sizeof(unsigned) * 2 * (size_t)sp->nmm, sp->rt, sp->general, &sp->w,
+                           sp->st.frame_entries, pv_ws ? sp->tab.frame_px : 0));
     sp->mm = (unsigned*)ctx->ws.p;
     hipLaunchKernelGGL(init_maxmin_kernel, dim3((sp->nmm + 255) / 256), dim3(256), 0, s, sp->mm, sp->nmm);
     hipLaunchKernelGGL(init_cells_kernel, dim3((unsigned)((sp->w.n_cells + 255) / 256)), dim3(256), 0, s, sp->w.cells, (long long)sp->w.n_cells);
     return SILENT_OK;
 }
 
-// have_mm: the extrema are already in sp.mm (no reduction pass)
+// have_mm: the extrema are already in sp.mm (no reduction pass).  sparse: the chain kernel left its value summary in sp.w.sum
+// (geometry sp.st) -- the sparse tail runs and the dense kernels only where it could not settle a (frame, level).
 static int select_run(silent_ctx* ctx, const char* who, const float* color, const float* value, const silent_extent* levels,
                       int n_levels, int n_frames, int channels, double top_percent, const SelectPlan& sp, bool have_mm,
-                      float* peak_value_out, int64_t* idx, size_t cap_per_frame, int64_t* counts, hipStream_t s) {
+                      float* peak_value_out, int64_t* idx, size_t cap_per_frame, int64_t* counts, hipStream_t s,
+                      bool sparse = false) {
     unsigned* mm = sp.mm;
     const RegionTab& rt = sp.rt;
     const KeypointWs& w = sp.w;
@@ -851,23 +901,35 @@ static int select_run(silent_ctx* ctx, const char* who, const float* color, cons
         hipLaunchKernelGGL(level_maxmin_kernel, dim3((unsigned)sp.rblocks), dim3(256), 0, s, value, value ? nullptr : color,
                            channels, sp.rtab, mm);
     const float a = (float)(1.0 - top_percent), b = (float)top_percent;
+    const int* dense_flags = nullptr;
+    if (sparse) {
+        // (sparse implies: 3 channels, cell tables, extrema present, no caller-side peak-value map)
+        HIP_TRY(ctx, hipMemsetAsync(w.zero_from, 0, w.zero_bytes, s));
+        const long long entries = sp.st.frame_entries * n_frames;
+        hipLaunchKernelGGL(sparse_select_kernel, dim3((unsigned)((entries + 255) / 256)), dim3(256), 0, s, color, sp.tab, sp.st, w.sum,
+                           n_frames, a, b, mm, rt, w.cells, w.cand, w.cand_n);
+        hipLaunchKernelGGL(sparse_finish_kernel, dim3((unsigned)n_frames), dim3(256), 0, s, sp.tab, rt, w.cells, w.cand, w.cand_n,
+                           w.dense_flags, w.hit_masks, w.chunk_counts);
+        dense_flags = w.dense_flags;
+    }
+    if (!peak_value_out) peak_value_out = w.pv;
     if (sp.general) {
         // many windows: the selection pass without the folded cell maxima, then the separable window maxima
         if (channels == 3)
             hipLaunchKernelGGL((select_peaks_kernel<3, false>), dim3((unsigned)sp.sblocks), dim3(256), 0, s, color, value, nullptr, nullptr,
-                               peak_value_out, sp.stab, a, b, mm, rt, nullptr);
+                               peak_value_out, sp.stab, a, b, mm, rt, nullptr, nullptr);
         else
             hipLaunchKernelGGL((select_peaks_kernel<1, false>), dim3((unsigned)sp.sblocks), dim3(256), 0, s, color, value, nullptr, nullptr,
-                               peak_value_out, sp.stab, a, b, mm, rt, nullptr);
+                               peak_value_out, sp.stab, a, b, mm, rt, nullptr, nullptr);
         TRY(region_window_maxima(ctx, who, peak_value_out, levels, n_levels, n_frames, rt, w, s));
     } else if (channels == 3) {
         hipLaunchKernelGGL((select_peaks_kernel<3, true>), dim3((unsigned)sp.sblocks), dim3(256), 0, s, color, value, nullptr, nullptr,
-                           peak_value_out, sp.stab, a, b, mm, rt, w.cells);
+                           peak_value_out, sp.stab, a, b, mm, rt, w.cells, dense_flags);
     } else {
         hipLaunchKernelGGL((select_peaks_kernel<1, true>), dim3((unsigned)sp.sblocks), dim3(256), 0, s, color, value, nullptr, nullptr,
-                           peak_value_out, sp.stab, a, b, mm, rt, w.cells);
+                           peak_value_out, sp.stab, a, b, mm, rt, w.cells, dense_flags);
     }
-    keypoint_passes(peak_value_out, sp.tab, sp.blocks, rt, w, sp.general, n_frames, idx, cap_per_frame, counts, s);
+    keypoint_passes(peak_value_out, sp.tab, sp.blocks, rt, w, sp.general, n_frames, idx, cap_per_frame, counts, s, dense_flags);
     return check_launch(ctx, who);
 }
 
@@ -877,11 +939,11 @@ SILENT_EXPORT int silent_select_keypoints_dev(silent_ctx* ctx, const float* colo
                                               int64_t* idx, size_t cap_per_frame, int64_t* counts, silent_stream stream) {
     NEED_CTX(ctx);
     const char* who = "silent_select_keypoints";
-    if (!color || !regions || !peak_value_out || !counts || (!idx && cap_per_frame))
+    if (!color || !regions || !counts || (!idx && cap_per_frame))
         return fail(ctx, SILENT_E_INVALID, std::string(who) + ": NULL pointer");
     if (channels != 1 && channels != 3) return fail(ctx, SILENT_E_UNSUPPORTED, std::string(who) + ": channels must be 1 or 3");
     SelectPlan sp;
-    TRY(select_prepare(ctx, who, levels, n_levels, n_frames, regions, (hipStream_t)stream, &sp));
+    TRY(select_prepare(ctx, who, levels, n_levels, n_frames, regions, (hipStream_t)stream, &sp, 0, !peak_value_out));
     return select_run(ctx, who, color, value, levels, n_levels, n_frames, channels, top_percent, sp, false, peak_value_out, idx,
                       cap_per_frame, counts, (hipStream_t)stream);
 }
@@ -1166,11 +1228,51 @@ SILENT_EXPORT int silent_rgb_chain_structure(const silent_rgb_chain_params* para
 }
 
 
+// Which fused kernel a chain launch over these levels uses and its tile height (output rows per tile).
+static int rgb_chain_tile_height(const silent_ctx* ctx, const silent_extent* levels, int n_levels, int n_frames, bool* pair) {
+    const unsigned kopts = ctx->tune[SILENT_TUNE_RGB];  // 1: dense, 2: no two-group, 8: 90-row tiles, bits 8-15: tile height / 2
+    // two pixels per lane on packed f32 (silent_rgb2.h; its buffer addressing wants levels below 2^30 bytes per map); 16: one pixel per lane
+    bool pair_kernel = !(kopts & 16u);
+    for (int l = 0; l < n_levels; ++l)
+        if ((long long)levels[l].h * levels[l].w * 12 >= (long long)kRgb2Out) pair_kernel = false;
+    // tile height: the one that minimises ceil(tiles / resident tiles) x (th + 14) row steps (silent_rgb.h)
+    int th = kRgbTH;
+    if ((kopts >> 8) & 0xffu) {
+        th = std::min(std::max((int)((kopts >> 8) & 0xffu) * 2, 2), 400);
+    } else if (!(kopts & 8u)) {
+        const long long resident = (pair_kernel ? 16ll / kRgb2Waves : 5ll) * ctx->n_cus;   // 128 / 94 VGPRs, 256 threads: 4 / 5 tiles per CU
+        const int tw = pair_kernel ? kRgb2TW : kRgbTW;
+        long long best = -1;
+        // Launches that fill the chip several times over keep round 1's 90 rows: a sweep on config 3 (scripts/sweep_rgb_th.py:
+        // 50 ... 156 rows = 1.40 1.32 1.30 1.37 1.35 1.40 1.32 1.36 1.30 1.37 ms) shows +-4 % with no trend the rounds
+        // model predicts (tiles are not equal: ragged edges, small levels).  The model decides where it is sharp: launches
+        // of about one round or less, where it picks short tiles (the latency of one wave's row walk sets the time).
+        long long tiles90 = 0;
+        for (int l = 0; l < n_levels; ++l)
+            tiles90 += (long long)((levels[l].w + tw - 1) / tw) * ((levels[l].h + kRgbTH - 1) / kRgbTH);
+        const bool model = tiles90 * n_frames < 2 * resident;
+        for (int cand = kRgbTHMin; model && cand <= kRgbTHMax; cand += 2) {
+            long long tiles = 0;
+            for (int l = 0; l < n_levels; ++l)
+                tiles += (long long)((levels[l].w + tw - 1) / tw) * ((levels[l].h + cand - 1) / cand);
+            tiles *= n_frames;
+            const long long cost = ((tiles + resident - 1) / resident) * (cand + 2 * kRgbHalo);
+            if (best < 0 || cost < best) {
+                best = cost;
+                th = cand;
+            }
+        }
+    }
+    *pair = pair_kernel;
+    return th;
+}
+
 // mm: optional per-level extrema slots (already initialised); *mm_done tells whether the launch filled them (only the pair
 // kernel's two-group instantiation does -- everything else leaves them to level_maxmin_kernel)
 static int rgb_chain_launch(silent_ctx* ctx, const char* who, const float* pyr, const silent_extent* levels, int n_levels,
                             int n_frames, const silent_rgb_chain_params* p, float* orient_out, float* line_end_out,
-                            float* value_out, unsigned* mm, bool* mm_done, silent_stream stream) {
+                            float* value_out, unsigned* mm, bool* mm_done, silent_stream stream, const SumTab* st = nullptr,
+                            float* sum = nullptr) {
     if (mm_done) *mm_done = false;
     if (!pyr || !p) return fail(ctx, SILENT_E_INVALID, std::string(who) + ": NULL pointer");
     if (!p->rgc || !p->rgby || !p->stripe || !p->blur || !p->end)
@@ -1192,38 +1294,8 @@ static int rgb_chain_launch(silent_ctx* ctx, const char* who, const float* pyr, 
         LevelTab tab;
         long long blocks;
         const unsigned kopts = ctx->tune[SILENT_TUNE_RGB];  // 1: dense, 2: no two-group, 8: 90-row tiles, bits 8-15: tile height / 2
-        // two pixels per lane on packed f32 (silent_rgb2.h; its buffer addressing wants levels below 2^30 bytes per map); 16: one pixel per lane
-        bool pair_kernel = !(kopts & 16u);
-        for (int l = 0; l < n_levels; ++l)
-            if ((long long)levels[l].h * levels[l].w * 12 >= (long long)kRgb2Out) pair_kernel = false;
-        // tile height: the one that minimises ceil(tiles / resident tiles) x (th + 14) row steps (silent_rgb.h)
-        int th = kRgbTH;
-        if ((kopts >> 8) & 0xffu) {
-            th = std::min(std::max((int)((kopts >> 8) & 0xffu) * 2, 2), 400);
-        } else if (!(kopts & 8u)) {
-            const long long resident = (pair_kernel ? 16ll / kRgb2Waves : 5ll) * ctx->n_cus;   // 128 / 94 VGPRs, 256 threads: 4 / 5 tiles per CU
-            const int tw = pair_kernel ? kRgb2TW : kRgbTW;
-            long long best = -1;
-            // Launches that fill the chip several times over keep round 1's 90 rows: a sweep on config 3 (scripts/sweep_rgb_th.py:
-            // 50 ... 156 rows = 1.40 1.32 1.30 1.37 1.35 1.40 1.32 1.36 1.30 1.37 ms) shows +-4 % with no trend the rounds
-            // model predicts (tiles are not equal: ragged edges, small levels).  The model decides where it is sharp: launches
-            // of about one round or less, where it picks short tiles (the latency of one wave's row walk sets the time).
-            long long tiles90 = 0;
-            for (int l = 0; l < n_levels; ++l)
-                tiles90 += (long long)((levels[l].w + tw - 1) / tw) * ((levels[l].h + kRgbTH - 1) / kRgbTH);
-            const bool model = tiles90 * n_frames < 2 * resident;
-            for (int cand = kRgbTHMin; model && cand <= kRgbTHMax; cand += 2) {
-                long long tiles = 0;
-                for (int l = 0; l < n_levels; ++l)
-                    tiles += (long long)((levels[l].w + tw - 1) / tw) * ((levels[l].h + cand - 1) / cand);
-                tiles *= n_frames;
-                const long long cost = ((tiles + resident - 1) / resident) * (cand + 2 * kRgbHalo);
-                if (best < 0 || cost < best) {
-                    best = cost;
-                    th = cand;
-                }
-            }
-        }
+        bool pair_kernel;
+        const int th = rgb_chain_tile_height(ctx, levels, n_levels, n_frames, &pair_kernel);
         TRY(build_level_tab(ctx, who, levels, n_levels, n_frames, pair_kernel ? kRgb2TW : kRgbTW, th, &tab, &blocks));
         if (p->flat_policy != SILENT_FLAT_IEEE && p->flat_policy != SILENT_FLAT_ZERO)
             return fail(ctx, SILENT_E_INVALID, std::string(who) + ": flat_policy must be SILENT_FLAT_IEEE or SILENT_FLAT_ZERO");
@@ -1247,10 +1319,33 @@ static int rgb_chain_launch(silent_ctx* ctx, const char* who, const float* pyr, 
             a2.prm = a.prm;
             a2.th = a.th;
             a2.mm = nullptr;
+            a2.sum = nullptr;
+            a2.sum_frame = 0;
+            std::memset(a2.sum_off, 0, sizeof(a2.sum_off));
             std::memset(a2.ws, 0, sizeof(a2.ws));
             rgb2_fill_stream(a.w, basic ? 0x111u : 0x1ffu, basic, two, two, a2.ws);
+            // silent_set_profiling: HIP events around THIS launch, on the stream it runs on (the fused RGB chain is the dominant
+            // kernel of silent_rgb_line_end / silent_rgb_keypoints, like gray_stream_kernel is of silent_gray_pass)
+            const bool prof = ctx->profiling && (ctx->prof_calls++ % ctx->prof_period) == 0;
+            const int prof_slot = ctx->prof_recorded % silent_ctx::kProfPairs;
+            if (prof) HIP_TRY(ctx, hipEventRecord(ctx->prof_ev[prof_slot][0], s));
+            struct ProfEnd {
+                silent_ctx* c; bool on; int slot; hipStream_t st; long long px;
+                ~ProfEnd() {
+                    if (!on) return;
+                    if (hipEventRecord(c->prof_ev[slot][1], st) == hipSuccess) {
+                        ++c->prof_recorded;
+                        c->prof_pixels = px;
+                    } else (void)hipGetLastError();
+                }
+            } prof_end{ctx, prof, prof_slot, s, tab.frame_px * n_frames};
             if (two && mm) {
                 a2.mm = mm;
+                if (st && sum && st->frame_entries > 0 && st->th == th) {   // value summary for the sparse selection tail
+                    a2.sum = sum;
+                    a2.sum_frame = st->frame_entries;
+                    for (int l = 0; l < kMaxLevels; ++l) a2.sum_off[l] = st->off[l];
+                }
                 hipLaunchKernelGGL((rgb_line_end2_kernel<0x111u, true, kRgbyA, kEndA0, kEndA1, kEndA2, true>), dim3((unsigned)blocks), dim3(64 * kRgb2Waves), 0, s, a2);
                 if (mm_done) *mm_done = true;
             } else
@@ -1316,7 +1411,7 @@ SILENT_EXPORT int silent_rgb_keypoints_dev(silent_ctx* ctx, const float* pyr, co
                                            int64_t* counts, silent_stream stream) {
     NEED_CTX(ctx);
     const char* who = "silent_rgb_keypoints";
-    if (!pyr || !p || !regions || !line_end_out || !peak_value_out || !counts || (!idx && cap_per_frame))
+    if (!pyr || !p || !regions || !line_end_out || !counts || (!idx && cap_per_frame))
         return fail(ctx, SILENT_E_INVALID, std::string(who) + ": NULL pointer");
     if (!p->rgc || !p->rgby || !p->stripe || !p->blur || !p->end)
         return fail(ctx, SILENT_E_INVALID, std::string(who) + ": a kernel pointer in params is NULL");
@@ -1330,14 +1425,44 @@ SILENT_EXPORT int silent_rgb_keypoints_dev(silent_ctx* ctx, const float* pyr, co
         return silent_select_keypoints_dev(ctx, line_end_out, value_out, levels, n_levels, n_frames, 3, top_percent, regions,
                                            peak_value_out, idx, cap_per_frame, counts, stream);
     }
+    // Without a caller-side peak-value map the tail runs sparse (silent_peaks.h, sparse_select_kernel): the chain kernel leaves
+    // a per-group maximum of the value map, and selection / NMS / keypoint search look only at the groups that reach their
+    // level's threshold; whatever that cannot settle exactly runs the dense kernels on a map in the workspace.
+    bool pair_kernel = false;
+    const int th = rgb_chain_tile_height(ctx, levels, n_levels, n_frames, &pair_kernel);
+    const bool want_sparse = !peak_value_out && pair_kernel && !(ctx->tune[SILENT_TUNE_RGB] & 32u);
     SelectPlan sp;
-    TRY(select_prepare(ctx, who, levels, n_levels, n_frames, regions, s, &sp));
+    TRY(select_prepare(ctx, who, levels, n_levels, n_frames, regions, s, &sp, want_sparse ? th : 0, !peak_value_out));
     bool mm_done = false;
-    TRY(rgb_chain_launch(ctx, who, pyr, levels, n_levels, n_frames, p, orient_out, line_end_out, value_out, sp.mm, &mm_done, stream));
+    TRY(rgb_chain_launch(ctx, who, pyr, levels, n_levels, n_frames, p, orient_out, line_end_out, value_out, sp.mm, &mm_done, stream,
+                         &sp.st, sp.w.sum));
+    const bool sparse = want_sparse && mm_done && sp.st.frame_entries > 0;
+    ctx->sparse_ran = sparse;
+    ctx->sparse_stream = s;
+    ctx->sparse_flags_off = (size_t)((char*)sp.w.dense_flags - (char*)ctx->ws.p);
+    ctx->sparse_candn_off = (size_t)((char*)sp.w.cand_n - (char*)ctx->ws.p);
+    ctx->sparse_pairs = n_frames * n_levels;
+    ctx->sparse_frames = n_frames;
     return select_run(ctx, who, line_end_out, mm_done ? nullptr : value_out, levels, n_levels, n_frames, 3, top_percent, sp, mm_done,
-                      peak_value_out, idx, cap_per_frame, counts, s);
+                      peak_value_out, idx, cap_per_frame, counts, s, sparse);
 }
 
+
+SILENT_EXPORT int silent_sparse_tail_stats(silent_ctx* ctx, int64_t* stats) {
+    NEED_CTX(ctx);
+    if (!stats) return fail(ctx, SILENT_E_INVALID, "silent_sparse_tail_stats: stats is NULL");
+    stats[0] = ctx->sparse_ran ? 1 : 0;
+    stats[1] = stats[2] = stats[3] = 0;
+    if (!ctx->sparse_ran || !ctx->ws.p) return SILENT_OK;
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->sparse_stream));
+    std::vector<int> flags((size_t)ctx->sparse_pairs), cn((size_t)ctx->sparse_frames);
+    HIP_TRY(ctx, hipMemcpy(flags.data(), (char*)ctx->ws.p + ctx->sparse_flags_off, flags.size() * sizeof(int), hipMemcpyDeviceToHost));
+    HIP_TRY(ctx, hipMemcpy(cn.data(), (char*)ctx->ws.p + ctx->sparse_candn_off, cn.size() * sizeof(int), hipMemcpyDeviceToHost));
+    stats[1] = ctx->sparse_pairs;
+    for (int f : flags) stats[2] += f ? 1 : 0;
+    for (int c : cn) stats[3] += c;
+    return SILENT_OK;
+}
 
 // ------------------------------------------------------------------------------------------ pyramid plan
 
@@ -2399,8 +2524,8 @@ SILENT_EXPORT int silent_rgb_keypoints(silent_ctx* ctx, const float* pyr, const 
     TRY(h2d(ctx, st.ptr<float>(i_in), pyr, b3));
     TRY(silent_rgb_keypoints_dev(ctx, st.ptr<float>(i_in), levels, n_levels, n_frames, p, top_percent, regions,
                                  orient_out ? st.ptr<float>(i_o) : nullptr, st.ptr<float>(i_l),
-                                 value_out ? st.ptr<float>(i_v) : nullptr, st.ptr<float>(i_p), st.ptr<int64_t>(i_i), cap_per_frame,
-                                 st.ptr<int64_t>(i_n), nullptr));
+                                 value_out ? st.ptr<float>(i_v) : nullptr, peak_value_out ? st.ptr<float>(i_p) : nullptr,
+                                 st.ptr<int64_t>(i_i), cap_per_frame, st.ptr<int64_t>(i_n), nullptr));
     TRY(sync0(ctx));
     if (orient_out) TRY(d2h(ctx, orient_out, st.ptr<float>(i_o), b3));
     if (line_end_out) TRY(d2h(ctx, line_end_out, st.ptr<float>(i_l), b3));
@@ -2571,8 +2696,8 @@ SILENT_EXPORT int silent_select_keypoints(silent_ctx* ctx, const float* color, c
     TRY(h2d(ctx, st.ptr<float>(i_c), color, bc));
     if (value) TRY(h2d(ctx, st.ptr<float>(i_v), value, bv));
     TRY(silent_select_keypoints_dev(ctx, st.ptr<float>(i_c), value ? st.ptr<float>(i_v) : nullptr, levels, n_levels, n_frames,
-                                    channels, top_percent, regions, st.ptr<float>(i_o), st.ptr<int64_t>(i_i), cap_per_frame,
-                                    st.ptr<int64_t>(i_n), nullptr));
+                                    channels, top_percent, regions, peak_value_out ? st.ptr<float>(i_o) : nullptr,
+                                    st.ptr<int64_t>(i_i), cap_per_frame, st.ptr<int64_t>(i_n), nullptr));
     TRY(sync0(ctx));
     if (peak_value_out) TRY(d2h(ctx, peak_value_out, st.ptr<float>(i_o), bv));
     if (cap_per_frame) TRY(d2h(ctx, idx, st.ptr<int64_t>(i_i), bi));

@@ -7,6 +7,10 @@ namespace silent {
 
 constexpr int kChunk = 1024;  // pixels per block for the 1-D (flattened level) kernels: 256 threads x 4
 
+// Value summary written by the fused RGB chain (rgb_line_end2_kernel, MM instantiation) for the sparse selection tail:
+// entry = max_pool(value) over one pixel PAIR x kSumRows rows of a chain tile.
+constexpr int kSumRowsLog2 = 4, kSumRows = 1 << kSumRowsLog2;
+
 // order-preserving float <-> uint map so that integer atomics give float max / min
 __device__ __forceinline__ unsigned f2ord(float f) {
     const unsigned u = __float_as_uint(f);
@@ -318,9 +322,12 @@ __global__ __launch_bounds__(256) void select_peaks_kernel(const float* __restri
                                                            float* __restrict__ pv_out, const LevelTab tab,
                                                            float one_minus_p, float p_f,
                                                            const unsigned* __restrict__ mm, const RegionTab rt,
-                                                           unsigned* __restrict__ cells) {
+                                                           unsigned* __restrict__ cells,
+                                                           const int* __restrict__ dense_flags) {
     constexpr int R = kSelTH;
     const TileCoord tc = locate_tile(tab, blockIdx.x);
+    // sparse tail (sparse_finish_kernel): only the (frame, level)s it could not settle run this pass
+    if (dense_flags && !dense_flags[tc.frame * tab.n_levels + tc.level]) return;
     const int H = tab.h[tc.level], W = tab.w[tc.level];
     const long long base_px = (long long)tc.frame * tab.frame_px + tab.px_off[tc.level];
     const int lane = threadIdx.x & 63;
@@ -627,10 +634,12 @@ __global__ __launch_bounds__(256) void region_count_kernel(const float* __restri
                                                            const RegionTab rt, const unsigned* __restrict__ cells,
                                                            const float* __restrict__ pooled_g,
                                                            int* __restrict__ chunk_counts,
-                                                           unsigned long long* __restrict__ hit_masks) {
+                                                           unsigned long long* __restrict__ hit_masks,
+                                                           const int* __restrict__ dense_flags) {
     __shared__ float s_pooled[kMaxWin * kMaxWin];
     __shared__ int s_cnt[4];
     const TileCoord tc = locate_tile(tab, blockIdx.x);
+    if (dense_flags && !dense_flags[tc.frame * tab.n_levels + tc.level]) return;   // settled by the sparse tail
     const RegionLevel& rl = rt.lv[tc.level];
     const int W = tab.w[tc.level];
     const int npx = tab.h[tc.level] * W;
@@ -663,6 +672,134 @@ __global__ __launch_bounds__(256) void region_count_kernel(const float* __restri
     if (lane == 0) s_cnt[wave] = n;
     __syncthreads();
     if (threadIdx.x == 0) chunk_counts[blockIdx.x] = s_cnt[0] + s_cnt[1] + s_cnt[2] + s_cnt[3];
+}
+
+// ---- sparse selection tail (config 3 without a peak-value map): a-10 -> a-9 -> a-8 -> a-11 looking only where something can be.
+// top_value_points keeps the pixels whose value reaches thr = (1 - p) * max + p * min of their level -- on natural and on
+// noise frames a handful per level.  Everything after it is local to those "passers":
+//   * a non-passer's peak value is 0 (or NaN where line_end holds a NaN): top = color * 0, and 0 * where(..) = 0 whatever
+//     the 3x3 maximum is;
+//   * a passer's peak value depends on the passers among its 8 neighbours only (non-passers and NaNs contribute 0 / nothing
+//     to max_pool, and a passer's own t_c >= 0 is in its window);
+//   * a window maximum of max_value_indices_region that is > 0 is the maximum over the passers in the window, and then the
+//     keypoints of the pixels mapped to that window are passers too (0 >= positive is false, NaN >= x is false).
+// So: the chain kernel leaves max_pool(value) per (pixel pair x kSumRows rows); sparse_select_kernel visits the entries that
+// reach thr, evaluates the passers with the SAME operations as select_peaks_kernel (bit-identical peak values), folds them
+// into the cell maxima and appends them to a per-frame candidate list; sparse_finish_kernel (one block per frame) checks per
+// level that every window maximum is > 0 -- if not (an empty window: every non-NaN pixel mapped to it is a keypoint), or if
+// the candidate list overflowed, the (frame, level) is flagged and the dense kernels run for it, every other block of them
+// exits at once -- and turns the candidates that reach their window maximum into hit bits + chunk counts, the form the
+// count pass leaves them in, so that scan and ordered write run unchanged (row-major order like tf.where by construction).
+constexpr int kCandCap = 16384;   // candidates per frame; more -> the frame runs the dense kernels
+struct SumTab {
+    int th, gpt;                       // tile height of the chain launch, groups per tile = ceil(th / kSumRows)
+    long long frame_entries;
+    long long off[kMaxLevels + 1];     // entry offset of level l inside a frame (off[n_levels] = frame_entries)
+};
+struct Candidate {
+    int level, y, x;
+    float pv;
+};
+
+// t_c = color_c * (value >= thr ? 1 : 0) of pixel (y, x) as select_peaks_kernel computes it; false outside the level
+__device__ __forceinline__ bool sparse_top(const float* __restrict__ lev, int H, int W, int y, int x, float thr, float (&t)[3],
+                                           bool* passer = nullptr) {
+    if (y < 0 || y >= H || x < 0 || x >= W) return false;
+    const float* __restrict__ px = lev + ((long long)y * W + x) * 3;
+    const float c0 = px[0], c1 = px[1], c2 = px[2];
+    const float v = __fmul_rn(__fadd_rn(__fadd_rn(c0, c1), c2), 1.0f / 3.0f);
+    const float m = v >= thr ? 1.0f : 0.0f;
+    if (passer) *passer = v >= thr;
+    t[0] = __fmul_rn(c0, m);
+    t[1] = __fmul_rn(c1, m);
+    t[2] = __fmul_rn(c2, m);
+    return true;
+}
+
+__global__ __launch_bounds__(256) void sparse_select_kernel(const float* __restrict__ color, const LevelTab tab, const SumTab st,
+                                                            const float* __restrict__ sum, int n_frames, float one_minus_p,
+                                                            float p_f, const unsigned* __restrict__ mm, const RegionTab rt,
+                                                            unsigned* __restrict__ cells, Candidate* __restrict__ cand,
+                                                            int* __restrict__ cand_n) {
+    const long long gid = (long long)blockIdx.x * 256 + threadIdx.x;
+    const int frame = (int)(gid / st.frame_entries);
+    if (frame >= n_frames) return;
+    long long rem = gid - (long long)frame * st.frame_entries;
+    int l = 0;
+#pragma unroll
+    for (int i = 1; i < kMaxLevels; ++i)
+        if (i < tab.n_levels && rem >= st.off[i]) l = i;
+    rem -= st.off[l];
+    const int H = tab.h[l], W = tab.w[l], nxp = (W + 1) >> 1;
+    const int gy = (int)(rem / nxp), xp = (int)(rem - (long long)gy * nxp);
+    const unsigned* slot = mm + ((long long)frame * tab.n_levels + l) * 2;
+    const float thr = __fadd_rn(__fmul_rn(one_minus_p, level_max(slot)), __fmul_rn(p_f, level_min(slot)));
+    const float s = sum[gid];
+    if (!(s >= thr)) return;   // no passer in this group (groups below the last image row hold no data: their row range is empty)
+    const int ty = gy / st.gpt, k = gy - ty * st.gpt;
+    const int r0 = ty * st.th + k * kSumRows;
+    const int r1 = min(min(r0 + kSumRows, (ty + 1) * st.th), H);
+    const float* __restrict__ lev = color + ((long long)frame * tab.frame_px + tab.px_off[l]) * 3;
+    const RegionLevel& rl = rt.lv[l];
+    for (int y = r0; y < r1; ++y)
+        for (int x = 2 * xp; x < min(2 * xp + 2, W); ++x) {
+            float tc_[3];
+            bool passer = false;
+            sparse_top(lev, H, W, y, x, thr, tc_, &passer);
+            if (!passer) continue;
+            float mx[3] = {kPoolLowest, kPoolLowest, kPoolLowest};
+            for (int dy = -1; dy <= 1; ++dy)
+                for (int dx = -1; dx <= 1; ++dx) {
+                    float t[3];
+                    if (!sparse_top(lev, H, W, y + dy, x + dx, thr, t)) continue;   // max_pool SAME ignores taps outside the level
+#pragma unroll
+                    for (int c = 0; c < 3; ++c) mx[c] = pool_max(mx[c], t[c]);       // ... and NaN taps
+                }
+            float o[3];
+#pragma unroll
+            for (int c = 0; c < 3; ++c) o[c] = __fmul_rn(tc_[c], tc_[c] == mx[c] ? tc_[c] : 0.0f);
+            const float pv = __fmul_rn(__fadd_rn(__fadd_rn(o[0], o[1]), o[2]), 1.0f / 3.0f);
+            int rs = 0, cs = 0;
+            for (int s_ = 1; s_ < rl.nrs; ++s_) rs = y >= rl.rcut[s_] ? s_ : rs;
+            for (int s_ = 1; s_ < rl.ncs; ++s_) cs = x >= rl.ccut[s_] ? s_ : cs;
+            atomicMax(cells + ((long long)frame * tab.n_levels + l) * kCells + rs * kMaxSeg + cs, f2ord(pool_max(kPoolLowest, pv)));
+            const int n = atomicAdd(cand_n + frame, 1);
+            if (n < kCandCap) cand[(long long)frame * kCandCap + n] = Candidate{l, y, x, pv};
+        }
+}
+
+// one block per frame; `tab` is the count / write pass's chunk table (kKpChunk pixels per block)
+__global__ __launch_bounds__(256) void sparse_finish_kernel(const LevelTab tab, const RegionTab rt, const unsigned* __restrict__ cells,
+                                                            const Candidate* __restrict__ cand, const int* __restrict__ cand_n,
+                                                            int* __restrict__ dense_flags, unsigned long long* __restrict__ hit_masks,
+                                                            int* __restrict__ chunk_counts) {
+    __shared__ float s_pooled[kMaxLevels][kMaxWin * kMaxWin];
+    __shared__ int s_ok[kMaxLevels];
+    const int f = blockIdx.x;
+    const int n = cand_n[f];
+    for (int l = 0; l < tab.n_levels; ++l)
+        load_pooled(cells + ((long long)f * tab.n_levels + l) * kCells, rt.lv[l], s_pooled[l]);
+    __syncthreads();
+    if ((int)threadIdx.x < tab.n_levels) {
+        const int l = threadIdx.x;
+        const RegionLevel& rl = rt.lv[l];
+        bool ok = n <= kCandCap;
+        for (int j = 0; j < rl.oh; ++j)
+            for (int i = 0; i < rl.ow; ++i) ok = ok && s_pooled[l][j * kMaxWin + i] > 0.0f;
+        s_ok[l] = ok;
+        dense_flags[f * tab.n_levels + l] = ok ? 0 : 1;
+    }
+    __syncthreads();
+    const int m = min(n, kCandCap);
+    for (int i = threadIdx.x; i < m; i += 256) {
+        const Candidate c = cand[(long long)f * kCandCap + i];
+        if (!s_ok[c.level]) continue;
+        if (!(c.pv >= region_thr<false>(c.y, c.x, rt.lv[c.level], s_pooled[c.level]))) continue;
+        const int p = c.y * tab.w[c.level] + c.x;
+        const long long blk = (long long)f * tab.tiles_per_frame + tab.tile_start[c.level] + (p / kKpChunk);
+        atomicOr(hit_masks + blk * (kKpChunk / 64) + ((p % kKpChunk) >> 6), 1ull << (p & 63));
+        atomicAdd(chunk_counts + blk, 1);
+    }
 }
 
 // pass 2: exclusive scan of the chunk counts of one frame (one block per frame)

@@ -127,6 +127,11 @@ struct Rgb2Args {
     RgbP prm;
     int th;   // output rows per tile (even)
     unsigned* mm;   // optional [n_frames][n_levels][2] ordered-uint slots (silent_peaks.h): max_pool(value), max_pool(-value) per level
+    // optional value summary for the sparse selection tail (silent_peaks.h, SumTab): per frame and level a [tiles_y * gpt][ceil(W / 2)]
+    // array, entry = max_pool(value) over one lane's pixel pair x kSumRows rows (MM instantiation only)
+    float* sum;
+    long long sum_frame;               // entries per frame
+    long long sum_off[kMaxLevels];     // entry offset of level l inside a frame
     alignas(64) float ws[kRgb2StreamMax];
 };
 static_assert(offsetof(Rgb2Args, ws) % 64 == 0, "weight blocks are whole 64-byte lines of the kernarg segment");
@@ -403,6 +408,16 @@ __global__ __launch_bounds__(64 * kRgb2Waves) __attribute__((amdgpu_waves_per_eu
     __shared__ f2 s_hist[kRgb2Waves][4][3][64];   // [wave][slot = row & 3][channel][lane]
     // MM: per-lane running max_pool(value) / max_pool(-value) of this tile, for the per-level extrema of a-10 (args.mm)
     float mm_mx = kPoolLowest, mm_nmn = kPoolLowest;
+    // MM: the same maximum per group of kSumRows output rows, stored per lane (= per pixel pair) when the group ends: the sparse
+    // selection tail looks only at the groups whose maximum reaches the level's threshold (silent_peaks.h, sparse_select_kernel).
+    // A raw buffer store like all the others: out of range (dropped) on every step but a group's last.
+    float mm_grp = kPoolLowest;
+    const int gpt = (R + kSumRows - 1) / kSumRows, nxp = (W + 1) >> 1;
+    const unsigned sum_bytes = (MM && args.sum) ? (unsigned)(((H + R - 1) / R) * gpt) * (unsigned)nxp * 4u : 0u;
+    const __amdgpu_buffer_rsrc_t r_sum = __builtin_amdgcn_make_buffer_rsrc(
+        (void*)(args.sum + (long long)tc.frame * args.sum_frame + args.sum_off[tc.level]), 0, sum_bytes, 0x00020000);
+    const int ssum = out0 ? (x0 >> 1) * 4 : kRgb2Out;
+    const int ylast = (y0 + R < H ? y0 + R : H) - 1;   // last output row of this tile
     __shared__ float s_tr[kRgb2Waves][128 * 3];   // [wave][one output row of the wave's 128 columns x 3 channels]
     float* const tr = s_tr[wave];
     // lane-major in (as held), pixel-major out; LDS operations of one wave execute in order, so no wait / barrier in between
@@ -436,9 +451,10 @@ __global__ __launch_bounds__(64 * kRgb2Waves) __attribute__((amdgpu_waves_per_eu
     fetch(nb1, 1);
     // The wait at the head of the row loop merges two paths: the back edge (14 younger operations behind the loads it waits for:
     // 6 + 6 stores and 2 loads) and this prologue (2: the second fetch) -- the compiler takes the minimum, vmcnt(2), which on
-    // the back edge waits for the previous iteration's 12 stores.  Twelve out-of-range (dropped) stores make both paths 14.
+    // the back edge waits for the previous iteration's 12 stores.  Twelve out-of-range (dropped) stores make both paths 14
+    // (MM: one summary store more per step, 14 make both 16).
 #pragma unroll
-    for (int k = 0; k < 12; ++k) __builtin_amdgcn_raw_buffer_store_b32(k, r_value, kRgb2Out + 64 * k, 0, 0);   // (distinct: identical ones are merged)
+    for (int k = 0; k < (MM ? 14 : 12); ++k) __builtin_amdgcn_raw_buffer_store_b32(k, r_value, kRgb2Out + 64 * k, 0, 0);   // (distinct: identical ones are merged)
 
     // one row step: `mine` holds this row; row + 2 is fetched into it as soon as the row has been taken
     auto step = [&](int row, i3 (&mine)[2]) {
@@ -576,6 +592,14 @@ __global__ __launch_bounds__(64 * kRgb2Waves) __attribute__((amdgpu_waves_per_eu
                 const float na = out0 ? -val.x : kPoolLowest, nb = out1 ? -val.y : kPoolLowest;
                 asm("v_max3_f32 %0, %1, %2, %3" : "=v"(mm_mx) : "v"(mm_mx), "v"(a), "v"(b));
                 asm("v_max3_f32 %0, %1, %2, %3" : "=v"(mm_nmn) : "v"(mm_nmn), "v"(na), "v"(nb));
+                asm("v_max3_f32 %0, %1, %2, %3" : "=v"(mm_grp) : "v"(mm_grp), "v"(a), "v"(b));
+            }
+            if constexpr (MM) {
+                const int k = yout - y0;
+                const bool gend = rows && (((k + 1) & (kSumRows - 1)) == 0 || yout == ylast);   // wave-uniform
+                const int so = gend ? (tc.ty * gpt + (k >> kSumRowsLog2)) * nxp * 4 : kRgb2Out;
+                __builtin_amdgcn_raw_buffer_store_b32(__float_as_int(mm_grp), r_sum, ssum + so, 0, 0);
+                mm_grp = gend ? kPoolLowest : mm_grp;
             }
             __builtin_amdgcn_raw_buffer_store_b64(i2{__float_as_int(val.x), __float_as_int(val.y)}, r_value, sv2 + rv, 0, 0);
             __builtin_amdgcn_raw_buffer_store_b32(__float_as_int(val.x), r_value, sv1 + rv, 0, 0);

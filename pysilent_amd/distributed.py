@@ -81,6 +81,44 @@ def max_over_ranks(value):
     return float(t.item())
 
 
+def device_identity(local):
+    """Who this rank's GPU is, for the scaling record: name, PCI bus id, uuid (what torch reports for device ``local``)."""
+    import torch
+    p = torch.cuda.get_device_properties(local)
+    bus = "%04x:%02x:%02x" % (getattr(p, "pci_domain_id", 0), getattr(p, "pci_bus_id", -1) & 0xff, getattr(p, "pci_device_id", 0))
+    return {"device_name": p.name, "pci_bus_id": bus, "uuid": str(getattr(p, "uuid", "")),
+            "gcn_arch": getattr(p, "gcnArchName", "")}
+
+
+def gather_records(record):
+    """Every rank contributes one picklable record; every rank gets the list ordered by rank (all_gather_object)."""
+    import torch.distributed as dist
+    if not (dist.is_available() and dist.is_initialized()):
+        return [record]
+    out = [None] * dist.get_world_size()
+    dist.all_gather_object(out, record)
+    return out
+
+
+def backend_name():
+    import torch.distributed as dist
+    if not (dist.is_available() and dist.is_initialized()):
+        return "none (single process)"
+    return "%s%s" % (dist.get_backend(), " (RCCL)" if dist.get_backend() == "nccl" else "")
+
+
+def duplicate_devices(records):
+    """Ranks that report the same GPU (same PCI bus id): [(rank_a, rank_b, bus)].  Empty = N distinct devices."""
+    seen, dup = {}, []
+    for r in records:
+        key = r.get("pci_bus_id")
+        if key in seen:
+            dup.append((seen[key], r["rank"], key))
+        else:
+            seen[key] = r["rank"]
+    return dup
+
+
 def barrier():
     import torch.distributed as dist
     if dist.is_available() and dist.is_initialized():

@@ -56,7 +56,8 @@ def unpack_constants(blob, layout):
 class LineEndPipeline(object):
     def __init__(self, frame_hw, mode="gray", n_levels=5, scale=2.0, n_orient=4, batch=1, device=None,
                  constants=None, center_dimensions=None, clip_hi=255.0, flat_policy="ieee", pad=2,
-                 max_keypoints_per_frame=None, selection=False, top_percent=0.1, keep_selection_maps=False, value_map=True):
+                 max_keypoints_per_frame=None, selection=False, top_percent=0.1, keep_selection_maps=False, value_map=True,
+                 peak_value_map=True, orient_map=True):
         import torch
         self.torch = torch
         self.mode = mode
@@ -85,7 +86,9 @@ class LineEndPipeline(object):
             self.cs = torch.empty(n, **f32)
             self.end = torch.empty(n * self.n_orient, **f32)
         else:
-            self.orient = torch.empty(n * 3, **f32)
+            # orient_map=False: SURVEY.md section 8d config 3 returns line_end + keypoints, the orientation map is optional
+            self.orient_map = bool(orient_map)
+            self.orient = torch.empty(n * 3, **f32) if self.orient_map else None
             self.line_end = torch.empty(n * 3, **f32)
             # value_map=False: the value map (a-8 of the line-end map) is not kept -- with selection the fused step needs it
             # nowhere (silent_rgb_keypoints), and BASELINE config 3 returns line_end + keypoints (+ orient) only
@@ -102,7 +105,10 @@ class LineEndPipeline(object):
                 if self.keep_selection_maps:
                     self.top = torch.empty(n * 3, **f32)
                     self.peaks = torch.empty(n * 3, **f32)
-                self.peak_value = torch.empty(n, **f32)
+                # peak_value_map=False (fused step only): nobody wants the selection's value map itself -- the keypoint tail
+                # then runs sparse (silent_rgb_keypoints with peak_value_out = NULL, csrc/silent_peaks.h)
+                self.peak_value_map = bool(peak_value_map) or self.keep_selection_maps
+                self.peak_value = torch.empty(n, **f32) if self.peak_value_map else None
             self.kp_cap = int(max_keypoints_per_frame or self.frame_px)
             self.kp_idx = torch.empty((self.batch, self.kp_cap, 4), dtype=torch.int64, device=self.tdev)
             self.kp_counts = torch.zeros(self.batch, dtype=torch.int64, device=self.tdev)
@@ -116,13 +122,13 @@ class LineEndPipeline(object):
     def algorithmic_bytes_per_frame(self):
         """4*[H*W*C (frame read) + P*C (pyramid written) + P*C (pyramid read) + P*sum(C_out returned)]"""
         h, w, c = self.frame_shape
-        outs = (1 + self.n_orient) if self.mode == "gray" else (3 + 3 + (1 if self.value_map else 0))
+        outs = (1 + self.n_orient) if self.mode == "gray" else (3 + (3 if self.orient_map else 0) + (1 if self.value_map else 0))
         return 4 * (h * w * c + 2 * self.frame_px * c + self.frame_px * outs)
 
     def filter_bytes_per_frame(self):
         """The filter pass alone: pyramid read once + every returned map written once."""
         c = self.channels
-        outs = (1 + self.n_orient) if self.mode == "gray" else (3 + 3 + (1 if self.value_map else 0))
+        outs = (1 + self.n_orient) if self.mode == "gray" else (3 + (3 if self.orient_map else 0) + (1 if self.value_map else 0))
         return 4 * self.frame_px * (c + outs)
 
     def pyramid_bytes_per_frame(self):
@@ -166,7 +172,8 @@ class LineEndPipeline(object):
         else:
             self.ctx.check(self._lib.silent_rgb_line_end_dev(
                 self.ctx.handle, C.c_void_p(self.pyr.data_ptr()), self.levels_c, self.n_levels, self.batch,
-                C.byref(self._params), C.c_void_p(self.orient.data_ptr()), C.c_void_p(self.line_end.data_ptr()),
+                C.byref(self._params), C.c_void_p(self.orient.data_ptr()) if self.orient is not None else None,
+                C.c_void_p(self.line_end.data_ptr()),
                 C.c_void_p(self.value.data_ptr()) if self.value is not None else None, s))
 
     def run_filters_keypoints(self, stream=None):
@@ -178,6 +185,12 @@ class LineEndPipeline(object):
             self.ctx.handle, p(self.pyr), self.levels_c, self.n_levels, self.batch, C.byref(self._params), self.top_percent,
             self.regions, p(self.orient), p(self.line_end), p(self.value), p(self.peak_value), p(self.kp_idx), self.kp_cap,
             p(self.kp_counts), s))
+
+    def sparse_tail_stats(self):
+        """What the sparse keypoint tail of the last fused step did: dict(ran, pairs, dense_pairs, candidates)."""
+        st = (C.c_int64 * 4)()
+        self.ctx.check(self._lib.silent_sparse_tail_stats(self.ctx.handle, st))
+        return {"ran": bool(st[0]), "pairs": int(st[1]), "dense_pairs": int(st[2]), "candidates": int(st[3])}
 
     def run_keypoints(self, stream=None):
         s = stream or self._stream()
@@ -243,7 +256,8 @@ class LineEndPipeline(object):
             out["cs"] = P(self.cs, self.extents, 1, self.batch)
             out["end"] = P(self.end, self.extents, self.n_orient, self.batch)
         else:
-            out["orient"] = P(self.orient, self.extents, 3, self.batch)
+            if self.orient is not None:
+                out["orient"] = P(self.orient, self.extents, 3, self.batch)
             out["line_end"] = P(self.line_end, self.extents, 3, self.batch)
             if self.value_map:
                 out["value"] = P(self.value, self.extents, 1, self.batch)
@@ -251,7 +265,8 @@ class LineEndPipeline(object):
                 if self.keep_selection_maps:
                     out["top"] = P(self.top, self.extents, 3, self.batch)
                     out["peaks"] = P(self.peaks, self.extents, 3, self.batch)
-                out["peak_value"] = P(self.peak_value, self.extents, 1, self.batch)
+                if self.peak_value is not None:
+                    out["peak_value"] = P(self.peak_value, self.extents, 1, self.batch)
             counts = self.kp_counts.cpu().numpy()
             if not allow_truncated and (counts > self.kp_cap).any():
                 # the asynchronous *_dev entry points cannot return SILENT_E_CAPACITY: counts[f] > cap IS the overflow flag

@@ -97,6 +97,37 @@ def test_bench_launcher_spawns_its_own_ranks():
     assert out["slowest_rank_time"] == 2.0           # MAX over ranks of (1 + rank)
     assert out["frames_of_rank0"] == [0, 2, 4, 6]    # frame i -> rank i mod N
     assert out["constants"] == ["cs", "end"]
+    # the scaling record proves itself: backend, world size, and per rank the device it ran on and its own time
+    d = out["dist"]
+    assert d["backend"].startswith("gloo") and d["world_size"] == 2 and d["distinct_devices"] == 2
+    assert [r["rank"] for r in d["ranks"]] == [0, 1]
+    assert [r["ms_per_step"] for r in d["ranks"]] == [1.0, 2.0]
+    assert len({r["pci_bus_id"] for r in d["ranks"]}) == 2 and len({r["pid"] for r in d["ranks"]}) == 2
+    for r in d["ranks"]:
+        assert set(r) >= {"rank", "local_rank", "device_name", "pci_bus_id", "ms_per_step", "host", "pid"}
+
+
+def test_bench_refuses_two_ranks_on_one_device():
+    """Two ranks that report the same PCI bus id: exit non-zero, no JSON line."""
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT")}
+    env.update(SILENT_BENCH_DRY="1", SILENT_DIST_BACKEND="gloo", SILENT_BENCH_DRY_SAME_BUS="1")
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2"], env=env, stdout=subprocess.PIPE,
+                       stderr=subprocess.PIPE, text=True, timeout=300)
+    assert p.returncode != 0
+    assert not [l for l in p.stdout.splitlines() if l.startswith("{")]
+    assert "share a GPU" in p.stderr
+
+
+def test_bench_launcher_dumps_the_failing_ranks_log(tmp_path):
+    """Rank 1 dies: the launcher exits with its code and prints the tail of rank 1's own log file."""
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT")}
+    env.update(SILENT_BENCH_DRY="1", SILENT_DIST_BACKEND="gloo", SILENT_BENCH_DRY_FAIL_RANK="1",
+               SILENT_BENCH_LOG_DIR=str(tmp_path), SILENT_BENCH_LAUNCH_TIMEOUT="120")
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2"], env=env, stdout=subprocess.PIPE,
+                       stderr=subprocess.PIPE, text=True, timeout=300)
+    assert p.returncode == 7
+    assert "rank 1 exited with code 7" in p.stderr and "fails on purpose" in p.stderr
+    assert (tmp_path / "rank1.log").exists() and (tmp_path / "rank0.log").exists()
 
 
 def test_bench_launcher_reports_a_failed_rank():

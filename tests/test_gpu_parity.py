@@ -763,6 +763,89 @@ def test_rgb_keypoints_composite_equals_chain_then_selection(rt, kernels, knob, 
     assert sum(len(k) for k in a["keypoints"]) > 0
 
 
+def _sparse_vs_dense(frames, hw, n_levels, flat_policy="ieee", cap=1 << 18, **kw):
+    """The fused step with the sparse tail (peak_value_map=False) against the same step with a peak-value map (dense
+    kernels): keypoints and counts must be identical; returns (sparse stats, outputs of the dense run)."""
+    import torch
+    from pysilent_amd.pipeline import LineEndPipeline
+    common = dict(mode="rgb", n_levels=n_levels, batch=len(frames), selection=True, value_map=False, flat_policy=flat_policy,
+                  max_keypoints_per_frame=cap, **kw)
+    sparse = LineEndPipeline(hw, peak_value_map=False, **common)
+    dense = LineEndPipeline(hw, peak_value_map=True, **common)
+    t = torch.from_numpy(frames).cuda()
+    sparse.step(t)
+    stats = sparse.sparse_tail_stats()
+    dense.step(t)
+    torch.cuda.synchronize()
+    a, b = sparse.outputs(allow_truncated=True), dense.outputs(allow_truncated=True)
+    assert "peak_value" not in a and "peak_value" in b
+    np.testing.assert_array_equal(a["keypoint_counts"], b["keypoint_counts"])
+    for f in range(len(frames)):
+        np.testing.assert_array_equal(a["keypoints"][f], b["keypoints"][f])
+    for name in ("orient", "line_end"):
+        x, y = a[name].data.cpu().numpy(), b[name].data.cpu().numpy()
+        assert np.array_equal(np.isnan(x), np.isnan(y)), name
+        np.testing.assert_array_equal(np.nan_to_num(x, nan=7.0), np.nan_to_num(y, nan=7.0), err_msg=name)
+    return stats, b
+
+
+@pytest.mark.parametrize("policy", ["ieee", "zero"])
+def test_sparse_keypoint_tail_equals_dense_tail(rt, kernels, policy):
+    """silent_rgb_keypoints without a peak-value map: selection / NMS / keypoint search evaluated only around the pixels that
+    reach their level's threshold.  Same keypoints as the dense kernels on noise, line drawings (NaN regions under 'ieee'),
+    NaN / inf pixels, a black frame (every window empty: every pixel a keypoint -> dense fallback), a constant frame and a
+    frame of tied plateaus."""
+    frames = np.stack([noise_frame(31, 150, 260, 3), structured_frame(32, 150, 260, 3), noise_frame(33, 150, 260, 3),
+                       np.zeros((150, 260, 3), np.float32), np.full((150, 260, 3), 90.0, np.float32),
+                       structured_frame(34, 150, 260, 3, n_lines=40)])
+    frames[2, 40:60, 100:140] = 0.0
+    frames[2, 70, 30, 1] = np.nan
+    frames[2, 90, 200, 0] = np.inf
+    frames[5] = np.round(frames[5] / 64.0) * 64.0          # few distinct colours: ties between line ends
+    stats, dense = _sparse_vs_dense(frames, (150, 260), 4, flat_policy=policy)
+    assert stats["ran"] and stats["pairs"] == 6 * 4
+    assert 0 < stats["dense_pairs"] < stats["pairs"]        # the black frame's levels fall back, the noise frame's do not
+    assert stats["candidates"] > 0
+    counts = dense["keypoint_counts"]
+    # the black frame: all NaN under 'ieee' (0 * inf; a NaN is never a keypoint), all 0 under 'zero' (every pixel a keypoint)
+    assert counts[0] > 0 and counts[3] == (0 if policy == "ieee" else sum(h * w for h, w in [(150, 260), (75, 130), (38, 65), (19, 32)]))
+
+
+def test_sparse_keypoint_tail_knob_and_tile_heights(rt, kernels):
+    """The summary geometry follows the chain launch's tile height (groups of 16 rows inside a tile): odd tile heights, tiles
+    shorter than a group, and the knob that switches the sparse tail off."""
+    frames = np.stack([noise_frame(41, 97, 233, 3), structured_frame(42, 97, 233, 3)])
+    for knob in (0, (9 << 8), (7 << 8), (20 << 8), (45 << 8), 8):       # tile heights 18 (model), 18, 14, 40, 90, 90
+        with rt.tuning(TUNE_RGB, knob):
+            stats, _ = _sparse_vs_dense(frames, (97, 233), 3)
+        assert stats["ran"], knob
+    with rt.tuning(TUNE_RGB, 32):
+        stats, _ = _sparse_vs_dense(frames, (97, 233), 3)
+    assert not stats["ran"]
+    with rt.tuning(TUNE_RGB, 16):                                        # one-pixel kernel: no summary -> dense tail
+        stats, _ = _sparse_vs_dense(frames, (97, 233), 3)
+    assert not stats["ran"]
+
+
+def test_sparse_keypoint_tail_candidate_overflow(rt, kernels):
+    """More than 16384 pixels reach the threshold in one frame (a regular grid of identical line ends): that frame runs the
+    dense kernels, the others stay sparse; keypoints identical."""
+    h, w = 400, 640
+    grid = np.zeros((h, w, 3), np.float32)
+    grid[::4, ::4] = (255.0, 128.0, 64.0)                   # 16 000 isolated dots, each with several line-end responses
+    frames = np.stack([grid, noise_frame(43, h, w, 3)])
+    stats, dense = _sparse_vs_dense(frames, (h, w), 2, flat_policy="zero", cap=h * w)
+    assert stats["ran"] and stats["candidates"] > 16384 and stats["dense_pairs"] >= 2
+
+
+def test_sparse_keypoint_tail_1080p(rt, kernels):
+    """Full size (what bench.py times for config 3): 1080p, 6 levels, two frames."""
+    frames = np.stack([noise_frame(2, 1080, 1920, 3), structured_frame(3, 1080, 1920, 3)])
+    stats, dense = _sparse_vs_dense(frames, (1080, 1920), 6)
+    assert stats["ran"] and stats["candidates"] < 20000
+    assert dense["keypoint_counts"].min() > 0
+
+
 def test_rgb_pipeline_with_selection_stage(rt, kernels):
     """chain -> top-percent (a-10, p = 0.1) -> NMS (a-9) -> value -> keypoints (a-11); every stage
     after the chain is index-like and compared bit for bit with the oracle applied to the GPU's own line-end map."""
