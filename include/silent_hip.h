@@ -377,9 +377,10 @@ int silent_rgb_chain_structure(const silent_rgb_chain_params* params, unsigned* 
  * accepts NULL line_end_out; idx / cap_per_frame / counts as silent_max_value_indices_region.
  * peak_value_out may be NULL (both forms): nobody then needs the selection's value map as a MAP, and the tail runs sparse --
  * the chain kernel leaves max_pool(value) per (pixel pair x 16 rows), and a-10 / a-9 / a-8 / a-11 are evaluated only around
- * the pixels that reach their level's threshold (a handful per level on natural and noise frames); a (frame, level) this
- * cannot settle exactly (a search window without a positive peak: all its pixels are keypoints; > 16384 candidates in a
- * frame) runs the dense kernels on a map in the context workspace.  Keypoints are identical either way (tested). */
+ * the pixels that reach their level's threshold (a handful per level on natural and noise frames).  A search window
+ * without a positive peak makes every non-NaN pixel mapped to it a keypoint: in a level without NaNs (the chain kernel
+ * notes them) the count pass synthesises that; with NaNs, or with > 16384 candidates in a frame, the (frame, level) runs
+ * the dense kernels on a map in the context workspace.  Keypoints are identical either way (tested). */
 int silent_rgb_keypoints(silent_ctx* ctx, const float* pyr, const silent_extent* levels, int n_levels, int n_frames,
                          const silent_rgb_chain_params* params, double top_percent, const silent_extent* regions,
                          float* orient_out, float* line_end_out, float* value_out, float* peak_value_out, int64_t* idx,
@@ -391,7 +392,9 @@ int silent_rgb_keypoints_dev(silent_ctx* ctx, const float* pyr, const silent_ext
 
 /* What the sparse tail of the LAST silent_rgb_keypoints[_dev] call of this context did (synchronises that call's stream):
  * stats[0] = 1 if it ran sparse, [1] = (frame, level) pairs, [2] = pairs it handed to the dense kernels, [3] = candidate
- * pixels (value >= threshold) it evaluated.  For tests and the bench report; no reference counterpart. */
+ * pixels (value >= threshold) it evaluated, [4] = pairs settled with a synthesised all-zero map (a search window without a
+ * positive peak in a level without NaNs: every pixel mapped to it is a keypoint).  stats holds 5 values.  For tests and the
+ * bench report; no reference counterpart. */
 int silent_sparse_tail_stats(silent_ctx* ctx, int64_t* stats);
 
 /* Host-only (no GPU needed): the weight STREAM silent_rgb_line_end hands to its pair kernel for these weights -- the

@@ -726,7 +726,7 @@ static int build_region_tab(silent_ctx* ctx, const char* who, const silent_exten
 }
 
 // workspace of the keypoint passes, after `reserve` bytes the caller keeps for itself:
-// cells | chunk_counts | hit_masks | cand_n | offsets | m1 | pooled | summary | candidates | dense flags | peak-value map
+// cells | chunk_counts | hit_masks | cand_n | nan flags | offsets | m1 | pooled | summary | candidates | modes | peak-value map
 struct KeypointWs {
     unsigned* cells;
     int* chunk_counts;
@@ -739,9 +739,10 @@ struct KeypointWs {
     float* sum = nullptr;            // the chain kernel's value summary (SumTab geometry)
     Candidate* cand = nullptr;       // [n_frames][kCandCap]
     int* cand_n = nullptr;           // [n_frames]
-    int* dense_flags = nullptr;      // [n_frames][n_levels]
+    int* dense_flags = nullptr;      // [n_frames][n_levels]: kTailSparse / kTailDense / kTailZero
+    int* nan_flags = nullptr;        // [n_frames][n_levels]: the chain kernel saw a NaN value in that level
     float* pv = nullptr;             // peak-value map of the (frame, level)s that run the dense kernels
-    void* zero_from = nullptr;       // chunk_counts | hit_masks | cand_n: one memset before a sparse tail
+    void* zero_from = nullptr;       // chunk_counts | hit_masks | cand_n | nan flags: one memset before a sparse tail's chain launch
     size_t zero_bytes = 0;
 };
 
@@ -752,7 +753,8 @@ static int keypoint_workspace(silent_ctx* ctx, hipStream_t stream, int n_levels,
     const size_t off_counts = off_cells + align_up(w->n_cells * sizeof(unsigned));
     const size_t off_masks = off_counts + align_up((size_t)blocks * sizeof(int));
     const size_t off_candn = off_masks + align_up((size_t)blocks * 4 * kKpPer * sizeof(unsigned long long));
-    const size_t off_offsets = off_candn + align_up((size_t)n_frames * sizeof(int));
+    const size_t off_nanf = off_candn + align_up((size_t)n_frames * sizeof(int));
+    const size_t off_offsets = off_nanf + align_up((size_t)n_frames * n_levels * sizeof(int));
     const size_t off_m1 = off_offsets + align_up((size_t)blocks * sizeof(long long));
     const size_t off_pooled = off_m1 + (general ? align_up((size_t)n_frames * rt.m1_per_frame * sizeof(float)) : 0);
     const size_t off_sum = off_pooled + (general ? align_up((size_t)n_frames * rt.pooled_per_frame * sizeof(float)) : 0);
@@ -769,6 +771,7 @@ static int keypoint_workspace(silent_ctx* ctx, hipStream_t stream, int n_levels,
     w->pooled = (float*)(base + off_pooled);
     w->hit_masks = (unsigned long long*)(base + off_masks);
     w->cand_n = (int*)(base + off_candn);
+    w->nan_flags = (int*)(base + off_nanf);
     w->sum = sum_entries ? (float*)(base + off_sum) : nullptr;
     w->cand = sum_entries ? (Candidate*)(base + off_cand) : nullptr;
     w->dense_flags = (int*)(base + off_flags);
@@ -805,11 +808,14 @@ static void keypoint_passes(const float* value, const LevelTab& tab, long long b
         hipLaunchKernelGGL(region_count_kernel<true>, dim3((unsigned)blocks), dim3(256), 0, s, value, tab, rt, w.cells, w.pooled, w.chunk_counts, w.hit_masks, dense_flags);
     else
         hipLaunchKernelGGL(region_count_kernel<false>, dim3((unsigned)blocks), dim3(256), 0, s, value, tab, rt, w.cells, w.pooled, w.chunk_counts, w.hit_masks, dense_flags);
+    if (dense_flags)   // sparse tail: the candidates' hits join what the count pass left
+        hipLaunchKernelGGL(sparse_finish_kernel, dim3((unsigned)n_frames), dim3(256), 0, s, tab, rt, w.cells, w.cand, w.cand_n, dense_flags,
+                           w.hit_masks, w.chunk_counts);
     hipLaunchKernelGGL(region_scan_kernel, dim3((unsigned)n_frames), dim3(256), 0, s, w.chunk_counts, w.chunk_offsets,
                        tab.tiles_per_frame, counts);
     if (!cap_per_frame) return;
     hipLaunchKernelGGL(region_write_kernel, dim3((unsigned)blocks), dim3(256), 0, s, tab, w.hit_masks, w.chunk_offsets, idx,
-                       (long long)cap_per_frame);
+                       (long long)cap_per_frame, w.chunk_counts);
 }
 
 SILENT_EXPORT int silent_max_value_indices_region_dev(silent_ctx* ctx, const float* value, const silent_extent* levels,
@@ -879,12 +885,17 @@ static int select_prepare(silent_ctx* ctx, const char* who, const silent_extent*
     TRY(build_region_tab(ctx, who, levels, n_levels, regions, &sp->rt, &sp->general));
     sp->nmm = n_frames * n_levels;
     std::memset(&sp->st, 0, sizeof(sp->st));
-    if (sparse_th > 0 && !sp->general) build_sum_tab(levels, n_levels, sparse_th, &sp->st);
+    if (sparse_th > 0 && !sp->general && n_frames <= 65535) {
+        build_sum_tab(levels, n_levels, sparse_th, &sp->st);
+        if (sp->st.frame_entries >= (1ll << 31)) std::memset(&sp->st, 0, sizeof(sp->st));   // (sparse_select_kernel indexes a frame with int)
+    }
     TRY(keypoint_workspace(ctx, s, n_levels, n_frames, sp->blocks, sizeof(unsigned) * 2 * (size_t)sp->nmm, sp->rt, sp->general, &sp->w,
                            sp->st.frame_entries, pv_ws ? sp->tab.frame_px : 0));
     sp->mm = (unsigned*)ctx->ws.p;
-    hipLaunchKernelGGL(init_maxmin_kernel, dim3((sp->nmm + 255) / 256), dim3(256), 0, s, sp->mm, sp->nmm);
-    hipLaunchKernelGGL(init_cells_kernel, dim3((unsigned)((sp->w.n_cells + 255) / 256)), dim3(256), 0, s, sp->w.cells, (long long)sp->w.n_cells);
+    if (sp->st.frame_entries > 0) HIP_TRY(ctx, hipMemsetAsync(sp->w.zero_from, 0, sp->w.zero_bytes, s));
+    const long long n_init = std::max<long long>(2ll * sp->nmm, (long long)sp->w.n_cells);
+    hipLaunchKernelGGL(init_select_kernel, dim3((unsigned)((n_init + 255) / 256)), dim3(256), 0, s, sp->mm, 2 * sp->nmm, sp->w.cells,
+                       (long long)sp->w.n_cells);
     return SILENT_OK;
 }
 
@@ -903,13 +914,11 @@ static int select_run(silent_ctx* ctx, const char* who, const float* color, cons
     const float a = (float)(1.0 - top_percent), b = (float)top_percent;
     const int* dense_flags = nullptr;
     if (sparse) {
-        // (sparse implies: 3 channels, cell tables, extrema present, no caller-side peak-value map)
-        HIP_TRY(ctx, hipMemsetAsync(w.zero_from, 0, w.zero_bytes, s));
-        const long long entries = sp.st.frame_entries * n_frames;
-        hipLaunchKernelGGL(sparse_select_kernel, dim3((unsigned)((entries + 255) / 256)), dim3(256), 0, s, color, sp.tab, sp.st, w.sum,
+        // (sparse implies: 3 channels, cell tables, extrema present, no caller-side peak-value map; select_prepare zeroed the counters)
+        hipLaunchKernelGGL(sparse_select_kernel, dim3((unsigned)((sp.st.frame_entries + 255) / 256), (unsigned)n_frames), dim3(256), 0, s, color, sp.tab, sp.st, w.sum,
                            n_frames, a, b, mm, rt, w.cells, w.cand, w.cand_n);
-        hipLaunchKernelGGL(sparse_finish_kernel, dim3((unsigned)n_frames), dim3(256), 0, s, sp.tab, rt, w.cells, w.cand, w.cand_n,
-                           w.dense_flags, w.hit_masks, w.chunk_counts);
+        hipLaunchKernelGGL(sparse_modes_kernel, dim3((unsigned)n_frames), dim3(64), 0, s, sp.tab, rt, w.cells, w.cand_n, w.nan_flags,
+                           w.dense_flags);
         dense_flags = w.dense_flags;
     }
     if (!peak_value_out) peak_value_out = w.pv;
@@ -1272,7 +1281,7 @@ static int rgb_chain_tile_height(const silent_ctx* ctx, const silent_extent* lev
 static int rgb_chain_launch(silent_ctx* ctx, const char* who, const float* pyr, const silent_extent* levels, int n_levels,
                             int n_frames, const silent_rgb_chain_params* p, float* orient_out, float* line_end_out,
                             float* value_out, unsigned* mm, bool* mm_done, silent_stream stream, const SumTab* st = nullptr,
-                            float* sum = nullptr) {
+                            float* sum = nullptr, int* nan_flags = nullptr) {
     if (mm_done) *mm_done = false;
     if (!pyr || !p) return fail(ctx, SILENT_E_INVALID, std::string(who) + ": NULL pointer");
     if (!p->rgc || !p->rgby || !p->stripe || !p->blur || !p->end)
@@ -1320,6 +1329,7 @@ static int rgb_chain_launch(silent_ctx* ctx, const char* who, const float* pyr, 
             a2.th = a.th;
             a2.mm = nullptr;
             a2.sum = nullptr;
+            a2.nan_flags = nullptr;
             a2.sum_frame = 0;
             std::memset(a2.sum_off, 0, sizeof(a2.sum_off));
             std::memset(a2.ws, 0, sizeof(a2.ws));
@@ -1343,6 +1353,7 @@ static int rgb_chain_launch(silent_ctx* ctx, const char* who, const float* pyr, 
                 a2.mm = mm;
                 if (st && sum && st->frame_entries > 0 && st->th == th) {   // value summary for the sparse selection tail
                     a2.sum = sum;
+                    a2.nan_flags = nan_flags;
                     a2.sum_frame = st->frame_entries;
                     for (int l = 0; l < kMaxLevels; ++l) a2.sum_off[l] = st->off[l];
                 }
@@ -1435,7 +1446,7 @@ SILENT_EXPORT int silent_rgb_keypoints_dev(silent_ctx* ctx, const float* pyr, co
     TRY(select_prepare(ctx, who, levels, n_levels, n_frames, regions, s, &sp, want_sparse ? th : 0, !peak_value_out));
     bool mm_done = false;
     TRY(rgb_chain_launch(ctx, who, pyr, levels, n_levels, n_frames, p, orient_out, line_end_out, value_out, sp.mm, &mm_done, stream,
-                         &sp.st, sp.w.sum));
+                         &sp.st, sp.w.sum, sp.w.nan_flags));
     const bool sparse = want_sparse && mm_done && sp.st.frame_entries > 0;
     ctx->sparse_ran = sparse;
     ctx->sparse_stream = s;
@@ -1452,14 +1463,15 @@ SILENT_EXPORT int silent_sparse_tail_stats(silent_ctx* ctx, int64_t* stats) {
     NEED_CTX(ctx);
     if (!stats) return fail(ctx, SILENT_E_INVALID, "silent_sparse_tail_stats: stats is NULL");
     stats[0] = ctx->sparse_ran ? 1 : 0;
-    stats[1] = stats[2] = stats[3] = 0;
+    stats[1] = stats[2] = stats[3] = stats[4] = 0;
     if (!ctx->sparse_ran || !ctx->ws.p) return SILENT_OK;
     HIP_TRY(ctx, hipStreamSynchronize(ctx->sparse_stream));
     std::vector<int> flags((size_t)ctx->sparse_pairs), cn((size_t)ctx->sparse_frames);
     HIP_TRY(ctx, hipMemcpy(flags.data(), (char*)ctx->ws.p + ctx->sparse_flags_off, flags.size() * sizeof(int), hipMemcpyDeviceToHost));
     HIP_TRY(ctx, hipMemcpy(cn.data(), (char*)ctx->ws.p + ctx->sparse_candn_off, cn.size() * sizeof(int), hipMemcpyDeviceToHost));
     stats[1] = ctx->sparse_pairs;
-    for (int f : flags) stats[2] += f ? 1 : 0;
+    for (int f : flags) stats[2] += f == kTailDense ? 1 : 0;
+    for (int f : flags) stats[4] += f == kTailZero ? 1 : 0;
     for (int c : cn) stats[3] += c;
     return SILENT_OK;
 }

@@ -10,6 +10,10 @@ constexpr int kChunk = 1024;  // pixels per block for the 1-D (flattened level) 
 // Value summary written by the fused RGB chain (rgb_line_end2_kernel, MM instantiation) for the sparse selection tail:
 // entry = max_pool(value) over one pixel PAIR x kSumRows rows of a chain tile.
 constexpr int kSumRowsLog2 = 4, kSumRows = 1 << kSumRowsLog2;
+// How the sparse tail (sparse_select_kernel, below) settles a (frame, level): by its candidates alone (every window maximum > 0); candidates + a synthesised all-zero
+// map in the count pass (some window without a positive peak, but the level holds no NaN: every pixel mapped to such a window
+// is a keypoint); or the dense kernels (such a window AND NaNs in the level, or too many candidates)
+constexpr int kTailSparse = 0, kTailDense = 1, kTailZero = 2;
 
 // order-preserving float <-> uint map so that integer atomics give float max / min
 __device__ __forceinline__ unsigned f2ord(float f) {
@@ -116,6 +120,13 @@ __global__ void init_maxmin_kernel(unsigned* mm, int n) {
         mm[2 * i] = pool_lowest_ord();      // max_pool(v)
         mm[2 * i + 1] = pool_lowest_ord();  // max_pool(-v): the minimum is -1.0 * this (top_value_points.py:19-21)
     }
+}
+
+// one launch for both tables of the selection tail (extrema slots and cell maxima start from lowest())
+__global__ void init_select_kernel(unsigned* mm, int n_mm2, unsigned* cells, long long n_cells) {
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i < n_mm2) mm[i] = pool_lowest_ord();
+    if (i < n_cells) cells[i] = pool_lowest_ord();
 }
 
 // If `color` is non-null the value is computed on the fly as get_value_from_color does.
@@ -326,8 +337,8 @@ __global__ __launch_bounds__(256) void select_peaks_kernel(const float* __restri
                                                            const int* __restrict__ dense_flags) {
     constexpr int R = kSelTH;
     const TileCoord tc = locate_tile(tab, blockIdx.x);
-    // sparse tail (sparse_finish_kernel): only the (frame, level)s it could not settle run this pass
-    if (dense_flags && !dense_flags[tc.frame * tab.n_levels + tc.level]) return;
+    // sparse tail (sparse_modes_kernel): only the (frame, level)s in dense mode run this pass
+    if (dense_flags && dense_flags[tc.frame * tab.n_levels + tc.level] != kTailDense) return;
     const int H = tab.h[tc.level], W = tab.w[tc.level];
     const long long base_px = (long long)tc.frame * tab.frame_px + tab.px_off[tc.level];
     const int lane = threadIdx.x & 63;
@@ -639,7 +650,10 @@ __global__ __launch_bounds__(256) void region_count_kernel(const float* __restri
     __shared__ float s_pooled[kMaxWin * kMaxWin];
     __shared__ int s_cnt[4];
     const TileCoord tc = locate_tile(tab, blockIdx.x);
-    if (dense_flags && !dense_flags[tc.frame * tab.n_levels + tc.level]) return;   // settled by the sparse tail
+    // sparse tail: kTailSparse levels are settled by the candidates alone; kTailZero levels hold no NaN and every pixel that is
+    // not a candidate has peak value 0, so the map is synthesised instead of read
+    const int mode = dense_flags ? dense_flags[tc.frame * tab.n_levels + tc.level] : kTailDense;
+    if (mode == kTailSparse) return;
     const RegionLevel& rl = rt.lv[tc.level];
     const int W = tab.w[tc.level];
     const int npx = tab.h[tc.level] * W;
@@ -648,8 +662,13 @@ __global__ __launch_bounds__(256) void region_count_kernel(const float* __restri
     const int seg = tc.tx * kKpChunk + wave * (kKpChunk / 4);
     // the chunk's values are requested before the window maxima are staged: the two latencies overlap
     float v[kKpPer];
+    if (mode == kTailDense) {
 #pragma unroll
-    for (int k = 0; k < kKpPer; ++k) v[k] = value[base_px + min(seg + k * 64 + lane, npx - 1)];
+        for (int k = 0; k < kKpPer; ++k) v[k] = value[base_px + min(seg + k * 64 + lane, npx - 1)];
+    } else {
+#pragma unroll
+        for (int k = 0; k < kKpPer; ++k) v[k] = 0.0f;
+    }
     const float* pooled = s_pooled;
     if constexpr (GEN) {
         pooled = pooled_g + (long long)tc.frame * rt.pooled_per_frame + rl.pooled_off;
@@ -701,100 +720,125 @@ struct Candidate {
     float pv;
 };
 
-// t_c = color_c * (value >= thr ? 1 : 0) of pixel (y, x) as select_peaks_kernel computes it; false outside the level
-__device__ __forceinline__ bool sparse_top(const float* __restrict__ lev, int H, int W, int y, int x, float thr, float (&t)[3],
+// t_c = color_c * (value >= thr ? 1 : 0) of pixel (y, x) as select_peaks_kernel computes it; lowest() outside the level
+// (max_pool SAME ignores such taps).  The address is clamped and the load unconditional: the 9 taps of a passer are requested
+// together, not one dependent round trip after the other.
+__device__ __forceinline__ void sparse_top(const float* __restrict__ lev, int H, int W, int y, int x, float thr, float (&t)[3],
                                            bool* passer = nullptr) {
-    if (y < 0 || y >= H || x < 0 || x >= W) return false;
-    const float* __restrict__ px = lev + ((long long)y * W + x) * 3;
+    const bool inside = y >= 0 && y < H && x >= 0 && x < W;
+    const float* __restrict__ px = lev + ((long long)min(max(y, 0), H - 1) * W + min(max(x, 0), W - 1)) * 3;
     const float c0 = px[0], c1 = px[1], c2 = px[2];
     const float v = __fmul_rn(__fadd_rn(__fadd_rn(c0, c1), c2), 1.0f / 3.0f);
     const float m = v >= thr ? 1.0f : 0.0f;
-    if (passer) *passer = v >= thr;
-    t[0] = __fmul_rn(c0, m);
-    t[1] = __fmul_rn(c1, m);
-    t[2] = __fmul_rn(c2, m);
-    return true;
+    if (passer) *passer = inside && v >= thr;
+    t[0] = inside ? __fmul_rn(c0, m) : kPoolLowest;
+    t[1] = inside ? __fmul_rn(c1, m) : kPoolLowest;
+    t[2] = inside ? __fmul_rn(c2, m) : kPoolLowest;
 }
 
+// grid: x = 256-entry chunks of one frame's summary, y = frame.  A lane looks at one entry; the entries that reach their level's
+// threshold are then handled one after the other by the WHOLE wave (lane i takes pixel i of the entry's 2 x kSumRows pixels),
+// so that a group costs two memory round trips instead of 32 dependent ones.
 __global__ __launch_bounds__(256) void sparse_select_kernel(const float* __restrict__ color, const LevelTab tab, const SumTab st,
                                                             const float* __restrict__ sum, int n_frames, float one_minus_p,
                                                             float p_f, const unsigned* __restrict__ mm, const RegionTab rt,
                                                             unsigned* __restrict__ cells, Candidate* __restrict__ cand,
                                                             int* __restrict__ cand_n) {
-    const long long gid = (long long)blockIdx.x * 256 + threadIdx.x;
-    const int frame = (int)(gid / st.frame_entries);
-    if (frame >= n_frames) return;
-    long long rem = gid - (long long)frame * st.frame_entries;
+    static_assert(2 * kSumRows <= 64, "one lane per pixel of a group");
+    const int frame = blockIdx.y;
+    const int e = (int)(blockIdx.x * 256 + threadIdx.x);   // (entries per frame < 2^31: host-checked)
+    const int lane = threadIdx.x & 63;
+    const bool live = e < (int)st.frame_entries;
     int l = 0;
 #pragma unroll
     for (int i = 1; i < kMaxLevels; ++i)
-        if (i < tab.n_levels && rem >= st.off[i]) l = i;
-    rem -= st.off[l];
-    const int H = tab.h[l], W = tab.w[l], nxp = (W + 1) >> 1;
-    const int gy = (int)(rem / nxp), xp = (int)(rem - (long long)gy * nxp);
+        if (i < tab.n_levels && e >= (int)st.off[i]) l = i;
     const unsigned* slot = mm + ((long long)frame * tab.n_levels + l) * 2;
     const float thr = __fadd_rn(__fmul_rn(one_minus_p, level_max(slot)), __fmul_rn(p_f, level_min(slot)));
-    const float s = sum[gid];
-    if (!(s >= thr)) return;   // no passer in this group (groups below the last image row hold no data: their row range is empty)
-    const int ty = gy / st.gpt, k = gy - ty * st.gpt;
-    const int r0 = ty * st.th + k * kSumRows;
-    const int r1 = min(min(r0 + kSumRows, (ty + 1) * st.th), H);
-    const float* __restrict__ lev = color + ((long long)frame * tab.frame_px + tab.px_off[l]) * 3;
-    const RegionLevel& rl = rt.lv[l];
-    for (int y = r0; y < r1; ++y)
-        for (int x = 2 * xp; x < min(2 * xp + 2, W); ++x) {
-            float tc_[3];
-            bool passer = false;
-            sparse_top(lev, H, W, y, x, thr, tc_, &passer);
-            if (!passer) continue;
-            float mx[3] = {kPoolLowest, kPoolLowest, kPoolLowest};
-            for (int dy = -1; dy <= 1; ++dy)
-                for (int dx = -1; dx <= 1; ++dx) {
-                    float t[3];
-                    if (!sparse_top(lev, H, W, y + dy, x + dx, thr, t)) continue;   // max_pool SAME ignores taps outside the level
+    const float s = live ? sum[(long long)frame * st.frame_entries + e] : kPoolLowest;
+    // (groups below the last image row hold no data: whatever is there, their row range is empty)
+    unsigned long long todo = __ballot(live && s >= thr);
+    while (todo) {   // wave-uniform
+        const int src = __ffsll((long long)todo) - 1;
+        todo &= todo - 1;
+        const int gl = __builtin_amdgcn_readlane(l, src);
+        const float gthr = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(thr), src));
+        const int rem = __builtin_amdgcn_readlane(e, src) - (int)st.off[gl];
+        const int H = tab.h[gl], W = tab.w[gl], nxp = (W + 1) >> 1;
+        const int gy = rem / nxp, xp = rem - gy * nxp;
+        const int ty = gy / st.gpt, k = gy - ty * st.gpt;
+        const int r0 = ty * st.th + k * kSumRows;
+        const int r1 = min(min(r0 + kSumRows, (ty + 1) * st.th), H);
+        const float* __restrict__ lev = color + ((long long)frame * tab.frame_px + tab.px_off[gl]) * 3;
+        const int y = r0 + (lane >> 1), x = 2 * xp + (lane & 1);
+        float tc_[3];
+        bool passer = false;
+        sparse_top(lev, H, W, min(y, H - 1), x, gthr, tc_, &passer);
+        passer = passer && lane < 2 * kSumRows && y < r1;
+        if (!passer) continue;   // (no wave-level operation below)
+        float mx[3] = {kPoolLowest, kPoolLowest, kPoolLowest};
+        float t[9][3];
 #pragma unroll
-                    for (int c = 0; c < 3; ++c) mx[c] = pool_max(mx[c], t[c]);       // ... and NaN taps
-                }
-            float o[3];
+        for (int j = 0; j < 9; ++j) sparse_top(lev, H, W, y + j / 3 - 1, x + j % 3 - 1, gthr, t[j]);
 #pragma unroll
-            for (int c = 0; c < 3; ++c) o[c] = __fmul_rn(tc_[c], tc_[c] == mx[c] ? tc_[c] : 0.0f);
-            const float pv = __fmul_rn(__fadd_rn(__fadd_rn(o[0], o[1]), o[2]), 1.0f / 3.0f);
-            int rs = 0, cs = 0;
-            for (int s_ = 1; s_ < rl.nrs; ++s_) rs = y >= rl.rcut[s_] ? s_ : rs;
-            for (int s_ = 1; s_ < rl.ncs; ++s_) cs = x >= rl.ccut[s_] ? s_ : cs;
-            atomicMax(cells + ((long long)frame * tab.n_levels + l) * kCells + rs * kMaxSeg + cs, f2ord(pool_max(kPoolLowest, pv)));
-            const int n = atomicAdd(cand_n + frame, 1);
-            if (n < kCandCap) cand[(long long)frame * kCandCap + n] = Candidate{l, y, x, pv};
-        }
+        for (int j = 0; j < 9; ++j)
+#pragma unroll
+            for (int c = 0; c < 3; ++c) mx[c] = pool_max(mx[c], t[j][c]);   // NaN taps are ignored like out-of-level ones
+        float o[3];
+#pragma unroll
+        for (int c = 0; c < 3; ++c) o[c] = __fmul_rn(tc_[c], tc_[c] == mx[c] ? tc_[c] : 0.0f);
+        const float pv = __fmul_rn(__fadd_rn(__fadd_rn(o[0], o[1]), o[2]), 1.0f / 3.0f);
+        const RegionLevel& rl = rt.lv[gl];
+        int rs = 0, cs = 0;
+        for (int s_ = 1; s_ < rl.nrs; ++s_) rs = y >= rl.rcut[s_] ? s_ : rs;
+        for (int s_ = 1; s_ < rl.ncs; ++s_) cs = x >= rl.ccut[s_] ? s_ : cs;
+        atomicMax(cells + ((long long)frame * tab.n_levels + gl) * kCells + rs * kMaxSeg + cs, f2ord(pool_max(kPoolLowest, pv)));
+        const int n = atomicAdd(cand_n + frame, 1);
+        if (n < kCandCap) cand[(long long)frame * kCandCap + n] = Candidate{gl, y, x, pv};
+    }
 }
 
-// one block per frame; `tab` is the count / write pass's chunk table (kKpChunk pixels per block)
+// one block per frame: the mode of every level (dense_flags[frame][level]), before the dense kernels
+__global__ __launch_bounds__(64) void sparse_modes_kernel(const LevelTab tab, const RegionTab rt, const unsigned* __restrict__ cells,
+                                                          const int* __restrict__ cand_n, const int* __restrict__ nan_flags,
+                                                          int* __restrict__ dense_flags) {
+    const int f = blockIdx.x, l = threadIdx.x;
+    if (l >= tab.n_levels) return;
+    const RegionLevel& rl = rt.lv[l];
+    const unsigned* c = cells + ((long long)f * tab.n_levels + l) * kCells;
+    bool all_pos = true;
+    for (int j = 0; j < rl.oh; ++j)
+        for (int i = 0; i < rl.ow; ++i) {
+            unsigned m = pool_lowest_ord();
+            for (int rs = rl.wy_lo[j]; rs < rl.wy_hi[j]; ++rs)
+                for (int cs = rl.wx_lo[i]; cs < rl.wx_hi[i]; ++cs) m = max(m, c[rs * kMaxSeg + cs]);
+            all_pos = all_pos && ord2f(m) > 0.0f;
+        }
+    const bool overflow = cand_n[f] > kCandCap;
+    int mode = kTailDense;
+    if (!overflow) mode = all_pos ? kTailSparse : (nan_flags[f * tab.n_levels + l] ? kTailDense : kTailZero);
+    dense_flags[f * tab.n_levels + l] = mode;
+}
+
+// one block per frame, AFTER the count pass; `tab` is the count / write pass's chunk table (kKpChunk pixels per block): the
+// candidates that reach a POSITIVE window maximum become hit bits + chunk counts (in a window without a positive peak the
+// count pass has already set every pixel of a kTailZero level)
 __global__ __launch_bounds__(256) void sparse_finish_kernel(const LevelTab tab, const RegionTab rt, const unsigned* __restrict__ cells,
                                                             const Candidate* __restrict__ cand, const int* __restrict__ cand_n,
-                                                            int* __restrict__ dense_flags, unsigned long long* __restrict__ hit_masks,
+                                                            const int* __restrict__ dense_flags, unsigned long long* __restrict__ hit_masks,
                                                             int* __restrict__ chunk_counts) {
     __shared__ float s_pooled[kMaxLevels][kMaxWin * kMaxWin];
-    __shared__ int s_ok[kMaxLevels];
     const int f = blockIdx.x;
     const int n = cand_n[f];
+    if (n > kCandCap) return;     // block-uniform: every level of this frame ran the dense kernels
     for (int l = 0; l < tab.n_levels; ++l)
         load_pooled(cells + ((long long)f * tab.n_levels + l) * kCells, rt.lv[l], s_pooled[l]);
     __syncthreads();
-    if ((int)threadIdx.x < tab.n_levels) {
-        const int l = threadIdx.x;
-        const RegionLevel& rl = rt.lv[l];
-        bool ok = n <= kCandCap;
-        for (int j = 0; j < rl.oh; ++j)
-            for (int i = 0; i < rl.ow; ++i) ok = ok && s_pooled[l][j * kMaxWin + i] > 0.0f;
-        s_ok[l] = ok;
-        dense_flags[f * tab.n_levels + l] = ok ? 0 : 1;
-    }
-    __syncthreads();
-    const int m = min(n, kCandCap);
-    for (int i = threadIdx.x; i < m; i += 256) {
+    for (int i = threadIdx.x; i < n; i += 256) {
         const Candidate c = cand[(long long)f * kCandCap + i];
-        if (!s_ok[c.level]) continue;
-        if (!(c.pv >= region_thr<false>(c.y, c.x, rt.lv[c.level], s_pooled[c.level]))) continue;
+        if (dense_flags[f * tab.n_levels + c.level] == kTailDense) continue;
+        const float thr = region_thr<false>(c.y, c.x, rt.lv[c.level], s_pooled[c.level]);
+        if (!(thr > 0.0f && c.pv >= thr)) continue;
         const int p = c.y * tab.w[c.level] + c.x;
         const long long blk = (long long)f * tab.tiles_per_frame + tab.tile_start[c.level] + (p / kKpChunk);
         atomicOr(hit_masks + blk * (kKpChunk / 64) + ((p % kKpChunk) >> 6), 1ull << (p & 63));
@@ -837,8 +881,10 @@ __global__ __launch_bounds__(256) void region_scan_kernel(const int* __restrict_
 // earlier 64-pixel groups + hits of the lower lanes of this group
 __global__ __launch_bounds__(256) void region_write_kernel(const LevelTab tab, const unsigned long long* __restrict__ hit_masks,
                                                            const long long* __restrict__ chunk_offsets,
-                                                           int64_t* __restrict__ idx, long long cap_per_frame) {
+                                                           int64_t* __restrict__ idx, long long cap_per_frame,
+                                                           const int* __restrict__ chunk_counts) {
     __shared__ int s_wave[4];
+    if (chunk_counts && chunk_counts[blockIdx.x] == 0) return;   // block-uniform: nothing to write in this chunk
     const TileCoord tc = locate_tile(tab, blockIdx.x);
     const int W = tab.w[tc.level];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;

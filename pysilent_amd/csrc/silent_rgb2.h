@@ -130,6 +130,7 @@ struct Rgb2Args {
     // optional value summary for the sparse selection tail (silent_peaks.h, SumTab): per frame and level a [tiles_y * gpt][ceil(W / 2)]
     // array, entry = max_pool(value) over one lane's pixel pair x kSumRows rows (MM instantiation only)
     float* sum;
+    int* nan_flags;                    // with sum: [n_frames][n_levels], set to 1 when a value of that level is a NaN (zero-initialised)
     long long sum_frame;               // entries per frame
     long long sum_off[kMaxLevels];     // entry offset of level l inside a frame
     alignas(64) float ws[kRgb2StreamMax];
@@ -412,6 +413,7 @@ __global__ __launch_bounds__(64 * kRgb2Waves) __attribute__((amdgpu_waves_per_eu
     // selection tail looks only at the groups whose maximum reaches the level's threshold (silent_peaks.h, sparse_select_kernel).
     // A raw buffer store like all the others: out of range (dropped) on every step but a group's last.
     float mm_grp = kPoolLowest;
+    unsigned long long mm_nan = 0;   // lanes that have seen a NaN value (scalar registers)
     const int gpt = (R + kSumRows - 1) / kSumRows, nxp = (W + 1) >> 1;
     const unsigned sum_bytes = (MM && args.sum) ? (unsigned)(((H + R - 1) / R) * gpt) * (unsigned)nxp * 4u : 0u;
     const __amdgpu_buffer_rsrc_t r_sum = __builtin_amdgcn_make_buffer_rsrc(
@@ -593,6 +595,7 @@ __global__ __launch_bounds__(64 * kRgb2Waves) __attribute__((amdgpu_waves_per_eu
                 asm("v_max3_f32 %0, %1, %2, %3" : "=v"(mm_mx) : "v"(mm_mx), "v"(a), "v"(b));
                 asm("v_max3_f32 %0, %1, %2, %3" : "=v"(mm_nmn) : "v"(mm_nmn), "v"(na), "v"(nb));
                 asm("v_max3_f32 %0, %1, %2, %3" : "=v"(mm_grp) : "v"(mm_grp), "v"(a), "v"(b));
+                mm_nan |= __ballot((out0 && val.x != val.x) || (out1 && val.y != val.y));
             }
             if constexpr (MM) {
                 const int k = yout - y0;
@@ -617,6 +620,7 @@ __global__ __launch_bounds__(64 * kRgb2Waves) __attribute__((amdgpu_waves_per_eu
             unsigned* slot = args.mm + ((long long)tc.frame * tab.n_levels + tc.level) * 2;
             atomicMax(slot, f2ord(mx));
             atomicMax(slot + 1, f2ord(nmn));
+            if (mm_nan && args.nan_flags) args.nan_flags[tc.frame * tab.n_levels + tc.level] = 1;
         }
     }
 }

@@ -188,9 +188,10 @@ class LineEndPipeline(object):
 
     def sparse_tail_stats(self):
         """What the sparse keypoint tail of the last fused step did: dict(ran, pairs, dense_pairs, candidates)."""
-        st = (C.c_int64 * 4)()
+        st = (C.c_int64 * 5)()
         self.ctx.check(self._lib.silent_sparse_tail_stats(self.ctx.handle, st))
-        return {"ran": bool(st[0]), "pairs": int(st[1]), "dense_pairs": int(st[2]), "candidates": int(st[3])}
+        return {"ran": bool(st[0]), "pairs": int(st[1]), "dense_pairs": int(st[2]), "zero_map_pairs": int(st[4]),
+                "candidates": int(st[3])}
 
     def run_keypoints(self, stream=None):
         s = stream or self._stream()
