@@ -69,6 +69,31 @@ def structured_frame(seed, h, w, c, n_lines=200):
     return img
 
 
+def margin_frame(seed, h, w, c=3, n_weak=10, central=True):
+    """Black background, weak clutter (1-px segments, amplitude < 110) and a few strong oblique segments: frames on which
+    the keypoint decisions have room (tests/kp_margin.py).  central=True puts the strong segments into the central box that
+    belongs to all four search windows of max_value_indices_region at region = extent / 2."""
+    rng = np.random.default_rng(5000 + seed)
+    img = np.zeros((h, w, c), np.float32)
+
+    def seg(x0, y0, ang, length, col, width=1):
+        for t in range(int(length)):
+            x, y = int(round(x0 + t * np.cos(ang))), int(round(y0 + t * np.sin(ang)))
+            img[max(0, y):min(h, y + width), max(0, x):min(w, x + width)] = col
+
+    for _ in range(n_weak):
+        seg(rng.integers(0, w), rng.integers(0, h), rng.uniform(0, 2 * np.pi), rng.integers(8, 40),
+            rng.integers(30, 110, c).astype(np.float32))
+    for k in range(3):
+        L = rng.integers(max(h // 8, 12), max(h // 5, 16))
+        ang = rng.uniform(0.2, np.pi / 2 - 0.2) + rng.integers(0, 4) * np.pi / 2
+        col = ((255.0 - 40.0 * k) * rng.uniform(0.3, 1.0, c)).astype(np.float32)
+        col[rng.integers(0, c)] = 255.0 - 40.0 * k
+        lo, hi = (0.32, 0.68) if central else (0.05, 0.95)
+        seg(rng.uniform(lo, hi) * w, rng.uniform(lo, hi) * h, ang, L, col, int(rng.integers(1, 3)))
+    return img
+
+
 WORST_REL = {}   # what -> (worst element-wise relative error at the asserted floor, same at the 1e-3 floor)
 
 
