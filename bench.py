@@ -359,8 +359,8 @@ def dist_record(D, rank, local, ident, own_ms):
     out = {"backend": D.backend_name(), "world_size": len(recs), "distinct_devices": len({r["pci_bus_id"] for r in recs}),
            "ranks": recs}
     if dup:
-        if rank == 0:
-            print("bench.py: ranks share a GPU: %s" % ", ".join("ranks %d and %d on %s" % d for d in dup), file=sys.stderr)
+        # (every rank says so: the launcher shows the log of whichever rank exits first)
+        print("bench.py rank %d: ranks share a GPU: %s" % (rank, ", ".join("ranks %d and %d on %s" % d for d in dup)), file=sys.stderr)
         D.finalize()
         sys.exit(3)
     return out

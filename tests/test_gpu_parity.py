@@ -8,6 +8,8 @@ import math
 import numpy as np
 import pytest
 
+import err_bound as eb
+
 import silent_oracle as so
 import c_oracle as co
 from conftest import assert_close, assert_regulated_close, noise_frame, structured_frame
@@ -29,6 +31,16 @@ def f32(k):
     return np.asarray(k, np.float64).astype(np.float32)
 
 
+def assert_gray_level_close(got_pyr, got_cs, got_end, want_pyr, want_cs, want_end, cs_kernel, bank, tag):
+    """pyramid level, CS map and line-end maps of the gray pass against the oracle's: range-relative 1e-5 and, element by
+    element, the propagated rounding bound (tests/err_bound.py)."""
+    e_pyr = eb.zoom(want_pyr)
+    e_cs, e_end = eb.gray_chain(want_pyr, cs_kernel, bank, want_cs, e_pyr)
+    assert_close(got_pyr, want_pyr, RTOL, scale=255.0, what="pyramid " + tag, bound=e_pyr)
+    assert_close(got_cs, want_cs, RTOL, scale=255.0, what="cs " + tag, bound=e_cs)
+    assert_close(got_end, want_end, RTOL, scale=255.0, what="end " + tag, bound=e_end)
+
+
 # ----------------------------------------------------------------------------- convolution
 
 @pytest.mark.parametrize("name", ["rgc", "rgby", "stripe", "end", "blur"])
@@ -36,7 +48,7 @@ def f32(k):
 def test_conv2d_reference_kernels(rt, kernels, name, shape):
     x = np.random.default_rng(7).integers(0, 256, shape).astype(np.float32)
     got = rt.conv2d_same(x, kernels[name], relu=True)
-    assert_close(got, so.conv2d_same(x, kernels[name], relu=True), RTOL, what=name)
+    assert_close(got, so.conv2d_same(x, kernels[name], relu=True), RTOL, what=name, bound=eb.conv(x, kernels[name]))
 
 
 @pytest.mark.parametrize("gen", ["rgb_2d_edge_tensors", "rgb_2d_edge_tensors_time_diff", "rgb_2d_end_tensors"])
@@ -48,10 +60,10 @@ def test_conv2d_7x7_thick_edge_banks(rt, gen):
     assert k.shape == (7, 7, 3, 3)
     x = structured_frame(5, 61, 83, 3)[None]
     raw = so.conv2d_same(x, k)
-    assert_close(apply_filter(x, k), raw, RTOL, what=gen)
+    assert_close(apply_filter(x, k), raw, RTOL, what=gen, bound=eb.conv(x, k))
     # clipped outputs: the rounding noise of the 147-tap sums follows the magnitude of the UNCLIPPED responses
     assert_close(rt.conv2d_same(x, k, relu=True, clip_hi=255.0), so.conv2d_same(x, k, relu=True, clip_hi=255.0), RTOL,
-                 scale=float(np.abs(raw).max()), what=gen + " relu clip")
+                 scale=float(np.abs(raw).max()), what=gen + " relu clip", bound=eb.conv(x, k))
 
 
 @pytest.mark.parametrize("kshape", [(3, 3, 1, 1), (3, 3, 1, 3), (3, 3, 1, 4), (3, 3, 1, 8), (3, 3, 3, 1), (3, 3, 3, 4),
@@ -61,10 +73,10 @@ def test_conv2d_shapes_including_generic_path(rt, kshape):
     x = (rng.standard_normal((2, 23, 71, kshape[2])) * 40).astype(np.float32)
     k = rng.standard_normal(kshape)
     raw = so.conv2d_same(x, k)
-    assert_close(rt.conv2d_same(x, k), raw, RTOL, what=str(kshape))
+    assert_close(rt.conv2d_same(x, k), raw, RTOL, what=str(kshape), bound=eb.conv(x, k))
     # clipped at 30 while the Gaussian-weight sums reach hundreds: the rounding noise follows the unclipped magnitude
     assert_close(rt.conv2d_same(x, k, relu=True, clip_hi=30.0), so.conv2d_same(x, k, relu=True, clip_hi=30.0), RTOL,
-                 scale=float(np.abs(raw).max()), what=str(kshape) + " relu clip")
+                 scale=float(np.abs(raw).max()), what=str(kshape) + " relu clip", bound=eb.conv(x, k))
 
 
 def test_conv2d_known_answers(rt, kernels):
@@ -90,14 +102,17 @@ def test_filters_api_matches_reference_chain(rt, kernels):
     from pysilent_amd.util.apply_filter import apply_filter
     x = noise_frame(3, 48, 64, 3)[None]
     rgc = filters.rgc_filter(x)
-    assert_close(rgc, so.conv2d_same(x, kernels["rgc"], relu=True), RTOL, what="rgc_filter")
+    assert_close(rgc, so.conv2d_same(x, kernels["rgc"], relu=True), RTOL, what="rgc_filter", bound=eb.conv(x, kernels["rgc"]))
     rgby = filters.rgby_filter(rgc)
-    assert_close(rgby, so.conv2d_same(rgc, kernels["rgby"], relu=True), RTOL, what="rgby_filter")
+    assert_close(rgby, so.conv2d_same(rgc, kernels["rgby"], relu=True), RTOL, what="rgby_filter", bound=eb.conv(rgc, kernels["rgby"]))
     orient = filters.orientation_filter(rgby)
     want = so.regulate(so.conv2d_same(rgby, kernels["stripe"], relu=True), kernels["blur"], 1.0, 0.1)
-    assert_close(orient, want, RTOL, what="orientation_filter")
+    stripe = so.conv2d_same(rgby, kernels["stripe"], relu=True)
+    assert_close(orient, want, RTOL, what="orientation_filter",
+                 bound=eb.regulate(stripe, kernels["blur"], 1.0, 0.1, eb.conv(rgby, kernels["stripe"])))
     le = apply_filter(orient, kernels["end"], relu=True, clip_hi=255.0)
-    assert_close(le, so.conv2d_same(orient, kernels["end"], relu=True, clip_hi=255.0), RTOL, what="apply_filter")
+    assert_close(le, so.conv2d_same(orient, kernels["end"], relu=True, clip_hi=255.0), RTOL, what="apply_filter",
+                 bound=eb.conv(orient, kernels["end"]))
     assert rgc.dtype == np.float32 and rgc.shape == x.shape
 
 
@@ -161,10 +176,11 @@ def test_regulate(rt, kernels, policy):
     want = so.regulate(x, kernels["blur"], 1.0, 0.1, policy)
     got = rt.regulate(x, kernels["blur"], 1.0, 0.1, policy)
     assert np.isnan(want).any() == (policy == "ieee")
-    assert_close(got, want, RTOL, what="regulate " + policy)
+    assert_close(got, want, RTOL, what="regulate " + policy, bound=eb.regulate(x, kernels["blur"], 1.0, 0.1, None, policy))
     small = (x * np.float32(1e-3)).astype(np.float32)      # blur < 1: the pow branch is live
     assert_close(rt.regulate(small, kernels["blur"], 1.0, 0.5, policy),
-                 so.regulate(small, kernels["blur"], 1.0, 0.5, policy), RTOL, what="regulate small")
+                 so.regulate(small, kernels["blur"], 1.0, 0.5, policy), RTOL, what="regulate small",
+                 bound=eb.regulate(small, kernels["blur"], 1.0, 0.5, None, policy))
 
 
 def test_regulate_gray_blur(rt):
@@ -172,7 +188,8 @@ def test_regulate_gray_blur(rt):
     x = (noise_frame(6, 33, 47, 1)[None] / 255.0).astype(np.float32)
     for size in (3, 7, 5):
         b = blur_tensor(2, size, 1, 1)
-        assert_close(rt.regulate(x, b, 2.0, 0.5), so.regulate(x, b, 2.0, 0.5), RTOL, what="blur %d" % size)
+        assert_close(rt.regulate(x, b, 2.0, 0.5), so.regulate(x, b, 2.0, 0.5), RTOL, what="blur %d" % size,
+                     bound=eb.regulate(x, b, 2.0, 0.5))
 
 
 # ----------------------------------------------------------------------------- fused gray pass
@@ -192,11 +209,13 @@ def test_gray_line_end_fused(rt, kernels, K):
     for l, lev in enumerate(levels):
         want_cs = so.conv2d_same(lev, kernels["cs_gray"], relu=True)
         want_end = so.conv2d_same(want_cs, bank, relu=True, clip_hi=255.0)
-        assert_close(cs.level(l), want_cs, RTOL, what="cs level %d" % l)
+        e_cs, e_end = eb.gray_chain(lev, kernels["cs_gray"], bank, want_cs)
+        assert_close(cs.level(l), want_cs, RTOL, what="cs level %d" % l, bound=e_cs)
         # the second conv reads the GPU's own cs map: compare against the oracle applied to that map too
-        assert_close(end.level(l), so.conv2d_same(np.ascontiguousarray(cs.level(l)), bank, relu=True, clip_hi=255.0),
-                     RTOL, what="end|gpu-cs level %d" % l)
-        assert_close(end.level(l), want_end, RTOL, scale=255.0, what="end level %d" % l)
+        gcs = np.ascontiguousarray(cs.level(l))
+        assert_close(end.level(l), so.conv2d_same(gcs, bank, relu=True, clip_hi=255.0), RTOL, what="end|gpu-cs level %d" % l,
+                     bound=eb.conv(gcs, bank))
+        assert_close(end.level(l), want_end, RTOL, scale=255.0, what="end level %d" % l, bound=e_end)
 
 
 def test_gray_line_end_equals_two_convs(rt, kernels):
@@ -220,14 +239,14 @@ def test_config1_640x480_three_levels_center_surround(rt, kernels):
     want_pyr = so.classic_pyramid(frame, 2.0, 3)
     cs, _ = rt.gray_line_end(pyr, kernels["cs_gray"], kernels["end4"], want_end=False)
     for l in range(3):
-        assert_close(pyr.level(l), want_pyr[l], RTOL, what="pyramid level %d" % l)
+        assert_close(pyr.level(l), want_pyr[l], RTOL, what="pyramid level %d" % l, bound=eb.zoom(want_pyr[l]))
         assert_close(cs.level(l), so.conv2d_same(want_pyr[l], kernels["cs_gray"], relu=True), RTOL, scale=255.0,
-                     what="cs level %d" % l)
+                     what="cs level %d" % l, bound=eb.conv(want_pyr[l], kernels["cs_gray"], eb.zoom(want_pyr[l])))
     # the 3-channel kernel of the reference's own test on the frame replicated to 3 channels
     from pysilent_amd.constant_convolutions import center_surround_tensor
     k3 = center_surround_tensor(2, [0, 1, 0], [1, 0, 0], [0, 0, 1], [1, 0, 0])
     x3 = np.repeat(want_pyr[2], 3, axis=3)
-    assert_close(rt.conv2d_same(x3, k3, relu=True), so.conv2d_same(x3, k3, relu=True), RTOL, what="cs 3ch")
+    assert_close(rt.conv2d_same(x3, k3, relu=True), so.conv2d_same(x3, k3, relu=True), RTOL, what="cs 3ch", bound=eb.conv(x3, k3))
 
 
 # ----------------------------------------------------------------------------- pyramid
@@ -242,7 +261,7 @@ def test_from_image_reference_layout(rt, shape, center, scale):
     got = zoom.from_image(img, shape[2], center, scale)
     want = so.zoom_from_image(img, shape[2], center, scale)     # calls scipy.ndimage.zoom like the reference
     assert got.shape == want.shape and got.dtype == np.float32
-    assert_close(got, want, RTOL, scale=255.0, what="from_image")
+    assert_close(got, want, RTOL, scale=255.0, what="from_image", bound=eb.zoom(want))
 
 
 def test_from_image_against_the_reference_wrappers_own_outputs(rt, golden_pyramid):
@@ -257,7 +276,7 @@ def test_from_image_against_the_reference_wrappers_own_outputs(rt, golden_pyrami
         center, scale = [int(par[0]), int(par[1])], float(par[2])
         got = zoom.from_image(img, img.shape[2], center, scale)
         assert got.shape == want.shape and got.dtype == np.float32, name
-        assert_close(got, want.astype(np.float32), RTOL, scale=255.0, what="from_image vs reference " + name)
+        assert_close(got, want.astype(np.float32), RTOL, scale=255.0, what="from_image vs reference " + name, bound=eb.zoom(want))
 
 
 @pytest.mark.parametrize("shape,scale,n", [((135, 240, 1), 2.0, 5), ((135, 240, 3), 2.0, 4), ((270, 480, 1), math.e ** .5, 6),
@@ -269,7 +288,7 @@ def test_classic_pyramid(rt, shape, scale, n):
     for f in range(2):
         want = so.classic_pyramid(frames[f], scale, n)
         for l in range(n):
-            assert_close(got.level(l)[f:f + 1], want[l], RTOL, scale=255.0, what="frame %d level %d" % (f, l))
+            assert_close(got.level(l)[f:f + 1], want[l], RTOL, scale=255.0, what="frame %d level %d" % (f, l), bound=eb.zoom(want[l]))
 
 
 @pytest.mark.parametrize("shape,scale,n", [((135, 240, 3), 2.0, 4), ((97, 131, 1), 1.7, 4), ((64, 64, 3), 2.0, 3), ((65, 129, 3), 2.0, 2),
@@ -288,7 +307,7 @@ def test_pyramid_single_read_kernel_equals_unit_plus_region(rt, shape, scale, n)
     np.testing.assert_array_equal(got.data, two.data)
     want = so.classic_pyramid(frames[2], scale, n)
     for l in range(n):
-        assert_close(got.level(l)[2:3], want[l], RTOL, scale=255.0, what="level %d" % l)
+        assert_close(got.level(l)[2:3], want[l], RTOL, scale=255.0, what="level %d" % l, bound=eb.zoom(want[l]))
 
 
 def test_pyramid_known_answers(rt):
@@ -560,15 +579,16 @@ def test_rgb_chain(rt, kernels, policy, frame):
     got = rt.rgb_line_end(x, kernels, flat_policy=policy)
     if frame == "noise":
         assert not np.isnan(want["line_end"]).any()            # SURVEY hard part 3: noise frames stay finite
-    assert_close(got["orient"], want["orient"], RTOL, what="orient")
+    bound = eb.rgb_chain(x, kernels, want, policy)
+    assert_close(got["orient"], want["orient"], RTOL, what="orient", bound=bound["orient"])
     # later stages: compare against the oracle continued from the GPU's own orient (isolates each stage) ...
-    le = so.pad_inwards(so.conv2d_same(np.ascontiguousarray(got["orient"]), kernels["end"], relu=True, clip_hi=255.0),
-                        [[0, 0], [2, 2], [2, 2], [0, 0]])
-    assert_close(got["line_end"], le, RTOL, what="line_end|gpu-orient")
+    g_orient = np.ascontiguousarray(got["orient"])
+    le = so.pad_inwards(so.conv2d_same(g_orient, kernels["end"], relu=True, clip_hi=255.0), [[0, 0], [2, 2], [2, 2], [0, 0]])
+    assert_close(got["line_end"], le, RTOL, what="line_end|gpu-orient", bound=eb.pad(eb.conv(g_orient, kernels["end"]), 2))
     np.testing.assert_array_equal(got["value"], so.value_from_color(np.ascontiguousarray(got["line_end"])))
     # ... and end to end
-    assert_close(got["line_end"], want["padded"], RTOL, scale=255.0, what="line_end")
-    assert_close(got["value"], want["value"], RTOL, scale=255.0, what="value")
+    assert_close(got["line_end"], want["padded"], RTOL, scale=255.0, what="line_end", bound=bound["padded"])
+    assert_close(got["value"], want["value"], RTOL, scale=255.0, what="value", bound=bound["value"])
 
 
 def test_rgb_chain_structured_and_dense_kernels_agree(rt, kernels):
@@ -594,8 +614,10 @@ def test_rgb_chain_structured_and_dense_kernels_agree(rt, kernels):
         assert_close(mid[name], dense[name], 2e-6, scale=255.0, what=name + " basic vs dense", rel_floor=None)
         assert not np.array_equal(fast[name], dense[name]) or name == "value"      # really different code paths
     want = so.rgb_line_end_chain(frames, kernels)
-    assert_close(fast["line_end"], want["padded"], RTOL, scale=255.0, what="line_end vs oracle")
-    assert_close(fast["orient"], want["orient"], RTOL, what="orient vs oracle")
+    bound = eb.rgb_chain(frames, kernels, want)
+    assert_close(fast["line_end"], want["padded"], RTOL, scale=255.0, what="line_end vs oracle", bound=bound["padded"])
+    assert_close(fast["orient"], want["orient"], RTOL, what="orient vs oracle", bound=bound["orient"])
+    assert_close(dense["line_end"], want["padded"], RTOL, scale=255.0, what="dense line_end vs oracle", bound=bound["padded"])
 
 
 @pytest.mark.parametrize("shape", [(2, 70, 131, 3), (1, 33, 448, 3), (1, 211, 449, 3), (3, 19, 5, 3), (1, 1, 1, 3),
@@ -652,8 +674,9 @@ def test_rgb_chain_regulation_roots(rt, kernels, root):
     frames = structured_frame(12, 64, 90, 3)[None]
     got = rt.rgb_line_end(frames, kernels, regulation_root=root, flat_policy="zero")
     want = so.rgb_line_end_chain(frames, kernels, flat_policy="zero", blur_root=root)
-    assert_close(got["orient"], want["orient"], RTOL, what="orient root %g" % root)
-    assert_close(got["line_end"], want["padded"], RTOL, scale=255.0, what="line_end root %g" % root)
+    bound = eb.rgb_chain(frames, kernels, want, "zero", blur_root=root)
+    assert_close(got["orient"], want["orient"], RTOL, what="orient root %g" % root, bound=bound["orient"])
+    assert_close(got["line_end"], want["padded"], RTOL, scale=255.0, what="line_end root %g" % root, bound=bound["padded"])
 
 
 def test_rgb_chain_on_packed_levels_and_keypoints(rt, kernels):
@@ -669,7 +692,8 @@ def test_rgb_chain_on_packed_levels_and_keypoints(rt, kernels):
         for l, lev in enumerate(levels):
             v = np.ascontiguousarray(got["value"].level(l)[f:f + 1])
             want = so.rgb_line_end_chain(lev[f:f + 1], kernels)
-            assert_close(got["line_end"].level(l)[f:f + 1], want["padded"], RTOL, scale=255.0, what="level %d" % l)
+            assert_close(got["line_end"].level(l)[f:f + 1], want["padded"], RTOL, scale=255.0, what="level %d" % l,
+                         bound=eb.rgb_chain(lev[f:f + 1], kernels, want)["padded"])
             r = so.max_value_indices_region(None, (1,) + regions[l] + (3,), v)
             r[:, 0] = l
             rows.append(r)
@@ -922,9 +946,7 @@ def test_gray_pass_equals_pyramid_then_filters(rt, kernels, shape, scale, n, K):
     np.testing.assert_array_equal(end.data, end2.data)
     want = so.classic_pyramid(frames[1], scale, n)
     for l, (wcs, wend) in enumerate(so.gray_line_end_pass(want, kernels["cs_gray"], bank)):
-        assert_close(pyr.level(l)[1:2], want[l], RTOL, scale=255.0, what="pyr %d" % l)
-        assert_close(cs.level(l)[1:2], wcs, RTOL, scale=255.0, what="cs %d" % l)
-        assert_close(end.level(l)[1:2], wend, RTOL, scale=255.0, what="end %d" % l)
+        assert_gray_level_close(pyr.level(l)[1:2], cs.level(l)[1:2], end.level(l)[1:2], want[l], wcs, wend, kernels["cs_gray"], bank, "%d" % l)
 
 
 def test_gray_pass_reference_layout_and_device_path(rt, kernels):
@@ -939,11 +961,10 @@ def test_gray_pass_reference_layout_and_device_path(rt, kernels):
     pyr, cs, end = plan.gray_pass(img[None], kernels["cs_gray"], kernels["end4"])
     want = so.zoom_from_image(img, 1, (80, 60), math.e ** .5)
     got = pyr.data.reshape(want.shape)
-    assert_close(got, want, RTOL, scale=255.0, what="pyramid")
     wcs = so.conv2d_same(want, kernels["cs_gray"], relu=True)
-    assert_close(cs.data.reshape(wcs.shape), wcs, RTOL, scale=255.0, what="cs")
     wend = so.conv2d_same(wcs, kernels["end4"], relu=True, clip_hi=255.0)
-    assert_close(end.data.reshape(wend.shape), wend, RTOL, scale=255.0, what="end")
+    assert_gray_level_close(got, cs.data.reshape(wcs.shape), end.data.reshape(wend.shape), want, wcs, wend, kernels["cs_gray"],
+                            kernels["end4"], "reference layout")
     dp, dc, de = plan.gray_pass(torch.from_numpy(img[None]).cuda(), kernels["cs_gray"], kernels["end4"])
     np.testing.assert_array_equal(dp.data.cpu().numpy(), pyr.data)
     np.testing.assert_array_equal(dc.data.cpu().numpy(), cs.data)
@@ -965,9 +986,8 @@ def test_gray_pass_tiny_and_tile_boundary_frames(rt, kernels, shape, n):
         np.testing.assert_array_equal(a.data, b.data)
     want = so.classic_pyramid(frames[2], 2.0, n)
     for l, (wcs, wend) in enumerate(so.gray_line_end_pass(want, kernels["cs_gray"], kernels["end4"])):
-        assert_close(pyr.level(l)[2:3], want[l], RTOL, scale=255.0, what="pyr %d" % l)
-        assert_close(cs.level(l)[2:3], wcs, RTOL, scale=255.0, what="cs %d" % l)
-        assert_close(end.level(l)[2:3], wend, RTOL, scale=255.0, what="end %d" % l)
+        assert_gray_level_close(pyr.level(l)[2:3], cs.level(l)[2:3], end.level(l)[2:3], want[l], wcs, wend, kernels["cs_gray"],
+                                kernels["end4"], "tiny %d" % l)
 
 
 def test_gray_pass_nan_and_inf_propagate_like_the_oracle(rt, kernels):
@@ -1009,8 +1029,9 @@ def test_gray_pass_nan_and_inf_propagate_like_the_oracle(rt, kernels):
     for l, lev in enumerate(levels):
         wcs = so.conv2d_same(lev, kernels["cs_gray"], relu=True)
         wend = so.conv2d_same(wcs, kernels["end4"], relu=True, clip_hi=255.0)
-        assert_close(cs.level(l), wcs, RTOL, scale=255.0, what="cs %d" % l)          # NaN pattern checked inside
-        assert_close(end.level(l), wend, RTOL, scale=255.0, what="end %d" % l)
+        e_cs, e_end = eb.gray_chain(lev, kernels["cs_gray"], kernels["end4"], wcs)
+        assert_close(cs.level(l), wcs, RTOL, scale=255.0, what="cs %d" % l, bound=e_cs)          # NaN pattern checked inside
+        assert_close(end.level(l), wend, RTOL, scale=255.0, what="end %d" % l, bound=e_end)
     assert np.isnan(end.level(0)).any() and np.nanmax(end.level(1)) <= 255.0
 
 
@@ -1023,10 +1044,8 @@ def test_config5_4k_8_levels_8_orientations_against_c_oracle(rt, kernels):
     pyr, cs, end = plan.gray_pass(frame[None], kernels["cs_gray"], kernels["end8"])
     want_pyr = co.classic_pyramid(frame, plan.extents)
     for l in range(8):
-        assert_close(pyr.level(l), want_pyr[l], RTOL, scale=255.0, what="pyramid %d" % l)
         wcs, wend = co.gray_line_end_level(want_pyr[l], kernels["cs_gray"], kernels["end8"])
-        assert_close(cs.level(l), wcs, RTOL, scale=255.0, what="cs %d" % l)
-        assert_close(end.level(l), wend, RTOL, scale=255.0, what="end %d" % l)
+        assert_gray_level_close(pyr.level(l), cs.level(l), end.level(l), want_pyr[l], wcs, wend, kernels["cs_gray"], kernels["end8"], "%d" % l)
 
 
 def test_config3_1080p_rgb_full_size_against_c_oracle(rt, kernels):
@@ -1045,14 +1064,16 @@ def test_config3_1080p_rgb_full_size_against_c_oracle(rt, kernels):
     want_pyr = co.classic_pyramid(frame, pipe.extents)
     rows = []
     for l, (h, w) in enumerate(pipe.extents):
-        assert_close(host("pyramid", l), want_pyr[l], RTOL, scale=255.0, what="pyramid %d" % l)
+        assert_close(host("pyramid", l), want_pyr[l], RTOL, scale=255.0, what="pyramid %d" % l, bound=eb.zoom(want_pyr[l]))
+        chain = {}
         x = want_pyr[l]
         for name in ("rgc", "rgby", "stripe"):
-            x = co.conv2d_same(x, kernels[name], relu=True)
-        orient = co.regulate(x, kernels["blur"], 1.0, 0.1)
-        line = co.pad_inwards(co.conv2d_same(orient, kernels["end"], relu=True, clip_hi=255.0), [[0, 0], [2, 2], [2, 2], [0, 0]])
-        assert_close(host("orient", l), orient, RTOL, what="orient %d" % l)
-        assert_close(host("line_end", l), line, RTOL, scale=255.0, what="line_end %d" % l)
+            x = chain[name] = co.conv2d_same(x, kernels[name], relu=True)
+        orient = chain["orient"] = co.regulate(x, kernels["blur"], 1.0, 0.1)
+        line = chain["padded"] = co.pad_inwards(co.conv2d_same(orient, kernels["end"], relu=True, clip_hi=255.0), [[0, 0], [2, 2], [2, 2], [0, 0]])
+        bound = eb.rgb_chain(want_pyr[l], kernels, chain, e_x=eb.zoom(want_pyr[l]))
+        assert_close(host("orient", l), orient, RTOL, what="orient %d" % l, bound=bound["orient"])
+        assert_close(host("line_end", l), line, RTOL, scale=255.0, what="line_end %d" % l, bound=bound["padded"])
         g_line, g_val = host("line_end", l), host("value", l)
         np.testing.assert_array_equal(g_val, co.value_from_color(g_line))
         top = co.top_value_points(g_line, 0.1, g_val)
@@ -1084,10 +1105,8 @@ def test_config2_1080p_full_size_against_c_oracle(rt, kernels):
         np.testing.assert_array_equal(a.data, b.data)          # the bench path (silent_gray_pass) == two-step path
     want_pyr = co.classic_pyramid(frame, pyr.extents)
     for l in range(5):
-        assert_close(pyr.level(l), want_pyr[l], RTOL, scale=255.0, what="pyramid %d" % l)
         wcs, wend = co.gray_line_end_level(want_pyr[l], kernels["cs_gray"], kernels["end4"])
-        assert_close(cs.level(l), wcs, RTOL, scale=255.0, what="cs %d" % l)
-        assert_close(end.level(l), wend, RTOL, scale=255.0, what="end %d" % l)
+        assert_gray_level_close(pyr.level(l), cs.level(l), end.level(l), want_pyr[l], wcs, wend, kernels["cs_gray"], kernels["end4"], "%d" % l)
     # size-independent properties: linearity of the pyramid, and ReLU/clip range of the responses
     pyr2 = classic_pyramid(frame * np.float32(0.5), 2.0, 5)
     np.testing.assert_allclose(pyr2.data, pyr.data * np.float32(0.5), rtol=1e-6, atol=1e-4)
@@ -1121,10 +1140,10 @@ def test_config4_per_rank_share_64_frames_against_c_oracle(rt, kernels):
     for j, frame in host_frames.items():
         want_pyr = co.classic_pyramid(frame, pipe.extents)
         for l in range(5):
-            assert_close(out["pyramid"].level(l)[j].cpu().numpy(), want_pyr[l][0], RTOL, scale=255.0, what="pyramid f%d l%d" % (j, l))
             wcs, wend = co.gray_line_end_level(want_pyr[l], kernels["cs_gray"], kernels["end4"])
-            assert_close(out["cs"].level(l)[j].cpu().numpy(), wcs[0], RTOL, scale=255.0, what="cs f%d l%d" % (j, l))
-            assert_close(out["end"].level(l)[j].cpu().numpy(), wend[0], RTOL, scale=255.0, what="end f%d l%d" % (j, l))
+            host = lambda name: out[name].level(l)[j:j + 1].cpu().numpy()
+            assert_gray_level_close(host("pyramid"), host("cs"), host("end"), want_pyr[l], wcs, wend, kernels["cs_gray"],
+                                    kernels["end4"], "f%d l%d" % (j, l))
     # every frame of the batch equals that frame run alone (batch position must not matter): compare per-frame sums
     solo = LineEndPipeline((1080, 1920), mode="gray", n_levels=5, n_orient=4, batch=1)
     for j in (1, 2, 30, 62):
@@ -1388,7 +1407,8 @@ def test_rgb_chain_on_plateau_frames_under_ieee_by_the_three_zone_rule(rt, kerne
     assert np.isnan(want["orient"]).sum() > 1000                 # the black region really produces the 0 * inf case
     le = so.pad_inwards(so.conv2d_same(np.ascontiguousarray(got["orient"]), ks["end"], relu=True, clip_hi=255.0),
                         [[0, 0], [2, 2], [2, 2], [0, 0]])
-    assert_close(got["line_end"], le, RTOL, scale=255.0, what="plateau line_end from the GPU's orient")
+    assert_close(got["line_end"], le, RTOL, scale=255.0, what="plateau line_end from the GPU's orient",
+                 bound=eb.pad(eb.conv(np.ascontiguousarray(got["orient"]), ks["end"]), 2))
     np.testing.assert_array_equal(got["value"], so.value_from_color(np.ascontiguousarray(got["line_end"])))
     print("plateau frames: %d residue-band values, NaN-or-residue differs from the oracle at %d of them" % (n_resid, n_flip))
 
@@ -1466,7 +1486,7 @@ def test_rgb_pyramid_walk_is_bit_identical_to_unit_plus_region_kernels(rt, shape
     want = so.classic_pyramid(clean, scale, n)
     res = plan.run(clean[None])
     for l in range(n):
-        assert_close(res.level(l), want[l], RTOL, scale=255.0, what="rgb walk level %d" % l)
+        assert_close(res.level(l), want[l], RTOL, scale=255.0, what="rgb walk level %d" % l, bound=eb.zoom(want[l]))
 
 
 # ----------------------------------------------------------------------------- one-pixel-per-lane strip walk (silent_walk1.h)

@@ -386,3 +386,72 @@ def test_rgb_chain_composition_against_torch(kernels, policy):
         assert np.abs(g[ok] - w[ok]).max() <= 2e-5 * scale, name
     if policy == "ieee":
         assert np.isnan(want["orient"]).any()       # the line drawing has flat regions: the policy was exercised
+
+
+@pytest.mark.parametrize("policy", ["ieee", "zero"])
+def test_rounding_bounds_hold_for_an_independent_float32_evaluation(kernels, policy):
+    """tests/err_bound.py (the element-wise rule of conftest.assert_close): torch's float32 convolutions are a float32
+    evaluation of the reference graph in ANOTHER order than the HIP kernels' -- every element of every map must sit inside
+    the propagated rounding bound (taps + 4) * 2^-24 * sum |w||x| around the oracle, and the bound must not be vacuous:
+    finite on nearly all elements, and on most of them a small multiple of 2^-24 of the largest intermediate response (the
+    unclipped stripe / orientation responses of a noise frame reach thousands: that, not the clipped 0..255 result, is the
+    scale of the terms that cancel in the line-end bank)."""
+    torch = pytest.importorskip("torch")
+    import err_bound as eb
+    F = torch.nn.functional
+    x = np.stack([noise_frame(13, 40, 56, 3), structured_frame(14, 40, 56, 3, 12)])
+    want = so.rgb_line_end_chain(x, kernels, flat_policy=policy)
+    bound = eb.rgb_chain(x, kernels, want, flat_policy=policy)
+
+    def conv(t, k):
+        kt = torch.from_numpy(np.asarray(k, np.float64).astype(np.float32)).permute(3, 2, 0, 1)
+        p = (kt.shape[-1] - 1) // 2
+        return F.conv2d(F.pad(t, (p, p, p, p)), kt)
+
+    t = torch.from_numpy(x).permute(0, 3, 1, 2)
+    got = {}
+    got["rgc"] = torch.relu(conv(t, kernels["rgc"]))
+    got["rgby"] = torch.relu(conv(got["rgc"], kernels["rgby"]))
+    got["stripe"] = torch.relu(conv(got["rgby"], kernels["stripe"]))
+    blur = conv(got["stripe"], kernels["blur"])
+    orient = got["stripe"] * (1.0 / torch.pow(torch.clamp(blur, max=1.0), 0.1))
+    if policy == "zero":
+        orient = torch.where(got["stripe"] == 0, torch.zeros_like(orient), orient)
+    got["orient"] = orient
+    got["line_end"] = torch.clamp(torch.relu(conv(orient, kernels["end"])), max=255.0)
+    mask = torch.zeros_like(got["line_end"])
+    mask[:, :, 2:-2, 2:-2] = 1.0
+    got["padded"] = got["line_end"] * mask
+    got["value"] = got["padded"].sum(1, keepdim=True) * np.float32(1.0 / 3.0)
+    for name in ("rgc", "rgby", "stripe", "orient", "line_end", "padded", "value"):
+        g = got[name].permute(0, 2, 3, 1).numpy().astype(np.float64)
+        w, e = want[name].astype(np.float64), bound[name]
+        ok = np.isfinite(g) & np.isfinite(w) & ~eb.unbounded(e)
+        assert (np.abs(g - w)[ok] <= e[ok] + 1e-38).all(), (name, float((np.abs(g - w)[ok] / np.maximum(e[ok], 1e-300)).max()))
+        assert ok.mean() > (0.5 if policy == "ieee" and name != "rgc" and name != "rgby" and name != "stripe" else 0.97), (name, ok.mean())
+        terms = max(float(np.abs(v[np.isfinite(v)]).max()) for v in want.values())
+        assert np.median(e[ok]) < 400 * 2.0 ** -24 * terms, (name, float(np.median(e[ok])), terms)
+
+
+def test_rounding_bound_of_a_single_convolution_and_of_the_gray_chain(kernels):
+    """The bound for one cancelling stencil: float32 accumulation (torch) against the oracle, and the two-stage gray chain."""
+    torch = pytest.importorskip("torch")
+    import err_bound as eb
+    F = torch.nn.functional
+    x = noise_frame(15, 37, 53, 1)[None]
+    cs, end = so.gray_line_end_pass([x], kernels["cs_gray"], kernels["end4"])[0]
+    e_cs, e_end = eb.gray_chain(x, kernels["cs_gray"], kernels["end4"], cs)
+
+    def conv(t, k):
+        kt = torch.from_numpy(np.asarray(k, np.float64).astype(np.float32)).permute(3, 2, 0, 1)
+        return F.conv2d(F.pad(t, (1, 1, 1, 1)), kt)
+
+    t = torch.from_numpy(x).permute(0, 3, 1, 2)
+    g_cs = torch.relu(conv(t, kernels["cs_gray"]))
+    g_end = torch.clamp(torch.relu(conv(g_cs, kernels["end4"])), max=255.0)
+    for g, w, e in ((g_cs, cs, e_cs), (g_end, end, e_end)):
+        d = np.abs(g.permute(0, 2, 3, 1).numpy().astype(np.float64) - w)
+        assert (d <= e + 1e-38).all() and e.max() < 2e-3 and np.median(e) < 1e-3      # (1e-5 * 255 = 2.5e-3)
+    # the pyramid's bound is a few ulps of the level itself
+    lev = so.classic_pyramid(x[0], 2.0, 2)[1]
+    assert np.all(eb.zoom(lev) <= 16 * 2.0 ** -24 * np.abs(lev) + 1e-11)
