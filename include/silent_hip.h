@@ -175,11 +175,11 @@ int silent_profile_elapsed_ms(silent_ctx* ctx, float* ms, int64_t* pixels);
 /* Kernel-selection knobs for tests and A/B timing (no reference counterpart: the reference has one code path).
  * Every context starts from the environment variables SILENT_GRAY_OPTS / SILENT_RGB_OPTS / SILENT_PYRAMID_OPTS, read
  * once in silent_create; silent_set_tuning changes a knob of one context afterwards.  Bits -- GRAY: 1 XCD-aware tile
- * order, 2 32-row filter tiles, 8 32-row fused tiles, 16 no single-read stream kernel, 32 XCD order in the stream
- * kernel, 128 strip-walk kernel for the unit level (256 / 512: its store policy / pyramid source); RGB: 1 dense weights, 2 no two-group form, 8 no short tiles,
- * 16 the one-pixel-per-lane chain kernel (default: two pixels per lane on packed f32, same bits), 32 no sparse keypoint tail, bits 8-15 tile height / 2; GRAY bit 18: one-pixel strip walk; PYRAMID: 1 no
- * single-read pyramid (gray stream kernel, RGB strip walk), 2 no RGB strip walk.  All variants give the same results (bit-identical, or within the re-association tolerance
- * for the RGB forms); the defaults are the fastest measured. */
+ * order, 2 32-row filter tiles, 8 32-row fused tiles, 16 no single-read stream kernel, 32 XCD order in the stream kernel;
+ * RGB: 1 dense weights, 2 no two-group form, 8 no short tiles, 16 the one-pixel-per-lane chain kernel (default: two pixels
+ * per lane on packed f32, same bits), 32 no sparse keypoint tail, bits 8-15 tile height / 2; PYRAMID: 1 no single-read pyramid
+ * (gray stream kernel, RGB strip walk), 2 no RGB strip walk.  All variants give the same results (bit-identical, or within
+ * the re-association tolerance for the RGB forms); the defaults are the fastest measured. */
 #define SILENT_TUNE_GRAY 0
 #define SILENT_TUNE_RGB 1
 #define SILENT_TUNE_PYRAMID 2
@@ -333,6 +333,25 @@ int silent_affine_clip(silent_ctx* ctx, const float* in, size_t n_values, const 
                        float* out);
 int silent_affine_clip_dev(silent_ctx* ctx, const float* in, size_t n_values, const silent_affine_params* params,
                            float* out, silent_stream stream);
+
+/* np.asarray(frame, dtype=np.float32) (slam_recognition/recognition_testing.py:141: the camera's uint8 frame becomes the
+ * float32 tensor the pyramid takes) and the colour-plane slicing of image_to_zoom_tensor (util/zoom/from_image.py:54-64,
+ * one scipy zoom per plane) as ONE strided cast on the device:
+ *     out[p * out_stride + out_offset + k] = (float)in[p * in_stride + in_offset + k]      p < n_pixels, k < count
+ * (strides / offsets in ELEMENTS).  in_dtype: SILENT_DT_*.  Widening (strides = count = channels), cutting plane c out of
+ * an interleaved image (in_stride = C, in_offset = c, count = 1, out_stride = 1) and interleaving planes back are all
+ * instances.  in and out must not overlap. */
+#define SILENT_DT_U8 0
+#define SILENT_DT_F32 1
+#define SILENT_DT_F64 2
+#define SILENT_DT_I32 3
+#define SILENT_DT_U16 4
+#define SILENT_DT_I16 5
+#define SILENT_DT_I64 6
+int silent_cast_interleave(silent_ctx* ctx, const void* in, int in_dtype, size_t n_pixels, int in_stride, int in_offset,
+                           int count, float* out, int out_stride, int out_offset);
+int silent_cast_interleave_dev(silent_ctx* ctx, const void* in, int in_dtype, size_t n_pixels, int in_stride, int in_offset,
+                               int count, float* out, int out_stride, int out_offset, silent_stream stream);
 
 /* tf.image.resize_nearest_neighbor with the TF1 defaults (align_corners = False), recognition_testing.py:82-83
  * and util/centroids.py:41: out(y, x) = in(min(floor(y * float32(in_h / out_h)), in_h - 1), ...).

@@ -29,6 +29,7 @@ RECOVERY_CONSTANT = 1
 RECOVERY_INPUT = 2
 MAX_LEVELS = 16
 TUNE_GRAY, TUNE_RGB, TUNE_PYRAMID = 0, 1, 2
+DT_U8, DT_F32, DT_F64, DT_I32, DT_U16, DT_I16, DT_I64 = 0, 1, 2, 3, 4, 5, 6
 ABI_VERSION = 1
 
 
@@ -122,6 +123,8 @@ _SIGNATURES = {
     "silent_boosting_step_dev": [_vp, _fp, _ep, _i, _i, C.POINTER(BoostingParams), _fp, _fp, _fp, _vp],
     "silent_affine_clip": [_vp, _fp, _sz, C.POINTER(AffineParams), _fp],
     "silent_affine_clip_dev": [_vp, _fp, _sz, C.POINTER(AffineParams), _fp, _vp],
+    "silent_cast_interleave": [_vp, _vp, _i, _sz, _i, _i, _i, _fp, _i, _i],
+    "silent_cast_interleave_dev": [_vp, _vp, _i, _sz, _i, _i, _i, _fp, _i, _i, _vp],
     "silent_resize_nearest": [_vp, _fp, _ep, _i, _i, _i, _ep, _fp],
     "silent_resize_nearest_dev": [_vp, _fp, _ep, _i, _i, _i, _ep, _fp, _vp],
     "silent_rgb_chain_structure": [C.POINTER(RgbChainParams), C.POINTER(C.c_uint), C.POINTER(C.c_uint)],

@@ -131,6 +131,44 @@ def is_torch_tensor(x):
     return type(x).__module__.split(".")[0] == "torch" and hasattr(x, "data_ptr")
 
 
+def _torch_dtype_code(t):
+    import torch
+    table = {torch.uint8: _lib.DT_U8, torch.float32: _lib.DT_F32, torch.float64: _lib.DT_F64, torch.int32: _lib.DT_I32,
+             torch.int16: _lib.DT_I16, torch.int64: _lib.DT_I64}
+    if hasattr(torch, "uint16"):
+        table[torch.uint16] = _lib.DT_U16
+    if t.dtype not in table:
+        raise TypeError("unsupported tensor dtype %s (uint8, int16, int32, int64, float32, float64)" % t.dtype)
+    return table[t.dtype]
+
+
+def cast_interleave(src, out, in_stride, in_offset, count, out_stride, out_offset, n_pixels):
+    """out[p * out_stride + out_offset + k] = float32(src[p * in_stride + in_offset + k]) on the GPU (silent_cast_interleave_dev,
+    torch's current stream): dtype widening, cutting a colour plane out of an interleaved image, interleaving planes."""
+    import torch
+    ctx = get_context(src.device.index or 0)
+    stream = C.c_void_p(torch.cuda.current_stream(src.device).cuda_stream)
+    ctx.check(_lib.load().silent_cast_interleave_dev(ctx.handle, C.c_void_p(src.data_ptr()), _torch_dtype_code(src), int(n_pixels),
+                                                    int(in_stride), int(in_offset), int(count), C.c_void_p(out.data_ptr()),
+                                                    int(out_stride), int(out_offset), stream))
+    return out
+
+
+def as_float32(t):
+    """A contiguous float32 GPU tensor with the values of ``t`` (np.asarray(frame, dtype=float32) of
+    recognition_testing.py:141 for device tensors).  float32 contiguous tensors pass through; any other dtype is widened
+    by the library's own cast kernel (no torch kernel on the path)."""
+    import torch
+    if t.dtype == torch.float32 and t.is_contiguous():
+        return t
+    if not t.is_contiguous():
+        raise ValueError("GPU tensors must be contiguous (NHWC, C innermost)")
+    out = torch.empty(t.shape, dtype=torch.float32, device=t.device)
+    if t.numel():
+        cast_interleave(t, out, 1, 0, 1, 1, 0, t.numel())
+    return out
+
+
 class PackedPyramid(object):
     """A batch of pyramids with per-level extents, packed as the C ABI wants it.
 
@@ -213,7 +251,7 @@ class _Operand(object):
             import torch
             if not buf.is_cuda:
                 raise TypeError("torch tensors must live on the GPU (use a numpy array for host data)")
-            buf = buf.to(torch.float32).contiguous()
+            buf = as_float32(buf)
             self.device = buf.device.index or 0
             self.stream = C.c_void_p(torch.cuda.current_stream(buf.device).cuda_stream)
             self.ptr = C.c_void_p(buf.data_ptr())
@@ -576,7 +614,7 @@ class PyramidPlan(object):
             import torch
             if tuple(frames.shape[1:]) != (h, w, c):
                 raise ValueError("frames must be [n, %d, %d, %d]" % (h, w, c))
-            f = frames.to(torch.float32).contiguous()
+            f = as_float32(frames)
             n = int(f.shape[0])
             out = torch.empty(n * self.frame_px * c, dtype=torch.float32, device=f.device)
             stream = C.c_void_p(torch.cuda.current_stream(f.device).cuda_stream)
@@ -615,7 +653,7 @@ class PyramidPlan(object):
             import torch
             if tuple(frames.shape[1:]) != (h, w, c):
                 raise ValueError("frames must be [n, %d, %d, 1]" % (h, w))
-            f = frames.to(torch.float32).contiguous()
+            f = as_float32(frames)
             n = int(f.shape[0])
             mk = lambda ch: torch.empty(n * self.frame_px * ch, dtype=torch.float32, device=f.device)
             pyr, cso, endo = mk(1), mk(1), mk(K)

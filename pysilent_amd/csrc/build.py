@@ -11,7 +11,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 PKG = os.path.dirname(HERE)
 OUT = os.path.join(PKG, "lib", "libsilent_hip.so")
 SOURCES = ["silent_api.hip"]
-DEPS = SOURCES + ["silent_common.h", "silent_conv.h", "silent_peaks.h", "silent_pyramid.h", "silent_rgb.h", "silent_rgb2.h", "silent_walk.h", "silent_walk_rgb.h", "silent_walk1.h",
+DEPS = SOURCES + ["silent_common.h", "silent_conv.h", "silent_peaks.h", "silent_pyramid.h", "silent_rgb.h", "silent_rgb2.h", "silent_walk_rgb.h",
                   os.path.join("..", "..", "include", "silent_hip.h")]
 
 

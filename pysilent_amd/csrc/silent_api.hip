@@ -17,9 +17,7 @@
 #include "silent_pyramid.h"
 #include "silent_rgb.h"
 #include "silent_rgb2.h"
-#include "silent_walk.h"
 #include "silent_walk_rgb.h"
-#include "silent_walk1.h"
 
 using namespace silent;
 
@@ -94,16 +92,12 @@ struct silent_pyramid_plan {
     void* stream_tables = nullptr;
     StreamTab stream{};
     int stream_unit_level = -1;
-    // in-walk pyramid of gray_walk_kernel (silent_walk.h): row program over the whole crop + column records per
-    // 120-column wave tile, when every general level resamples the unit level's crop with <= 64 outputs per tile
+    // in-walk pyramid of pyramid_walk3_kernel (silent_walk_rgb.h): row program over the whole crop (completion records) +
+    // column records per 36-pixel wave tile, when every general level resamples the unit level's crop
     bool walk_pyr_ok = false;
     int walk_unit_level = -1;
     void* walk_tables = nullptr;
     WalkPyr walk{};
-    // the same for gray_walk1_kernel (one pixel per lane, completion records)
-    bool walk1_ok = false;
-    void* walk1_tables = nullptr;
-    WalkPyr walk1{};
 };
 
 static thread_local std::string g_create_err;
@@ -1058,6 +1052,45 @@ SILENT_EXPORT int silent_affine_clip_dev(silent_ctx* ctx, const float* in, size_
     return check_launch(ctx, who);
 }
 
+static size_t dtype_size(int dt) {
+    switch (dt) {
+        case SILENT_DT_U8: return 1;
+        case SILENT_DT_U16: case SILENT_DT_I16: return 2;
+        case SILENT_DT_F32: case SILENT_DT_I32: return 4;
+        case SILENT_DT_F64: case SILENT_DT_I64: return 8;
+        default: return 0;
+    }
+}
+
+SILENT_EXPORT int silent_cast_interleave_dev(silent_ctx* ctx, const void* in, int in_dtype, size_t n_pixels, int in_stride,
+                                             int in_offset, int count, float* out, int out_stride, int out_offset,
+                                             silent_stream stream) {
+    NEED_CTX(ctx);
+    const char* who = "silent_cast_interleave";
+    if (!in || !out) return fail(ctx, SILENT_E_INVALID, std::string(who) + ": NULL pointer");
+    if (!dtype_size(in_dtype)) return fail(ctx, SILENT_E_UNSUPPORTED, std::string(who) + ": unknown in_dtype");
+    if (n_pixels == 0) return fail(ctx, SILENT_E_INVALID, std::string(who) + ": empty tensor");
+    if (count < 1 || in_offset < 0 || out_offset < 0 || in_stride < in_offset + count || out_stride < out_offset + count)
+        return fail(ctx, SILENT_E_INVALID, std::string(who) + ": need 0 <= offset and offset + count <= stride on both sides");
+    const long long total = (long long)n_pixels * count;
+    const unsigned grid = (unsigned)std::min<long long>((total + 255) / 256, 256ll * 64);
+    hipStream_t s = (hipStream_t)stream;
+    const long long n = (long long)n_pixels;
+#define CAST_CASE(DT, T) \
+    case DT: hipLaunchKernelGGL(cast_interleave_kernel<T>, dim3(grid), dim3(256), 0, s, (const T*)in, out, n, in_stride, in_offset, count, out_stride, out_offset); break
+    switch (in_dtype) {
+        CAST_CASE(SILENT_DT_U8, unsigned char);
+        CAST_CASE(SILENT_DT_F32, float);
+        CAST_CASE(SILENT_DT_F64, double);
+        CAST_CASE(SILENT_DT_I32, int);
+        CAST_CASE(SILENT_DT_U16, unsigned short);
+        CAST_CASE(SILENT_DT_I16, short);
+        CAST_CASE(SILENT_DT_I64, long long);
+    }
+#undef CAST_CASE
+    return check_launch(ctx, who);
+}
+
 SILENT_EXPORT int silent_resize_nearest_dev(silent_ctx* ctx, const float* in, const silent_extent* in_levels,
                                             int n_levels, int n_frames, int channels, const silent_extent* out_levels,
                                             float* out, silent_stream stream) {
@@ -1767,10 +1800,9 @@ SILENT_EXPORT int silent_pyramid_plan_create(silent_ctx* ctx, int frame_h, int f
             }
         }
     }
-    // ---- in-walk pyramid tables: one unit level, every other level resamples the unit level's crop, and the walk's own
-    // limits (outputs per wave tile; slots for the rolling format).  mode 0: gray_walk_kernel (two pixels per lane, rolling
-    // accumulators), 1: pyramid_walk3_kernel (RGB, completion records), 2: gray_walk1_kernel (one pixel per lane, completion
-    // records).  1-channel plans get modes 0 and 2, 3-channel plans mode 1.
+    // ---- in-walk pyramid tables of pyramid_walk3_kernel (3 channels): one unit level, every other level resamples the unit
+    // level's crop, and the walk's own limits (outputs per wave tile).  Row program: one record per source row of the crop,
+    // "an output row of level g completes here" + its 6 vertical weights; column records per 36-pixel wave tile.
     {
         int unit = -1, n_unit = 0;
         for (int l = 0; l < n_levels; ++l)
@@ -1785,25 +1817,16 @@ SILENT_EXPORT int silent_pyramid_plan_create(silent_ctx* ctx, int frame_h, int f
                 same_crop = d.src_y0 == u.src_y0 && d.src_x0 == u.src_x0 && d.src_h == u.src_h && d.src_w == u.src_w;
             }
         }
-        auto build_walk = [&](int mode, WalkPyr& wout, void*& tables_out, bool& ok_out) {
+        auto build_walk = [&](WalkPyr& wout, void*& tables_out, bool& ok_out) {
             bool ok = true;
             const PyrLevelDev& u = tab.lv[unit];
             const int G = tab.n_general;
-            const bool completion = mode != 0;                       // record format
-            const int Gp = stream_pad_levels(G), PR = completion ? w3_prog_row(Gp) : walk_prog_row(Gp);
-            const int tile_px = mode == 1 ? kW3Px : (mode == 2 ? kW1Cols : kWalkCols);
-            const int strip_px = mode == 1 ? kW3StripPx : (mode == 2 ? kW1StripW : kWalkStripW);
-            const int waves_x = ((u.out_w + strip_px - 1) / strip_px) * (strip_px / tile_px);
-            const int rec_total = mode == 1 ? w3_rec_total(Gp) : (mode == 2 ? w1_rec_total(Gp) : walk_rec_total(Gp));
-            auto cap = [&](int g) { return mode == 1 ? w3_rec_cap(g) : (mode == 2 ? w1_rec_cap(g) : walk_rec_cap(g)); };
-            auto base = [&](int g) { return mode == 1 ? w3_rec_base(g) : (mode == 2 ? w1_rec_base(g) : walk_rec_base(g)); };
+            const int Gp = stream_pad_levels(G), PR = w3_prog_row(Gp);
+            const int waves_x = ((u.out_w + kW3StripPx - 1) / kW3StripPx) * kW3NC;
+            const int rec_total = w3_rec_total(Gp);
             const size_t n_rec = (size_t)u.out_h + 8;                 // stream rows y = -4 .. out_h + 3 at index y + 4
             const size_t n_rec_pad = n_rec + 2 * kWalkCH;             // the loader fetches whole chunks of records
             std::vector<int> prog(n_rec_pad * PR, 0), hdr((size_t)G * waves_x * 2, 0), rec((size_t)waves_x * rec_total * 8, 0);
-            if (!completion)
-                for (size_t r = 0; r < n_rec_pad; ++r)
-                    for (int gg = 0; gg < Gp; ++gg) prog[r * PR + gg] = 7 << 4;  // inert: feeds nothing, no slot completes
-            std::vector<char> used(completion ? 1 : n_rec * G * kWalkMaxSlots, 0);
             int g = 0;
             for (int l = 0; l < n_levels && ok; ++l) {
                 const PyrLevelDev& d = tab.lv[l];
@@ -1811,7 +1834,7 @@ SILENT_EXPORT int silent_pyramid_plan_create(silent_ctx* ctx, int frame_h, int f
                 const int zc = std::min(d.zoom_w, d.out_w), zr = std::min(d.zoom_h, d.out_h);
                 const int* yb = ybase.data() + d.ytab_off;
                 const int* xb = xbase.data() + d.xtab_off;
-                for (int oy = 0; oy < zr && ok && completion; ++oy) {
+                for (int oy = 0; oy < zr && ok; ++oy) {
                     // one record entry per COMPLETING row: flag + output row, 6 weights
                     if (yb[oy] < 0 || yb[oy] >= u.out_h) { ok = false; break; }
                     const size_t r = (size_t)(yb[oy] + 7);              // the last tap sits on stream row y = yb + 3, index y + 4
@@ -1821,44 +1844,19 @@ SILENT_EXPORT int silent_pyramid_plan_create(silent_ctx* ctx, int frame_h, int f
                     pr[g] = 1 | (oy << 8);
                     std::memcpy(pr + Gp + 6 * g, &yw[(size_t)(d.ytab_off + oy) * 6], 24);
                 }
-                for (int oy = 0; oy < zr && ok && !completion; ++oy) {
-                    if (yb[oy] < 0 || yb[oy] >= u.out_h) { ok = false; break; }
-                    const int slot = oy % walk_slots(g);
-                    for (int j = 0; j < 6; ++j) {
-                        const size_t r = (size_t)(yb[oy] + 2 + j);       // tap j sits on stream row y = yb - 2 + j
-                        if (r >= n_rec) { ok = false; break; }
-                        const size_t e = r * G + g;
-                        if (used[e * kWalkMaxSlots + slot]) { ok = false; break; }  // two live rows in one slot: step too small
-                        used[e * kWalkMaxSlots + slot] = 1;
-                        int* pr = prog.data() + r * PR;
-                        int& meta = pr[g];
-                        std::memcpy(pr + walk_w_off(Gp, g) + slot, &yw[(size_t)(d.ytab_off + oy) * 6 + j], 4);
-                        meta |= 128;
-                        if (j == 0) meta |= 1 << slot;
-                        if (j == 5) {
-                            if (((meta >> 4) & 7) != 7) { ok = false; break; }  // two rows completing together
-                            meta = (meta & 0x8f) | (slot << 4) | (oy << 8);
-                        }
-                    }
-                }
                 int ox = 0;
                 for (int wx = 0; wx < waves_x && ok; ++wx) {
-                    const int xw0 = wx * tile_px;
+                    const int xw0 = wx * kW3Px;
                     while (ox < zc && xb[ox] < xw0) ++ox;
                     int n = 0;
-                    while (ox + n < zc && xb[ox + n] < xw0 + tile_px) ++n;
-                    if (n > cap(g)) { ok = false; break; }               // outputs per wave tile: zoom steps >= 1.875 per level
+                    while (ox + n < zc && xb[ox + n] < xw0 + kW3Px) ++n;
+                    if (n > w3_rec_cap(g)) { ok = false; break; }        // outputs per wave tile: zoom steps >= 1.875 per level
                     hdr[((size_t)g * waves_x + wx) * 2] = ox;
                     hdr[((size_t)g * waves_x + wx) * 2 + 1] = n;
                     for (int j = 0; j < n; ++j) {
-                        int* r = rec.data() + ((size_t)wx * rec_total + base(g) + j) * 8;
-                        if (mode == 1) {
-                            r[0] = (xb[ox + j] - xw0) * 3;               // FLOAT index of tap 0, channel 0 (line starts at pixel xw0 - 2)
-                            if (r[0] < 0 || r[0] + 2 + 15 > kW3TileF - 1) { ok = false; break; }
-                        } else {
-                            r[0] = xb[ox + j] - xw0 + 2;                 // lane / column of tap 0 (index 0 <-> column xw0 - 4)
-                            if (r[0] < 0 || r[0] + 5 > (mode == 2 ? 63 : 127)) { ok = false; break; }
-                        }
+                        int* r = rec.data() + ((size_t)wx * rec_total + w3_rec_base(g) + j) * 8;
+                        r[0] = (xb[ox + j] - xw0) * 3;                   // FLOAT index of tap 0, channel 0 (line starts at pixel xw0 - 2)
+                        if (r[0] < 0 || r[0] + 2 + 15 > kW3TileF - 1) { ok = false; break; }
                         std::memcpy(r + 1, &xw[(size_t)(d.xtab_off + ox + j) * 6], 24);
                     }
                     ox += n;
@@ -1886,13 +1884,7 @@ SILENT_EXPORT int silent_pyramid_plan_create(silent_ctx* ctx, int frame_h, int f
             ok_out = true;
         };
         plan->walk_unit_level = n_unit == 1 ? unit : -1;
-        if (same_crop) {
-            if (channels == 3) build_walk(1, plan->walk, plan->walk_tables, plan->walk_pyr_ok);
-            else {
-                build_walk(0, plan->walk, plan->walk_tables, plan->walk_pyr_ok);
-                build_walk(2, plan->walk1, plan->walk1_tables, plan->walk1_ok);
-            }
-        }
+        if (same_crop && channels == 3) build_walk(plan->walk, plan->walk_tables, plan->walk_pyr_ok);
     }
     *out = plan;
     return SILENT_OK;
@@ -1904,7 +1896,6 @@ SILENT_EXPORT void silent_pyramid_plan_destroy(silent_pyramid_plan* plan) {
     if (plan->tables) (void)hipFree(plan->tables);
     if (plan->stream_tables) (void)hipFree(plan->stream_tables);
     if (plan->walk_tables) (void)hipFree(plan->walk_tables);
-    if (plan->walk1_tables) (void)hipFree(plan->walk1_tables);
     delete plan;
 }
 
@@ -2048,99 +2039,6 @@ SILENT_EXPORT int silent_profile_elapsed_ms(silent_ctx* ctx, float* ms, int64_t*
     return SILENT_OK;
 }
 
-// Strip-walk kernel (silent_walk.h) for the unit level: eligible when there is exactly one unit level, rows / crop /
-// canvas are 16-byte aligned, the bank has 4 or 8 orientations, and the batch is large enough to give every CU two blocks
-// of at least 64 rows (small batches keep the tile kernels: they have 30x the blocks).  force: tuning bit 128.
-static bool walk_plan(const silent_ctx* ctx, const silent_pyramid_plan* plan, int n_frames, int n_orient, bool force,
-                      int blocks_per_cu, int seg_rows_knob, WalkTab* wt, int* unit_level) {
-    const PyrTab& pt = plan->tab;
-    if (pt.C != 1 || (n_orient != 4 && n_orient != 8)) return false;
-    int unit = -1, n_unit = 0;
-    for (int l = 0; l < pt.n_levels; ++l)
-        if (pt.lv[l].kind == kPyrUnit) { unit = l; ++n_unit; }
-    if (n_unit != 1) return false;
-    const PyrLevelDev& d = pt.lv[unit];
-    if (pt.W % 4 || d.src_x0 % 4 || d.src_w % 4 || d.out_w % 4 || pt.frame_px_out % 2 || pt.px_off[unit] % 2) return false;
-    if (d.out_h < d.src_h || d.out_w < d.src_w) return false;
-    std::memset(wt, 0, sizeof(*wt));
-    wt->H = pt.H; wt->W = pt.W;
-    wt->src_y0 = d.src_y0; wt->src_x0 = d.src_x0; wt->src_h = d.src_h; wt->src_w = d.src_w;
-    wt->out_h = d.out_h; wt->out_w = d.out_w;
-    wt->eff_h = std::min(d.zoom_h, d.out_h); wt->eff_w = std::min(d.zoom_w, d.out_w);
-    wt->strips_x = (d.out_w + kWalkStripW - 1) / kWalkStripW;
-    const long long per_seg = (long long)n_frames * wt->strips_x;
-    const int max_segs = std::max(1, d.out_h / 64);
-    const long long want = (long long)blocks_per_cu * ctx->n_cus;
-    int segs = (int)std::min<long long>(max_segs, (want + per_seg - 1) / per_seg);
-    if (per_seg * segs < 2ll * ctx->n_cus && !force) return false;
-    int seg_rows = (d.out_h + segs - 1) / segs;
-    if (seg_rows_knob > 0) seg_rows = std::min(seg_rows_knob, d.out_h);   // A/B knob: rows per segment
-    seg_rows = (seg_rows + kWalkCH - 1) / kWalkCH * kWalkCH;
-    wt->seg_rows = seg_rows;
-    wt->segs_y = (d.out_h + seg_rows - 1) / seg_rows;
-    wt->frame_px = pt.frame_px_out;
-    wt->px_off = pt.px_off[unit];
-    for (int j = 0; j < 5; ++j) wt->wx[j] = plan->unit_w[j];
-    *unit_level = unit;
-    return true;
-}
-
-// Geometry of gray_walk1_kernel (silent_walk1.h): one unit level + walk tables, 16-byte aligned rows and crop.
-template <class Kern>
-static bool walk1_plan(const silent_ctx* ctx, const silent_pyramid_plan* plan, int n_frames, Kern kern, WalkTab* wt) {
-    const PyrTab& pt = plan->tab;
-    if (pt.C != 1 || !plan->walk1_ok || plan->walk_unit_level < 0) return false;
-    const PyrLevelDev& d = pt.lv[plan->walk_unit_level];
-    if (pt.W % 4 || d.src_x0 % 4 || d.src_w % 4 || d.src_w < 8) return false;
-    std::memset(wt, 0, sizeof(*wt));
-    wt->H = pt.H; wt->W = pt.W;
-    wt->src_y0 = d.src_y0; wt->src_x0 = d.src_x0; wt->src_h = d.src_h; wt->src_w = d.src_w;
-    wt->out_h = d.out_h; wt->out_w = d.out_w;
-    wt->eff_h = std::min(d.zoom_h, d.out_h); wt->eff_w = std::min(d.zoom_w, d.out_w);
-    wt->strips_x = (d.out_w + kW1StripW - 1) / kW1StripW;
-    int per_cu = 0;
-    (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kern, kW1Threads, 0);
-    (void)hipGetLastError();
-    // all blocks take the same time: the launch lasts ceil(blocks / resident blocks) rounds of (segment rows + 8) row steps
-    const long long per_seg = (long long)n_frames * wt->strips_x;
-    const long long resident = (long long)std::max(per_cu, 1) * ctx->n_cus;
-    const int max_segs = std::max(1, d.out_h / 32);
-    long long best_cost = -1;
-    int seg_rows = d.out_h;
-    for (int segs = 1; segs <= max_segs; ++segs) {
-        int rows = (d.out_h + segs - 1) / segs;
-        rows = (rows + kWalkCH - 1) / kWalkCH * kWalkCH;
-        const long long n_seg = (d.out_h + rows - 1) / rows;
-        const long long cost = ((per_seg * n_seg + resident - 1) / resident) * (rows + 8);
-        if (best_cost < 0 || cost < best_cost) {
-            best_cost = cost;
-            seg_rows = rows;
-        }
-    }
-    wt->seg_rows = seg_rows;
-    wt->segs_y = (d.out_h + seg_rows - 1) / seg_rows;
-    wt->frame_px = pt.frame_px_out;
-    wt->px_off = pt.px_off[plan->walk_unit_level];
-    for (int j = 0; j < 5; ++j) wt->wx[j] = plan->unit_w[j];
-    return true;
-}
-
-template <int K>
-static bool launch_walk1(silent_ctx* ctx, const silent_pyramid_plan* plan, const float* frames, int n_frames, float* pyr,
-                         float* cs_out, float* end_out, const GrayW& w, float clip_hi, hipStream_t s) {
-    WalkTab wt;
-    if (plan->walk1.G <= 4) {
-        if (!walk1_plan(ctx, plan, n_frames, gray_walk1_kernel<K, 4>, &wt)) return false;
-        hipLaunchKernelGGL((gray_walk1_kernel<K, 4>), dim3((unsigned)((long long)n_frames * wt.segs_y * wt.strips_x)), dim3(kW1Threads), 0, s,
-                           frames, pyr, cs_out, end_out, wt, plan->walk1, w, clip_hi);
-    } else {
-        if (!walk1_plan(ctx, plan, n_frames, gray_walk1_kernel<K, 7>, &wt)) return false;
-        hipLaunchKernelGGL((gray_walk1_kernel<K, 7>), dim3((unsigned)((long long)n_frames * wt.segs_y * wt.strips_x)), dim3(kW1Threads), 0, s,
-                           frames, pyr, cs_out, end_out, wt, plan->walk1, w, clip_hi);
-    }
-    return true;
-}
-
 SILENT_EXPORT int silent_gray_pass_dev(silent_ctx* ctx, const silent_pyramid_plan* plan, const float* frames,
                                        int n_frames, const float* cs_kernel, const float* end_bank, int n_orient,
                                        float clip_hi, float* pyr, float* cs_out, float* end_out,
@@ -2158,22 +2056,10 @@ SILENT_EXPORT int silent_gray_pass_dev(silent_ctx* ctx, const silent_pyramid_pla
     hipStream_t s = (hipStream_t)stream;
     const PyrTab& pt = plan->tab;
     const int kopts = (int)ctx->tune[SILENT_TUNE_GRAY];  // A/B knobs: bit3 32-row fused tiles, bit4 disable the stream path
-    // strip-walk kernel for the unit level: OFF by default -- measured on 64 x 1080p (profiles/r02/walk_kernel.txt) it
-    // moves 15 % fewer bytes than the tile kernel but at a lower HBM efficiency, 0.73-0.79 ms for the unit level alone
-    // against 0.78-0.85 ms for the tile kernel's whole job.  Bit 128 selects it (bit 256: plain instead of non-temporal
-    // stores, bit 512: other levels by the region kernel, bits 10-11 / 12-17: blocks per CU / rows per segment).
-    WalkTab wt;
-    int walk_unit = -1;
-    const bool walk_path = (kopts & 128) && end_out && walk_plan(ctx, plan, n_frames, n_orient, true, 2 + ((kopts >> 10) & 3), 32 * ((kopts >> 12) & 63), &wt, &walk_unit);
-    const bool walk_pyr = walk_path && plan->walk_pyr_ok && pt.C == 1 && !(kopts & 512);   // other levels from the same walk
-    // one-pixel-per-lane strip walk (silent_walk1.h): pyramid of all levels + unit-level filters, bit 18 selects it
-    const bool walk1_path = (kopts & (1 << 18)) && !walk_path && end_out && plan->walk1_ok && pt.C == 1 &&
-                            plan->walk_unit_level >= 0 && !(pt.W % 4) && !(pt.lv[plan->walk_unit_level].src_x0 % 4) &&
-                            !(pt.lv[plan->walk_unit_level].src_w % 4) && pt.lv[plan->walk_unit_level].src_w >= 8;
-    const bool stream_path = plan->stream_ok && !(kopts & 16) && !walk_path && !walk1_path;
+    const bool stream_path = plan->stream_ok && !(kopts & 16);
     // 1. non-unit levels of the pyramid: by the region kernel, unless the stream kernel of step 2 produces them
     //    from the same single read of the frame; plus the zero fill of canvases larger than their zoomed crop
-    TRY(launch_pyramid(ctx, who, plan, frames, n_frames, pyr, s, false, !stream_path && !walk_pyr && !walk1_path));
+    TRY(launch_pyramid(ctx, who, plan, frames, n_frames, pyr, s, false, !stream_path));
     // 2. unit levels: pyramid + CS + end in one kernel
     const int fth = (!stream_path && (kopts & 8)) ? 32 : kFusedTH;
     FusedTab ft;
@@ -2212,30 +2098,7 @@ SILENT_EXPORT int silent_gray_pass_dev(silent_ctx* ctx, const silent_pyramid_pla
         ctx->prof_sample = ctx->profiling && (ctx->prof_calls++ % ctx->prof_period) == 0;
         const int prof_slot = ctx->prof_recorded % silent_ctx::kProfPairs;
         if (ctx->prof_sample) HIP_TRY(ctx, hipEventRecord(ctx->prof_ev[prof_slot][0], s));
-        if (walk1_path) {
-            bool ok1 = false;
-            if (n_orient == 3) ok1 = launch_walk1<3>(ctx, plan, frames, n_frames, pyr, cs_out, end_out, w, clip_hi, s);
-            else if (n_orient == 4) ok1 = launch_walk1<4>(ctx, plan, frames, n_frames, pyr, cs_out, end_out, w, clip_hi, s);
-            else ok1 = launch_walk1<8>(ctx, plan, frames, n_frames, pyr, cs_out, end_out, w, clip_hi, s);
-            if (!ok1) return fail(ctx, SILENT_E_HIP, std::string(who) + ": internal error: walk1 plan rejected after eligibility check");
-        } else if (walk_path) {
-            const long long wblocks = (long long)n_frames * wt.segs_y * wt.strips_x;
-#define WALK_LAUNCH(K_, NT_, G_) \
-    hipLaunchKernelGGL((gray_walk_kernel<K_, NT_, G_>), dim3((unsigned)wblocks), dim3(walk_threads(G_)), 0, s, frames, pyr, cs_out, end_out, wt, wpyr, w, clip_hi)
-#define WALK_G(K_, NT_)                                   \
-    do {                                                  \
-        if (!walk_pyr) WALK_LAUNCH(K_, NT_, 0);           \
-        else if (plan->walk.G <= 4) WALK_LAUNCH(K_, NT_, 4); \
-        else WALK_LAUNCH(K_, NT_, 7);                     \
-    } while (0)
-            WalkPyr wpyr{};
-            if (walk_pyr) wpyr = plan->walk;
-            const bool nt = !(kopts & 256);
-            if (n_orient == 4) { if (nt) WALK_G(4, true); else WALK_G(4, false); }
-            else { if (nt) WALK_G(8, true); else WALK_G(8, false); }
-#undef WALK_G
-#undef WALK_LAUNCH
-        } else if (stream_path) {
+        if (stream_path) {
             const StreamTab& st = plan->stream;
 #define STREAM_LAUNCH(K_, G_) \
     hipLaunchKernelGGL((gray_stream_kernel<K_, G_>), dim3((unsigned)blocks), dim3(64 * kFusedWaves), 0, s, frames, pyr, cs_out, end_out, ft, st, w, clip_hi, (unsigned)((kopts >> 5) & 1))
@@ -2643,6 +2506,25 @@ SILENT_EXPORT int silent_affine_clip(silent_ctx* ctx, const float* in, size_t n_
     TRY(silent_affine_clip_dev(ctx, st.ptr<float>(i_x), n_values, params, st.ptr<float>(i_x), nullptr));
     TRY(sync0(ctx));
     return d2h(ctx, out, st.ptr<float>(i_x), b);
+}
+
+SILENT_EXPORT int silent_cast_interleave(silent_ctx* ctx, const void* in, int in_dtype, size_t n_pixels, int in_stride,
+                                         int in_offset, int count, float* out, int out_stride, int out_offset) {
+    NEED_CTX(ctx);
+    if (!in || !out) return fail(ctx, SILENT_E_INVALID, "silent_cast_interleave: NULL pointer");
+    const size_t es = dtype_size(in_dtype);
+    if (!es) return fail(ctx, SILENT_E_UNSUPPORTED, "silent_cast_interleave: unknown in_dtype");
+    if (n_pixels == 0 || in_stride < 1 || out_stride < 1) return fail(ctx, SILENT_E_INVALID, "silent_cast_interleave: empty tensor");
+    Stage st(ctx);
+    const size_t bi = n_pixels * (size_t)in_stride * es, bo = n_pixels * (size_t)out_stride * 4;
+    const size_t i_x = st.add(bi), i_o = st.add(bo);
+    TRY(st.commit());
+    TRY(h2d(ctx, st.ptr<char>(i_x), in, bi));
+    TRY(h2d(ctx, st.ptr<float>(i_o), out, bo));      // the elements of out that this call does not write keep their values
+    TRY(silent_cast_interleave_dev(ctx, st.ptr<char>(i_x), in_dtype, n_pixels, in_stride, in_offset, count, st.ptr<float>(i_o),
+                                   out_stride, out_offset, nullptr));
+    TRY(sync0(ctx));
+    return d2h(ctx, out, st.ptr<float>(i_o), bo);
 }
 
 SILENT_EXPORT int silent_resize_nearest(silent_ctx* ctx, const float* in, const silent_extent* in_levels, int n_levels,

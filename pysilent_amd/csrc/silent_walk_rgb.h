@@ -1,6 +1,6 @@
 // pyramid_walk3_kernel: the whole zoom pyramid of a 3-channel (interleaved RGB) frame from ONE read of the frame, as a
 // strip walk with a dedicated loader wave -- the structure of gray_walk_kernel (silent_walk.h) applied to the pyramid of
-// BASELINE config 3, where round 1 ran two kernels (pyramid_unit_kernel<3> + pyramid_region_kernel<3>: the frame is fetched
+// BASELINE config 3 (the gray kernel is kept as a record under scripts/ubench/walk_kernels/), where round 1 ran two kernels (pyramid_unit_kernel<3> + pyramid_region_kernel<3>: the frame is fetched
 // 2.95x, the region kernel moves 1.64x its algorithmic bytes and is latency-bound at 1.9 TB/s).
 //
 // Everything is indexed in FLOATS of the interleaved row (pixel p, channel c <-> float 3p + c):
@@ -24,9 +24,45 @@
 #include <type_traits>
 
 #include "silent_common.h"
-#include "silent_walk.h"
+#include "silent_conv.h"
 
 namespace silent {
+
+// ---- shared strip-walk declarations (the gray strip-walk kernels of round 2 that also used them are not part of the product:
+// scripts/ubench/walk_kernels/, profiles/r02/walk_kernel.txt)
+constexpr int kWalkCH = 8;                          // rows per record chunk the host pads the row program to
+constexpr int kWalkSlots = 3;                       // chunks in the ring
+
+// tables of the in-walk pyramid (device memory owned by the plan)
+struct WalkPyr {
+    int G;                        // general levels (<= template G; the rest are inert)
+    const int* row_prog;          // [out_h + 8 (+ padding)][w3_prog_row(Gp)]: record of stream row y at index y + 4
+    const int* col_hdr;           // [G][waves_x][2]: first output column, number of outputs of the wave tile
+    const int* col_rec;           // [waves_x][w3_rec_total(Gp)][8]: float index of tap 0 in the wave's line, 6 weights, pad
+    long long px_off[8];          // pixel offset of level g inside one pyramid
+    int out_w[8];
+};
+
+struct WalkTab {
+    int H, W;                            // frame extents
+    int src_y0, src_x0, src_h, src_w;    // crop the unit level resamples (zoom 1)
+    int out_h, out_w, eff_h, eff_w;      // canvas, and the part of it the zoomed crop covers
+    int strips_x, segs_y, seg_rows;      // decomposition: block = (frame, segment of seg_rows output rows, strip)
+    long long frame_px, px_off;          // pixels of one pyramid, offset of the unit level in it
+    float wx[5];                         // [1, 26, 66, 26, 1] / 120 as float32 (both axes)
+};
+
+// compile-time loop: the body gets its index as an integral constant
+template <int I, int N, class F>
+__device__ __forceinline__ void walk_static_for(F&& f) {
+    if constexpr (I < N) {
+        f(std::integral_constant<int, I>{});
+        walk_static_for<I + 1, N>(f);
+    }
+}
+
+typedef __attribute__((address_space(3))) void* walk_lds_ptr;
+typedef const __attribute__((address_space(1))) void* walk_glb_ptr;
 
 constexpr int kW3NC = 4;                        // consumer waves per block
 constexpr int kW3Px = 36;                       // pixels per consumer wave

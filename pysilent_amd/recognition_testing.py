@@ -71,7 +71,7 @@ class LineEndDisplayer(PyramidDisplayer):
         import torch
         rt = _runtime
         if _runtime.is_torch_tensor(pyramid_tensor):
-            x = pyramid_tensor.to(torch.float32)
+            x = rt.as_float32(pyramid_tensor)
         else:
             x = torch.from_numpy(np.ascontiguousarray(pyramid_tensor, np.float32)).to(
                 torch.device("cuda", self.device_index))
@@ -142,7 +142,7 @@ class LineEndDisplayer(PyramidDisplayer):
         dev = torch.device("cuda", self.device_index)
         if isinstance(frame, np.ndarray) and frame.dtype == np.uint8:
             # camera frames: 1 byte per sample over PCIe, widened on the device (exact)
-            z_tensor = torch.from_numpy(np.ascontiguousarray(frame)).to(dev).to(torch.float32)
+            z_tensor = _runtime.as_float32(torch.from_numpy(np.ascontiguousarray(frame)).to(dev))
         else:
             z_tensor = torch.from_numpy(np.ascontiguousarray(frame, dtype=np.float32)).to(dev)
         z_tensor = zoom.from_image(z_tensor, self.output_colors, self.output_size, self.zoom_ratio)

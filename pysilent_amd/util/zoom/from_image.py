@@ -86,12 +86,26 @@ def image_to_zoom_tensor(image, num_colors, center_dimensions, scale):
     if int(num_colors) not in (1, 3):
         # the kernels take 1 or 3 interleaved channels; the reference zooms every colour plane on its own
         # (from_image.py:54-64), so any other count is that many single-channel pyramids side by side
-        planes = [image_to_zoom_tensor(frames[0][..., c:c + 1].contiguous() if _runtime.is_torch_tensor(frames)
-                                       else np.ascontiguousarray(frames[0][..., c:c + 1]), 1, center_dimensions, scale)
-                  for c in range(int(num_colors))]
-        if _runtime.is_torch_tensor(planes[0]):
+        n_col = int(num_colors)
+        if _runtime.is_torch_tensor(frames):
             import torch
-            return torch.cat(planes, dim=-1)
+            src = frames[0]
+            if not src.is_contiguous():
+                raise ValueError("GPU tensors must be contiguous (NHWC, C innermost)")
+            npx = int(src.shape[0] * src.shape[1])
+            out = None
+            for c in range(n_col):
+                # plane c cut out of the interleaved image (and widened) by the library's strided cast ...
+                plane = torch.empty((src.shape[0], src.shape[1], 1), dtype=torch.float32, device=src.device)
+                _runtime.cast_interleave(src, plane, n_col, c, 1, 1, 0, npx)
+                z = image_to_zoom_tensor(plane, 1, center_dimensions, scale)
+                if out is None:
+                    out = torch.empty(tuple(z.shape[:3]) + (n_col,), dtype=torch.float32, device=src.device)
+                # ... and its pyramid interleaved into channel c of the result by the same kernel
+                _runtime.cast_interleave(z.contiguous(), out, 1, 0, 1, n_col, c, z.numel())
+            return out
+        planes = [image_to_zoom_tensor(np.ascontiguousarray(frames[0][..., c:c + 1]), 1, center_dimensions, scale)
+                  for c in range(n_col)]
         return np.concatenate(planes, axis=-1)
     levels = reference_levels(tuple(frames.shape[1:3]), center_dimensions, scale)
     packed = _plan(tuple(frames.shape[1:]), levels, dev).run(frames)

@@ -1,4 +1,6 @@
 #!/bin/bash
+# ROUND-2 RECORD: the gray strip-walk kernels are no longer in the product tree (scripts/ubench/walk_kernels/README.md);
+# run this inside a checkout of the round-2 tree:  git worktree add /tmp/r02 745bae6
 # Leave-one-out builds of gray_walk1_kernel (results wrong on purpose), patched scratch copies of csrc/ (never product code).
 set -e
 cd "$(dirname "$0")/.."

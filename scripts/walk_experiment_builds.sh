@@ -1,4 +1,6 @@
 #!/bin/bash
+# ROUND-2 RECORD: the gray strip-walk kernels are no longer in the product tree (scripts/ubench/walk_kernels/README.md);
+# run this inside a checkout of the round-2 tree:  git worktree add /tmp/r02 745bae6
 # Leave-one-out builds of gray_walk_kernel (results wrong on purpose) made by PATCHING A SCRATCH COPY of csrc/ -- the product
 # sources carry no experiment branches.  usage: scripts/walk_experiment_builds.sh ; then on the GPU box
 #   scripts/ab_libs.sh pysilent_amd/lib/libsilent_hip.so gpurun_exp/libwalk_noarith.so ...   (AB_ONLY=walk)

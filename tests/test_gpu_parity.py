@@ -279,6 +279,47 @@ def test_from_image_against_the_reference_wrappers_own_outputs(rt, golden_pyrami
         assert_close(got, want.astype(np.float32), RTOL, scale=255.0, what="from_image vs reference " + name, bound=eb.zoom(want))
 
 
+def test_cast_interleave_and_device_frames_of_any_dtype(rt):
+    """silent_cast_interleave: np.asarray(frame, float32) (recognition_testing.py:141) and the colour-plane slicing of
+    from_image.py:54-64 as one strided cast kernel -- widening, plane extraction, interleaving; host and device forms; and
+    the entry points fed GPU tensors that are not float32 (no torch kernel on that path)."""
+    import ctypes as C
+    import torch
+    from pysilent_amd import _lib
+    from pysilent_amd.util import zoom
+    rng = np.random.default_rng(3)
+    lib, ctx = _lib.load(), rt.get_context()
+    for dt, code in ((np.uint8, _lib.DT_U8), (np.float64, _lib.DT_F64), (np.int32, _lib.DT_I32), (np.int16, _lib.DT_I16),
+                     (np.uint16, _lib.DT_U16), (np.int64, _lib.DT_I64), (np.float32, _lib.DT_F32)):
+        x = (rng.standard_normal((37, 5)) * 100).astype(dt) if dt in (np.float64, np.float32) else rng.integers(0, 120, (37, 5)).astype(dt)
+        out = np.full((37, 7), -1.0, np.float32)
+        ctx.check(lib.silent_cast_interleave(ctx.handle, x.ctypes.data, code, 37, 5, 1, 3, out.ctypes.data, 7, 2))
+        want = np.full((37, 7), -1.0, np.float32)
+        want[:, 2:5] = x[:, 1:4].astype(np.float32)
+        np.testing.assert_array_equal(out, want, err_msg=str(dt))
+    bad = np.zeros(4, np.float32)
+    assert lib.silent_cast_interleave(ctx.handle, bad.ctypes.data, 99, 4, 1, 0, 1, bad.ctypes.data, 1, 0) == _lib.SILENT_E_UNSUPPORTED
+    assert lib.silent_cast_interleave(ctx.handle, bad.ctypes.data, _lib.DT_F32, 4, 1, 1, 1, bad.ctypes.data, 1, 0) == _lib.SILENT_E_INVALID
+    # device tensors of other dtypes through the wrappers
+    img8 = rng.integers(0, 256, (60, 80, 3)).astype(np.uint8)
+    a = zoom.from_image(torch.from_numpy(img8).cuda(), 3, (40, 30), 2.0)
+    b = zoom.from_image(img8.astype(np.float32), 3, (40, 30), 2.0)
+    np.testing.assert_array_equal(a.cpu().numpy(), b)
+    np.testing.assert_array_equal(rt.nms3x3(torch.from_numpy(img8[None].astype(np.float64)).cuda(), "fired").cpu().numpy(),
+                                  rt.nms3x3(img8[None].astype(np.float32), "fired"))
+    # colour counts the kernels do not take interleaved (from_image.py zooms plane by plane): cut, zoom, interleave on the device
+    for ncol in (2, 4):
+        img = rng.integers(0, 256, (50, 70, ncol)).astype(np.float32)
+        dev = zoom.from_image(torch.from_numpy(img).cuda(), ncol, (32, 24), 2.0)
+        host = zoom.from_image(img, ncol, (32, 24), 2.0)
+        assert dev.shape == host.shape and dev.shape[-1] == ncol
+        np.testing.assert_array_equal(dev.cpu().numpy(), host)
+        assert_close(host, so.zoom_from_image(img, ncol, (32, 24), 2.0), RTOL, scale=255.0, what="from_image %d colours" % ncol,
+                     bound=eb.zoom(so.zoom_from_image(img, ncol, (32, 24), 2.0)))
+    with pytest.raises(ValueError):
+        rt.nms3x3(torch.from_numpy(img8[None].astype(np.float32)).cuda()[:, :, ::2], "fired")       # not contiguous
+
+
 @pytest.mark.parametrize("shape,scale,n", [((135, 240, 1), 2.0, 5), ((135, 240, 3), 2.0, 4), ((270, 480, 1), math.e ** .5, 6),
                                            ((48, 64, 1), 2.0, 2), ((100, 37, 1), 1.3, 7)])
 def test_classic_pyramid(rt, shape, scale, n):
@@ -1270,60 +1311,6 @@ def test_entry_points_leave_the_callers_device_alone(rt):
     assert torch.cuda.current_device() == before
 
 
-# ----------------------------------------------------------------------------- strip-walk kernel (silent_walk.h)
-
-@pytest.mark.parametrize("shape,scale,n,K,B", [((135, 240, 1), 2.0, 5, 4, 2),         # two segments of 72 rows, one strip
-                                               ((97, 132, 1), 1.7, 4, 8, 3),           # K = 8 store transpose, ragged strip
-                                               ((64, 300, 1), 2.0, 3, 4, 1),
-                                               ((200, 1000, 1), 2.0, 4, 4, 2),         # three strips (480 + 480 + 40 columns)
-                                               ((200, 964, 1), 2.0, 2, 8, 1),          # last strip holds 4 columns only
-                                               ((270, 480, 1), math.e ** .5, 6, 4, 2), # exactly one full strip
-                                               ((8, 8, 1), 2.0, 1, 4, 2),              # one chunk, fewer rows than a chunk
-                                               ((9, 484, 1), 2.0, 2, 4, 1),
-                                               ((1080, 1920, 1), 2.0, 5, 4, 2),        # config 2 geometry, 15 seams per frame
-                                               ((540, 960, 1), 2.0, 8, 8, 2),          # 7 general levels (config 5 shape / 4)
-                                               ((300, 480, 1), 2.5, 4, 4, 1)])         # zoom step 2.5
-def test_gray_walk_kernel_is_bit_identical_to_the_tile_kernels(rt, kernels, shape, scale, n, K, B):
-    """The strip-walk kernel (loader wave + two pixels per lane, tuning bit 128 selects it) against the
-    tile kernels (the default path): the same arithmetic in the same order, so every map is equal bit for bit --
-    across segment seams, strip seams, ragged right edges and both store layouts."""
-    from pysilent_amd.util.zoom.from_image import classic_levels
-    frames = np.stack([structured_frame(20 + s, *shape, n_lines=60) + noise_frame(s, *shape) * np.float32(0.25) for s in range(B)])
-    plan = rt.PyramidPlan(shape[0], shape[1], 1, classic_levels(shape[:2], scale, n))
-    bank = kernels["end%d" % K]
-    with rt.tuning(TUNE_GRAY, 128):
-        pyr, cs, end = plan.gray_pass(frames, kernels["cs_gray"], bank)
-    with rt.tuning(TUNE_GRAY, 128 | 256 | 512):                 # plain instead of non-temporal stores; other levels by
-        pyr_p, cs_p, end_p = plan.gray_pass(frames, kernels["cs_gray"], bank)   # the region kernel instead of the walk
-    with rt.tuning(TUNE_GRAY, 0):
-        pyr2, cs2, end2 = plan.gray_pass(frames, kernels["cs_gray"], bank)
-    for a, b_, c_ in ((pyr, pyr_p, pyr2), (cs, cs_p, cs2), (end, end_p, end2)):
-        np.testing.assert_array_equal(a.data, c_.data)
-        np.testing.assert_array_equal(b_.data, c_.data)
-    want = so.classic_pyramid(frames[B - 1], scale, n)
-    wcs, wend = so.gray_line_end_pass(want[:1], kernels["cs_gray"], bank)[0]
-    assert_close(cs.level(0)[B - 1:B], wcs, RTOL, scale=255.0, what="walk cs")
-    assert_close(end.level(0)[B - 1:B], wend, RTOL, scale=255.0, what="walk end")
-
-
-def test_gray_walk_kernel_nan_and_inf_frames(rt, kernels):
-    """Non-finite pixels propagate through the walk kernel exactly as through the tile kernels."""
-    from pysilent_amd.util.zoom.from_image import classic_levels
-    frames = np.stack([noise_frame(s, 150, 488, 1) for s in range(2)])
-    frames[0, 70:74, 100:104] = np.nan
-    frames[1, 0, 0] = np.inf
-    frames[1, 149, 487] = -np.inf
-    frames[0, 71, 479:482] = np.inf                              # across the strip seam
-    plan = rt.PyramidPlan(150, 488, 1, classic_levels((150, 488), 2.0, 3))
-    with rt.tuning(TUNE_GRAY, 128):
-        got = plan.gray_pass(frames, kernels["cs_gray"], kernels["end4"])
-    with rt.tuning(TUNE_GRAY, 0):
-        ref = plan.gray_pass(frames, kernels["cs_gray"], kernels["end4"])
-    for a, b_ in zip(got, ref):
-        np.testing.assert_array_equal(a.data, b_.data)
-    assert np.isnan(got[2].data).any()
-
-
 # ----------------------------------------------------------------------------- a-11 with any region_shape
 
 @pytest.mark.parametrize("shape,region", [((2, 192, 288, 3), (1, 3, 3, 3)),        # the reference's centroid_region_shape as regions: 64 x 96 windows
@@ -1487,39 +1474,6 @@ def test_rgb_pyramid_walk_is_bit_identical_to_unit_plus_region_kernels(rt, shape
     res = plan.run(clean[None])
     for l in range(n):
         assert_close(res.level(l), want[l], RTOL, scale=255.0, what="rgb walk level %d" % l, bound=eb.zoom(want[l]))
-
-
-# ----------------------------------------------------------------------------- one-pixel-per-lane strip walk (silent_walk1.h)
-
-WALK1 = 1 << 18
-
-
-@pytest.mark.parametrize("shape,scale,n,K,B", [((135, 240, 1), 2.0, 5, 4, 2),         # one strip (224) + a ragged one
-                                               ((97, 132, 1), 2.0, 4, 8, 3),           # K = 8 store transpose
-                                               ((64, 300, 1), 2.0, 3, 3, 1),           # K = 3
-                                               ((200, 1000, 1), 2.0, 4, 4, 2),         # five strips
-                                               ((200, 228, 1), 2.0, 2, 8, 1),          # second strip holds 4 columns
-                                               ((270, 480, 1), 2.5, 4, 4, 2),
-                                               ((8, 8, 1), 2.0, 2, 4, 2),
-                                               ((540, 960, 1), 2.0, 8, 8, 2),          # 7 general levels
-                                               ((1080, 1920, 1), 2.0, 5, 4, 2)])       # config 2 geometry
-def test_gray_walk1_kernel_is_bit_identical_to_the_tile_kernels(rt, kernels, shape, scale, n, K, B):
-    """gray_walk1_kernel (loader wave + 12-row ring, one pixel per lane, other levels from a 6-row window at completion,
-    tuning bit 18) against the tile kernels: every map equal bit for bit across segment and strip seams, ragged edges,
-    K = 3 / 4 / 8, NaN / inf pixels."""
-    from pysilent_amd.util.zoom.from_image import classic_levels
-    frames = np.stack([structured_frame(20 + s, *shape, n_lines=60) + noise_frame(s, *shape) * np.float32(0.25) for s in range(B)])
-    if shape[0] > 20:
-        frames[0, shape[0] // 2, shape[1] // 3] = np.nan
-        frames[B - 1, 3, shape[1] - 2] = np.inf
-    plan = rt.PyramidPlan(shape[0], shape[1], 1, classic_levels(shape[:2], scale, n))
-    bank = kernels["end%d" % K]
-    with rt.tuning(TUNE_GRAY, WALK1):
-        got = plan.gray_pass(frames, kernels["cs_gray"], bank)
-    with rt.tuning(TUNE_GRAY, 0):
-        ref = plan.gray_pass(frames, kernels["cs_gray"], bank)
-    for a, b_ in zip(got, ref):
-        np.testing.assert_array_equal(a.data, b_.data)
 
 
 def test_workspace_follows_the_callers_stream(rt):
