@@ -22,6 +22,7 @@ runs of configs 3 and 5; ``cpu_baseline`` times the CPU oracle on the host cores
 import argparse
 import hashlib
 import json
+import math
 import os
 import socket
 import subprocess
@@ -43,6 +44,10 @@ WORKLOADS = {
     # configs[2]: 1080p RGB, 6-level pyramid, normalize + peak extraction
     "config3": dict(hw=(1080, 1920), mode="rgb", n_levels=6, n_orient=3, frames=32,
                     name="1080p RGB, 6-level pyramid (scale 2), rgc>rgby>stripe>regulate>end>pad>value, top 10 %, NMS, keypoints"),
+    # the reference's OWN pyramid layout (LineEndDisplayer defaults, pyramid_displayer.py:22: output_size (288, 192), zoom ratio
+    # e ** .5; util/zoom/from_image.py:45-64: nested centre crops resampled to one fixed size) on batched 1080p RGB frames
+    "reference_layout": dict(hw=(1080, 1920), mode="rgb", n_levels=4, n_orient=3, frames=32, center=(288, 192), scale=math.e ** .5,
+                             name="1080p RGB, the reference's layout: 4 levels of 288x192 (centre crops, zoom e^-s/2), chain + keypoints"),
     # configs[4]: 4K, 8-level pyramid, 8-orientation bank
     "config5": dict(hw=(2160, 3840), mode="gray", n_levels=8, n_orient=8, frames=16,
                     name="4K gray, 8-level pyramid (scale 2), CS + 8-orientation line-end"),
@@ -238,6 +243,8 @@ def make_pipeline(wl, B, local, consts, **over):
         # peak-value map are intermediates the fused step never writes (silent_rgb_keypoints: extrema in the chain kernel,
         # sparse keypoint tail)
         kw = {"selection": True, "value_map": False, "peak_value_map": False}
+    if "center" in wl:
+        kw.update(center_dimensions=wl["center"], scale=wl["scale"])
     kw.update(over)
     return LineEndPipeline((h, w), mode=wl["mode"], n_levels=wl["n_levels"], n_orient=wl["n_orient"], batch=B,
                            device=local, constants=consts, max_keypoints_per_frame=1 << 16, **kw)
@@ -487,6 +494,8 @@ def run_rank(args):
             out["other_workloads"].update(config3_variants(torch, D, local, dev, rank, world))
         if args.workload != "config5":
             out["other_workloads"]["config5"] = side_workload(torch, D, "config5", local, dev, rank, world)
+        if args.workload != "reference_layout":
+            out["other_workloads"]["reference_layout"] = side_workload(torch, D, "reference_layout", local, dev, rank, world)
     if world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(wl, consts)
     else:

@@ -419,7 +419,7 @@ int silent_sparse_tail_stats(silent_ctx* ctx, int64_t* stats);
 /* Host-only (no GPU needed): the weight STREAM silent_rgb_line_end hands to its pair kernel for these weights -- the
  * weights in the order the kernel consumes them (csrc/silent_rgb2.h), zero-padded to whole pairs of 16-float blocks.
  * knobs: SILENT_TUNE_RGB bits 0 / 1.  variant: 2 two-group, 1 basic (diagonal rgc + channel-sum stripe), 0 dense;
- * n_used = 193 / 265 / 373.  stream must hold SILENT_RGB_STREAM_MAX floats.  For tests of the host logic. */
+ * n_used = 160 / 265 / 373 (two-group: the mirror-symmetric blur travels as 16 folded weights).  stream must hold SILENT_RGB_STREAM_MAX floats.  For tests of the host logic. */
 #define SILENT_RGB_STREAM_MAX 384
 int silent_rgb_chain_stream(const silent_rgb_chain_params* params, unsigned knobs, float* stream, int* n_used, int* variant);
 int silent_rgb_line_end(silent_ctx* ctx, const float* pyr, const silent_extent* levels, int n_levels, int n_frames,

@@ -1218,7 +1218,8 @@ static void analyze_rgb_chain(const silent_rgb_chain_params* p, RgbStructure* r)
 // The RGB chain's weights as the fused kernels take them: HWIO -> [o][dy][dx][i], the blur's profile, and -- where the
 // host FINDS the structure in the actual weights (what the reference's generators produce, but checked, not assumed) --
 // the two-group blocks: rgc channel-diagonal (27 fmas), stripe a filter of the channel sum (27), rgby and the end bank
-// two-group (27 + 18 each): 193 instead of 373 fmas per pixel.  Anything else runs the dense instantiation.
+// two-group (27 + 18 each), and the blur mirror-symmetric (16 fmas + 10 adds instead of 49 fmas): 160 weights instead of 373
+// per pixel.  Anything else runs the basic (diagonal rgc + channel-sum stripe) or the dense instantiation.
 // kopts: SILENT_TUNE_RGB bits 0 (dense) and 1 (no two-group form).
 static void pack_rgb_weights(const silent_rgb_chain_params* p, unsigned kopts, RgbW* w, bool* basic, bool* two) {
     auto repack = [](const float* hwio, float* dst) {  // HWIO [dy][dx][i][o] -> [o][dy][dx][i]
@@ -1235,7 +1236,12 @@ static void pack_rgb_weights(const silent_rgb_chain_params* p, unsigned kopts, R
     RgbStructure rs;
     analyze_rgb_chain(p, &rs);
     *basic = rs.rgc_diag && rs.stripe_sum && !(kopts & 1u);
-    *two = *basic && !(kopts & 2u) && rs.rgby_two && rs.end_two && rs.rgby_mask[0] == kRgbyA && rs.rgby_mask[1] == kRgbyA &&
+    // the blur's mirror symmetry (what blur_tensor generates: a function of the distance), folded by the two-group kernels
+    bool blur_sym = true;
+    for (int dy = 0; dy < 7; ++dy)
+        for (int dx = 0; dx < 7; ++dx)
+            if (w->blur[dy * 7 + dx] != w->blur[(6 - dy) * 7 + dx] || w->blur[dy * 7 + dx] != w->blur[dy * 7 + (6 - dx)]) blur_sym = false;
+    *two = *basic && !(kopts & 2u) && blur_sym && rs.rgby_two && rs.end_two && rs.rgby_mask[0] == kRgbyA && rs.rgby_mask[1] == kRgbyA &&
            rs.rgby_mask[2] == kRgbyA && rs.end_mask[0] == kEndA0 && rs.end_mask[1] == kEndA1 && rs.end_mask[2] == kEndA2;
     if (*two) {
         std::memcpy(w->rgby, rs.rgby_w, sizeof(rs.rgby_w));

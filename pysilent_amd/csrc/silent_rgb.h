@@ -356,7 +356,29 @@ __global__ __launch_bounds__(256) void rgb_line_end_kernel(const RgbArgs args) {
             s7[5] = from_lane_above(s7[4]);
             s7[6] = from_lane_above(s7[5]);
             float bdone;
-            {
+            if constexpr (RGBY_A != kDense && END_A0 != kDense) {
+                // mirror-symmetric blur, folded exactly like rgb_line_end2_kernel's (silent_rgb2.h): same operations, same order
+                kfloat_p kb = wp + 4 * 81;
+                __builtin_amdgcn_sched_barrier(0);
+                asm volatile("" : "+s"(kb));
+                const float F[4] = {s7[0] + s7[6], s7[1] + s7[5], s7[2] + s7[4], s7[3]};
+                float P[4];
+#pragma unroll
+                for (int d = 0; d < 4; ++d) P[d] = F[0] * kb[(3 + d) * 7 + 0];
+#pragma unroll
+                for (int j = 1; j < 4; ++j)
+#pragma unroll
+                    for (int d = 0; d < 4; ++d) P[d] = __builtin_fmaf(F[j], kb[(3 + d) * 7 + j], P[d]);
+                asm volatile("" : "+v"(P[0]), "+v"(P[1]), "+v"(P[2]), "+v"(P[3]));
+                bdone = pb[0] + P[3];
+                pb[0] = pb[1] + P[2];
+                pb[1] = pb[2] + P[1];
+                pb[2] = pb[3] + P[0];
+                pb[3] = pb[4] + P[1];
+                pb[4] = pb[5] + P[2];
+                pb[5] = P[3];
+                pb[6] = 0.0f;
+            } else {
                 // output row q-3+k takes kernel row dy = 6 - k from this stripe row
                 float nb[7];
 #pragma unroll

@@ -63,7 +63,10 @@ struct Rgb2Layout {
     static constexpr int n_rgc = 9 * rgb2_popc(RGC_PAIRS & 0x1ffu);
     static constexpr int n_rgby = RGBY_TWO ? 45 : 81;
     static constexpr int n_stripe = STRIPE_SUM ? 27 : 81;
-    static constexpr int n_blur = 49;
+    // the two-group instantiation also takes the blur in its MIRROR-SYMMETRIC form (host-checked, blur_tensor's profile is a
+    // function of the distance): 16 weights w[|dy|][min(dx, 6 - dx)] instead of 49, see the blur stage of the kernel
+    static constexpr bool blur_sym = RGBY_TWO && END_TWO;
+    static constexpr int n_blur = blur_sym ? 16 : 49;
     static constexpr int n_end = END_TWO ? 45 : 81;
     static constexpr int b_rgc = 0, b_rgby = b_rgc + n_rgc, b_stripe = b_rgby + n_rgby, b_blur = b_stripe + n_stripe,
                          b_end = b_blur + n_blur, total = b_end + n_end;
@@ -79,6 +82,7 @@ constexpr int rgb2_conv_pos(unsigned pairs, int o, int dy, int dx, int i) {
 }
 // host side: fill the stream from the RgbW block (same enumeration as the kernel's)
 inline int rgb2_fill_stream(const RgbW& w, unsigned rgc_pairs, bool stripe_sum, bool rgby_two, bool end_two, float* out) {
+    const bool blur_sym = rgby_two && end_two;   // (Rgb2Layout::blur_sym; the host only picks the two-group form for a symmetric blur)
     int n = 0;
     auto conv = [&](const float* k, unsigned pairs) {  // k: [o][dy][dx][i]
         const int base = n;
@@ -108,9 +112,15 @@ inline int rgb2_fill_stream(const RgbW& w, unsigned rgc_pairs, bool stripe_sum, 
     } else {
         conv(w.stripe, 0x1ffu);
     }
-    for (int dx = 0; dx < 7; ++dx)
-        for (int k = 0; k < 7; ++k) out[n + dx * 7 + k] = w.blur[(6 - k) * 7 + dx];
-    n += 49;
+    if (blur_sym) {   // for folded column j = 0..3 (dx = j and 6 - j): for d = |dy| = 0..3
+        for (int j = 0; j < 4; ++j)
+            for (int d = 0; d < 4; ++d) out[n + j * 4 + d] = w.blur[(3 + d) * 7 + j];
+        n += 16;
+    } else {
+        for (int dx = 0; dx < 7; ++dx)
+            for (int k = 0; k < 7; ++k) out[n + dx * 7 + k] = w.blur[(6 - k) * 7 + dx];
+        n += 49;
+    }
     if (end_two) two(w.end);
     else conv(w.end, 0x1ffu);
     const int total = n;
@@ -529,8 +539,31 @@ __global__ __launch_bounds__(64 * kRgb2Waves) __attribute__((amdgpu_waves_per_eu
             T[4] = f2{s.y, c};
             T[5] = f2{c, d};
             T[6] = f2{d, f};
-            // the seven pending blur rows advance side by side: for dx: for k (stream order dx * 7 + k)
             f2 nb[7];
+            if constexpr (L::blur_sym) {
+                // Mirror-symmetric blur (w[dy][dx] = w[6 - dy][dx] = w[dy][6 - dx]): fold the columns (3 adds), one partial sum
+                // per |dy| (P[d] = sum_j w[d][j] F[j], 16 packed fmas), and every pending row takes the partial sum of ITS |dy|
+                // (7 adds) -- 26 instead of 49 instructions.  All terms are >= 0 (relu outputs, positive weights), so "the blur
+                // is exactly 0" still means "every value of the window is 0" in this order too.
+                f2 F[4] = {T[0] + T[6], T[1] + T[5], T[2] + T[4], T[3]};
+                f2 P[4];
+                rgb2_for<0, 4>([&](auto jj) {
+                    constexpr int j = decltype(jj)::value;
+                    rgb2_for<0, 4>([&](auto dd) {      // the four chains side by side (stream order j * 4 + d)
+                        constexpr int d = decltype(dd)::value, p = L::b_blur + j * 4 + d;
+                        if constexpr (j == 0) P[d] = ws.template mul<p>(F[0]);
+                        else P[d] = ws.template fma<p>(F[j], P[d]);
+                    });
+                });
+                nb[0] = pb[0] + P[3];
+                nb[1] = pb[1] + P[2];
+                nb[2] = pb[2] + P[1];
+                nb[3] = pb[3] + P[0];
+                nb[4] = pb[4] + P[1];
+                nb[5] = pb[5] + P[2];
+                nb[6] = P[3];
+            } else {
+            // the seven pending blur rows advance side by side: for dx: for k (stream order dx * 7 + k)
             rgb2_for<0, 7>([&](auto xx) {
                 constexpr int dx = decltype(xx)::value;
                 rgb2_for<0, 7>([&](auto kk) {
@@ -543,6 +576,7 @@ __global__ __launch_bounds__(64 * kRgb2Waves) __attribute__((amdgpu_waves_per_eu
                     }
                 });
             });
+            }
             bdone = nb[0];
 #pragma unroll
             for (int k = 0; k < 6; ++k) pb[k] = nb[k + 1];

@@ -70,6 +70,11 @@ class LineEndPipeline(object):
         self.frame_shape = (h, w, self.channels)
         levels = (reference_levels((h, w), center_dimensions, scale) if center_dimensions is not None
                   else classic_levels((h, w), scale, n_levels))
+        self.crop_px = None
+        if center_dimensions is not None:
+            y0 = min(l[0] for l in levels); x0 = min(l[1] for l in levels)
+            y1 = max(l[0] + l[2] for l in levels); x1 = max(l[1] + l[3] for l in levels)
+            self.crop_px = (y1 - y0) * (x1 - x0)
         self.plan = _runtime.PyramidPlan(h, w, self.channels, levels, self.device_index)
         self.extents = self.plan.extents
         self.frame_px = self.plan.frame_px
@@ -120,8 +125,11 @@ class LineEndPipeline(object):
 
     # -- byte accounting -------------------------------------------------------
     def algorithmic_bytes_per_frame(self):
-        """4*[H*W*C (frame read) + P*C (pyramid written) + P*C (pyramid read) + P*sum(C_out returned)]"""
+        """4*[H*W*C (frame read) + P*C (pyramid written) + P*C (pyramid read) + P*sum(C_out returned)]; for crop layouts the
+        frame read is the largest crop any level resamples (the part of the frame the pyramid depends on)."""
         h, w, c = self.frame_shape
+        if self.crop_px is not None:
+            h, w = 1, self.crop_px
         outs = (1 + self.n_orient) if self.mode == "gray" else (3 + (3 if self.orient_map else 0) + (1 if self.value_map else 0))
         return 4 * (h * w * c + 2 * self.frame_px * c + self.frame_px * outs)
 

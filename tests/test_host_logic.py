@@ -201,6 +201,17 @@ def test_rgb_weight_stream_is_the_kernels_consumption_order():
                 b[6 - k, dx] = next(it)
         return b
 
+    def take_blur_folded(it):          # mirror-symmetric form: for j = min(dx, 6 - dx) = 0..3: for d = |dy| = 0..3
+        q = np.zeros((4, 4), np.float32)
+        for j in range(4):
+            for d in range(4):
+                q[d, j] = next(it)
+        b = np.zeros((7, 7), np.float32)
+        for dy in range(7):
+            for dx in range(7):
+                b[dy, dx] = q[abs(dy - 3), min(dx, 6 - dx)]
+        return b
+
     # dense
     stream, n, variant, a = _chain_stream(consts, knobs=1)
     assert (n, variant) == (373, 0) and not np.isnan(stream).any() and not stream[n:].any()
@@ -223,15 +234,20 @@ def test_rgb_weight_stream_is_the_kernels_consumption_order():
     assert next(it, None) is None
     # two-group (what the reference's kernels get)
     stream, n, variant, a = _chain_stream(consts)
-    assert (n, variant) == (193, 2) and len(stream) % 32 == 0 and not stream[n:].any()
+    assert (n, variant) == (27 + 45 + 27 + 16 + 45, 2) and len(stream) % 32 == 0 and not stream[n:].any()
     _, masks = _chain_structure(consts)
     it = iter(stream[:n])
     np.testing.assert_array_equal(take_conv(it, 0x111), a["rgc"] * np.eye(3, dtype=np.float32))
     np.testing.assert_allclose(take_two(it, masks[:3]), a["rgby"], rtol=2e-6, atol=1e-9)
     np.testing.assert_array_equal(take_sum(it), a["stripe"][:, :, 0, :])
-    np.testing.assert_array_equal(take_blur(it), a["blur"][:, :, 0, 0])
+    np.testing.assert_array_equal(take_blur_folded(it), a["blur"][:, :, 0, 0])      # 16 folded weights rebuild all 49
     np.testing.assert_allclose(take_two(it, masks[3:]), a["end"], rtol=2e-6, atol=1e-9)
     assert next(it, None) is None
+    # a blur that is channel-uniform but NOT mirror-symmetric: no folded form, the basic instantiation
+    skew = {k: np.array(v, np.float32) for k, v in consts.items()}
+    skew["blur"][0, 0] *= 2.0
+    stream, n, variant, a = _chain_stream(skew)
+    assert (n, variant) == (27 + 81 + 27 + 49 + 81, 1)
     # generic weights: the dense stream whatever the knobs say
     rng = np.random.default_rng(3)
     noise = {k: rng.standard_normal(np.shape(v)).astype(np.float32) for k, v in consts.items()}
