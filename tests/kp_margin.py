@@ -24,14 +24,17 @@ import silent_oracle as so
 F32 = np.float32
 
 
-def chain_maps(level, kernels, flat_policy="ieee", pad=2):
-    """line_end (padded) of one pyramid level [1, h, w, 3] through the C oracle (bit-identical to the NumPy one)."""
+def chain_maps(level, kernels, flat_policy="ieee", pad=2, chain=None):
+    """line_end (padded) of one pyramid level [1, h, w, 3] through the C oracle (bit-identical to the NumPy one); ``chain``:
+    optional dict that receives every intermediate map (the keys of silent_oracle.rgb_line_end_chain)."""
+    chain = {} if chain is None else chain
     x = level
     for name in ("rgc", "rgby", "stripe"):
-        x = co.conv2d_same(x, kernels[name], relu=True)
-    orient = co.regulate(x, kernels["blur"], 1.0, 0.1, flat_policy)
-    line = co.conv2d_same(orient, kernels["end"], relu=True, clip_hi=255.0)
-    return co.pad_inwards(line, [[0, 0], [pad, pad], [pad, pad], [0, 0]])
+        x = chain[name] = co.conv2d_same(x, kernels[name], relu=True)
+    orient = chain["orient"] = co.regulate(x, kernels["blur"], 1.0, 0.1, flat_policy)
+    line = chain["line_end"] = co.conv2d_same(orient, kernels["end"], relu=True, clip_hi=255.0)
+    chain["padded"] = co.pad_inwards(line, [[0, 0], [pad, pad], [pad, pad], [0, 0]])
+    return chain["padded"]
 
 
 def selection_of(line, top_percent=0.1):
@@ -96,13 +99,17 @@ def level_margins(line, top_percent=0.1, tiny=1e-3):
     return out, pv
 
 
-def oracle_keypoints(frame, n_levels, kernels, flat_policy="ieee", top_percent=0.1, scale=2.0):
+def oracle_keypoints(frame, n_levels, kernels, flat_policy="ieee", top_percent=0.1, scale=2.0, keep=None):
+    """keep: optional list that receives (pyramid level, dict of the oracle's chain maps) of every level."""
     h, w, _ = frame.shape
     extents = so.classic_extents(h, w, scale, n_levels)
     pyr = co.classic_pyramid(frame, extents)
     rows, margins = [], []
     for l, lev in enumerate(pyr):
-        line = chain_maps(lev, kernels, flat_policy)
+        chain = {}
+        line = chain_maps(lev, kernels, flat_policy, chain=chain)
+        if keep is not None:
+            keep.append((lev, chain))
         m, pv = level_margins(line, top_percent)
         lh, lw = extents[l]
         r = co.max_value_indices_region(None, (1, max(lh // 2, 1), max(lw // 2, 1), 3), pv)
