@@ -299,7 +299,56 @@ def case_rgb_keypoints(rng, k):
     return desc
 
 
-CASES = {"gray_pass": case_gray_pass, "rgb": case_rgb, "select": case_select, "ops": case_ops, "rgb_keypoints": case_rgb_keypoints}
+def case_sparse_tail(rng, k):
+    """silent_rgb_keypoints with the sparse keypoint tail (no peak-value map) against the same call with the map (dense
+    kernels): identical keypoints on random extents, level counts, tile heights, thresholds, policies and frame kinds
+    (noise, line drawings, plateaus with ties, black / constant frames, NaN / inf pixels)."""
+    import torch
+    from pysilent_amd.pipeline import LineEndPipeline
+    h, w = int(rng.integers(8, 260)), int(rng.integers(8, 420))
+    if rng.integers(0, 5) == 0:
+        w = int(rng.choice([111, 112, 113, 223, 224, 225, 337])) + int(rng.integers(-1, 2))
+    n, B = int(rng.integers(1, 6)), int(rng.integers(1, 4))
+    th = int(rng.choice([0, 0, 0, 7, 9, 16, 20, 33, 45]))
+    kr = (th << 8) | int(rng.choice([0, 0, 0, 8]))
+    policy = "zero" if rng.integers(0, 2) else "ieee"
+    p = float(rng.choice([0.0, 0.1, 0.1, 0.1, 0.37, 0.9, 1.0]))
+    desc = "sparse_tail h=%d w=%d n=%d B=%d knob=%d %s p=%g" % (h, w, n, B, kr, policy, p)
+    try:
+        consts = {x: k[x] for x in ("rgc", "rgby", "stripe", "blur", "end")}
+        kw = dict(mode="rgb", n_levels=n, batch=B, selection=True, top_percent=p, flat_policy=policy, constants=consts,
+                  max_keypoints_per_frame=h * w * 2, value_map=False)
+        sparse = LineEndPipeline((h, w), peak_value_map=False, **kw)
+        dense = LineEndPipeline((h, w), peak_value_map=True, **kw)
+    except ValueError as e:
+        return desc + " (no such pyramid)" if "pyramid" in str(e) or "level" in str(e) else desc + " (plan refused: %s)" % str(e)[:60]
+    frames = np.stack([frame(rng, h, w, 3) for _ in range(B)])
+    kind = rng.integers(0, 8)
+    if kind == 0:
+        frames[0] = 0.0
+    elif kind == 1:
+        frames[0] = float(rng.integers(1, 255))
+    elif kind == 2:
+        frames[0, int(rng.integers(0, h)), int(rng.integers(0, w)), int(rng.integers(0, 3))] = rng.choice([np.nan, np.inf, -np.inf])
+    t = torch.from_numpy(frames).cuda()
+    rt.get_context().set_tuning(_lib.TUNE_RGB, kr)
+    sparse.step(t)
+    stats = sparse.sparse_tail_stats()
+    dense.step(t)
+    torch.cuda.synchronize()
+    rt.get_context().set_tuning(_lib.TUNE_RGB, 0)
+    assert stats["ran"], desc
+    a, b = sparse.outputs(allow_truncated=True), dense.outputs(allow_truncated=True)
+    np.testing.assert_array_equal(a["keypoint_counts"], b["keypoint_counts"], err_msg=desc)
+    for f in range(B):
+        np.testing.assert_array_equal(a["keypoints"][f], b["keypoints"][f], err_msg=desc)
+    x, y = a["line_end"].data.cpu().numpy(), b["line_end"].data.cpu().numpy()
+    np.testing.assert_array_equal(np.nan_to_num(x, nan=7.0), np.nan_to_num(y, nan=7.0), err_msg=desc + " line_end")
+    return desc + " [dense %d zero %d of %d]" % (stats["dense_pairs"], stats["zero_map_pairs"], stats["pairs"])
+
+
+CASES = {"gray_pass": case_gray_pass, "rgb": case_rgb, "select": case_select, "ops": case_ops, "rgb_keypoints": case_rgb_keypoints,
+         "sparse_tail": case_sparse_tail}
 BIG = {"big": case_big}
 
 

@@ -1,13 +1,43 @@
 #!/usr/bin/env python3
-"""Turn the rocprofv3 outputs of scripts/profile_bench.sh into the small committed summaries under profiles/<tag>/."""
-import collections, csv, json, os, shutil, sys
+"""Turn the rocprofv3 outputs of scripts/profile_bench.sh into the small committed summaries under profiles/<tag>/.
 
-tag = sys.argv[1] if len(sys.argv) > 1 else "r01"
-frames = int(sys.argv[2]) if len(sys.argv) > 2 else 64
+    python scripts/summarize_profile.py <tag> <frames per dispatch> [run ...] [--kernel SUBSTR]
+
+Every ``run`` is the tag of one profile_bench.sh call (gpurun_out/prof_<run>/), normally one per gpurun call = one box.  The
+pool's boxes differ by up to 8 % on the same binary, so the summary that is committed is the one of the MEDIAN run by the
+dominant kernel's average duration -- never the best -- and profiles/<tag>/README.md lists the average of every run.
+Without runs: the single call gpurun_out/prof_<tag>/."""
+import collections
+import csv
+import json
+import os
+import shutil
+import sys
+
+args = [a for a in sys.argv[1:] if not a.startswith("--")]
+kernel_sub = "gray_stream_kernel"
+if "--kernel" in sys.argv:
+    kernel_sub = sys.argv[sys.argv.index("--kernel") + 1]
+    args.remove(kernel_sub)
+tag = args[0] if args else "r01"
+frames = int(args[1]) if len(args) > 1 else 64
+runs = args[2:] or [tag]
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-P = os.path.join(root, "gpurun_out", "prof_" + tag)
 out = os.path.join(root, "profiles", tag)
 os.makedirs(out, exist_ok=True)
+
+
+def stats_of(run):
+    p = os.path.join(root, "gpurun_out", "prof_" + run, "trace", "trace_kernel_stats.csv")
+    rows = list(csv.DictReader(open(p)))
+    dom = [r for r in rows if kernel_sub in r["Name"]]
+    return (float(dom[0]["AverageNs"]) / 1e3 if dom else float("nan")), rows
+
+
+per_run = {r: stats_of(r) for r in runs}
+order = sorted(runs, key=lambda r: per_run[r][0])
+median = order[len(order) // 2] if len(order) % 2 else order[len(order) // 2 - 1]      # (even count: the lower middle)
+P = os.path.join(root, "gpurun_out", "prof_" + median)
 shutil.copy(os.path.join(P, "trace", "trace_kernel_stats.csv"), os.path.join(out, "kernel_stats.csv"))
 try:
     shutil.copy(os.path.join(P, "trace", "trace_agent_info.csv"), os.path.join(out, "agent_info.csv"))
@@ -16,7 +46,11 @@ except OSError:
 summ = {}
 for name, f in (("FETCH_SIZE", "pmc_fetch/fetch_counter_collection.csv"), ("WRITE_SIZE", "pmc_write/write_counter_collection.csv")):
     agg = collections.defaultdict(list)
-    for r in csv.DictReader(open(os.path.join(P, f))):
+    try:
+        rows = csv.DictReader(open(os.path.join(P, f)))
+    except OSError:
+        continue
+    for r in rows:
         if r["Counter_Name"] == name:
             agg[r["Kernel_Name"]].append(float(r["Counter_Value"]))
     for k, v in agg.items():
@@ -33,6 +67,10 @@ with open(os.path.join(out, "kernel_trace_silent.csv"), "w") as fh:
     w.writerow(cols + ["Duration_ns"])
     for r in rows:
         w.writerow([r.get(c, "") for c in cols] + [int(r["End_Timestamp"]) - int(r["Start_Timestamp"])])
+with open(os.path.join(out, "runs.json"), "w") as fh:
+    json.dump({"dominant_kernel": kernel_sub, "average_us_per_run": {r: round(per_run[r][0], 2) for r in runs}, "median_run": median,
+               "csrc_revision": bench.csrc_revision()}, fh, indent=1)
+print("runs (average us of %s): %s -> median run %s" % (kernel_sub, {r: round(per_run[r][0], 1) for r in runs}, median))
 for line in open(os.path.join(out, "kernel_stats.csv")):
     print(line.strip()[:150])
 for k, v in summ.items():
