@@ -94,6 +94,7 @@ _SIGNATURES = {
     "silent_gray_pass": [_vp, _vp, _fp, _i, _fp, _fp, _i, _f, _fp, _fp, _fp],
     "silent_gray_pass_dev": [_vp, _vp, _fp, _i, _fp, _fp, _i, _f, _fp, _fp, _fp, _vp],
     "silent_pyramid_plan_is_streamable": [_vp],
+    "silent_pyramid_plan_walk_plans": [_vp, C.POINTER(C.c_int)],
     "silent_gather_d2h": [_vp, _vp, C.POINTER(C.c_void_p), C.POINTER(C.c_size_t), _i, _vp],
     "silent_set_profiling": [_vp, _i],
     "silent_set_tuning": [_vp, _i, _u],

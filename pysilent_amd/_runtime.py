@@ -637,6 +637,13 @@ class PyramidPlan(object):
         """True when silent_gray_pass takes the single-read stream kernel for this plan."""
         return bool(_lib.load().silent_pyramid_plan_is_streamable(self.handle))
 
+    @property
+    def walk_plans(self):
+        """(number of walk plans, pixels per consumer wave) of a 3-channel plan; (0, 0): unit + region kernels."""
+        px = C.c_int(0)
+        n = _lib.load().silent_pyramid_plan_walk_plans(self.handle, C.byref(px))
+        return int(n), int(px.value)
+
     def gray_pass(self, frames, cs_kernel, end_bank, clip_hi=255.0):
         """Whole grayscale hot path (silent_gray_pass): frames [n,H,W,1] -> (pyramid, cs, end) PackedPyramids.
         Same results as run() + gray_line_end(), one pass less over level 0."""

@@ -17,8 +17,16 @@
 //     completed row goes through a wave-private LDS line, and lane 3j + c gathers the 6 taps of channel c of output pixel j
 //     (3 floats apart) with column records staged in LDS -- the arithmetic order of the region kernel, bit-identical.
 // Same protocol as the gray walk: one raw s_barrier per chunk, uniform trip counts, the consumers' vmcnt queue holds
-// stores only.  Eligibility (host): one unit level, every other level resamples its crop with a zoom step >= 1.875,
-// W, src_x0, src_w multiples of 4, out_w even, even pyramid offsets.
+// stores only.
+// Round 3: a launch runs up to kW3MaxPlans WALK PLANS side by side (block -> frame, plan, segment, strip).  A plan is one crop
+// of the frame with an optional unit level and the general levels that resample THAT crop.  A classic pyramid is one plan
+// (unit level + every other level on the whole frame).  The reference's layout (image_to_zoom_tensor, from_image.py:45-64:
+// nested centre crops, each resampled to one fixed size) is one plan per level: the unit level on the innermost crop, every
+// other level alone on its own crop -- each mirrors at ITS crop's edge exactly like scipy does on the cropped array, and the
+// nested re-reads of one frame sit next to each other in the launch (Infinity Cache).  The ring row is addressed in floats
+// of the FRAME row from a 16-byte aligned origin (any crop offset), PX = 36 or 32 pixels per consumer wave (32: zoom steps
+// down to 1.6, the reference's e ** .5).  Eligibility (host): W a multiple of 4, <= 21 outputs per wave tile and level,
+// unit levels with even out_w and even pyramid offsets.
 #pragma once
 
 #include <type_traits>
@@ -65,43 +73,74 @@ typedef __attribute__((address_space(3))) void* walk_lds_ptr;
 typedef const __attribute__((address_space(1))) void* walk_glb_ptr;
 
 constexpr int kW3NC = 4;                        // consumer waves per block
-constexpr int kW3Px = 36;                       // pixels per consumer wave
-constexpr int kW3StripPx = kW3NC * kW3Px;       // 144 pixels per block
-constexpr int kW3HaloL = 4, kW3HaloR = 3;       // ring halo in pixels (left one keeps the ring row 16-byte aligned)
+constexpr int kW3HaloL = 4, kW3HaloR = 3;       // ring halo in pixels
+constexpr int kW3MaxPlans = 8;                  // walk plans per launch
 constexpr int kW3TileL = 2;                     // a wave's line starts 2 pixels left of its first pixel ...
 constexpr int kW3TileF = 124;                   // ... and holds 124 floats (41 pixels + 1 float): taps -2 .. +3 of its anchors
-constexpr int kW3RowF = 456;                    // floats per ring row ((144 + 7) * 3 = 453 used)
+constexpr int kW3RowF = 456;                    // floats per ring row ((144 + 7) * 3 = 453 used, + up to 3 of alignment shift)
 constexpr int kW3Threads = (kW3NC + 1) * 64;
 constexpr int kW3CH = 4;                        // rows per chunk: a 12-row ring (22 KB) instead of 24 rows -- the loader is far from
                                                 // being the limit (all loads alone: 0.14 ms), the consumers are latency-bound and
                                                 // want waves: 31 KB of LDS per block = 4 blocks (16 consumer waves) per CU instead of 3
-// column records per wave tile and level (output PIXELS anchored in a wave's 36 pixels at zoom step >= 1.875 ^ (g + 1))
-__host__ __device__ constexpr int w3_rec_cap(int g) { return g == 0 ? 21 : (g == 1 ? 11 : (g == 2 ? 6 : (g == 3 ? 4 : (g <= 5 ? 2 : 1)))); }
-__host__ __device__ constexpr int w3_rec_base(int g) {
+// column records per wave tile and level: output PIXELS anchored in a wave's PX pixels (36: zoom steps >= 1.875 ^ (g + 1);
+// 32: >= 1.6 ^ (g + 1)); never more than 21 (the gather works on lane 3 j + c)
+__host__ __device__ constexpr int w3_rec_cap(int px, int g) {
+    return px == 36 ? (g == 0 ? 21 : (g == 1 ? 11 : (g == 2 ? 6 : (g == 3 ? 4 : (g <= 5 ? 2 : 1)))))
+                    : (g == 0 ? 21 : (g == 1 ? 14 : (g == 2 ? 9 : (g == 3 ? 6 : (g == 4 ? 5 : 3)))));
+}
+__host__ __device__ constexpr int w3_rec_base(int px, int g) {
     int n = 0;
-    for (int i = 0; i < g; ++i) n += w3_rec_cap(i);
+    for (int i = 0; i < g; ++i) n += w3_rec_cap(px, i);
     return n;
 }
-__host__ __device__ constexpr int w3_rec_total(int g) { return w3_rec_base(g); }
+__host__ __device__ constexpr int w3_rec_total(int px, int g) { return w3_rec_base(px, g); }
+
+// one walk plan (see the header)
+struct Walk3Plan {
+    int src_y0, src_x0, src_h, src_w;    // the crop this plan walks (frame coordinates)
+    int shift;                           // (src_x0 * 3) mod 4: floats between the aligned ring origin and the crop's pixel - 4
+    int has_unit;                        // the plan stores a unit (zoom 1) level
+    int out_h, out_w, eff_h, eff_w;      // walk extents: the unit level's canvas and the part the crop covers (no unit level: the crop)
+    int strips_x, segs_y, seg_rows;      // decomposition of this plan
+    int block0;                          // first block of this plan among one frame's blocks
+    long long px_off;                    // offset of the unit level in one pyramid
+    WalkPyr pyr;                         // general levels of this plan (G may be 0)
+};
+struct Walk3Args {
+    int H, W;                            // frame extents
+    int n_plans, blocks_per_frame;
+    long long frame_px;                  // pixels of one pyramid
+    float wx[5];                         // [1, 26, 66, 26, 1] / 120 as float32 (both axes)
+    Walk3Plan plan[kW3MaxPlans];
+};
 // row record of the walk: [meta(0) .. meta(Gp-1)] [6 weights of level 0] ... [6 weights of level Gp-1], padded to a multiple
 // of 4 dwords.  meta: bit 0 "an output row of this level completes with this source row", bits 8.. that output row.
 __host__ __device__ constexpr int w3_prog_row(int gp) { return (gp * 7 + 3) / 4 * 4; }
 
-template <int G>
+template <int G, int PX>
 __global__ __launch_bounds__(kW3Threads) void pyramid_walk3_kernel(const float* __restrict__ frames, float* __restrict__ pyr,
-                                                                    const WalkTab tab, const WalkPyr wp) {
+                                                                    const Walk3Args args) {
     static_assert(G == stream_pad_levels(G), "row programs are padded to 4 or 7 levels");
+    static_assert(PX == 36 || PX == 32, "");
+    constexpr int kW3Px = PX, kW3StripPx = kW3NC * PX;
     constexpr int PR = w3_prog_row(G);
+    constexpr int kRecTotal = w3_rec_total(PX, G);
     __shared__ __attribute__((aligned(16))) float s_ring[kWalkSlots * kW3CH][kW3RowF];          // 43.8 KB
     __shared__ __attribute__((aligned(16))) int s_prog[kWalkSlots * kW3CH * PR];                // row records of the ring's chunks
     __shared__ __attribute__((aligned(16))) float s_line[kW3NC * 128];                            // a completed row, per wave
-    __shared__ __attribute__((aligned(16))) int s_rec[kW3NC * w3_rec_total(G) * 8];               // column records, per wave
+    __shared__ __attribute__((aligned(16))) int s_rec[kW3NC * kRecTotal * 8];                     // column records, per wave
 
-    const unsigned bid = blockIdx.x;
-    const int strip = (int)(bid % (unsigned)tab.strips_x);
-    const unsigned rest = bid / (unsigned)tab.strips_x;
-    const int seg = (int)(rest % (unsigned)tab.segs_y);
-    const int frame = (int)(rest / (unsigned)tab.segs_y);
+    const int frame = (int)(blockIdx.x / (unsigned)args.blocks_per_frame);
+    int rest = (int)(blockIdx.x - (unsigned)frame * (unsigned)args.blocks_per_frame);
+    int pi = 0;
+#pragma unroll
+    for (int i = 1; i < kW3MaxPlans; ++i)
+        if (i < args.n_plans && rest >= args.plan[i].block0) pi = i;
+    const Walk3Plan& tab = args.plan[pi];          // (scalar loads: the plan index is block-uniform)
+    const WalkPyr& wp = tab.pyr;
+    rest -= tab.block0;
+    const int strip = rest % tab.strips_x;
+    const int seg = rest / tab.strips_x;
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int seg_y0 = seg * tab.seg_rows;
@@ -113,17 +152,19 @@ __global__ __launch_bounds__(kW3Threads) void pyramid_walk3_kernel(const float* 
 
     if (wave == kW3NC) {
         // ------------------------------------------------------------------ loader: LDS-DMA only
-        const float* __restrict__ src = frames + (long long)frame * tab.H * tab.W * 3;
-        const int rowf = tab.src_w * 3;                        // floats of a crop row (multiple of 4: host-checked)
-        // 4-float groups are aligned in the row, so a group lies wholly inside the crop or wholly outside; outside groups are
-        // clamped to a valid address and never read (the consumers read mirrored pixels instead)
-        const int f0 = min(max(R0 * 3 + lane * 4, 0), rowf - 4) + tab.src_x0 * 3;
-        const int f1 = min(max(R0 * 3 + 256 + lane * 4, 0), rowf - 4) + tab.src_x0 * 3;
+        const float* __restrict__ src = frames + (long long)frame * args.H * args.W * 3;
+        const int rowf = args.W * 3;                           // floats of a FRAME row (multiple of 4: host-checked)
+        // ring float r <-> frame-row float A + r, A = the crop's pixel R0 minus the alignment shift: a multiple of 4, so every
+        // 4-float group is a 16-byte aligned piece of the frame row.  Groups that stick out of the row are clamped to a valid
+        // address; whatever lies outside the CROP is never read (the consumers read mirrored pixels instead)
+        const int A = (tab.src_x0 + R0) * 3 - tab.shift;
+        const int f0 = min(max(A + lane * 4, 0), rowf - 4);
+        const int f1 = min(max(A + 256 + lane * 4, 0), rowf - 4);
         auto issue = [&](int c, int slot) {
 #pragma unroll
             for (int r = 0; r < kW3CH; ++r) {
                 const int y = seg_y0 - 4 + c * kW3CH + r;
-                const float* rp = src + (long long)(mirror_near(y, tab.src_h) + tab.src_y0) * tab.W * 3;
+                const float* rp = src + (long long)(mirror_near(y, tab.src_h) + tab.src_y0) * args.W * 3;
                 float* dst = &s_ring[slot * kW3CH + r][0];
                 __builtin_amdgcn_global_load_lds((walk_glb_ptr)(rp + f0), (walk_lds_ptr)dst, 16, 0, 0);
                 if (lane < (kW3RowF - 256) / 4)
@@ -163,30 +204,32 @@ __global__ __launch_bounds__(kW3Threads) void pyramid_walk3_kernel(const float* 
         px[k] = p;
 #pragma unroll
         for (int d = 0; d < 5; ++d)
-            off[k][d] = min(max((mirror_near(p + d - 2, tab.src_w) - R0) * 3 + c, 0), kW3RowF - 1);
+            off[k][d] = min(max((mirror_near(p + d - 2, tab.src_w) - R0) * 3 + c + tab.shift, 0), kW3RowF - 1);
     }
     const bool out_lane = px[0] >= wx0 && px[1] < wx0 + kW3Px && px[1] < tab.out_w && lane < 62;   // both floats or neither
     const bool eff0 = px[0] < tab.eff_w, eff1 = px[1] < tab.eff_w;
-    const long long base_f = ((long long)frame * tab.frame_px + tab.px_off) * 3 + (long long)(wx0 - kW3TileL) * 3 + 2 * lane;
+    const long long base_f = ((long long)frame * args.frame_px + tab.px_off) * 3 + (long long)(wx0 - kW3TileL) * 3 + 2 * lane;
+    const bool has_unit = tab.has_unit != 0;                    // block-uniform
 
     float hist[6][2];                                           // the lane's two floats on the last 6 source rows
 #pragma unroll
     for (int j = 0; j < 6; ++j) hist[j][0] = hist[j][1] = 0.0f;
     int gx0[G], gn[G];
-    const long long frame_px0 = (long long)frame * tab.frame_px;
-    int* const my_rec = s_rec + wave * (w3_rec_total(G) * 8);
+    const long long frame_px0 = (long long)frame * args.frame_px;
+    int* const my_rec = s_rec + wave * (kRecTotal * 8);
     float* const my_line = s_line + wave * 128;
     {
         const int wx_tile = strip * kW3NC + wave;
-        const int4* __restrict__ src4 = reinterpret_cast<const int4*>(wp.col_rec) + (long long)wx_tile * (w3_rec_total(G) * 2);
+        const int4* __restrict__ src4 = reinterpret_cast<const int4*>(wp.col_rec) + (long long)wx_tile * (kRecTotal * 2);
         int4* dst4 = reinterpret_cast<int4*>(my_rec);
-        for (int i = lane; i < w3_rec_total(G) * 2; i += 64) dst4[i] = src4[i];
+        if (wp.G > 0)
+            for (int i = lane; i < kRecTotal * 2; i += 64) dst4[i] = src4[i];
         typedef const __attribute__((address_space(4))) int* const_int_ptr;
 #pragma unroll
         for (int g = 0; g < G; ++g) {
-            const int gg = min(g, wp.G - 1);
+            const int gg = max(min(g, wp.G - 1), 0);
             const_int_ptr h = (const_int_ptr)(wp.col_hdr + ((long long)gg * (tab.strips_x * kW3NC) + wx_tile) * 2);
-            gx0[g] = h[0];
+            gx0[g] = wp.G > 0 ? h[0] : 0;
             gn[g] = g < wp.G ? h[1] : 0;
         }
         asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");   // records staged (the only vector loads of a consumer)
@@ -221,24 +264,26 @@ __global__ __launch_bounds__(kW3Threads) void pyramid_walk3_kernel(const float* 
                     meta_v[4 * e] = q.x; meta_v[4 * e + 1] = q.y; meta_v[4 * e + 2] = q.z; meta_v[4 * e + 3] = q.w;
                 }
                 // ---- unit level: horizontal 5 taps (same fma order as pyramid_unit_kernel), then the vertical window
+                if (has_unit) {
 #pragma unroll
                 for (int k = 0; k < 2; ++k) {
-                    float h = tab.wx[0] * t[k][0];
-                    h = __builtin_fmaf(tab.wx[1], t[k][1], h);
-                    h = __builtin_fmaf(tab.wx[2], t[k][2], h);
-                    h = __builtin_fmaf(tab.wx[3], t[k][3], h);
-                    h = __builtin_fmaf(tab.wx[4], t[k][4], h);
+                    float h = args.wx[0] * t[k][0];
+                    h = __builtin_fmaf(args.wx[1], t[k][1], h);
+                    h = __builtin_fmaf(args.wx[2], t[k][2], h);
+                    h = __builtin_fmaf(args.wx[3], t[k][3], h);
+                    h = __builtin_fmaf(args.wx[4], t[k][4], h);
 #pragma unroll
                     for (int j = 0; j < 4; ++j) hw[j][k] = hw[j + 1][k];
                     hw[4][k] = h;
                 }
+                }
                 const int p = seg_y0 + s - 6;                   // level-0 row that completes with source row y = p + 2
-                if (p >= seg_y0 && p < seg_y0 + seg_h) {        // wave-uniform (rows above are warm-up)
-                    float v0 = tab.wx[0] * hw[0][0], v1 = tab.wx[0] * hw[0][1];
+                if (has_unit && p >= seg_y0 && p < seg_y0 + seg_h) {        // wave-uniform (rows above are warm-up)
+                    float v0 = args.wx[0] * hw[0][0], v1 = args.wx[0] * hw[0][1];
 #pragma unroll
                     for (int j = 1; j < 5; ++j) {
-                        v0 = __builtin_fmaf(tab.wx[j], hw[j][0], v0);
-                        v1 = __builtin_fmaf(tab.wx[j], hw[j][1], v1);
+                        v0 = __builtin_fmaf(args.wx[j], hw[j][0], v0);
+                        v1 = __builtin_fmaf(args.wx[j], hw[j][1], v1);
                     }
                     const bool prow = p < tab.eff_h;
                     v0 = (prow && eff0) ? v0 : 0.0f;            // canvas beyond the zoomed crop
@@ -263,8 +308,8 @@ __global__ __launch_bounds__(kW3Threads) void pyramid_walk3_kernel(const float* 
                         const int meta = __builtin_amdgcn_readfirstlane(meta_v[g]);
                         if (!(meta & 1)) return;                // wave-uniform: no row of level g completes here
                         const int oy = meta >> 8;
-                        const int jj = min(gj, w3_rec_cap(g) - 1);
-                        const int4* __restrict__ rc = reinterpret_cast<const int4*>(my_rec + (w3_rec_base(g) + jj) * 8);
+                        const int jj = min(gj, w3_rec_cap(PX, g) - 1);
+                        const int4* __restrict__ rc = reinterpret_cast<const int4*>(my_rec + (w3_rec_base(PX, g) + jj) * 8);
                         const int4 ra = rc[0], rb = rc[1];
                         const float* __restrict__ wv = reinterpret_cast<const float*>(prow + G + 6 * g);   // 6 vertical weights (broadcast)
                         float v0 = __builtin_fmaf(wv[0], hist[0][0], 0.0f), v1 = __builtin_fmaf(wv[0], hist[0][1], 0.0f);

@@ -1465,6 +1465,7 @@ def test_rgb_pyramid_walk_is_bit_identical_to_unit_plus_region_kernels(rt, shape
     frames[0, shape[0] // 2, shape[1] // 3, 1] = np.nan
     frames[B - 1, 0, 0, 2] = np.inf
     plan = rt.PyramidPlan(shape[0], shape[1], 3, classic_levels(shape[:2], scale, n))
+    assert plan.walk_plans == ((1, 36 if scale >= 1.875 else 32) if shape[1] % 4 == 0 and n > 1 else (0, 0))
     got = plan.run(frames)
     with rt.tuning(TUNE_PYRAMID, 2):
         two = plan.run(frames)
@@ -1474,6 +1475,54 @@ def test_rgb_pyramid_walk_is_bit_identical_to_unit_plus_region_kernels(rt, shape
     res = plan.run(clean[None])
     for l in range(n):
         assert_close(res.level(l), want[l], RTOL, scale=255.0, what="rgb walk level %d" % l, bound=eb.zoom(want[l]))
+
+
+@pytest.mark.parametrize("shape,center,scale,B", [((1080, 1920, 3), (288, 192), math.e ** .5, 2),    # the reference's defaults on 1080p: 4 plans
+                                                  ((480, 640, 3), (288, 192), math.e ** .5, 3),      # ... on its 640 x 480 camera frame: 2 plans
+                                                  ((480, 640, 3), (160, 120), math.e ** .5, 1),      # 3 levels
+                                                  ((270, 480, 3), (62, 45), 2.0, 2),                 # odd crop offsets (alignment shift 1..3)
+                                                  ((300, 500, 3), (100, 37), 1.7, 2),                # one axis clips first
+                                                  ((97, 132, 3), (32, 24), 1.7, 1)])
+def test_rgb_pyramid_walk_on_the_references_crop_layout(rt, shape, center, scale, B):
+    """The reference's own pyramid layout (image_to_zoom_tensor, from_image.py:45-64: nested centre crops resampled to one
+    fixed size) through ONE launch of the strip-walk kernel, one walk plan per level, each mirroring at its own crop's edge
+    like scipy does on the cropped array: every level equal bit for bit to the unit + region kernels (PYRAMID knob 2), and
+    both within tolerance of the oracle (which calls scipy.ndimage.zoom like the reference)."""
+    from pysilent_amd.util.zoom.from_image import reference_levels
+    levels = reference_levels(shape[:2], center, scale)
+    frames = np.stack([noise_frame(80 + s_, *shape) for s_ in range(B)])
+    frames[0, shape[0] // 2, shape[1] // 2, 1] = np.nan          # inside every crop
+    frames[B - 1, shape[0] // 2 - 3, shape[1] // 2 + 5, 0] = np.inf
+    plan = rt.PyramidPlan(shape[0], shape[1], 3, levels)
+    n_plans, px = plan.walk_plans
+    assert n_plans == len(levels) and px in (32, 36), (n_plans, px)
+    got = plan.run(frames)
+    with rt.tuning(TUNE_PYRAMID, 2):
+        two = plan.run(frames)
+    a, b = np.asarray(got.data), np.asarray(two.data)
+    assert np.array_equal(np.isnan(a), np.isnan(b))
+    np.testing.assert_array_equal(np.nan_to_num(a, nan=7.0), np.nan_to_num(b, nan=7.0))
+    clean = noise_frame(98, *shape)
+    want = so.zoom_from_image(clean, 3, center, scale)
+    res = plan.run(clean[None])
+    assert_close(res.data.reshape(want.shape), want, RTOL, scale=255.0, what="reference layout through the walk", bound=eb.zoom(want))
+
+
+@pytest.mark.parametrize("shape,scale,n", [((270, 480, 3), math.e ** .5, 5), ((135, 240, 3), 1.7, 3), ((200, 300, 3), 1.6, 3)])
+def test_rgb_pyramid_walk_takes_zoom_steps_down_to_1_6(rt, shape, scale, n):
+    """Classic pyramids at the reference's zoom ratio e ** .5 (and down to 1.6): 32 instead of 36 pixels per consumer wave keep
+    the outputs per wave tile within the 21 the gather takes; bit-identical to the unit + region kernels."""
+    from pysilent_amd.util.zoom.from_image import classic_levels
+    frames = np.stack([noise_frame(90 + s_, *shape) for s_ in range(2)])
+    plan = rt.PyramidPlan(shape[0], shape[1], 3, classic_levels(shape[:2], scale, n))
+    assert plan.walk_plans == (1, 32)
+    got = plan.run(frames)
+    with rt.tuning(TUNE_PYRAMID, 2):
+        two = plan.run(frames)
+    np.testing.assert_array_equal(got.data, two.data)
+    want = so.classic_pyramid(frames[1], scale, n)
+    for l in range(n):
+        assert_close(got.level(l)[1:2], want[l], RTOL, scale=255.0, what="walk px 32 level %d" % l, bound=eb.zoom(want[l]))
 
 
 def test_workspace_follows_the_callers_stream(rt):
