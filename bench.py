@@ -323,8 +323,10 @@ def side_workload(torch, D, name, local, dev, rank, world, label=None, **over):
     pipe = make_pipeline(wl, B, local, consts, **over)
     frames = make_frames(torch, D, wl, B, rank, world, dev)
     torch.cuda.synchronize(dev)
-    steps = 20
-    elapsed = timed_steps(torch, D, pipe, frames, steps, 5, dev)
+    # 30 untimed steps first: building the pipeline and the synthetic frames leaves the GPU idle for a second or two, and the
+    # first ~20 launches after an idle period run inside the power-management transient (profiles/r02/launch_drift.txt)
+    steps = 30
+    elapsed = timed_steps(torch, D, pipe, frames, steps, 30, dev)
     dom = dominant_kernel(torch, pipe, frames, wl, B, dev, launches=16)
     h, w = wl["hw"]
     whole = pipe.algorithmic_bytes_per_frame() * B * steps / elapsed / 1e9
