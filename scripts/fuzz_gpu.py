@@ -347,8 +347,51 @@ def case_sparse_tail(rng, k):
     return desc + " [dense %d zero %d of %d]" % (stats["dense_pairs"], stats["zero_map_pairs"], stats["pairs"])
 
 
+def case_crop_walk(rng, k):
+    """3-channel pyramids in the reference's crop layout (image_to_zoom_tensor: nested centre crops) and classic ones at small
+    zoom steps: the strip-walk kernel's walk plans against the unit + region kernels (bit for bit) and the oracle."""
+    from pysilent_amd.util.zoom.from_image import reference_levels
+    h, w = int(rng.integers(40, 400)), int(rng.integers(10, 160)) * 4
+    scale = float(rng.choice([1.6, math.e ** .5, 1.7, 2.0, 2.5]))
+    B = int(rng.integers(1, 4))
+    if rng.integers(0, 3) == 0:
+        n = int(rng.integers(2, 6))
+        desc = "crop_walk classic h=%d w=%d scale=%.3f n=%d B=%d" % (h, w, scale, n, B)
+        try:
+            levels = classic_levels((h, w), scale, n)
+        except ValueError:
+            return desc + " (no such pyramid)"
+        want_fn = lambda img: np.concatenate([l.reshape(-1) for l in so.classic_pyramid(img, scale, n)])
+    else:
+        cw, ch = int(rng.integers(4, max(5, w // 2))), int(rng.integers(4, max(5, h // 2)))
+        desc = "crop_walk reference h=%d w=%d center=(%d,%d) scale=%.3f B=%d" % (h, w, cw, ch, scale, B)
+        try:
+            levels = reference_levels((h, w), (cw, ch), scale)
+        except (ValueError, ZeroDivisionError):
+            return desc + " (no such pyramid)"
+        if not levels or len(levels) > 12:
+            return desc + " (no such pyramid)"
+        want_fn = lambda img: so.zoom_from_image(img, 3, (cw, ch), scale).reshape(-1)
+    frames = np.stack([frame(rng, h, w, 3) for _ in range(B)])
+    try:
+        plan = rt.PyramidPlan(h, w, 3, levels)
+    except ValueError as e:
+        return desc + " (plan refused: %s)" % str(e)[:60]
+    n_plans, px = plan.walk_plans
+    got = plan.run(frames)
+    rt.get_context().set_tuning(_lib.TUNE_PYRAMID, 2)
+    two = plan.run(frames)
+    rt.get_context().set_tuning(_lib.TUNE_PYRAMID, 0)
+    np.testing.assert_array_equal(got.data, two.data, err_msg=desc)
+    f = int(rng.integers(0, B))
+    want = want_fn(frames[f])
+    per = got.data.reshape(B, -1)
+    assert_close(per[f], want, RTOL, scale=255.0, what=desc)
+    return desc + (" [walk %d x %d]" % (n_plans, px) if n_plans else " [region]")
+
+
 CASES = {"gray_pass": case_gray_pass, "rgb": case_rgb, "select": case_select, "ops": case_ops, "rgb_keypoints": case_rgb_keypoints,
-         "sparse_tail": case_sparse_tail}
+         "sparse_tail": case_sparse_tail, "crop_walk": case_crop_walk}
 BIG = {"big": case_big}
 
 
@@ -369,7 +412,7 @@ def main():
         try:
             desc = {**CASES, **BIG}[name](np.random.default_rng(sub), k)
             kind = name + " ok"
-            for mark in ("big gray", "big rgb", "(no such pyramid)", "(plan refused", "(keypoints refused", "[stream]", "[region]"):
+            for mark in ("big gray", "big rgb", "(no such pyramid)", "(plan refused", "(keypoints refused", "[stream]", "[region]", "[walk"):
                 if mark in desc:
                     kind = name + " " + mark
             tally[kind] = tally.get(kind, 0) + 1
