@@ -166,8 +166,8 @@ int silent_pyramid_plan_is_streamable(const silent_pyramid_plan* plan);
 /* 3-channel plans: the number of WALK PLANS silent_pyramid runs this pyramid with in ONE launch of the strip-walk kernel (frame rows
  * DMA'd once per crop into an LDS ring): 1 for a classic whole-frame pyramid (unit level + every other level on the same crop), one
  * per level for crop layouts such as the reference's (image_to_zoom_tensor, util/zoom/from_image.py:45-64: nested centre crops); 0
- * when the plan falls back to the unit + region kernels (more than 8 levels of a crop layout, more than 21 outputs per wave tile:
- * zoom steps below 1.6, frame width not a multiple of 4).  pixels_per_wave (may be NULL): 36 or 32. */
+ * when the plan falls back to the unit + region kernels (more than 8 levels of a crop layout; more than 21 outputs per wave tile:
+ * zoom steps below 1.6; frame width not a multiple of 4).  pixels_per_wave (may be NULL): 36 or 32. */
 int silent_pyramid_plan_walk_plans(const silent_pyramid_plan* plan, int* pixels_per_wave);
 
 /* Optional HIP-event timing of the DOMINANT kernel of the last silent_gray_pass_dev call (the fused

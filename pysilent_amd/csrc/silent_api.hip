@@ -1847,8 +1847,8 @@ SILENT_EXPORT int silent_pyramid_plan_create(silent_ctx* ctx, int frame_h, int f
         bool usable = !hp.empty() && (int)hp.size() <= kW3MaxPlans;
         for (const HostPlan& h : hp) {
             if (h.unit >= 0) {
-                const PyrLevelDev& u = tab.lv[h.unit];   // 8-byte stores of the unit level, canvas at least as large as the crop
-                if (u.out_w % 2 || tab.frame_px_out % 2 || tab.px_off[h.unit] % 2 || u.out_h < u.src_h || u.out_w < u.src_w) usable = false;
+                const PyrLevelDev& u = tab.lv[h.unit];   // canvas at least as large as the crop
+                if (u.out_h < u.src_h || u.out_w < u.src_w) usable = false;
             }
             const PyrLevelDev& c = tab.lv[h.unit >= 0 ? h.unit : h.gen[0]];
             if (c.src_w < 8) usable = false;

@@ -25,8 +25,7 @@
 // other level alone on its own crop -- each mirrors at ITS crop's edge exactly like scipy does on the cropped array, and the
 // nested re-reads of one frame sit next to each other in the launch (Infinity Cache).  The ring row is addressed in floats
 // of the FRAME row from a 16-byte aligned origin (any crop offset), PX = 36 or 32 pixels per consumer wave (32: zoom steps
-// down to 1.6, the reference's e ** .5).  Eligibility (host): W a multiple of 4, <= 21 outputs per wave tile and level,
-// unit levels with even out_w and even pyramid offsets.
+// down to 1.6, the reference's e ** .5).  Eligibility (host): W a multiple of 4, <= 21 outputs per wave tile and level.
 #pragma once
 
 #include <type_traits>
@@ -194,21 +193,25 @@ __global__ __launch_bounds__(kW3Threads) void pyramid_walk3_kernel(const float* 
     // ---------------------------------------------------------------------- consumers
     const int wx0 = X0 + wave * kW3Px;                          // first pixel of this wave
     const bool live = wx0 < tab.out_w;                          // wave-uniform; a dead wave still meets every barrier
-    // the lane's two floats: line floats 2 lane, 2 lane + 1 <-> pixel wx0 - 2 + (2 lane + k) / 3, channel (2 lane + k) % 3
+    // the lane's two floats: line floats lane and lane + 64 <-> pixel wx0 - 2 + i / 3, channel i % 3 (i = lane + 64 k).  Stride 1
+    // across the lanes: the ring reads and the line writes are free of bank conflicts (floats 2 lane, 2 lane + 1 gave 2-way
+    // conflicts on every ds_read_b32: SQ_LDS_BANK_CONFLICT was 1.6x the LDS instruction cycles), and a store instruction writes
+    // 256 contiguous bytes without any alignment condition on the level
     int off[2][5];                                              // ring offsets of the 5 horizontal taps (pixel - 2 .. + 2) of each float
     int px[2];
 #pragma unroll
     for (int k = 0; k < 2; ++k) {
-        const int i = 2 * lane + k;
+        const int i = lane + 64 * k;
         const int p = wx0 - kW3TileL + i / 3, c = i % 3;
         px[k] = p;
 #pragma unroll
         for (int d = 0; d < 5; ++d)
             off[k][d] = min(max((mirror_near(p + d - 2, tab.src_w) - R0) * 3 + c + tab.shift, 0), kW3RowF - 1);
     }
-    const bool out_lane = px[0] >= wx0 && px[1] < wx0 + kW3Px && px[1] < tab.out_w && lane < 62;   // both floats or neither
+    const bool out0 = px[0] >= wx0 && px[0] < wx0 + kW3Px && px[0] < tab.out_w;
+    const bool out1 = px[1] >= wx0 && px[1] < wx0 + kW3Px && px[1] < tab.out_w && lane + 64 < kW3TileF;
     const bool eff0 = px[0] < tab.eff_w, eff1 = px[1] < tab.eff_w;
-    const long long base_f = ((long long)frame * args.frame_px + tab.px_off) * 3 + (long long)(wx0 - kW3TileL) * 3 + 2 * lane;
+    const long long base_f = ((long long)frame * args.frame_px + tab.px_off) * 3 + (long long)(wx0 - kW3TileL) * 3 + lane;
     const bool has_unit = tab.has_unit != 0;                    // block-uniform
 
     float hist[6][2];                                           // the lane's two floats on the last 6 source rows
@@ -288,10 +291,9 @@ __global__ __launch_bounds__(kW3Threads) void pyramid_walk3_kernel(const float* 
                     const bool prow = p < tab.eff_h;
                     v0 = (prow && eff0) ? v0 : 0.0f;            // canvas beyond the zoomed crop
                     v1 = (prow && eff1) ? v1 : 0.0f;
-                    if (out_lane) {
-                        typedef float nf2 __attribute__((ext_vector_type(2)));
-                        *reinterpret_cast<nf2*>(pyr + base_f + (long long)p * tab.out_w * 3) = nf2{v0, v1};
-                    }
+                    float* __restrict__ po = pyr + base_f + (long long)p * tab.out_w * 3;
+                    if (out0) po[0] = v0;
+                    if (out1) po[64] = v1;
                 }
                 // ---- the other levels: the window of the last 6 source rows, and a row of level g when the record says so
 #pragma unroll
@@ -318,8 +320,8 @@ __global__ __launch_bounds__(kW3Threads) void pyramid_walk3_kernel(const float* 
                             v0 = __builtin_fmaf(wv[j], hist[j][0], v0);
                             v1 = __builtin_fmaf(wv[j], hist[j][1], v1);
                         }
-                        typedef float nf2 __attribute__((ext_vector_type(2)));
-                        *reinterpret_cast<nf2*>(my_line + 2 * lane) = nf2{v0, v1};
+                        my_line[lane] = v0;
+                        my_line[lane + 64] = v1;
                         __builtin_amdgcn_wave_barrier();
                         const float* tp = my_line + min(ra.x + gc, kW3TileF - 16);   // taps 3 floats apart (clamped: idle lanes)
                         float acc = __int_as_float(ra.y) * tp[0];
