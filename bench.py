@@ -414,11 +414,16 @@ def run_rank(args):
     # a short box must say so before any collective does (device_count does not initialise the GPU)
     want = 1 if share else max(args.gpus, int(os.environ.get("LOCAL_RANK", "0")) + 1)
     have = torch.cuda.device_count()
-    if have < want:
+    # a launcher that hands every rank ONE device through a visibility mask: that device is index 0 for this rank (the dist
+    # record's PCI bus ids still prove N distinct devices)
+    masked = have == 1 and args.gpus > 1 and any(os.environ.get(v) for v in ("HIP_VISIBLE_DEVICES", "ROCR_VISIBLE_DEVICES", "CUDA_VISIBLE_DEVICES"))
+    if have < want and not masked:
         print("bench.py: --gpus %d needs %d visible GPUs, torch.cuda.device_count() is %d" % (args.gpus, want, have), file=sys.stderr)
         sys.exit(4)
-    rank, world, local = D.init(backend=os.environ.get("SILENT_DIST_BACKEND"), device=0 if share else None)
-    if share:
+    if masked:
+        os.environ["SILENT_DEVICE"] = "0"
+    rank, world, local = D.init(backend=os.environ.get("SILENT_DIST_BACKEND"), device=0 if (share or masked) else None)
+    if share or masked:
         local = 0
     if world != args.gpus:
         raise SystemExit("--gpus %d but WORLD_SIZE is %d" % (args.gpus, world))
