@@ -359,6 +359,28 @@ def config3_variants(torch, D, local, dev, rank, world):
     return out
 
 
+_REAL_STDOUT = None
+
+
+def quiet_stdout():
+    """Rank 0 prints ONE JSON line: everything else that lands on file descriptor 1 (RCCL's version banner, gloo's connection
+    notes, library chatter) is sent to stderr; emit_line() writes to the real stdout."""
+    global _REAL_STDOUT
+    if _REAL_STDOUT is None:
+        sys.stdout.flush()
+        _REAL_STDOUT = os.dup(1)
+        os.dup2(2, 1)
+
+
+def emit_line(text):
+    sys.stdout.flush()
+    if _REAL_STDOUT is None:
+        print(text)
+        sys.stdout.flush()
+    else:
+        os.write(_REAL_STDOUT, (text + "\n").encode())
+
+
 def dist_record(D, rank, local, ident, own_ms):
     """all_gather of one record per rank -> the ``dist`` object of the JSON line; exits non-zero (every rank) when two
     ranks report the same GPU: N ranks must have seen N distinct devices."""
@@ -393,13 +415,14 @@ def dry_run(args):
     ident = {"device_name": "dry-run (no GPU)", "pci_bus_id": "dry:%02d" % (0 if same else rank), "uuid": "", "gcn_arch": ""}
     dist = dist_record(D, rank, local, ident, 1.0 + rank)
     if rank == 0:
-        print(json.dumps({"metric": METRIC, "value": None, "dry_run": True, "n_gpus": world, "slowest_rank_time": slow,
-                          "frames_of_rank0": mine, "constants": sorted(consts), "dist": dist}))
+        emit_line(json.dumps({"metric": METRIC, "value": None, "dry_run": True, "n_gpus": world, "slowest_rank_time": slow,
+                              "frames_of_rank0": mine, "constants": sorted(consts), "dist": dist}))
     D.finalize()
 
 
 def run_rank(args):
     wl = WORKLOADS[args.workload]
+    quiet_stdout()
     if os.environ.get("SILENT_BENCH_DRY") == "1":
         return dry_run(args)
 
@@ -507,7 +530,7 @@ def run_rank(args):
         out["cpu_baseline"] = cpu_baseline(wl, consts)
     else:
         out["cpu_baseline"] = None
-    print(json.dumps(out))
+    emit_line(json.dumps(out))
     D.finalize()
 
 

@@ -92,6 +92,7 @@ def test_bench_launcher_spawns_its_own_ranks():
     assert p.returncode == 0, p.stderr[-2000:]
     lines = [l for l in p.stdout.splitlines() if l.startswith("{")]
     assert len(lines) == 1, p.stdout
+    assert p.stdout.strip() == lines[0]            # stdout holds the JSON line and nothing else (gloo / RCCL banners go to stderr)
     out = json.loads(lines[0])
     assert out["n_gpus"] == 2 and out["dry_run"] is True
     assert out["slowest_rank_time"] == 2.0           # MAX over ranks of (1 + rank)
