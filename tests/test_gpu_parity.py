@@ -1374,6 +1374,53 @@ def test_select_keypoints_with_many_windows(rt):
         np.testing.assert_array_equal(idx[f, :counts[f]], kp[f])
 
 
+def test_rgb_keypoints_host_entry_point_with_and_without_the_peak_value_map(rt, kernels):
+    """silent_rgb_keypoints, the HOST-pointer twin (pyramid in host memory, maps and int64 rows back): with a peak-value map
+    (dense tail) and with peak_value_out = NULL (sparse tail) the same rows, equal to the device pipeline's; and
+    silent_select_keypoints with peak_value_out = NULL (the map then lives in the context workspace)."""
+    import ctypes as C
+    import torch
+    from pysilent_amd import _lib
+    from pysilent_amd.pipeline import LineEndPipeline
+    h, w, n_levels, B = 150, 260, 3, 2
+    frames = np.stack([noise_frame(51, h, w, 3), structured_frame(52, h, w, 3)])
+    pipe = LineEndPipeline((h, w), mode="rgb", n_levels=n_levels, batch=B, selection=True, value_map=False, peak_value_map=False,
+                           max_keypoints_per_frame=h * w * 2)
+    pipe.step(torch.from_numpy(frames).cuda())
+    torch.cuda.synchronize()
+    dev = pipe.outputs()
+    pyr = np.ascontiguousarray(dev["pyramid"].data.cpu().numpy())
+    ctx, lib = rt.get_context(), _lib.load()
+    lv = (_lib.Extent * n_levels)(*[_lib.Extent(eh, ew) for eh, ew in pipe.extents])
+    rg = (_lib.Extent * n_levels)(*[_lib.Extent(max(eh // 2, 1), max(ew // 2, 1)) for eh, ew in pipe.extents])
+    fp = C.POINTER(C.c_float)
+    ks = {k: np.ascontiguousarray(v, np.float32) for k, v in pipe.consts.items()}
+    params = _lib.RgbChainParams(*[ks[k].ctypes.data_as(fp) for k in ("rgc", "rgby", "stripe", "blur", "end")], 1.0, 0.1, _lib.FLAT_IEEE, 255.0, 2)
+    cap = pipe.frame_px
+    got = {}
+    for with_map in (True, False):
+        line = np.empty(B * pipe.frame_px * 3, np.float32)
+        pv = np.empty(B * pipe.frame_px, np.float32)
+        idx = np.empty((B, cap, 4), np.int64)
+        counts = np.zeros(B, np.int64)
+        ctx.check(lib.silent_rgb_keypoints(ctx.handle, pyr.ctypes.data, lv, n_levels, B, C.byref(params), C.c_double(0.1), rg, None,
+                                           line.ctypes.data, None, pv.ctypes.data if with_map else None, idx.ctypes.data, cap,
+                                           counts.ctypes.data))
+        got[with_map] = (line, [idx[f, :counts[f]].copy() for f in range(B)], pv)
+    for f in range(B):
+        np.testing.assert_array_equal(got[True][1][f], dev["keypoints"][f])
+        np.testing.assert_array_equal(got[False][1][f], dev["keypoints"][f])
+    a, b = got[True][0], dev["line_end"].data.cpu().numpy()
+    np.testing.assert_array_equal(np.nan_to_num(a, nan=7.0), np.nan_to_num(b, nan=7.0))
+    # silent_select_keypoints on the host's line_end, without a peak-value map
+    idx = np.empty((B, cap, 4), np.int64)
+    counts = np.zeros(B, np.int64)
+    ctx.check(lib.silent_select_keypoints(ctx.handle, got[True][0].ctypes.data, None, lv, n_levels, B, 3, C.c_double(0.1), rg, None,
+                                          idx.ctypes.data, cap, counts.ctypes.data))
+    for f in range(B):
+        np.testing.assert_array_equal(idx[f, :counts[f]], dev["keypoints"][f])
+
+
 def test_rgb_chain_on_plateau_frames_under_ieee_by_the_three_zone_rule(rt, kernels):
     """Plateau frames (flat coloured regions whose stencil taps cancel to rounding residue, black regions whose taps are
     exactly 0, and edges between them) under the reference's default flat policy: the regulator's NaN pattern must equal
