@@ -353,9 +353,20 @@ def config3_variants(torch, D, local, dev, rank, world):
            "config3_line_end_only": side_workload(torch, D, "config3", local, dev, rank, world,
                                                   label="config 3, SURVEY 8d output set: line_end + keypoints (no orientation map)",
                                                   orient_map=False),
-           "config3_dense_tail": side_workload(torch, D, "config3", local, dev, rank, world,
-                                               label="config 3 with the selection's peak-value map returned (dense keypoint tail)",
-                                               peak_value_map=True)}
+           "config3_peak_value_map": side_workload(torch, D, "config3", local, dev, rank, world,
+                                                   label="config 3 with the selection's peak-value map returned too (sparse tail + zero fill)",
+                                                   peak_value_map=True)}
+    # the round-2 tail for comparison: the dense selection / count kernels on every level (SILENT_TUNE_RGB bit 5)
+    from pysilent_amd import _lib, _runtime
+    ctx = _runtime.get_context(local)
+    old = ctx.get_tuning(_lib.TUNE_RGB)
+    ctx.set_tuning(_lib.TUNE_RGB, old | 32)
+    try:
+        out["config3_dense_tail"] = side_workload(torch, D, "config3", local, dev, rank, world,
+                                                  label="config 3 with the dense keypoint tail of round 2 (peak-value map through memory)",
+                                                  peak_value_map=True)
+    finally:
+        ctx.set_tuning(_lib.TUNE_RGB, old)
     return out
 
 

@@ -401,12 +401,14 @@ int silent_rgb_chain_structure(const silent_rgb_chain_params* params, unsigned* 
  * threshold needs (top_value_points.py:16-27) while it writes line_end, so the separate reduction pass and -- unless value_out
  * is given -- the value map itself are never moved through memory.  orient_out / value_out may be NULL; the host form also
  * accepts NULL line_end_out; idx / cap_per_frame / counts as silent_max_value_indices_region.
- * peak_value_out may be NULL (both forms): nobody then needs the selection's value map as a MAP, and the tail runs sparse --
+ * peak_value_out may be NULL (both forms): nobody then needs the selection's value map as a MAP.  Either way the tail runs sparse --
  * the chain kernel leaves max_pool(value) per (pixel pair x 16 rows), and a-10 / a-9 / a-8 / a-11 are evaluated only around
  * the pixels that reach their level's threshold (a handful per level on natural and noise frames).  A search window
  * without a positive peak makes every non-NaN pixel mapped to it a keypoint: in a level without NaNs (the chain kernel
  * notes them) the count pass synthesises that; with NaNs, or with > 16384 candidates in a frame, the (frame, level) runs
- * the dense kernels on a map in the context workspace.  Keypoints are identical either way (tested). */
+ * the dense kernels on a map in the context workspace.  With peak_value_out given, the map is zero-filled and receives the
+ * evaluated pixels' values; levels that hold NaNs run the dense pass (a NaN pixel's peak value is a NaN).  Keypoints and map are
+ * identical either way (tested). */
 int silent_rgb_keypoints(silent_ctx* ctx, const float* pyr, const silent_extent* levels, int n_levels, int n_frames,
                          const silent_rgb_chain_params* params, double top_percent, const silent_extent* regions,
                          float* orient_out, float* line_end_out, float* value_out, float* peak_value_out, int64_t* idx,

@@ -799,14 +799,14 @@ static int region_window_maxima(silent_ctx* ctx, const char* who, const float* v
 // count -> scan -> ordered write, given the cell maxima
 static void keypoint_passes(const float* value, const LevelTab& tab, long long blocks, const RegionTab& rt, const KeypointWs& w,
                             bool general, int n_frames, int64_t* idx, size_t cap_per_frame, int64_t* counts, hipStream_t s,
-                            const int* dense_flags = nullptr) {
+                            const int* dense_flags = nullptr, float* caller_map = nullptr) {
     if (general)
         hipLaunchKernelGGL(region_count_kernel<true>, dim3((unsigned)blocks), dim3(256), 0, s, value, tab, rt, w.cells, w.pooled, w.chunk_counts, w.hit_masks, dense_flags);
     else
         hipLaunchKernelGGL(region_count_kernel<false>, dim3((unsigned)blocks), dim3(256), 0, s, value, tab, rt, w.cells, w.pooled, w.chunk_counts, w.hit_masks, dense_flags);
     if (dense_flags)   // sparse tail: the candidates' hits join what the count pass left
         hipLaunchKernelGGL(sparse_finish_kernel, dim3((unsigned)n_frames), dim3(256), 0, s, tab, rt, w.cells, w.cand, w.cand_n, dense_flags,
-                           w.hit_masks, w.chunk_counts);
+                           w.hit_masks, w.chunk_counts, caller_map);
     hipLaunchKernelGGL(region_scan_kernel, dim3((unsigned)n_frames), dim3(256), 0, s, w.chunk_counts, w.chunk_offsets,
                        tab.tiles_per_frame, counts);
     if (!cap_per_frame) return;
@@ -909,12 +909,15 @@ static int select_run(silent_ctx* ctx, const char* who, const float* color, cons
                            channels, sp.rtab, mm);
     const float a = (float)(1.0 - top_percent), b = (float)top_percent;
     const int* dense_flags = nullptr;
+    float* const caller_map = peak_value_out;
     if (sparse) {
         // (sparse implies: 3 channels, cell tables, extrema present, no caller-side peak-value map; select_prepare zeroed the counters)
         hipLaunchKernelGGL(sparse_select_kernel, dim3((unsigned)((sp.st.frame_entries + 255) / 256), (unsigned)n_frames), dim3(256), 0, s, color, sp.tab, sp.st, w.sum,
                            n_frames, a, b, mm, rt, w.cells, w.cand, w.cand_n);
         hipLaunchKernelGGL(sparse_modes_kernel, dim3((unsigned)n_frames), dim3(64), 0, s, sp.tab, rt, w.cells, w.cand_n, w.nan_flags,
-                           w.dense_flags);
+                           w.dense_flags, peak_value_out ? 1 : 0);
+        if (peak_value_out)   // the map the caller takes: zeros wherever the dense pass will not write
+            hipLaunchKernelGGL(sparse_fill_map_kernel, dim3((unsigned)sp.blocks), dim3(256), 0, s, sp.tab, w.dense_flags, peak_value_out);
         dense_flags = w.dense_flags;
     }
     if (!peak_value_out) peak_value_out = w.pv;
@@ -934,7 +937,8 @@ static int select_run(silent_ctx* ctx, const char* who, const float* color, cons
         hipLaunchKernelGGL((select_peaks_kernel<1, true>), dim3((unsigned)sp.sblocks), dim3(256), 0, s, color, value, nullptr, nullptr,
                            peak_value_out, sp.stab, a, b, mm, rt, w.cells, dense_flags);
     }
-    keypoint_passes(peak_value_out, sp.tab, sp.blocks, rt, w, sp.general, n_frames, idx, cap_per_frame, counts, s, dense_flags);
+    keypoint_passes(peak_value_out, sp.tab, sp.blocks, rt, w, sp.general, n_frames, idx, cap_per_frame, counts, s, dense_flags,
+                    dense_flags ? caller_map : nullptr);
     return check_launch(ctx, who);
 }
 
@@ -1482,7 +1486,7 @@ SILENT_EXPORT int silent_rgb_keypoints_dev(silent_ctx* ctx, const float* pyr, co
     // level's threshold; whatever that cannot settle exactly runs the dense kernels on a map in the workspace.
     bool pair_kernel = false;
     const int th = rgb_chain_tile_height(ctx, levels, n_levels, n_frames, &pair_kernel);
-    const bool want_sparse = !peak_value_out && pair_kernel && !(ctx->tune[SILENT_TUNE_RGB] & 32u);
+    const bool want_sparse = pair_kernel && !(ctx->tune[SILENT_TUNE_RGB] & 32u);
     SelectPlan sp;
     TRY(select_prepare(ctx, who, levels, n_levels, n_frames, regions, s, &sp, want_sparse ? th : 0, !peak_value_out));
     bool mm_done = false;

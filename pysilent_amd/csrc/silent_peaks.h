@@ -801,7 +801,7 @@ __global__ __launch_bounds__(256) void sparse_select_kernel(const float* __restr
 // one block per frame: the mode of every level (dense_flags[frame][level]), before the dense kernels
 __global__ __launch_bounds__(64) void sparse_modes_kernel(const LevelTab tab, const RegionTab rt, const unsigned* __restrict__ cells,
                                                           const int* __restrict__ cand_n, const int* __restrict__ nan_flags,
-                                                          int* __restrict__ dense_flags) {
+                                                          int* __restrict__ dense_flags, int map_wanted) {
     const int f = blockIdx.x, l = threadIdx.x;
     if (l >= tab.n_levels) return;
     const RegionLevel& rl = rt.lv[l];
@@ -816,8 +816,25 @@ __global__ __launch_bounds__(64) void sparse_modes_kernel(const LevelTab tab, co
         }
     const bool overflow = cand_n[f] > kCandCap;
     int mode = kTailDense;
-    if (!overflow) mode = all_pos ? kTailSparse : (nan_flags[f * tab.n_levels + l] ? kTailDense : kTailZero);
+    // map_wanted: the caller takes the peak-value MAP too.  Without NaNs in the level it is zeros + the candidates' values
+    // (sparse_fill_map_kernel, sparse_finish_kernel); a NaN pixel's peak value is a NaN, which only the dense pass can place
+    const bool has_nan = nan_flags[f * tab.n_levels + l] != 0;
+    if (!overflow) mode = (map_wanted && has_nan) ? kTailDense : (all_pos ? kTailSparse : (has_nan ? kTailDense : kTailZero));
     dense_flags[f * tab.n_levels + l] = mode;
+}
+
+// zero-fill of the caller's peak-value map on the (frame, level)s the dense pass does not write (`tab`: kKpChunk pixels per block)
+__global__ __launch_bounds__(256) void sparse_fill_map_kernel(const LevelTab tab, const int* __restrict__ dense_flags,
+                                                              float* __restrict__ pv_map) {
+    const TileCoord tc = locate_tile(tab, blockIdx.x);
+    if (dense_flags[tc.frame * tab.n_levels + tc.level] == kTailDense) return;
+    const int npx = tab.h[tc.level] * tab.w[tc.level];
+    float* __restrict__ dst = pv_map + (long long)tc.frame * tab.frame_px + tab.px_off[tc.level];
+#pragma unroll
+    for (int k = 0; k < kKpPer; ++k) {
+        const int p = tc.tx * kKpChunk + k * 256 + threadIdx.x;
+        if (p < npx) dst[p] = 0.0f;
+    }
 }
 
 // one block per frame, AFTER the count pass; `tab` is the count / write pass's chunk table (kKpChunk pixels per block): the
@@ -826,7 +843,7 @@ __global__ __launch_bounds__(64) void sparse_modes_kernel(const LevelTab tab, co
 __global__ __launch_bounds__(256) void sparse_finish_kernel(const LevelTab tab, const RegionTab rt, const unsigned* __restrict__ cells,
                                                             const Candidate* __restrict__ cand, const int* __restrict__ cand_n,
                                                             const int* __restrict__ dense_flags, unsigned long long* __restrict__ hit_masks,
-                                                            int* __restrict__ chunk_counts) {
+                                                            int* __restrict__ chunk_counts, float* __restrict__ pv_map) {
     __shared__ float s_pooled[kMaxLevels][kMaxWin * kMaxWin];
     const int f = blockIdx.x;
     const int n = cand_n[f];
@@ -837,6 +854,8 @@ __global__ __launch_bounds__(256) void sparse_finish_kernel(const LevelTab tab, 
     for (int i = threadIdx.x; i < n; i += 256) {
         const Candidate c = cand[(long long)f * kCandCap + i];
         if (dense_flags[f * tab.n_levels + c.level] == kTailDense) continue;
+        if (pv_map)      // the caller's peak-value map: zero-filled for this level (sparse_fill_map_kernel), the passers' values go in
+            pv_map[(long long)f * tab.frame_px + tab.px_off[c.level] + (long long)c.y * tab.w[c.level] + c.x] = c.pv;
         const float thr = region_thr<false>(c.y, c.x, rt.lv[c.level], s_pooled[c.level]);
         if (!(thr > 0.0f && c.pv >= thr)) continue;
         const int p = c.y * tab.w[c.level] + c.x;

@@ -836,21 +836,29 @@ def _sparse_vs_dense(frames, hw, n_levels, flat_policy="ieee", cap=1 << 18, **kw
     common = dict(mode="rgb", n_levels=n_levels, batch=len(frames), selection=True, value_map=False, flat_policy=flat_policy,
                   max_keypoints_per_frame=cap, **kw)
     sparse = LineEndPipeline(hw, peak_value_map=False, **common)
+    mapped = LineEndPipeline(hw, peak_value_map=True, **common)          # sparse machinery + the map (zero fill, scatter)
     dense = LineEndPipeline(hw, peak_value_map=True, **common)
     t = torch.from_numpy(frames).cuda()
+    from pysilent_amd import _runtime as rt
+    knob = rt.get_context().get_tuning(TUNE_RGB)
     sparse.step(t)
     stats = sparse.sparse_tail_stats()
-    dense.step(t)
+    mapped.step(t)
+    map_stats = mapped.sparse_tail_stats()
+    with rt.tuning(TUNE_RGB, knob | 32):                                  # the dense kernels for everything: the reference
+        dense.step(t)
+        assert not dense.sparse_tail_stats()["ran"]
     torch.cuda.synchronize()
-    a, b = sparse.outputs(allow_truncated=True), dense.outputs(allow_truncated=True)
-    assert "peak_value" not in a and "peak_value" in b
-    np.testing.assert_array_equal(a["keypoint_counts"], b["keypoint_counts"])
-    for f in range(len(frames)):
-        np.testing.assert_array_equal(a["keypoints"][f], b["keypoints"][f])
-    for name in ("orient", "line_end"):
-        x, y = a[name].data.cpu().numpy(), b[name].data.cpu().numpy()
-        assert np.array_equal(np.isnan(x), np.isnan(y)), name
-        np.testing.assert_array_equal(np.nan_to_num(x, nan=7.0), np.nan_to_num(y, nan=7.0), err_msg=name)
+    a, m, b = sparse.outputs(allow_truncated=True), mapped.outputs(allow_truncated=True), dense.outputs(allow_truncated=True)
+    assert "peak_value" not in a and "peak_value" in b and map_stats["ran"] == stats["ran"]
+    for got in (a, m):
+        np.testing.assert_array_equal(got["keypoint_counts"], b["keypoint_counts"])
+        for f in range(len(frames)):
+            np.testing.assert_array_equal(got["keypoints"][f], b["keypoints"][f])
+        for name in ("orient", "line_end") + (("peak_value",) if "peak_value" in got else ()):
+            x, y = got[name].data.cpu().numpy(), b[name].data.cpu().numpy()
+            assert np.array_equal(np.isnan(x), np.isnan(y)), name
+            np.testing.assert_array_equal(np.nan_to_num(x, nan=7.0), np.nan_to_num(y, nan=7.0), err_msg=name)
     return stats, b
 
 
