@@ -1194,7 +1194,51 @@ struct RgbStructure {
     bool rgc_diag, stripe_sum, rgby_two, end_two;
     unsigned rgby_mask[3], end_mask[3];
     float rgby_w[45], end_w[45];  // structured weight blocks: scale[dy][dx][i], mixA[i][o], mixB[i][o]
+    // the symmetric forms of silent_rgb2.h (RgbSym): rgc per channel mirror-symmetric in both axes; rgby = S (x) A around the
+    // centre + B at the centre with S mirror-symmetric in both axes
+    bool rgc_sym, rgby_mix;
+    RgbSym sym;
 };
+
+// K[t][i][o] (HWIO, t = dy * 3 + dx) = S[t] * A[i][o] for t != centre, with S[t] = S[mirror(t)]?  A is the tap vector of the
+// largest off-centre tap (S = 1 there), S the least-squares factor of every other tap; accepted when the float32 factors
+// reproduce every weight within 2e-7 of the largest one (the tolerance of two_group_channel).  B = the centre tap as it is.
+static bool rgby_mix_form(const float* k, RgbSym* sym) {
+    double kmax = 0.0;
+    for (int j = 0; j < 81; ++j) kmax = std::max(kmax, (double)std::fabs(k[j]));
+    const double tol = 2e-7 * kmax;
+    auto at = [&](int t, int io) { return (double)k[t * 9 + io]; };
+    int ref = -1;
+    double best = 0.0;
+    for (int t = 0; t < 9; ++t) {
+        if (t == 4) continue;
+        double n = 0.0;
+        for (int io = 0; io < 9; ++io) n = std::max(n, std::fabs(at(t, io)));
+        if (n > best) {
+            best = n;
+            ref = t;
+        }
+    }
+    if (ref < 0 || best <= tol) return false;
+    float S[9];
+    double den = 0.0;
+    for (int io = 0; io < 9; ++io) den += at(ref, io) * at(ref, io);
+    for (int t = 0; t < 9; ++t) {
+        double num = 0.0;
+        for (int io = 0; io < 9; ++io) num += at(t, io) * at(ref, io);
+        S[t] = t == 4 ? 0.0f : (float)(num / den);
+    }
+    for (int t = 0; t < 9; ++t)
+        for (int io = 0; io < 9 && t != 4; ++io)
+            if (std::fabs((double)S[t] * (double)k[ref * 9 + io] - at(t, io)) > tol) return false;
+    if (S[0] != S[2] || S[0] != S[6] || S[0] != S[8] || S[1] != S[7] || S[3] != S[5]) return false;
+    for (int io = 0; io < 9; ++io) {
+        sym->rgby[io] = k[ref * 9 + io];        // A[i][o]
+        sym->rgby[9 + io] = S[io];              // S[dy][dx] (io used as t)
+        sym->rgby[18 + io] = k[4 * 9 + io];     // B[i][o]
+    }
+    return true;
+}
 
 static void analyze_rgb_chain(const silent_rgb_chain_params* p, RgbStructure* r) {
     r->rgc_diag = r->stripe_sum = true;
@@ -1219,6 +1263,17 @@ static void analyze_rgb_chain(const silent_rgb_chain_params* p, RgbStructure* r)
     };
     r->rgby_two = two(p->rgby, r->rgby_mask, r->rgby_w);
     r->end_two = two(p->end, r->end_mask, r->end_w);
+    std::memset(&r->sym, 0, sizeof(r->sym));
+    r->rgc_sym = r->rgc_diag;
+    for (int c = 0; c < 3 && r->rgc_sym; ++c) {
+        auto w = [&](int dy, int dx) { return p->rgc[((dy * 3 + dx) * 3 + c) * 3 + c]; };
+        if (w(0, 0) != w(0, 2) || w(0, 0) != w(2, 0) || w(0, 0) != w(2, 2) || w(0, 1) != w(2, 1) || w(1, 0) != w(1, 2)) r->rgc_sym = false;
+        r->sym.rgc[c * 4 + 0] = w(0, 0);
+        r->sym.rgc[c * 4 + 1] = w(0, 1);
+        r->sym.rgc[c * 4 + 2] = w(1, 0);
+        r->sym.rgc[c * 4 + 3] = w(1, 1);
+    }
+    r->rgby_mix = rgby_mix_form(p->rgby, &r->sym);
 }
 
 // The RGB chain's weights as the fused kernels take them: HWIO -> [o][dy][dx][i], the blur's profile, and -- where the
@@ -1227,7 +1282,8 @@ static void analyze_rgb_chain(const silent_rgb_chain_params* p, RgbStructure* r)
 // two-group (27 + 18 each), and the blur mirror-symmetric (16 fmas + 10 adds instead of 49 fmas): 160 weights instead of 373
 // per pixel.  Anything else runs the basic (diagonal rgc + channel-sum stripe) or the dense instantiation.
 // kopts: SILENT_TUNE_RGB bits 0 (dense) and 1 (no two-group form).
-static void pack_rgb_weights(const silent_rgb_chain_params* p, unsigned kopts, RgbW* w, bool* basic, bool* two) {
+static void pack_rgb_weights(const silent_rgb_chain_params* p, unsigned kopts, RgbW* w, bool* basic, bool* two, RgbSym* sym = nullptr,
+                             bool* use_sym = nullptr) {
     auto repack = [](const float* hwio, float* dst) {  // HWIO [dy][dx][i][o] -> [o][dy][dx][i]
         for (int o = 0; o < 3; ++o)
             for (int dy = 0; dy < 3; ++dy)
@@ -1253,6 +1309,9 @@ static void pack_rgb_weights(const silent_rgb_chain_params* p, unsigned kopts, R
         std::memcpy(w->rgby, rs.rgby_w, sizeof(rs.rgby_w));
         std::memcpy(w->end, rs.end_w, sizeof(rs.end_w));
     }
+    // the symmetric forms on top of the two-group ones (pair kernel only; kopts bit 6 keeps the two-group instantiation)
+    if (use_sym) *use_sym = *two && !(kopts & 64u) && rs.rgc_sym && rs.rgby_mix;
+    if (sym) *sym = rs.sym;
 }
 
 SILENT_EXPORT int silent_rgb_chain_stream(const silent_rgb_chain_params* params, unsigned knobs, float* stream, int* n_used,
@@ -1260,11 +1319,12 @@ SILENT_EXPORT int silent_rgb_chain_stream(const silent_rgb_chain_params* params,
     if (!params || !stream || !n_used || !variant || !params->rgc || !params->rgby || !params->stripe || !params->blur || !params->end)
         return SILENT_E_INVALID;
     RgbW w;
-    bool basic, two;
-    pack_rgb_weights(params, knobs, &w, &basic, &two);
+    RgbSym sym;
+    bool basic, two, use_sym;
+    pack_rgb_weights(params, knobs, &w, &basic, &two, &sym, &use_sym);
     std::memset(stream, 0, sizeof(float) * SILENT_RGB_STREAM_MAX);
-    *n_used = rgb2_fill_stream(w, basic ? 0x111u : 0x1ffu, basic, two, two, stream);
-    *variant = two ? 2 : basic ? 1 : 0;
+    *n_used = rgb2_fill_stream(w, basic ? 0x111u : 0x1ffu, basic, two, two, stream, use_sym ? &sym : nullptr);
+    *variant = use_sym ? 3 : two ? 2 : basic ? 1 : 0;
     return SILENT_OK;
 }
 
@@ -1272,7 +1332,8 @@ SILENT_EXPORT int silent_rgb_chain_structure(const silent_rgb_chain_params* para
     if (!params || !flags || !params->rgc || !params->rgby || !params->stripe || !params->end) return SILENT_E_INVALID;
     RgbStructure r;
     analyze_rgb_chain(params, &r);
-    *flags = (r.rgc_diag ? 1u : 0u) | (r.stripe_sum ? 2u : 0u) | (r.rgby_two ? 4u : 0u) | (r.end_two ? 8u : 0u);
+    *flags = (r.rgc_diag ? 1u : 0u) | (r.stripe_sum ? 2u : 0u) | (r.rgby_two ? 4u : 0u) | (r.end_two ? 8u : 0u) | (r.rgc_sym ? 16u : 0u) |
+             (r.rgby_mix ? 32u : 0u);
     if (masks)
         for (int i = 0; i < 3; ++i) {
             masks[i] = r.rgby_two ? r.rgby_mask[i] : 0u;
@@ -1361,8 +1422,9 @@ static int rgb_chain_launch(silent_ctx* ctx, const char* who, const float* pyr, 
         a.tab = tab;
         a.th = th;
         a.prm = RgbP{p->regulation_value, p->regulation_root, p->flat_policy, p->clip_hi, p->pad};
-        bool basic, two;
-        pack_rgb_weights(p, kopts, &a.w, &basic, &two);
+        bool basic, two, use_sym;
+        RgbSym sym;
+        pack_rgb_weights(p, kopts, &a.w, &basic, &two, &sym, &use_sym);
         if (pair_kernel) {
             Rgb2Args a2;
             a2.pyr = a.pyr;
@@ -1378,7 +1440,7 @@ static int rgb_chain_launch(silent_ctx* ctx, const char* who, const float* pyr, 
             a2.sum_frame = 0;
             std::memset(a2.sum_off, 0, sizeof(a2.sum_off));
             std::memset(a2.ws, 0, sizeof(a2.ws));
-            rgb2_fill_stream(a.w, basic ? 0x111u : 0x1ffu, basic, two, two, a2.ws);
+            rgb2_fill_stream(a.w, basic ? 0x111u : 0x1ffu, basic, two, two, a2.ws, use_sym ? &sym : nullptr);
             // silent_set_profiling: HIP events around THIS launch, on the stream it runs on (the fused RGB chain is the dominant
             // kernel of silent_rgb_line_end / silent_rgb_keypoints, like gray_stream_kernel is of silent_gray_pass)
             const bool prof = ctx->profiling && (ctx->prof_calls++ % ctx->prof_period) == 0;
@@ -1402,10 +1464,12 @@ static int rgb_chain_launch(silent_ctx* ctx, const char* who, const float* pyr, 
                     a2.sum_frame = st->frame_entries;
                     for (int l = 0; l < kMaxLevels; ++l) a2.sum_off[l] = st->off[l];
                 }
-                hipLaunchKernelGGL((rgb_line_end2_kernel<0x111u, true, kRgbyA, kEndA0, kEndA1, kEndA2, true>), dim3((unsigned)blocks), dim3(64 * kRgb2Waves), 0, s, a2);
+                if (use_sym) hipLaunchKernelGGL((rgb_line_end2_kernel<0x111u, true, kRgbyA, kEndA0, kEndA1, kEndA2, true, true>), dim3((unsigned)blocks), dim3(64 * kRgb2Waves), 0, s, a2);
+                else hipLaunchKernelGGL((rgb_line_end2_kernel<0x111u, true, kRgbyA, kEndA0, kEndA1, kEndA2, true>), dim3((unsigned)blocks), dim3(64 * kRgb2Waves), 0, s, a2);
                 if (mm_done) *mm_done = true;
             } else
-            if (two) hipLaunchKernelGGL((rgb_line_end2_kernel<0x111u, true, kRgbyA, kEndA0, kEndA1, kEndA2>), dim3((unsigned)blocks), dim3(64 * kRgb2Waves), 0, s, a2);
+            if (use_sym) hipLaunchKernelGGL((rgb_line_end2_kernel<0x111u, true, kRgbyA, kEndA0, kEndA1, kEndA2, false, true>), dim3((unsigned)blocks), dim3(64 * kRgb2Waves), 0, s, a2);
+            else if (two) hipLaunchKernelGGL((rgb_line_end2_kernel<0x111u, true, kRgbyA, kEndA0, kEndA1, kEndA2>), dim3((unsigned)blocks), dim3(64 * kRgb2Waves), 0, s, a2);
             else if (basic) hipLaunchKernelGGL((rgb_line_end2_kernel<0x111u, true, kDense, kDense, kDense, kDense>), dim3((unsigned)blocks), dim3(64 * kRgb2Waves), 0, s, a2);
             else hipLaunchKernelGGL((rgb_line_end2_kernel<0x1ffu, false, kDense, kDense, kDense, kDense>), dim3((unsigned)blocks), dim3(64 * kRgb2Waves), 0, s, a2);
         } else if (two) {

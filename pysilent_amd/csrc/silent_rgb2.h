@@ -57,20 +57,36 @@ constexpr int kRgb2StreamMax = SILENT_RGB_STREAM_MAX;  // 4 x 81 + 49 = 373 floa
 
 constexpr int rgb2_popc(unsigned v) { return v ? (int)(v & 1u) + rgb2_popc(v >> 1) : 0; }
 
+// The "symmetric" forms (SYM instantiation; host-checked structure of the weights, silent_api.hip analyze_rgb_chain):
+//   rgc   channel-diagonal, every channel's 3x3 kernel mirror-symmetric in both axes (midget_rgc: a centre-surround profile):
+//         per channel [corner, edge_h (above / below the centre), edge_v (left / right), centre];
+//   rgby  K[t][i][o] = S[t] * A[i][o] for the 8 taps around the centre, S mirror-symmetric in both axes, + B[i][o] at the centre
+//         (rgby_3: one surround profile times one channel-mix matrix, another matrix at the centre): the channels are mixed FIRST
+//         (Z_o = sum_i A[i][o] x_i, all nine terms: a zero entry still carries a NaN / inf on like the reference's 0 * x does),
+//         then ONE symmetric 3x3 filter per output;
+//   stripe (channel sum) in the paired form below.
+struct RgbSym {
+    float rgc[12];    // [channel][corner, edge_h, edge_v, centre]
+    float rgby[27];   // A[i][o] at 0..8, S[dy][dx] at 9..17 (centre 0), B[i][o] at 18..26
+};
+constexpr int kSymRgc = 12, kSymRgby = 27, kSymStripe = 48;
+
 // Stage sizes / bases in the stream for an instantiation
-template <unsigned RGC_PAIRS, bool STRIPE_SUM, bool RGBY_TWO, bool END_TWO>
+template <unsigned RGC_PAIRS, bool STRIPE_SUM, bool RGBY_TWO, bool END_TWO, bool SYM = false>
 struct Rgb2Layout {
-    static constexpr int n_rgc = 9 * rgb2_popc(RGC_PAIRS & 0x1ffu);
-    static constexpr int n_rgby = RGBY_TWO ? 45 : 81;
-    static constexpr int n_stripe = STRIPE_SUM ? 27 : 81;
+    static constexpr int n_rgc = SYM ? kSymRgc : 9 * rgb2_popc(RGC_PAIRS & 0x1ffu);
+    static constexpr int n_rgby = SYM ? kSymRgby : RGBY_TWO ? 45 : 81;
+    static constexpr int n_stripe = SYM ? kSymStripe : STRIPE_SUM ? 27 : 81;
     // the two-group instantiation also takes the blur in its MIRROR-SYMMETRIC form (host-checked, blur_tensor's profile is a
     // function of the distance): 16 weights w[|dy|][min(dx, 6 - dx)] instead of 49, see the blur stage of the kernel
     static constexpr bool blur_sym = RGBY_TWO && END_TWO;
     static constexpr int n_blur = blur_sym ? 16 : 49;
     static constexpr int n_end = END_TWO ? 45 : 81;
-    static constexpr int b_rgc = 0, b_rgby = b_rgc + n_rgc, b_stripe = b_rgby + n_rgby, b_blur = b_stripe + n_stripe,
-                         b_end = b_blur + n_blur, total = b_end + n_end;
+    // (SYM: the stripe block holds SGPR PAIRS (left weight, right weight) and starts on an even position)
+    static constexpr int b_rgc = 0, b_rgby = b_rgc + n_rgc, b_stripe = (b_rgby + n_rgby + (SYM ? 1 : 0)) & ~(SYM ? 1 : 0),
+                         b_blur = b_stripe + n_stripe, b_end = b_blur + n_blur, total = b_end + n_end;
     static constexpr int blocks = ((total + 2 * kRgb2Blk - 1) / (2 * kRgb2Blk)) * 2;
+    static_assert(!SYM || (STRIPE_SUM && RGBY_TWO && END_TWO), "the symmetric forms extend the two-group instantiation");
 };
 
 // stream position of term (o, dy, dx, i) of a pair-masked 3x3x3->3 stage: for o: for active (dx, i): for dy = 2, 1, 0
@@ -80,8 +96,9 @@ constexpr int rgb2_conv_pos(unsigned pairs, int o, int dy, int dx, int i) {
     const int rank = dx * rgb2_popc(row) + rgb2_popc(row & ((1u << i) - 1u));
     return before + rank * 3 + (2 - dy);
 }
-// host side: fill the stream from the RgbW block (same enumeration as the kernel's)
-inline int rgb2_fill_stream(const RgbW& w, unsigned rgc_pairs, bool stripe_sum, bool rgby_two, bool end_two, float* out) {
+// host side: fill the stream from the RgbW block (same enumeration as the kernel's); sym: the symmetric forms (two-group only)
+inline int rgb2_fill_stream(const RgbW& w, unsigned rgc_pairs, bool stripe_sum, bool rgby_two, bool end_two, float* out,
+                            const RgbSym* sym = nullptr) {
     const bool blur_sym = rgby_two && end_two;   // (Rgb2Layout::blur_sym; the host only picks the two-group form for a symmetric blur)
     int n = 0;
     auto conv = [&](const float* k, unsigned pairs) {  // k: [o][dy][dx][i]
@@ -101,6 +118,39 @@ inline int rgb2_fill_stream(const RgbW& w, unsigned rgc_pairs, bool stripe_sum, 
         for (int t = 0; t < 18; ++t) out[n + 27 + t] = k[27 + t];  // term t = group * 3 + i, then o: consumed (t, o) in this order
         n += 45;
     };
+    if (sym) {
+        // rgc: the three channels side by side: corner, edge_v (with the side sum), edge_h, centre (with the pixel itself)
+        for (int c = 0; c < 3; ++c) {
+            out[n + 0 + c] = sym->rgc[c * 4 + 0];
+            out[n + 3 + c] = sym->rgc[c * 4 + 2];
+            out[n + 6 + c] = sym->rgc[c * 4 + 1];
+            out[n + 9 + c] = sym->rgc[c * 4 + 3];
+        }
+        n += kSymRgc;
+        // rgby: A[i][o] (i outer), the profile's corner / edge_v / edge_h once per output, B[i][o] (i outer)
+        for (int t = 0; t < 9; ++t) out[n + t] = sym->rgby[t];
+        for (int o = 0; o < 3; ++o) {
+            out[n + 9 + o] = sym->rgby[9 + 0];     // corner
+            out[n + 12 + o] = sym->rgby[9 + 3];    // edge_v: left / right of the centre
+            out[n + 15 + o] = sym->rgby[9 + 1];    // edge_h: above / below
+        }
+        for (int t = 0; t < 9; ++t) out[n + 18 + t] = sym->rgby[18 + t];
+        n += kSymRgby;
+        if (n & 1) out[n++] = 0.0f;
+        // stripe of the channel sum, per output: (left, right) pairs of rows dy = 2, 1, 0; the three centres + a pad; (right, left) pairs
+        for (int o = 0; o < 3; ++o) {
+            for (int dy = 0; dy < 3; ++dy) {
+                const float l = w.stripe[((o * 3 + dy) * 3 + 0) * 3], c = w.stripe[((o * 3 + dy) * 3 + 1) * 3], r = w.stripe[((o * 3 + dy) * 3 + 2) * 3];
+                out[n + (2 - dy) * 2] = l;
+                out[n + (2 - dy) * 2 + 1] = r;
+                out[n + 6 + (2 - dy)] = c;
+                out[n + 10 + (2 - dy) * 2] = r;
+                out[n + 10 + (2 - dy) * 2 + 1] = l;
+            }
+            out[n + 9] = 0.0f;
+            n += 16;
+        }
+    } else {
     conv(w.rgc, rgc_pairs & 0x1ffu);
     if (rgby_two) two(w.rgby);
     else conv(w.rgby, 0x1ffu);
@@ -111,6 +161,7 @@ inline int rgb2_fill_stream(const RgbW& w, unsigned rgc_pairs, bool stripe_sum, 
         n += 27;
     } else {
         conv(w.stripe, 0x1ffu);
+    }
     }
     if (blur_sym) {   // for folded column j = 0..3 (dx = j and 6 - j): for d = |dy| = 0..3
         for (int j = 0; j < 4; ++j)
@@ -208,6 +259,26 @@ struct WStream {
         else asm volatile("v_pk_mul_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,1]" : "=v"(r) : "v"(x), "s"(w));
         return r;
     }
+    // The mov-free neighbour forms (SYM instantiation).  IDX even: the SGPR pair (w[IDX], w[IDX + 1]) as it lies, the halves of x
+    // SWAPPED: lo = x.hi * w[IDX] + c.lo, hi = x.lo * w[IDX + 1] + c.hi.  With x = (above(c.x), below(c.y)) and the pair
+    // (left weight, right weight) that is the left tap of pixel lo and the right tap of pixel hi in ONE instruction; with x = the
+    // pixel pair itself and the pair (right weight, left weight) the right tap of lo (its neighbour hi) and the left tap of hi.
+    template <int IDX>
+    __device__ __forceinline__ f2 fma_sw(const f2& x, const f2& c) {
+        static_assert((IDX & 1) == 0, "an aligned SGPR pair");
+        const u64 w = pair<IDX>();
+        f2 r;
+        asm volatile("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[1,0,0] op_sel_hi:[0,1,1]" : "=v"(r) : "v"(x), "s"(w), "v"(c));
+        return r;
+    }
+    template <int IDX>
+    __device__ __forceinline__ f2 fma0_sw(const f2& x) {
+        static_assert((IDX & 1) == 0, "an aligned SGPR pair");
+        const u64 w = pair<IDX>();
+        f2 r;
+        asm volatile("v_pk_fma_f32 %0, %1, %2, 0 op_sel:[1,0,0] op_sel_hi:[0,1,0]" : "=v"(r) : "v"(x), "s"(w));
+        return r;
+    }
     // skip stream positions [FROM, TO) that carry no fma (padding): still crosses block boundaries in order
     template <int FROM, int TO>
     __device__ __forceinline__ void skip() {
@@ -237,6 +308,31 @@ __device__ __forceinline__ void neighbours2(const f2& c, f2& l, f2& r) {
     l.y = c.x;
     r.x = c.y;
     r.y = from_lane_above(c.x);
+}
+
+// The same neighbours WITHOUT the two moves: packed f32 instructions pick either dword of a VGPR pair for either half (op_sel /
+// op_sel_hi), so with side = (above(c.x), below(c.y)) -- two DPP writes into one pair --
+//   l + r       = (side.hi + c.hi, side.lo + c.lo)                      one v_pk_add_f32 with both operands' halves swapped
+//   wl l + wr r = fma_sw(side, (wl, wr)) then fma_sw(c, (wr, wl))       (WStream::fma_sw)
+__device__ __forceinline__ f2 side_pair(const f2& c) { return f2{from_lane_above(c.x), from_lane_below(c.y)}; }
+__device__ __forceinline__ f2 pk_add_swap_both(const f2& a, const f2& b) {   // (a.hi + b.hi, a.lo + b.lo)
+    f2 r;
+    asm("v_pk_add_f32 %0, %1, %2 op_sel:[1,1] op_sel_hi:[0,0]" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+__device__ __forceinline__ f2 pk_add_swap_second(const f2& a, const f2& b) {   // (a.lo + b.hi, a.hi + b.lo)
+    f2 r;
+    asm("v_pk_add_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,0]" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+// clip(relu(v), hi) with the reference's NaN behaviour in two instructions: gfx950's v_maximum3_f32 / v_minimum3_f32 are the
+// IEEE-754-2019 maximum / minimum -- a NaN operand comes back as it is, sign and payload (scripts/ubench/max3_nan.hip).  Against
+// (v < 0 ? 0 : v) the only difference is -0 -> +0.
+__device__ __forceinline__ float relu_clip_max3(float v, float hi) {
+    float r;
+    asm("v_maximum3_f32 %0, %1, 0, 0" : "=v"(r) : "v"(v));
+    asm("v_minimum3_f32 %0, %1, %2, %2" : "=v"(r) : "v"(r), "s"(hi));
+    return r;
 }
 
 // One arriving row of a dense / pair-masked 3x3 x 3->3 convolution (conv3_roll of silent_rgb.h on pixel pairs).  The three
@@ -350,13 +446,18 @@ __device__ __forceinline__ void conv3_roll2_sum(const f2 (&s)[3], WS& ws, f2 (&p
 }
 
 __device__ __forceinline__ float relu_ok(float v, bool ok) { return ok ? relu_tf(v) : 0.0f; }
+__device__ __forceinline__ float relu_max3(float v) {   // relu_tf in one instruction (see relu_clip_max3)
+    float r;
+    asm("v_maximum3_f32 %0, %1, 0, 0" : "=v"(r) : "v"(v));
+    return r;
+}
 
 // MM: also accumulate the per-level extrema of the value map (args.mm) -- a separate instantiation with a 3-waves/SIMD register
 // budget: the plain kernel sits at the 128-VGPR edge, and forced into that budget the extra pointer, masks and accumulators
 // spill to scratch (+16 %; with 3 waves +4 %)
-template <unsigned RGC_PAIRS, bool STRIPE_SUM, unsigned RGBY_A, unsigned END_A0, unsigned END_A1, unsigned END_A2, bool MM = false>
+template <unsigned RGC_PAIRS, bool STRIPE_SUM, unsigned RGBY_A, unsigned END_A0, unsigned END_A1, unsigned END_A2, bool MM = false, bool SYM = false>
 __global__ __launch_bounds__(64 * kRgb2Waves) __attribute__((amdgpu_waves_per_eu(MM ? 3 : 4, 8))) void rgb_line_end2_kernel(const Rgb2Args args) {
-    typedef Rgb2Layout<RGC_PAIRS, STRIPE_SUM, RGBY_A != kDense, END_A0 != kDense> L;
+    typedef Rgb2Layout<RGC_PAIRS, STRIPE_SUM, RGBY_A != kDense, END_A0 != kDense, SYM> L;
     static_assert(L::blocks * kRgb2Blk <= kRgb2StreamMax, "stream fits its kernarg array");
     const int R = args.th, NROWS = R + 2 * kRgb2RowHalo;
     const float* __restrict__ pyr = args.pyr;
@@ -432,16 +533,18 @@ __global__ __launch_bounds__(64 * kRgb2Waves) __attribute__((amdgpu_waves_per_eu
     const int ylast = (y0 + R < H ? y0 + R : H) - 1;   // last output row of this tile
     __shared__ float s_tr[kRgb2Waves][128 * 3];   // [wave][one output row of the wave's 128 columns x 3 channels]
     float* const tr = s_tr[wave];
-    // lane-major in (as held), pixel-major out; LDS operations of one wave execute in order, so no wait / barrier in between
+    // lane-major in AS HELD -- [lane][channel][half]: three 8-byte writes of the register pairs, no shuffling moves --, pixel-major
+    // out: pixel p of the wave's 128 columns is half p & 1 of lane p >> 1, its channels 2 floats apart.  The reading lane j takes
+    // pixel j (store A) and pixel 64 + j (store B): float addresses 6 (j >> 1) + (j & 1) + {0, 2, 4} hit 64 different banks.  LDS
+    // operations of one wave execute in order, so no wait / barrier in between.
     typedef int i3 __attribute__((ext_vector_type(3)));
+    f2* const tr_in = reinterpret_cast<f2*>(tr) + lane * 3;
+    const float* const tr_out = tr + (lane >> 1) * 6 + (lane & 1);
     auto store_row3 = [&](const f2 (&val)[3], __amdgpu_buffer_rsrc_t rsrc, int ro) {
 #pragma unroll
-        for (int c = 0; c < 3; ++c) {
-            tr[lane * 6 + c] = val[c].x;
-            tr[lane * 6 + 3 + c] = val[c].y;
-        }
-        const i3 da = {__float_as_int(tr[lane * 3 + 0]), __float_as_int(tr[lane * 3 + 1]), __float_as_int(tr[lane * 3 + 2])};
-        const i3 db = {__float_as_int(tr[192 + lane * 3 + 0]), __float_as_int(tr[192 + lane * 3 + 1]), __float_as_int(tr[192 + lane * 3 + 2])};
+        for (int c = 0; c < 3; ++c) tr_in[c] = val[c];
+        const i3 da = {__float_as_int(tr_out[0]), __float_as_int(tr_out[2]), __float_as_int(tr_out[4])};
+        const i3 db = {__float_as_int(tr_out[192]), __float_as_int(tr_out[194]), __float_as_int(tr_out[196])};
         __builtin_amdgcn_raw_buffer_store_b96(da, rsrc, sta + ro, 0, kRgb2StoreAux);
         __builtin_amdgcn_raw_buffer_store_b96(db, rsrc, stb + ro, 0, kRgb2StoreAux);
     };
@@ -468,6 +571,23 @@ __global__ __launch_bounds__(64 * kRgb2Waves) __attribute__((amdgpu_waves_per_eu
 #pragma unroll
     for (int k = 0; k < (MM ? 14 : 12); ++k) __builtin_amdgcn_raw_buffer_store_b32(k, r_value, kRgb2Out + 64 * k, 0, 0);   // (distinct: identical ones are merged)
 
+    // relu of a stage's row + zero outside the level (the next stage's SAME padding).  SYM: one v_maximum3_f32 per value, and the
+    // selects only where a lane or the row can be outside -- a wave whose 128 columns all lie inside the level skips them on every
+    // row inside the level (wave-uniform branch)
+    const bool cols_in = __builtin_amdgcn_readfirstlane(__all(col0 && col1) ? 1 : 0) != 0;
+    auto relu_stage = [&](f2 (&g)[3], bool rok) {
+        if constexpr (SYM) {
+#pragma unroll
+            for (int c = 0; c < 3; ++c) g[c] = f2{relu_max3(g[c].x), relu_max3(g[c].y)};
+            if (!(rok && cols_in)) {
+#pragma unroll
+                for (int c = 0; c < 3; ++c) g[c] = f2{(rok && col0) ? g[c].x : 0.0f, (rok && col1) ? g[c].y : 0.0f};
+            }
+        } else {
+#pragma unroll
+            for (int c = 0; c < 3; ++c) g[c] = f2{relu_ok(g[c].x, rok && col0), relu_ok(g[c].y, rok && col1)};
+        }
+    };
     // one row step: `mine` holds this row; row + 2 is fetched into it as soon as the row has been taken
     auto step = [&](int row, i3 (&mine)[2]) {
         const int yin = y0 - kRgb2RowHalo + row;  // input row of this step
@@ -476,17 +596,60 @@ __global__ __launch_bounds__(64 * kRgb2Waves) __attribute__((amdgpu_waves_per_eu
 #pragma unroll
         for (int c = 0; c < 3; ++c) {
             v[1][c] = f2{__int_as_float(mine[0][c]), __int_as_float(mine[1][c])};
-            neighbours2(v[1][c], v[0][c], v[2][c]);
         }
         asm volatile("" : "+v"(v[1][0]), "+v"(v[1][1]), "+v"(v[1][2]));   // taken: the buffer is free
         fetch(mine, row + 2);   // (rows past the tile's last input row are fetched and not used)
-        conv3_roll2<RGC_PAIRS & 0x1ffu, L::b_rgc>(v, ws, a1, b1, g);
-        {
-            const bool rok = yin - 1 >= 0 && yin - 1 < H;
+        if constexpr (SYM) {
+            // per channel a 3x3 kernel that is mirror-symmetric in both axes: F = l + r; the arriving row gives the rows above and
+            // below it corner * F + edge_h * c and its own row edge_v * F + centre * c: 4 fmas + 2 adds instead of 9 fmas
+            f2 F[3], E[3], M[3];
 #pragma unroll
-            for (int c = 0; c < 3; ++c) g[c] = f2{relu_ok(g[c].x, rok && col0), relu_ok(g[c].y, rok && col1)};
+            for (int c = 0; c < 3; ++c) F[c] = pk_add_swap_both(side_pair(v[1][c]), v[1][c]);
+            rgb2_for<0, 3>([&](auto cc) { constexpr int c = decltype(cc)::value; E[c] = ws.template mul<L::b_rgc + c>(F[c]); });
+            rgb2_for<0, 3>([&](auto cc) { constexpr int c = decltype(cc)::value; M[c] = ws.template fma<L::b_rgc + 3 + c>(F[c], b1[c]); });
+            rgb2_for<0, 3>([&](auto cc) { constexpr int c = decltype(cc)::value; E[c] = ws.template fma<L::b_rgc + 6 + c>(v[1][c], E[c]); });
+            rgb2_for<0, 3>([&](auto cc) { constexpr int c = decltype(cc)::value; M[c] = ws.template fma<L::b_rgc + 9 + c>(v[1][c], M[c]); });
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+                g[c] = a1[c] + E[c];
+                a1[c] = M[c];
+                b1[c] = E[c];
+            }
+        } else {
+#pragma unroll
+            for (int c = 0; c < 3; ++c) neighbours2(v[1][c], v[0][c], v[2][c]);
+            conv3_roll2<RGC_PAIRS & 0x1ffu, L::b_rgc>(v, ws, a1, b1, g);
+        }
+        {
+            relu_stage(g, yin - 1 >= 0 && yin - 1 < H);
         }
         // ---- rgby: completes row yin - 2
+        if constexpr (SYM) {
+            // K = S (x) A around the centre + B at the centre: mix the channels first (Z_o = sum_i A[i][o] x_i), then one
+            // mirror-symmetric profile per output (S's centre is 0) and the centre's own mix: 9 + 3 + 6 + 3 + 3 + 9 = 33 instead of 45
+            constexpr int B = L::b_rgby;
+            f2 Z[3], F[3], E[3], M[3];
+            rgb2_for<0, 9>([&](auto tt) {
+                constexpr int t = decltype(tt)::value, i = t / 3, o = t % 3;
+                if constexpr (i == 0) Z[o] = ws.template mul<B + t>(g[0]);
+                else Z[o] = ws.template fma<B + t>(g[i], Z[o]);
+            });
+#pragma unroll
+            for (int o = 0; o < 3; ++o) F[o] = pk_add_swap_both(side_pair(Z[o]), Z[o]);
+            rgb2_for<0, 3>([&](auto oo) { constexpr int o = decltype(oo)::value; E[o] = ws.template mul<B + 9 + o>(F[o]); });
+            rgb2_for<0, 3>([&](auto oo) { constexpr int o = decltype(oo)::value; M[o] = ws.template fma<B + 12 + o>(F[o], b2[o]); });
+            rgb2_for<0, 3>([&](auto oo) { constexpr int o = decltype(oo)::value; E[o] = ws.template fma<B + 15 + o>(Z[o], E[o]); });
+            rgb2_for<0, 9>([&](auto tt) {
+                constexpr int t = decltype(tt)::value, i = t / 3, o = t % 3;
+                M[o] = ws.template fma<B + 18 + t>(g[i], M[o]);
+            });
+#pragma unroll
+            for (int o = 0; o < 3; ++o) {
+                g[o] = a2[o] + E[o];
+                a2[o] = M[o];
+                b2[o] = E[o];
+            }
+        } else {
 #pragma unroll
         for (int c = 0; c < 3; ++c) {
             v[1][c] = g[c];
@@ -494,13 +657,38 @@ __global__ __launch_bounds__(64 * kRgb2Waves) __attribute__((amdgpu_waves_per_eu
         }
         if constexpr (RGBY_A != kDense) conv3_roll2_struct<RGBY_A, RGBY_A, RGBY_A, L::b_rgby>(v, ws, a2, b2, g);
         else conv3_roll2<0x1ffu, L::b_rgby>(v, ws, reinterpret_cast<f2 (&)[3]>(a2), reinterpret_cast<f2 (&)[3]>(b2), g);
+        }
         {
-            const bool rok = yin - 2 >= 0 && yin - 2 < H;
-#pragma unroll
-            for (int c = 0; c < 3; ++c) g[c] = f2{relu_ok(g[c].x, rok && col0), relu_ok(g[c].y, rok && col1)};
+            relu_stage(g, yin - 2 >= 0 && yin - 2 < H);
         }
         // ---- stripe: completes row q = yin - 3
-        if constexpr (STRIPE_SUM) {
+        if constexpr (SYM) {
+            // stripe of the channel sum, left / right taps in the paired forms (no moves): per output 3 x (side pair, centre, self pair)
+            const f2 S = (g[0] + g[1]) + g[2];
+            const f2 D = side_pair(S);
+            f2 npa[3], npb[3];
+            rgb2_for<0, 3>([&](auto oo) {
+                constexpr int o = decltype(oo)::value, B = L::b_stripe + o * 16;
+                f2 t2 = a3[o], t1 = b3[o], t0;
+                t2 = ws.template fma_sw<B + 0>(D, t2);
+                t1 = ws.template fma_sw<B + 2>(D, t1);
+                t0 = ws.template fma0_sw<B + 4>(D);
+                t2 = ws.template fma<B + 6>(S, t2);
+                t1 = ws.template fma<B + 7>(S, t1);
+                t0 = ws.template fma<B + 8>(S, t0);
+                t2 = ws.template fma_sw<B + 10>(S, t2);
+                t1 = ws.template fma_sw<B + 12>(S, t1);
+                t0 = ws.template fma_sw<B + 14>(S, t0);
+                g[o] = t2;
+                npa[o] = t1;
+                npb[o] = t0;
+            });
+#pragma unroll
+            for (int o = 0; o < 3; ++o) {
+                a3[o] = npa[o];
+                b3[o] = npb[o];
+            }
+        } else if constexpr (STRIPE_SUM) {
             f2 s3[3];
             s3[1] = (g[0] + g[1]) + g[2];
             neighbours2(s3[1], s3[0], s3[2]);
@@ -514,9 +702,7 @@ __global__ __launch_bounds__(64 * kRgb2Waves) __attribute__((amdgpu_waves_per_eu
             conv3_roll2<0x1ffu, L::b_stripe>(v, ws, a3, b3, g);
         }
         {
-            const bool rok = yin - 3 >= 0 && yin - 3 < H;
-#pragma unroll
-            for (int c = 0; c < 3; ++c) g[c] = f2{relu_ok(g[c].x, rok && col0), relu_ok(g[c].y, rok && col1)};
+            relu_stage(g, yin - 3 >= 0 && yin - 3 < H);
         }
         f2 xs3[3];   // the stripe row of three steps ago
 #pragma unroll
@@ -530,6 +716,19 @@ __global__ __launch_bounds__(64 * kRgb2Waves) __attribute__((amdgpu_waves_per_eu
             const f2 s = (g[0] + g[1]) + g[2];
             // T[k] = (sum at x0 + k - 3, sum at x1 + k - 3)
             f2 T[7];
+            f2 nb[7];
+            if constexpr (SYM) {
+                // the folded columns straight from three DPP pairs (a = below(s.x), b = below(s.y), c = above(s.x), d = above(s.y),
+                // e = below(b), f = above(c)): F0 = T0 + T6 = (e + d, a + f), F1 = T1 + T5 = (a + c, b + d), F2 = T2 + T4 =
+                // (b + s.y, s.x + c) -- the same sums as below without building the seven shifted pairs (8 moves)
+                const f2 X = side_pair(s);                                          // (c, b)
+                const f2 Y = f2{from_lane_below(s.x), from_lane_above(s.y)};        // (a, d)
+                const f2 Q = f2{from_lane_below(X.y), from_lane_above(X.x)};        // (e, f)
+                T[0] = pk_add_swap_second(Q, Y);
+                T[1] = Y + X;
+                T[2] = pk_add_swap_both(X, s);
+                T[3] = s;
+            } else {
             const float a = from_lane_below(s.x), b = from_lane_below(s.y), c = from_lane_above(s.x), d = from_lane_above(s.y);
             const float e = from_lane_below(b), f = from_lane_above(c);
             T[0] = f2{e, a};
@@ -539,13 +738,22 @@ __global__ __launch_bounds__(64 * kRgb2Waves) __attribute__((amdgpu_waves_per_eu
             T[4] = f2{s.y, c};
             T[5] = f2{c, d};
             T[6] = f2{d, f};
-            f2 nb[7];
+            }
             if constexpr (L::blur_sym) {
                 // Mirror-symmetric blur (w[dy][dx] = w[6 - dy][dx] = w[dy][6 - dx]): fold the columns (3 adds), one partial sum
                 // per |dy| (P[d] = sum_j w[d][j] F[j], 16 packed fmas), and every pending row takes the partial sum of ITS |dy|
                 // (7 adds) -- 26 instead of 49 instructions.  All terms are >= 0 (relu outputs, positive weights), so "the blur
                 // is exactly 0" still means "every value of the window is 0" in this order too.
-                f2 F[4] = {T[0] + T[6], T[1] + T[5], T[2] + T[4], T[3]};
+                f2 F[4];
+                if constexpr (SYM) {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) F[j] = T[j];
+                } else {
+                    F[0] = T[0] + T[6];
+                    F[1] = T[1] + T[5];
+                    F[2] = T[2] + T[4];
+                    F[3] = T[3];
+                }
                 f2 P[4];
                 rgb2_for<0, 4>([&](auto jj) {
                     constexpr int j = decltype(jj)::value;
@@ -586,7 +794,23 @@ __global__ __launch_bounds__(64 * kRgb2Waves) __attribute__((amdgpu_waves_per_eu
         f2 o3[3];
         {
             const bool rok = t >= 0 && t < H;
-            const f2 rr = {regulator_ratio(bdone.x, prm.rv, prm.root), regulator_ratio(bdone.y, prm.rv, prm.root)};
+            f2 rr;
+            if constexpr (SYM) {
+                // regulator_ratio (silent_rgb.h) for both halves side by side: min(b, 1) as v_minimum3_f32 (a NaN stays), the two
+                // log2 / exp2 chains interleaved, ONE rarely taken branch for the denormal / root = 0 cases of either half
+                float m0, m1;
+                asm("v_minimum3_f32 %0, %1, 1.0, 1.0" : "=v"(m0) : "v"(bdone.x));
+                asm("v_minimum3_f32 %0, %1, 1.0, 1.0" : "=v"(m1) : "v"(bdone.y));
+                rr = f2{prm.rv * __builtin_amdgcn_exp2f(-prm.root * __builtin_amdgcn_logf(m0)),
+                        prm.rv * __builtin_amdgcn_exp2f(-prm.root * __builtin_amdgcn_logf(m1))};
+                const bool s0 = (m0 > 0.0f && m0 < 7.8886e-31f) || prm.root == 0.0f, s1 = (m1 > 0.0f && m1 < 7.8886e-31f) || prm.root == 0.0f;
+                if (s0 || s1) {
+                    if (s0) rr.x = prm.rv / powf(m0, prm.root);
+                    if (s1) rr.y = prm.rv / powf(m1, prm.root);
+                }
+            } else {
+                rr = f2{regulator_ratio(bdone.x, prm.rv, prm.root), regulator_ratio(bdone.y, prm.rv, prm.root)};
+            }
 #pragma unroll
             for (int c = 0; c < 3; ++c) {
                 const f2 xs = xs3[c];
@@ -595,7 +819,11 @@ __global__ __launch_bounds__(64 * kRgb2Waves) __attribute__((amdgpu_waves_per_eu
                     if (xs.x == 0.0f) y.x = 0.0f;
                     if (xs.y == 0.0f) y.y = 0.0f;
                 }
-                o3[c] = f2{(rok && col0) ? y.x : 0.0f, (rok && col1) ? y.y : 0.0f};
+                o3[c] = y;
+            }
+            if (!(SYM && rok && cols_in)) {   // (SYM: the selects only where a lane or the row can be outside, like relu_stage)
+#pragma unroll
+                for (int c = 0; c < 3; ++c) o3[c] = f2{(rok && col0) ? o3[c].x : 0.0f, (rok && col1) ? o3[c].y : 0.0f};
             }
         }
         {
@@ -618,7 +846,8 @@ __global__ __launch_bounds__(64 * kRgb2Waves) __attribute__((amdgpu_waves_per_eu
             f2 le[3];
 #pragma unroll
             for (int c = 0; c < 3; ++c)
-                le[c] = mk * f2{clip_hi_tf(relu_tf(g[c].x), prm.clip_hi), clip_hi_tf(relu_tf(g[c].y), prm.clip_hi)};
+                le[c] = SYM ? mk * f2{relu_clip_max3(g[c].x, prm.clip_hi), relu_clip_max3(g[c].y, prm.clip_hi)}
+                            : mk * f2{clip_hi_tf(relu_tf(g[c].x), prm.clip_hi), clip_hi_tf(relu_tf(g[c].y), prm.clip_hi)};
             const int ro = rows ? yout * W * 12 : kRgb2Out, rv = rows ? yout * W * 4 : kRgb2Out;
             store_row3(le, r_line, ro);
             const f2 val = ((le[0] + le[1]) + le[2]) * inv3p;

@@ -11,7 +11,7 @@ pipe = LineEndPipeline((1080, 1920), mode="rgb", n_levels=6, batch=B, device=0, 
 frames = torch.randint(0, 256, (B, 1080, 1920, 3), device="cuda").float()
 pipe.run_pyramid(frames)
 torch.cuda.synchronize()
-ths = [0, 50, 72, 90, 96, 100, 104, 108, 120, 136, 156]
+ths = [int(t) for t in os.environ.get("SWEEP_TH", "0,50,72,90,96,100,104,108,120,136,156").split(",")]
 times = {t: [] for t in ths}
 for rnd in range(6):
     for t in ths:

@@ -663,13 +663,14 @@ def test_rgb_chain_structured_and_dense_kernels_agree(rt, kernels):
 
 @pytest.mark.parametrize("shape", [(2, 70, 131, 3), (1, 33, 448, 3), (1, 211, 449, 3), (3, 19, 5, 3), (1, 1, 1, 3),
                                    (1, 100, 113, 3), (1, 95, 912, 3)])
-@pytest.mark.parametrize("variant", [0, 1, 2])
+@pytest.mark.parametrize("variant", [64, 1, 2])
 def test_rgb_pair_kernel_is_bit_identical_to_the_one_pixel_kernel(rt, kernels, shape, variant):
-    """rgb_line_end2_kernel (two adjacent pixels per lane, v_pk_fma_f32 with the SGPR weight for both halves; default) against
+    """rgb_line_end2_kernel (two adjacent pixels per lane, v_pk_fma_f32 with the SGPR weight for both halves) against
     rgb_line_end_kernel (TUNE_RGB bit 16): each half of a packed fma chain is the fmaf chain of its pixel in the same order,
-    so every output bit must agree -- for the structured, the basic and the dense instantiation, on odd widths, widths
-    around the 112 / 448-column wave / tile boundaries, single pixels, NaN / inf pixels, both flat policies and 18 / 90-row
-    tiles."""
+    so every output bit must agree -- for the two-group (64: the symmetric forms off), the basic and the dense instantiation, on
+    odd widths, widths around the 112 / 448-column wave / tile boundaries, single pixels, NaN / inf pixels, both flat policies
+    and 18 / 90-row tiles.  (The symmetric forms -- the default on the reference's kernels -- sum a pixel's left and right taps in
+    an order that depends on its column parity: test_rgb_symmetric_forms_against_the_two_group_kernel.)"""
     rng = np.random.default_rng(shape[1] * 1000 + shape[2])
     frames = np.stack([noise_frame(50 + i, shape[1], shape[2], 3) for i in range(shape[0])])
     if shape[1] > 8:
@@ -692,6 +693,50 @@ def test_rgb_pair_kernel_is_bit_identical_to_the_one_pixel_kernel(rt, kernels, s
                 assert a.shape == b.shape
                 assert np.array_equal(np.isnan(a), np.isnan(b)), (name, policy, tall)
                 np.testing.assert_array_equal(np.nan_to_num(a, nan=7.0), np.nan_to_num(b, nan=7.0), err_msg="%s %s %d" % (name, policy, tall))
+
+
+@pytest.mark.parametrize("shape", [(2, 70, 131, 3), (1, 33, 448, 3), (1, 211, 449, 3), (3, 19, 5, 3), (1, 1, 1, 3), (1, 2, 2, 3),
+                                   (1, 100, 113, 3), (1, 95, 912, 3)])
+def test_rgb_symmetric_forms_against_the_two_group_kernel(rt, kernels, shape):
+    """The default instantiation on the reference's kernels (csrc/silent_rgb2.h, SYM: rgc folded over both mirror axes, rgby as
+    channel mix -> one symmetric profile -> centre mix, left / right taps as swapped-half packed fmas without moves, relu + clip
+    of the line-end as v_maximum3 / v_minimum3) against the two-group instantiation (TUNE_RGB bit 6), which is bit-identical to
+    the one-pixel kernel.  Re-association only: the NaN / inf footprint must be THE SAME (zero weights of the channel mixes are
+    multiplied, not skipped, like the reference's 0 * x), finite values agree to a few ulp of the response range and both sit
+    inside the oracle's element-wise rounding bound."""
+    rng = np.random.default_rng(shape[1] * 1000 + shape[2])
+    frames = np.stack([noise_frame(150 + i, shape[1], shape[2], 3) for i in range(shape[0])])
+    if shape[1] > 8:
+        frames[0, 3:9, : max(1, shape[2] // 3)] = 0.0            # a flat region: 0 * inf under 'ieee'
+    clean = frames.copy()
+    if shape[1] * shape[2] > 64:
+        ys = rng.integers(0, shape[1], 5)
+        xs = rng.integers(0, shape[2], 5)
+        frames[0, ys[0], xs[0], 1] = np.nan
+        frames[0, ys[1], xs[1], 0] = -np.nan
+        frames[0, ys[2], xs[2], 2] = np.inf
+        frames[0, ys[3], xs[3], 0] = -np.inf
+    for policy in ("ieee", "zero"):
+        for x in (frames, clean):
+            for tall in (0, 8):
+                with rt.tuning(TUNE_RGB, tall):
+                    sym = rt.rgb_line_end(x, kernels, flat_policy=policy)
+                with rt.tuning(TUNE_RGB, tall | 64):
+                    two = rt.rgb_line_end(x, kernels, flat_policy=policy)
+                for name in ("orient", "line_end", "value"):
+                    a, b = sym[name], two[name]
+                    assert np.array_equal(np.isnan(a), np.isnan(b)), (name, policy, tall)
+                    assert np.array_equal(np.isinf(a), np.isinf(b)), (name, policy, tall)
+                    fin = np.isfinite(b)
+                    np.testing.assert_array_equal(np.signbit(a[~fin & ~np.isnan(b)]), np.signbit(b[~fin & ~np.isnan(b)]))
+                    if fin.any() and x is clean:
+                        assert_close(np.where(fin, a, 0), np.where(fin, b, 0), 2e-6, scale=255.0, what="%s %s symmetric vs two-group" % (name, policy), rel_floor=None)
+        want = so.rgb_line_end_chain(clean, kernels, policy)
+        bound = eb.rgb_chain(clean, kernels, want, policy)
+        got = rt.rgb_line_end(clean, kernels, flat_policy=policy)
+        assert_close(got["orient"], want["orient"], RTOL, what="orient " + policy, bound=bound["orient"])
+        assert_close(got["line_end"], want["padded"], RTOL, scale=255.0, what="line_end " + policy, bound=bound["padded"])
+        assert_close(got["value"], want["value"], RTOL, scale=255.0, what="value " + policy, bound=bound["value"])
 
 
 def test_rgb_chain_output_subsets(rt, kernels):

@@ -232,8 +232,8 @@ def test_rgb_weight_stream_is_the_kernels_consumption_order():
     np.testing.assert_array_equal(take_blur(it), a["blur"][:, :, 0, 0])
     np.testing.assert_array_equal(take_conv(it, 0x1ff), a["end"])
     assert next(it, None) is None
-    # two-group (what the reference's kernels get)
-    stream, n, variant, a = _chain_stream(consts)
+    # two-group (the reference's kernels with the symmetric forms switched off: knob bit 6)
+    stream, n, variant, a = _chain_stream(consts, knobs=64)
     assert (n, variant) == (27 + 45 + 27 + 16 + 45, 2) and len(stream) % 32 == 0 and not stream[n:].any()
     _, masks = _chain_structure(consts)
     it = iter(stream[:n])
@@ -243,6 +243,46 @@ def test_rgb_weight_stream_is_the_kernels_consumption_order():
     np.testing.assert_array_equal(take_blur_folded(it), a["blur"][:, :, 0, 0])      # 16 folded weights rebuild all 49
     np.testing.assert_allclose(take_two(it, masks[3:]), a["end"], rtol=2e-6, atol=1e-9)
     assert next(it, None) is None
+    # symmetric forms (what the reference's kernels get): rgc per channel (corner, edge_h, edge_v, centre); rgby = S (x) A around the
+    # centre + B at the centre; the stripe bank as (left, right) SGPR pairs, centres, (right, left) pairs per output
+    stream, n, variant, a = _chain_stream(consts)
+    assert (n, variant) == (12 + 27 + 1 + 48 + 16 + 45, 3) and not stream[n:].any()
+    it = iter(stream[:n])
+    q = np.array([next(it) for _ in range(12)], np.float32).reshape(4, 3)            # [corner, edge_v, edge_h, centre][channel]
+    rgc = np.zeros((3, 3, 3, 3), np.float32)
+    for c in range(3):
+        corner, edge_v, edge_h, centre = q[:, c]
+        rgc[:, :, c, c] = [[corner, edge_h, corner], [edge_v, centre, edge_v], [corner, edge_h, corner]]
+    np.testing.assert_array_equal(rgc, a["rgc"])
+    A = np.array([next(it) for _ in range(9)], np.float32).reshape(3, 3)             # [i][o]
+    prof = np.array([next(it) for _ in range(9)], np.float32).reshape(3, 3)          # [corner, edge_v, edge_h][o]: one value per output
+    assert (prof == prof[:, :1]).all()
+    corner, edge_v, edge_h = prof[:, 0]
+    S = np.array([[corner, edge_h, corner], [edge_v, 0, edge_v], [corner, edge_h, corner]], np.float64)
+    B = np.array([next(it) for _ in range(9)], np.float32).reshape(3, 3)
+    rgby = S[:, :, None, None] * A[None, None].astype(np.float64)
+    rgby[1, 1] += B
+    np.testing.assert_allclose(rgby, a["rgby"], rtol=2e-6, atol=1e-9)
+    assert next(it) == 0.0                                                            # the pair block starts on an even position
+    stripe = np.zeros((3, 3, 3), np.float32)                                          # [dy][dx][o]
+    for o in range(3):
+        blk = [next(it) for _ in range(16)]
+        for k, dy in enumerate((2, 1, 0)):
+            l, r, c = blk[2 * k], blk[2 * k + 1], blk[6 + k]
+            assert (blk[10 + 2 * k], blk[10 + 2 * k + 1]) == (r, l)
+            stripe[dy, :, o] = (l, c, r)
+        assert blk[9] == 0.0
+    np.testing.assert_array_equal(stripe, a["stripe"][:, :, 0, :])
+    np.testing.assert_array_equal(take_blur_folded(it), a["blur"][:, :, 0, 0])
+    np.testing.assert_allclose(take_two(it, masks[3:]), a["end"], rtol=2e-6, atol=1e-9)
+    assert next(it, None) is None
+    # an rgc that is not mirror-symmetric, an rgby whose surround is not one profile: the two-group stream
+    lop = {k: np.array(v, np.float32) for k, v in consts.items()}
+    lop["rgc"][0, 0, 1, 1] *= 1.5
+    assert _chain_stream(lop)[2] == 2
+    lop = {k: np.array(v, np.float32) for k, v in consts.items()}
+    lop["rgby"][0, 1, 1, 2] *= 1.5                     # (still two-group per input channel? no: a third direction for channel 1)
+    assert _chain_stream(lop)[2] in (1, 2)
     # a blur that is channel-uniform but NOT mirror-symmetric: no folded form, the basic instantiation
     skew = {k: np.array(v, np.float32) for k, v in consts.items()}
     skew["blur"][0, 0] *= 2.0
@@ -266,7 +306,7 @@ def test_rgb_chain_structure_of_the_reference_kernels():
     from pysilent_amd.pipeline import default_constants
     consts = default_constants("rgb")
     flags, masks = _chain_structure(consts)
-    assert flags == 0b1111
+    assert flags == 0b111111           # + rgc mirror-symmetric per channel, rgby = profile (x) channel mix + a centre mix
     assert masks == [0x010, 0x010, 0x010, 0x1f9, 0x119, 0x11f]
     # the end bank's groups are the signs of the three orientation profiles (oriented_end_detector.py:47-53)
     end = consts["end"].astype(np.float64)
@@ -279,7 +319,7 @@ def test_rgb_chain_structure_of_the_reference_kernels():
     noise = {k: rng.standard_normal(np.shape(v)).astype(np.float32) for k, v in consts.items()}
     assert _chain_structure(noise)[0] == 0
     mixed = dict(consts, rgby=noise["rgby"])
-    assert _chain_structure(mixed)[0] == 0b1011
+    assert _chain_structure(mixed)[0] == 0b011011
 
 
 def test_additive_filter_mirrors_the_reference_constant():
