@@ -1348,8 +1348,11 @@ static int rgb_chain_tile_height(const silent_ctx* ctx, const silent_extent* lev
     const unsigned kopts = ctx->tune[SILENT_TUNE_RGB];  // 1: dense, 2: no two-group, 8: 90-row tiles, bits 8-15: tile height / 2
     // two pixels per lane on packed f32 (silent_rgb2.h; its buffer addressing wants levels below 2^30 bytes per map); 16: one pixel per lane
     bool pair_kernel = !(kopts & 16u);
+    // (its range-check addressing: (H + 16) rows of a map below kRgb2Out, (H + tile height + 16) rows below 2^32 - kRgb2Out)
     for (int l = 0; l < n_levels; ++l)
-        if ((long long)levels[l].h * levels[l].w * 12 >= (long long)kRgb2Out) pair_kernel = false;
+        if ((long long)(levels[l].h + 16) * levels[l].w * 12 >= (long long)kRgb2Out ||
+            (long long)(levels[l].h + 512 + 16) * levels[l].w * 12 >= (1ll << 32) - (long long)kRgb2Out)
+            pair_kernel = false;
     // tile height: the one that minimises ceil(tiles / resident tiles) x (th + 14) row steps (silent_rgb.h)
     int th = kRgbTH;
     if ((kopts >> 8) & 0xffu) {

@@ -485,17 +485,26 @@ __global__ __launch_bounds__(64 * kRgb2Waves) __attribute__((amdgpu_waves_per_eu
     const bool col0 = x0 >= 0 && x0 < W, col1 = x1 >= 0 && x1 < W;
     const bool out_lane = lane >= kRgb2Halo / 2 && lane < 64 - kRgb2Halo / 2;
     const bool out0 = out_lane && x0 < W, out1 = out_lane && x1 < W;
-    // All pixel traffic goes through RAW BUFFER instructions on per-level resources (base = this frame's level, num_records =
-    // its bytes): a lane or row outside the image gets an offset >= kRgb2Out, which the range check turns into a load of 0 --
-    // the zero padding of the SAME convolutions -- or into a dropped store.  So there is no clamping, no select and, above
-    // all, NO BRANCH around a store: every step issues the same 2 loads + 6 stores, the compiler knows the in-order vmcnt
-    // distance exactly, and the wait for a row fetched two steps ago does not wait for the stores issued since (with
-    // exec-masked store blocks it cannot know how many were issued and waits for all of them: 1.06 ms, 0.83 without stores).
-    const unsigned lvl_bytes = (unsigned)H * (unsigned)W * 12u;   // < kRgb2Out (host-checked)
+    // All pixel traffic goes through RAW BUFFER instructions whose range check does the bounds work: the pyramid is read through a
+    // per-LEVEL resource (base = this frame's level, num_records = its bytes) with the byte offset row * row bytes + lane part --
+    // a row above the level makes it negative (= huge as the unsigned number the hardware compares), a row below it or a lane
+    // outside (lane part kRgb2Out) makes it >= num_records: a load of 0, the zero padding of the SAME convolutions.  The maps are
+    // written through per-TILE resources (base = the tile's first row, num_records = its rows), offsets relative to that row: the
+    // rows of the pipeline's fill and drain (above / below the tile) and the lanes outside are dropped stores.  So there is no
+    // clamping, no select, no scalar row test and, above all, NO BRANCH around a store: every step issues the same 2 loads + 6
+    // stores, the compiler knows the in-order vmcnt distance exactly, and the wait for a row fetched two steps ago does not wait
+    // for the stores issued since (with exec-masked store blocks it cannot know how many were issued and waits for all of them:
+    // 1.06 ms, 0.83 without stores).  Offsets are computed in unsigned arithmetic; the host keeps (H + 16) rows below kRgb2Out
+    // and (H + tile height + 16) rows below 2^32 - kRgb2Out, so no sum wraps back into range.
+    const int rb = W * 12;                                   // bytes per row of a 3-channel map
+    const int rows_t = R < H - y0 ? R : H - y0;             // output rows of this tile (>= 1)
+    const unsigned lvl_bytes = (unsigned)H * (unsigned)rb;
+    const unsigned tile_bytes = (unsigned)rows_t * (unsigned)rb;
+    const long long tile_px = base_px + (long long)y0 * W;
     const __amdgpu_buffer_rsrc_t r_src = __builtin_amdgcn_make_buffer_rsrc((void*)src, 0, lvl_bytes, 0x00020000);
-    const __amdgpu_buffer_rsrc_t r_orient = __builtin_amdgcn_make_buffer_rsrc((void*)(orient_out + base_px * 3), 0, orient_out ? lvl_bytes : 0u, 0x00020000);
-    const __amdgpu_buffer_rsrc_t r_line = __builtin_amdgcn_make_buffer_rsrc((void*)(line_out + base_px * 3), 0, line_out ? lvl_bytes : 0u, 0x00020000);
-    const __amdgpu_buffer_rsrc_t r_value = __builtin_amdgcn_make_buffer_rsrc((void*)(value_out + base_px), 0, value_out ? lvl_bytes / 3u : 0u, 0x00020000);
+    const __amdgpu_buffer_rsrc_t r_orient = __builtin_amdgcn_make_buffer_rsrc((void*)(orient_out + tile_px * 3), 0, orient_out ? tile_bytes : 0u, 0x00020000);
+    const __amdgpu_buffer_rsrc_t r_line = __builtin_amdgcn_make_buffer_rsrc((void*)(line_out + tile_px * 3), 0, line_out ? tile_bytes : 0u, 0x00020000);
+    const __amdgpu_buffer_rsrc_t r_value = __builtin_amdgcn_make_buffer_rsrc((void*)(value_out + tile_px), 0, value_out ? tile_bytes / 3u : 0u, 0x00020000);
     const int in0 = col0 ? x0 * 12 : kRgb2Out, in1 = col1 ? x1 * 12 : kRgb2Out;     // byte offsets inside a row, or out of range
     // Stores: a lane's own pixel pair would make every x3 store instruction write 12 of every 24 bytes (its partner instruction
     // the other 12) -- measured 15 % slower than runs of whole pixels per instruction (profiles/r02/rgb_pair_kernel.txt).  So an
@@ -526,11 +535,10 @@ __global__ __launch_bounds__(64 * kRgb2Waves) __attribute__((amdgpu_waves_per_eu
     float mm_grp = kPoolLowest;
     unsigned long long mm_nan = 0;   // lanes that have seen a NaN value (scalar registers)
     const int gpt = (R + kSumRows - 1) / kSumRows, nxp = (W + 1) >> 1;
-    const unsigned sum_bytes = (MM && args.sum) ? (unsigned)(((H + R - 1) / R) * gpt) * (unsigned)nxp * 4u : 0u;
+    const unsigned sum_bytes = (MM && args.sum) ? (unsigned)((rows_t + kSumRows - 1) / kSumRows) * (unsigned)nxp * 4u : 0u;   // this tile's groups
     const __amdgpu_buffer_rsrc_t r_sum = __builtin_amdgcn_make_buffer_rsrc(
-        (void*)(args.sum + (long long)tc.frame * args.sum_frame + args.sum_off[tc.level]), 0, sum_bytes, 0x00020000);
+        (void*)(args.sum + (long long)tc.frame * args.sum_frame + args.sum_off[tc.level] + (long long)tc.ty * gpt * nxp), 0, sum_bytes, 0x00020000);
     const int ssum = out0 ? (x0 >> 1) * 4 : kRgb2Out;
-    const int ylast = (y0 + R < H ? y0 + R : H) - 1;   // last output row of this tile
     __shared__ float s_tr[kRgb2Waves][128 * 3];   // [wave][one output row of the wave's 128 columns x 3 channels]
     float* const tr = s_tr[wave];
     // lane-major in AS HELD -- [lane][channel][half]: three 8-byte writes of the register pairs, no shuffling moves --, pixel-major
@@ -545,8 +553,8 @@ __global__ __launch_bounds__(64 * kRgb2Waves) __attribute__((amdgpu_waves_per_eu
         for (int c = 0; c < 3; ++c) tr_in[c] = val[c];
         const i3 da = {__float_as_int(tr_out[0]), __float_as_int(tr_out[2]), __float_as_int(tr_out[4])};
         const i3 db = {__float_as_int(tr_out[192]), __float_as_int(tr_out[194]), __float_as_int(tr_out[196])};
-        __builtin_amdgcn_raw_buffer_store_b96(da, rsrc, sta + ro, 0, kRgb2StoreAux);
-        __builtin_amdgcn_raw_buffer_store_b96(db, rsrc, stb + ro, 0, kRgb2StoreAux);
+        __builtin_amdgcn_raw_buffer_store_b96(da, rsrc, (int)((unsigned)sta + (unsigned)ro), 0, kRgb2StoreAux);
+        __builtin_amdgcn_raw_buffer_store_b96(db, rsrc, (int)((unsigned)stb + (unsigned)ro), 0, kRgb2StoreAux);
     };
 #pragma unroll
     for (int k = 0; k < 4; ++k)
@@ -557,10 +565,9 @@ __global__ __launch_bounds__(64 * kRgb2Waves) __attribute__((amdgpu_waves_per_eu
     // a move (a move would consume the load early)
     i3 nb0[2], nb1[2];
     auto fetch = [&](i3 (&buf)[2], int row) {
-        const int y = y0 - kRgb2RowHalo + row;
-        const int ro = (y >= 0 && y < H) ? y * W * 12 : kRgb2Out;
-        buf[0] = __builtin_amdgcn_raw_buffer_load_b96(r_src, in0 + ro, 0, 0);
-        buf[1] = __builtin_amdgcn_raw_buffer_load_b96(r_src, in1 + ro, 0, 0);
+        const unsigned ro = (unsigned)((y0 - kRgb2RowHalo + row) * rb);   // (a row outside the level: out of range by itself)
+        buf[0] = __builtin_amdgcn_raw_buffer_load_b96(r_src, (int)((unsigned)in0 + ro), 0, 0);
+        buf[1] = __builtin_amdgcn_raw_buffer_load_b96(r_src, (int)((unsigned)in1 + ro), 0, 0);
     };
     fetch(nb0, 0);
     fetch(nb1, 1);
@@ -571,26 +578,34 @@ __global__ __launch_bounds__(64 * kRgb2Waves) __attribute__((amdgpu_waves_per_eu
 #pragma unroll
     for (int k = 0; k < (MM ? 14 : 12); ++k) __builtin_amdgcn_raw_buffer_store_b32(k, r_value, kRgb2Out + 64 * k, 0, 0);   // (distinct: identical ones are merged)
 
-    // relu of a stage's row + zero outside the level (the next stage's SAME padding).  SYM: one v_maximum3_f32 per value, and the
-    // selects only where a lane or the row can be outside -- a wave whose 128 columns all lie inside the level skips them on every
-    // row inside the level (wave-uniform branch)
-    const bool cols_in = __builtin_amdgcn_readfirstlane(__all(col0 && col1) ? 1 : 0) != 0;
-    auto relu_stage = [&](f2 (&g)[3], bool rok) {
+    // Masks.  Every stage's row is forced to 0 outside the level (the next stage's SAME padding) and the line-end map inside the
+    // pad border.  For most steps of most waves nothing of that can bite: `inside` (one unsigned compare per step) says that the
+    // seven rows this step touches lie in the level, the output row outside the pad border, and -- cols_ok, per wave -- all 128
+    // columns inside both; then the selects and the mask product are skipped (wave-uniform branches).  Otherwise the row tests
+    // are (unsigned)y < H.
+    const bool cols_ok = __builtin_amdgcn_readfirstlane(__all(col0 && col1 && padc0 && padc1) ? 1 : 0) != 0;
+    const int in_hi = (H - prm.pad < H - 6 ? H - prm.pad : H - 6) - prm.pad;   // yout in [pad, pad + in_hi): rows yout .. yout + 6 in the level
+    const unsigned in_len = (cols_ok && in_hi > 0) ? (unsigned)in_hi : 0u;
+    auto relu_stage = [&](f2 (&g)[3], int y, int outside) {
         if constexpr (SYM) {
 #pragma unroll
             for (int c = 0; c < 3; ++c) g[c] = f2{relu_max3(g[c].x), relu_max3(g[c].y)};
-            if (!(rok && cols_in)) {
-#pragma unroll
-                for (int c = 0; c < 3; ++c) g[c] = f2{(rok && col0) ? g[c].x : 0.0f, (rok && col1) ? g[c].y : 0.0f};
-            }
         } else {
 #pragma unroll
-            for (int c = 0; c < 3; ++c) g[c] = f2{relu_ok(g[c].x, rok && col0), relu_ok(g[c].y, rok && col1)};
+            for (int c = 0; c < 3; ++c) g[c] = f2{relu_tf(g[c].x), relu_tf(g[c].y)};
+        }
+        if (outside != 0) {
+            const bool rok = (unsigned)y < (unsigned)H;
+#pragma unroll
+            for (int c = 0; c < 3; ++c) g[c] = f2{(rok && col0) ? g[c].x : 0.0f, (rok && col1) ? g[c].y : 0.0f};
         }
     };
     // one row step: `mine` holds this row; row + 2 is fetched into it as soon as the row has been taken
     auto step = [&](int row, i3 (&mine)[2]) {
         const int yin = y0 - kRgb2RowHalo + row;  // input row of this step
+        // 0 inside, -1 otherwise: kept as an INTEGER (both differences non-negative <=> inside) and compared where it is used -- a
+        // bool that lives across blocks travels as a lane mask through a VGPR (v_cndmask + v_cmp per use)
+        const int outside = ((yin - 7 - prm.pad) | ((int)in_len - 1 - (yin - 7 - prm.pad))) >> 31;
         f2 v[3][3], g[3];
         // ---- rgc: completes row yin - 1
 #pragma unroll
@@ -621,7 +636,7 @@ __global__ __launch_bounds__(64 * kRgb2Waves) __attribute__((amdgpu_waves_per_eu
             conv3_roll2<RGC_PAIRS & 0x1ffu, L::b_rgc>(v, ws, a1, b1, g);
         }
         {
-            relu_stage(g, yin - 1 >= 0 && yin - 1 < H);
+            relu_stage(g, yin - 1, outside);
         }
         // ---- rgby: completes row yin - 2
         if constexpr (SYM) {
@@ -659,7 +674,7 @@ __global__ __launch_bounds__(64 * kRgb2Waves) __attribute__((amdgpu_waves_per_eu
         else conv3_roll2<0x1ffu, L::b_rgby>(v, ws, reinterpret_cast<f2 (&)[3]>(a2), reinterpret_cast<f2 (&)[3]>(b2), g);
         }
         {
-            relu_stage(g, yin - 2 >= 0 && yin - 2 < H);
+            relu_stage(g, yin - 2, outside);
         }
         // ---- stripe: completes row q = yin - 3
         if constexpr (SYM) {
@@ -702,7 +717,7 @@ __global__ __launch_bounds__(64 * kRgb2Waves) __attribute__((amdgpu_waves_per_eu
             conv3_roll2<0x1ffu, L::b_stripe>(v, ws, a3, b3, g);
         }
         {
-            relu_stage(g, yin - 3 >= 0 && yin - 3 < H);
+            relu_stage(g, yin - 3, outside);
         }
         f2 xs3[3];   // the stripe row of three steps ago
 #pragma unroll
@@ -793,7 +808,6 @@ __global__ __launch_bounds__(64 * kRgb2Waves) __attribute__((amdgpu_waves_per_eu
         const int t = yin - 6;
         f2 o3[3];
         {
-            const bool rok = t >= 0 && t < H;
             f2 rr;
             if constexpr (SYM) {
                 // regulator_ratio (silent_rgb.h) for both halves side by side: min(b, 1) as v_minimum3_f32 (a NaN stays), the two
@@ -811,25 +825,25 @@ __global__ __launch_bounds__(64 * kRgb2Waves) __attribute__((amdgpu_waves_per_eu
             } else {
                 rr = f2{regulator_ratio(bdone.x, prm.rv, prm.root), regulator_ratio(bdone.y, prm.rv, prm.root)};
             }
+            int flat_policy = prm.flat_policy;
+            asm volatile("" : "+s"(flat_policy));   // compared here, every step: hoisted out of the loop the bool travels through a VGPR
 #pragma unroll
             for (int c = 0; c < 3; ++c) {
                 const f2 xs = xs3[c];
                 f2 y = xs * rr;
-                if (prm.flat_policy == SILENT_FLAT_ZERO) {
+                if (flat_policy == SILENT_FLAT_ZERO) {
                     if (xs.x == 0.0f) y.x = 0.0f;
                     if (xs.y == 0.0f) y.y = 0.0f;
                 }
                 o3[c] = y;
             }
-            if (!(SYM && rok && cols_in)) {   // (SYM: the selects only where a lane or the row can be outside, like relu_stage)
+            if (outside != 0) {
+                const bool rok = (unsigned)t < (unsigned)H;
 #pragma unroll
                 for (int c = 0; c < 3; ++c) o3[c] = f2{(rok && col0) ? o3[c].x : 0.0f, (rok && col1) ? o3[c].y : 0.0f};
             }
         }
-        {
-            const int ro = (t >= y0 && t < y0 + R && t < H) ? t * W * 12 : kRgb2Out;
-            store_row3(o3, r_orient, ro);
-        }
+        store_row3(o3, r_orient, (t - y0) * rb);
         // ---- end bank: completes row yout = yin - 7
 #pragma unroll
         for (int c = 0; c < 3; ++c) {
@@ -838,21 +852,24 @@ __global__ __launch_bounds__(64 * kRgb2Waves) __attribute__((amdgpu_waves_per_eu
         }
         if constexpr (END_A0 != kDense) conv3_roll2_struct<END_A0, END_A1, END_A2, L::b_end>(v, ws, a5, b5, g);
         else conv3_roll2<0x1ffu, L::b_end>(v, ws, reinterpret_cast<f2 (&)[3]>(a5), reinterpret_cast<f2 (&)[3]>(b5), g);
-        const int yout = yin - 7;
+        const int yout = yin - 7, k = yout - y0;   // k: output row inside the tile
         {
-            const bool rows = yout >= y0 && yout < H;
-            const bool padr = yout >= prm.pad && yout < H - prm.pad;
-            const f2 mk = {(padc0 && padr) ? 1.0f : 0.0f, (padc1 && padr) ? 1.0f : 0.0f};
             f2 le[3];
 #pragma unroll
             for (int c = 0; c < 3; ++c)
-                le[c] = SYM ? mk * f2{relu_clip_max3(g[c].x, prm.clip_hi), relu_clip_max3(g[c].y, prm.clip_hi)}
-                            : mk * f2{clip_hi_tf(relu_tf(g[c].x), prm.clip_hi), clip_hi_tf(relu_tf(g[c].y), prm.clip_hi)};
-            const int ro = rows ? yout * W * 12 : kRgb2Out, rv = rows ? yout * W * 4 : kRgb2Out;
-            store_row3(le, r_line, ro);
+                le[c] = SYM ? f2{relu_clip_max3(g[c].x, prm.clip_hi), relu_clip_max3(g[c].y, prm.clip_hi)}
+                            : f2{clip_hi_tf(relu_tf(g[c].x), prm.clip_hi), clip_hi_tf(relu_tf(g[c].y), prm.clip_hi)};
+            if (outside != 0) {   // pad_inwards: the product with a 0 / 1 mask (a NaN in the border stays a NaN, like the reference's)
+                const bool padr = yout >= prm.pad && yout < H - prm.pad;
+                const f2 mk = {(padc0 && padr) ? 1.0f : 0.0f, (padc1 && padr) ? 1.0f : 0.0f};
+#pragma unroll
+                for (int c = 0; c < 3; ++c) le[c] = mk * le[c];
+            }
+            store_row3(le, r_line, k * rb);
             const f2 val = ((le[0] + le[1]) + le[2]) * inv3p;
             typedef int i2 __attribute__((ext_vector_type(2)));
-            if (MM && rows) {   // wave-uniform.  v_max3_f32 drops NaN operands like pool_max does (max_pool semantics, silent_peaks.h)
+            const int norow = (k | (rows_t - 1 - k)) >> 31;   // 0: an output row of this tile (wave-uniform, an integer like `outside`)
+            if (MM && norow == 0) {   // v_max3_f32 drops NaN operands like pool_max does (max_pool semantics, silent_peaks.h)
                 const float a = out0 ? val.x : kPoolLowest, b = out1 ? val.y : kPoolLowest;
                 const float na = out0 ? -val.x : kPoolLowest, nb = out1 ? -val.y : kPoolLowest;
                 asm("v_max3_f32 %0, %1, %2, %3" : "=v"(mm_mx) : "v"(mm_mx), "v"(a), "v"(b));
@@ -861,14 +878,14 @@ __global__ __launch_bounds__(64 * kRgb2Waves) __attribute__((amdgpu_waves_per_eu
                 mm_nan |= __ballot((out0 && val.x != val.x) || (out1 && val.y != val.y));
             }
             if constexpr (MM) {
-                const int k = yout - y0;
-                const bool gend = rows && (((k + 1) & (kSumRows - 1)) == 0 || yout == ylast);   // wave-uniform
-                const int so = gend ? (tc.ty * gpt + (k >> kSumRowsLog2)) * nxp * 4 : kRgb2Out;
-                __builtin_amdgcn_raw_buffer_store_b32(__float_as_int(mm_grp), r_sum, ssum + so, 0, 0);
+                const bool gend = norow == 0 && (((k + 1) & (kSumRows - 1)) == 0 || k == rows_t - 1);   // wave-uniform
+                const unsigned so = gend ? (unsigned)((k >> kSumRowsLog2) * nxp * 4) : (unsigned)kRgb2Out;
+                __builtin_amdgcn_raw_buffer_store_b32(__float_as_int(mm_grp), r_sum, (int)((unsigned)ssum + so), 0, 0);
                 mm_grp = gend ? kPoolLowest : mm_grp;
             }
-            __builtin_amdgcn_raw_buffer_store_b64(i2{__float_as_int(val.x), __float_as_int(val.y)}, r_value, sv2 + rv, 0, 0);
-            __builtin_amdgcn_raw_buffer_store_b32(__float_as_int(val.x), r_value, sv1 + rv, 0, 0);
+            const unsigned rv = (unsigned)(k * W * 4);
+            __builtin_amdgcn_raw_buffer_store_b64(i2{__float_as_int(val.x), __float_as_int(val.y)}, r_value, (int)((unsigned)sv2 + rv), 0, 0);
+            __builtin_amdgcn_raw_buffer_store_b32(__float_as_int(val.x), r_value, (int)((unsigned)sv1 + rv), 0, 0);
         }
         ws.template skip<L::total, L::blocks * kRgb2Blk>();
     };

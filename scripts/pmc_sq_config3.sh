@@ -1,0 +1,26 @@
+#!/bin/bash
+# SQ counters of the config-3 kernels alone (scripts/ab_config3_parts.py: pyramid, chain + sparse tail): per launch and per wave.
+#   usage (GPU box, repo root): scripts/pmc_sq_config3.sh <tag>
+set -o pipefail
+TAG=${1:-c3}
+REPO=$(pwd)
+OUT=$REPO/gpurun_out/pmc_$TAG
+mkdir -p $OUT
+export TMPDIR=/tmp
+cd /tmp
+rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_INSTS_VALU SQ_WAVES GRBM_GUI_ACTIVE --output-format csv -d $OUT/p1 -o p1 -- python3 $REPO/scripts/ab_config3_parts.py > $OUT/p1.log 2>&1 || exit 1
+rocprofv3 --pmc SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_ACTIVE_INST_VMEM SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_LDS SQ_INSTS_SMEM --output-format csv -d $OUT/p2 -o p2 -- python3 $REPO/scripts/ab_config3_parts.py > $OUT/p2.log 2>&1 || exit 1
+python3 - <<PY
+import csv, glob, collections
+for p in ("p1", "p2"):
+    for f in glob.glob("$OUT/%s/**/*counter_collection.csv" % p, recursive=True):
+        acc = collections.defaultdict(lambda: collections.defaultdict(float)); n = collections.Counter()
+        for r in csv.DictReader(open(f)):
+            k = r["Kernel_Name"].split("(")[0][:60]
+            acc[k][r["Counter_Name"]] += float(r["Counter_Value"])
+            if r["Counter_Name"] in ("SQ_WAVES", "SQ_INSTS_SALU"): n[k] += 1
+        for k, d in acc.items():
+            if "rgb_line_end2" not in k and "walk3" not in k: continue
+            print(p, k, "launches", n[k])
+            for c, v in sorted(d.items()): print("   %-24s %.4g per launch" % (c, v / max(n[k], 1)))
+PY
