@@ -184,7 +184,8 @@ int silent_profile_elapsed_ms(silent_ctx* ctx, float* ms, int64_t* pixels);
  * once in silent_create; silent_set_tuning changes a knob of one context afterwards.  Bits -- GRAY: 1 XCD-aware tile
  * order, 2 32-row filter tiles, 8 32-row fused tiles, 16 no single-read stream kernel, 32 XCD order in the stream kernel;
  * RGB: 1 dense weights, 2 no two-group form, 8 no short tiles, 16 the one-pixel-per-lane chain kernel (default: two pixels
- * per lane on packed f32, same bits), 32 no sparse keypoint tail, bits 8-15 tile height / 2; PYRAMID: 1 no single-read pyramid
+ * per lane on packed f32, same bits), 32 no sparse keypoint tail, 64 no symmetric forms (the two-group instantiation of the pair
+ * kernel, bit-identical to the one-pixel kernel), bits 8-15 tile height / 2; PYRAMID: 1 no single-read pyramid
  * (gray stream kernel, RGB strip walk), 2 no RGB strip walk.  All variants give the same results (bit-identical, or within
  * the re-association tolerance for the RGB forms); the defaults are the fastest measured. */
 #define SILENT_TUNE_GRAY 0
@@ -391,8 +392,9 @@ typedef struct silent_rgb_chain_params {
 
 /* Host-only: which structure silent_rgb_line_end finds in the weights (no GPU needed).  flags: bit 0 rgc is
  * channel-diagonal, bit 1 stripe does not depend on the input channel, bit 2 rgby / bit 3 end are "two-group" kernels
- * (every tap vector K[t][i][:] a multiple of one of two vectors).  masks (may be NULL): 6 words, the group-A tap masks
- * (bit dy * 3 + dx) of rgby and end per input channel. */
+ * (every tap vector K[t][i][:] a multiple of one of two vectors), bit 4 every channel of rgc is mirror-symmetric in both axes,
+ * bit 5 rgby = S (x) A around the centre + B at the centre with a profile S that is mirror-symmetric in both axes.  masks (may
+ * be NULL): 6 words, the group-A tap masks (bit dy * 3 + dx) of rgby and end per input channel. */
 int silent_rgb_chain_structure(const silent_rgb_chain_params* params, unsigned* flags, unsigned* masks);
 
 /* Config 3 from the pyramid on in ONE call (recognition_testing.py:69-77 followed by a-10 -> a-9 -> a-8 -> a-11 on its result):
@@ -427,8 +429,10 @@ int silent_sparse_tail_stats(silent_ctx* ctx, int64_t* stats);
 
 /* Host-only (no GPU needed): the weight STREAM silent_rgb_line_end hands to its pair kernel for these weights -- the
  * weights in the order the kernel consumes them (csrc/silent_rgb2.h), zero-padded to whole pairs of 16-float blocks.
- * knobs: SILENT_TUNE_RGB bits 0 / 1.  variant: 2 two-group, 1 basic (diagonal rgc + channel-sum stripe), 0 dense;
- * n_used = 160 / 265 / 373 (two-group: the mirror-symmetric blur travels as 16 folded weights).  stream must hold SILENT_RGB_STREAM_MAX floats.  For tests of the host logic. */
+ * knobs: SILENT_TUNE_RGB bits 0 / 1 / 6.  variant: 3 symmetric forms (rgc folded over both mirror axes, rgby as channel mix ->
+ * one profile -> centre mix, the stripe bank as left / right SGPR pairs), 2 two-group, 1 basic (diagonal rgc + channel-sum
+ * stripe), 0 dense; n_used = 149 / 160 / 265 / 373 (two-group and symmetric: the mirror-symmetric blur travels as 16 folded
+ * weights).  stream must hold SILENT_RGB_STREAM_MAX floats.  For tests of the host logic. */
 #define SILENT_RGB_STREAM_MAX 384
 int silent_rgb_chain_stream(const silent_rgb_chain_params* params, unsigned knobs, float* stream, int* n_used, int* variant);
 int silent_rgb_line_end(silent_ctx* ctx, const float* pyr, const silent_extent* levels, int n_levels, int n_frames,
