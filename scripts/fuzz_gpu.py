@@ -89,7 +89,7 @@ def case_rgb(rng, k):
     B = int(rng.integers(1, 3))
     # 0: specialised kernel, short tiles; 8: 90-row tiles; 1 / 2: dense / no two-group forms; 9, 10: combinations;
     # + 16: the one-pixel-per-lane kernel instead of the pair kernel; widths around its 112 / 224-column wave / tile boundaries
-    kr = int(rng.choice([0, 0, 8, 1, 2, 9, 10])) | (16 if rng.integers(0, 4) == 0 else 0)
+    kr = int(rng.choice([0, 0, 8, 1, 2, 9, 10, 64, 72])) | (16 if rng.integers(0, 4) == 0 else 0)   # (64: two-group instead of the symmetric forms)
     if rng.integers(0, 6) == 0:
         w = int(rng.choice([111, 112, 113, 223, 224, 225, 336, 337, 449])) + int(rng.integers(-1, 2))
     rt.get_context().set_tuning(_lib.TUNE_RGB, kr)
