@@ -888,10 +888,11 @@ static int select_prepare(silent_ctx* ctx, const char* who, const silent_extent*
     TRY(keypoint_workspace(ctx, s, n_levels, n_frames, sp->blocks, sizeof(unsigned) * 2 * (size_t)sp->nmm, sp->rt, sp->general, &sp->w,
                            sp->st.frame_entries, pv_ws ? sp->tab.frame_px : 0));
     sp->mm = (unsigned*)ctx->ws.p;
-    if (sp->st.frame_entries > 0) HIP_TRY(ctx, hipMemsetAsync(sp->w.zero_from, 0, sp->w.zero_bytes, s));
     const long long n_init = std::max<long long>(2ll * sp->nmm, (long long)sp->w.n_cells);
-    hipLaunchKernelGGL(init_select_kernel, dim3((unsigned)((n_init + 255) / 256)), dim3(256), 0, s, sp->mm, 2 * sp->nmm, sp->w.cells,
-                       (long long)sp->w.n_cells);
+    const long long n_zero16 = sp->st.frame_entries > 0 ? (long long)(sp->w.zero_bytes / 16) : 0;   // (every piece of the workspace is align_up'ed)
+    const long long init_blocks = std::max((n_init + 255) / 256, std::min<long long>((n_zero16 + 255) / 256, 8ll * ctx->n_cus));
+    hipLaunchKernelGGL(init_select_kernel, dim3((unsigned)init_blocks), dim3(256), 0, s, sp->mm, 2 * sp->nmm, sp->w.cells,
+                       (long long)sp->w.n_cells, (uint4*)sp->w.zero_from, n_zero16);
     return SILENT_OK;
 }
 

@@ -122,11 +122,13 @@ __global__ void init_maxmin_kernel(unsigned* mm, int n) {
     }
 }
 
-// one launch for both tables of the selection tail (extrema slots and cell maxima start from lowest())
-__global__ void init_select_kernel(unsigned* mm, int n_mm2, unsigned* cells, long long n_cells) {
+// one launch for the tables of the selection tail: extrema slots and cell maxima start from lowest(); the sparse tail's counters,
+// hit masks and flags (one 16-byte aligned region of the workspace, n_zero16 pieces) from 0
+__global__ void init_select_kernel(unsigned* mm, int n_mm2, unsigned* cells, long long n_cells, uint4* zero, long long n_zero16) {
     const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
     if (i < n_mm2) mm[i] = pool_lowest_ord();
     if (i < n_cells) cells[i] = pool_lowest_ord();
+    for (long long k = i; k < n_zero16; k += (long long)gridDim.x * 256) zero[k] = uint4{0u, 0u, 0u, 0u};
 }
 
 // If `color` is non-null the value is computed on the fly as get_value_from_color does.

@@ -12,13 +12,17 @@
 //     DPP shifts per pixel; the wave covers 128 columns of which 112 produce outputs (halo 8 px = 4 lanes per side;
 //     7 are needed): column redundancy 1.14x instead of 1.28x;
 //   * weights: a STREAM in consumption order (below), read in 16-float blocks with one block of prefetch;
-//   * memory: raw buffer loads / stores (range check = zero padding / dropped store, no branch around a store so that the
-//     in-order vmcnt distance is static), input rows fetched two steps ahead, output rows transposed through LDS so that
-//     every store instruction writes a run of whole pixels, nt on the maps nobody on the GPU reads back;
+//   * memory: raw buffer loads / stores whose range check does every bounds test (per-level resource for the loads, per-tile
+//     resources for the maps: zero padding / dropped store, no branch around a store so that the in-order vmcnt distance is
+//     static), input rows fetched two steps ahead, output rows transposed through LDS so that every store instruction writes a
+//     run of whole pixels, nt on the maps nobody on the GPU reads back;
 //   * the three stripe rows that wait for their blur row live in LDS: 128 VGPRs, 4 waves / SIMD.
 // All packed fmas are `asm volatile`: they stay in program order between the scalar loads around them, which is what the
 // result-laundering did in silent_rgb.h.
-// History and leave-one-out measurements: profiles/r02/rgb_pair_kernel.txt, DESIGN.md 4.5.
+// Round 3: the SYM instantiation (the symmetric forms of the reference's kernels: rgc folded over both mirror axes, rgby as
+// channel mix -> one profile -> centre mix, left / right taps as swapped-half packed fmas on SGPR pairs, NaN-propagating
+// v_maximum3 / v_minimum3 for relu and clip) -- the one tier that is NOT bit-identical to the one-pixel kernel.
+// History and leave-one-out measurements: profiles/r02/rgb_pair_kernel.txt, profiles/r03_experiments.txt, DESIGN.md 4.5.
 #pragma once
 
 #include "silent_peaks.h"
