@@ -7,7 +7,9 @@ import numpy as np, torch
 from pysilent_amd.pipeline import LineEndPipeline
 
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 32
-pipe = LineEndPipeline((1080, 1920), mode="rgb", n_levels=6, batch=B, device=0, max_keypoints_per_frame=1 << 16, selection=True)
+pipe = LineEndPipeline((1080, 1920), mode="rgb", n_levels=6, batch=B, device=0, max_keypoints_per_frame=1 << 16, selection=True,
+                       value_map=False, peak_value_map=False)
+run = pipe.run_filters_keypoints if os.environ.get("SWEEP_KP") else pipe.run_filters   # (the extrema instantiation + sparse tail | the plain chain)
 frames = torch.randint(0, 256, (B, 1080, 1920, 3), device="cuda").float()
 pipe.run_pyramid(frames)
 torch.cuda.synchronize()
@@ -19,7 +21,7 @@ for rnd in range(6):
         a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         a.record()
         for _ in range(5):
-            pipe.run_filters()
+            run()
         b.record()
         torch.cuda.synchronize()
         if rnd >= 1:
