@@ -246,8 +246,11 @@ def make_pipeline(wl, B, local, consts, **over):
     if "center" in wl:
         kw.update(center_dimensions=wl["center"], scale=wl["scale"])
     kw.update(over)
+    # keypoint capacity = every pyramid pixel of a frame (the LineEndPipeline default): a window without a positive peak makes
+    # every pixel mapped to it a keypoint (top_value_points.py:32-45), noise frames produce ~10^5 .. 10^6 rows, and a smaller
+    # cap would drop rows inside the timed region (round 3's 1 << 16 did)
     return LineEndPipeline((h, w), mode=wl["mode"], n_levels=wl["n_levels"], n_orient=wl["n_orient"], batch=B,
-                           device=local, constants=consts, max_keypoints_per_frame=1 << 16, **kw)
+                           device=local, constants=consts, **kw)
 
 
 def make_frames(torch, D, wl, B, rank, world, dev):
@@ -338,8 +341,16 @@ def side_workload(torch, D, name, local, dev, rank, world, label=None, **over):
            "dominant_kernel_frac_of_hbm_peak": round(dom["bytes"] / (dom["ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}
     if wl["mode"] == "rgb":
         pipe.step(frames)
+        pipe.wait()
         out["sparse_keypoint_tail"] = pipe.sparse_tail_stats()
-        out["keypoints_per_frame"] = round(float(pipe.kp_counts.float().mean().item()), 1)
+        counts = pipe.kp_counts.cpu().numpy()
+        out["keypoints_per_frame"] = round(float(counts.mean()), 1)
+        out["max_keypoints_in_a_frame"] = int(counts.max())
+        out["keypoint_capacity_per_frame"] = int(pipe.kp_cap)
+        out["keypoints_truncated_frames"] = int((counts > pipe.kp_cap).sum())
+        if out["keypoints_truncated_frames"]:
+            raise RuntimeError("bench.py %s: %d frame(s) produced more keypoint rows than the capacity %d (max %d): rows were "
+                               "dropped inside the timed region" % (name, out["keypoints_truncated_frames"], pipe.kp_cap, counts.max()))
     del pipe, frames
     torch.cuda.empty_cache()
     return out

@@ -57,7 +57,7 @@ class LineEndPipeline(object):
     def __init__(self, frame_hw, mode="gray", n_levels=5, scale=2.0, n_orient=4, batch=1, device=None,
                  constants=None, center_dimensions=None, clip_hi=255.0, flat_policy="ieee", pad=2,
                  max_keypoints_per_frame=None, selection=False, top_percent=0.1, keep_selection_maps=False, value_map=True,
-                 peak_value_map=True, orient_map=True):
+                 peak_value_map=True, orient_map=True, overlap=False):
         import torch
         self.torch = torch
         self.mode = mode
@@ -85,7 +85,18 @@ class LineEndPipeline(object):
         self.clip_hi, self.flat_policy, self.pad = float(clip_hi), flat_policy, int(pad)
         n = self.batch * self.frame_px
         f32 = dict(dtype=torch.float32, device=self.tdev)
-        self.pyr = torch.empty(n * self.channels, **f32)
+        # overlap=True (rgb): consecutive steps overlap on two internal streams -- the pyramid of batch n + 1 (latency-bound walk
+        # kernel) runs beside the chain kernel and the small launches of the keypoint tail of batch n; the pyramid is then
+        # double-buffered (pipeline.pyr = the last step's).  step() stays "enqueue the whole path for this batch", but on the
+        # pipeline's own streams: wait() orders the caller's stream behind the results, outputs() does so itself.
+        self.overlap = bool(overlap) and mode == "rgb"
+        self._pyrs = [torch.empty(n * self.channels, **f32) for _ in range(2 if self.overlap else 1)]
+        self.pyr = self._pyrs[0]
+        if self.overlap:
+            self._walk_stream, self._chain_stream = torch.cuda.Stream(self.tdev), torch.cuda.Stream(self.tdev)
+            self._pyr_ready = [torch.cuda.Event() for _ in range(2)]
+            self._pyr_free = [None, None]           # recorded behind the chain launch that read the buffer
+            self._steps = 0
         if mode == "gray":
             self.n_orient = int(self.consts["end"].shape[3])
             self.cs = torch.empty(n, **f32)
@@ -241,8 +252,39 @@ class LineEndPipeline(object):
         self.ctx.check(self._lib.silent_profile_elapsed_ms(self.ctx.handle, C.byref(ms), C.byref(px)))
         return ms.value, px.value
 
+    def _step_overlapped(self, frames):
+        torch = self.torch
+        k = self._steps & 1
+        self._steps += 1
+        self.pyr = self._pyrs[k]
+        ws, cs = self._walk_stream, self._chain_stream
+        ws.wait_stream(torch.cuda.current_stream(self.tdev))     # the frames were produced on the caller's stream
+        if self._pyr_free[k] is not None:
+            ws.wait_event(self._pyr_free[k])                      # the chain of two steps ago has read this buffer
+        self.run_pyramid(frames, C.c_void_p(ws.cuda_stream))
+        self._pyr_ready[k].record(ws)
+        cs.wait_event(self._pyr_ready[k])
+        s = C.c_void_p(cs.cuda_stream)
+        if self.selection and not self.keep_selection_maps:
+            self.run_filters_keypoints(s)
+        else:
+            self.run_filters(s)
+            self.run_keypoints(s)
+        if self._pyr_free[k] is None:
+            self._pyr_free[k] = torch.cuda.Event()
+        self._pyr_free[k].record(cs)
+
+    def wait(self):
+        """Order the caller's current stream behind everything step() has enqueued (a no-op without ``overlap``)."""
+        if self.overlap:
+            cur = self.torch.cuda.current_stream(self.tdev)
+            cur.wait_stream(self._chain_stream)
+            cur.wait_stream(self._walk_stream)
+
     def step(self, frames):
         """One pass of the hot path over one batch of frames (asynchronous)."""
+        if self.overlap:
+            return self._step_overlapped(frames)
         s = self._stream()
         if self.mode == "gray":
             self.run_gray_pass(frames, s)
@@ -260,6 +302,7 @@ class LineEndPipeline(object):
         produced more keypoints than ``max_keypoints_per_frame`` (like the host entry point's SILENT_E_CAPACITY) unless
         ``allow_truncated``; ``keypoint_counts`` always holds the true counts."""
         P = _runtime.PackedPyramid
+        self.wait()
         out = {"pyramid": P(self.pyr, self.extents, self.channels, self.batch)}
         if self.mode == "gray":
             out["cs"] = P(self.cs, self.extents, 1, self.batch)
