@@ -107,9 +107,14 @@ def launch_ranks(n, argv, timeout_s=None):
         logs.append(path)
         log = open(path, "wb")
         # rank 0: stdout is the JSON line (relayed), stderr goes to its log; ranks >= 1: both to the log
+        # (rank 0's stdout goes to a FILE, not a pipe: nothing a library prints to fd 1 can fill a pipe buffer and block the
+        # rank while this loop only polls exit codes)
+        out0 = open(os.path.join(logdir, "rank0.out"), "wb") if r == 0 else None
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + list(argv), env=env,
-                                      stdout=subprocess.PIPE if r == 0 else log, stderr=log, text=(r == 0) or None))
+                                      stdout=out0 if r == 0 else log, stderr=log))
         log.close()
+        if out0:
+            out0.close()
     deadline = time.time() + timeout_s
     rc, failed = 0, None
     pending = set(range(n))
@@ -135,7 +140,11 @@ def launch_ranks(n, argv, timeout_s=None):
                   file=sys.stderr)
             for r in sorted(pending):
                 print("---- rank %d, tail of %s ----\n%s" % (r, logs[r], _tail(logs[r])), file=sys.stderr)
-    out = procs[0].stdout.read() if procs[0].stdout else ""
+    try:
+        with open(os.path.join(logdir, "rank0.out"), "r", errors="replace") as f:
+            out = f.read()
+    except OSError:
+        out = ""
     if failed is not None:
         print("bench.py launcher: rank %d exited with code %d; tail of %s:\n%s" % (failed, rc, logs[failed], _tail(logs[failed])),
               file=sys.stderr)
@@ -185,44 +194,75 @@ def pmc_traffic_per_launch(kernel_substr, frames_in_launch):
 
 # ------------------------------------------------------------------------------------------ CPU baselines
 
+def _native_oracle():
+    """the C port is built -O3 -march=native ON the box that times it (`make -C oracle native`; the
+    library that travels with the snapshot is -march=x86-64-v3).  Falls back to the portable build when gcc is missing."""
+    path = os.path.join(ROOT, "oracle", "libsilent_oracle_native.so")
+    try:
+        subprocess.run(["make", "-C", os.path.join(ROOT, "oracle"), "-s", "-B", "native"], check=True, timeout=120,
+                       stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+        os.environ["SILENT_ORACLE_SO"] = path
+        return "-O3 -march=native -fopenmp (built on this host)"
+    except (OSError, subprocess.SubprocessError):
+        return "-O3 -march=x86-64-v3 -fopenmp (portable build; `make native` failed here)"
+
+
 def cpu_baseline(wl, consts, budget_s=12.0):
     """The CPU oracle timed on this box's host cores, on a bounded sample of the same workload; the oracle is the
     thing timed here, never part of the GPU path.
       B2 (the reported ``value``, kind "port"): oracle/silent_oracle.c, one frame per OpenMP thread.
       B1 ("numpy_scipy"): oracle/silent_oracle.py, the closest analogue of the reference's host path -- the same
-          scipy.ndimage.zoom(order=5, prefilter=False) call for the pyramid, NumPy for the stencils, one process."""
+          scipy.ndimage.zoom(order=5, prefilter=False) call for the pyramid, NumPy for the stencils, one process.
+    gray: pyramid + CS + K-orientation line-end (configs 2 / 5); rgb: pyramid + the reference chain + top 10 % + NMS + value +
+    per-region keypoint indices (config 3; the op list of recognition_testing.py:69-90)."""
+    flags = _native_oracle()
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import c_oracle as co
     import silent_oracle as so
     from pysilent_amd.distributed import synthetic_frame
     h, w = wl["hw"]
-    if wl["mode"] != "gray":
+    if "center" in wl:
         return None
+    rgb = wl["mode"] == "rgb"
+    c = 3 if rgb else 1
     extents = so.classic_extents(h, w, 2.0, wl["n_levels"])
     threads = co.num_threads()
     batch = max(threads, 1)
-    frames = np.empty((batch, h, w, 1), np.float32)
+    frames = np.empty((batch, h, w, c), np.float32)
     for i in range(batch):
-        frames[i] = synthetic_frame(i % 16, h, w, 1)
-    co.gray_pass_frames(frames[:min(batch, 8)], extents, consts["cs"], consts["end"])      # warm: page faults, OpenMP team
+        frames[i] = synthetic_frame(i % 16, h, w, c)
+    if rgb:
+        ks = {k: consts[k] for k in ("rgc", "rgby", "stripe", "blur", "end")}
+        run = lambda fr: co.rgb_pass_frames(fr, extents, ks, "ieee", 0.1)
+        what = "pyramid + rgc>rgby>stripe>regulate>end>pad>value + top 10 % + NMS + keypoint indices"
+    else:
+        run = lambda fr: co.gray_pass_frames(fr, extents, consts["cs"], consts["end"])
+        what = "pyramid + CS + %d-orientation line-end" % wl["n_orient"]
+    run(frames[:min(batch, 8)])      # warm: page faults, OpenMP team
     n, total = 0, 0.0
     while total < budget_s and n < 64 * batch:
         t = time.perf_counter()
-        co.gray_pass_frames(frames, extents, consts["cs"], consts["end"])
+        run(frames)
         total += time.perf_counter() - t
         n += batch
     out = {"value": round(n * h * w / total / 1e6, 3), "unit": "Mpx/s", "cores": threads, "kind": "port",
-           "sample": "%d synthetic %dx%d frames, whole pass (pyramid + CS + %d-orientation line-end), "
-                     "oracle/silent_oracle.c -O3 -fopenmp, one frame per thread, float64 accumulation, %.1f s wall"
-                     % (n, w, h, wl["n_orient"], total),
+           "sample": "%d synthetic %dx%dx%d frames, whole pass (%s), oracle/silent_oracle.c %s, one frame per thread, "
+                     "float64 accumulation, %.1f s wall" % (n, w, h, c, what, flags, total),
            "host_cpus": os.cpu_count(), "affinity": len(os.sched_getaffinity(0))}
     # B1: a handful of frames through the NumPy / SciPy oracle
     n1, t1 = 0, 0.0
-    while t1 < 8.0 and n1 < 8:
-        frame = synthetic_frame(n1, h, w, 1)
+    while t1 < 8.0 and n1 < (2 if rgb else 8):
+        frame = synthetic_frame(n1, h, w, c)
         t = time.perf_counter()
         pyr = so.classic_pyramid(frame, 2.0, wl["n_levels"])
-        so.gray_line_end_pass(pyr, consts["cs"], consts["end"])
+        if rgb:
+            for lev in pyr:
+                line = so.rgb_line_end_chain(lev, ks)["padded"]
+                top = so.top_value_points(line, 0.1)
+                pv = so.value_from_color(so.nms3x3(top, "product"))
+                so.max_value_indices_region(None, (1, max(lev.shape[1] // 2, 1), max(lev.shape[2] // 2, 1), 3), pv)
+        else:
+            so.gray_line_end_pass(pyr, consts["cs"], consts["end"])
         t1 += time.perf_counter() - t
         n1 += 1
     out["numpy_scipy"] = {"value": round(n1 * h * w / t1 / 1e6, 3), "unit": "Mpx/s", "kind": "reference-like",
@@ -241,8 +281,9 @@ def make_pipeline(wl, B, local, consts, **over):
     if wl["mode"] == "rgb":
         # config 3 returns line_end + keypoints (+ orient, optional in SURVEY.md section 8d): the value map and the selection's
         # peak-value map are intermediates the fused step never writes (silent_rgb_keypoints: extrema in the chain kernel,
-        # sparse keypoint tail)
-        kw = {"selection": True, "value_map": False, "peak_value_map": False}
+        # sparse keypoint tail).  overlap: consecutive steps overlap on the pipeline's two streams (the pyramid of batch n + 1
+        # beside the chain + keypoint tail of batch n; every step still enqueues the whole path of its batch)
+        kw = {"selection": True, "value_map": False, "peak_value_map": False, "overlap": True}
     if "center" in wl:
         kw.update(center_dimensions=wl["center"], scale=wl["scale"])
     kw.update(over)
@@ -260,6 +301,26 @@ def make_frames(torch, D, wl, B, rank, world, dev):
     for j, gi in enumerate(D.shard_frame_indices(B * world, rank, world)):
         frames[j] = torch.from_numpy(D.synthetic_frame(gi, h, w, c)).to(dev)
     return frames
+
+
+def settle(torch, pipe, frames, dev, window=10, tol=0.01, cap=100):
+    """Untimed settle loop before the W warm-ups: after an idle period (pipeline construction, synthetic frames) the first
+    launches of a ~1 ms pass run inside the chip's idle -> load power transient (profiles/r02/launch_drift.txt), and W = 5 steps
+    are 5 ms.  Windows of ``window`` steps are repeated until two consecutive ones agree to ``tol`` (at most ``cap`` steps).
+    Per rank, no collective.  Returns (steps run, ms per step of the last window)."""
+    run, prev, cur = 0, None, None
+    while run < cap:
+        torch.cuda.synchronize(dev)
+        t0 = time.perf_counter()
+        for _ in range(window):
+            pipe.step(frames)
+        torch.cuda.synchronize(dev)
+        cur = (time.perf_counter() - t0) / window * 1e3
+        run += window
+        if prev is not None and abs(cur - prev) <= tol * prev:
+            break
+        prev = cur
+    return run, cur
 
 
 def timed_steps(torch, D, pipe, frames, steps, warmup, dev):
@@ -283,6 +344,11 @@ def dominant_kernel(torch, pipe, frames, wl, B, dev, launches=24):
     """Average launch duration of the dominant kernel from HIP events, in a loop of its own AFTER the timed region: the
     library brackets gray_stream_kernel (gray) / rgb_line_end2_kernel (rgb) with an event pair on the stream it launches on
     (silent_set_profiling / silent_profile_elapsed_ms) while the ordinary step runs -- i.e. the very instantiation the step uses."""
+    # (the kernel is priced ALONE on the chip: with overlap=True the next batch's pyramid kernel runs beside it)
+    overlapped = getattr(pipe, "overlap", False)
+    if overlapped:
+        torch.cuda.synchronize(dev)
+        pipe.overlap = False
     pipe.set_profiling(1)
     ms, px = [], 0
     for _ in range(launches // 8):
@@ -293,6 +359,9 @@ def dominant_kernel(torch, pipe, frames, wl, B, dev, launches=24):
         ms.append(float(t))
         pipe.set_profiling(1)                    # restart the ring
     pipe.set_profiling(0)
+    if overlapped:
+        torch.cuda.synchronize(dev)
+        pipe.overlap = True
     dom_ms = float(np.mean(ms))
     if wl["mode"] == "gray":
         other_px = pipe.frame_px * B - px
@@ -326,20 +395,24 @@ def side_workload(torch, D, name, local, dev, rank, world, label=None, **over):
     pipe = make_pipeline(wl, B, local, consts, **over)
     frames = make_frames(torch, D, wl, B, rank, world, dev)
     torch.cuda.synchronize(dev)
-    # 30 untimed steps first: building the pipeline and the synthetic frames leaves the GPU idle for a second or two, and the
+    # settle first: building the pipeline and the synthetic frames leaves the GPU idle for a second or two, and the
     # first ~20 launches after an idle period run inside the power-management transient (profiles/r02/launch_drift.txt)
     steps = 30
-    elapsed = timed_steps(torch, D, pipe, frames, steps, 30, dev)
+    settled, _ = settle(torch, pipe, frames, dev)
+    elapsed = timed_steps(torch, D, pipe, frames, steps, 5, dev)
     dom = dominant_kernel(torch, pipe, frames, wl, B, dev, launches=16)
     h, w = wl["hw"]
     whole = pipe.algorithmic_bytes_per_frame() * B * steps / elapsed / 1e9
-    out = {"workload": label or wl["name"], "frames_per_step": B, "ms_per_step": round(elapsed / steps * 1e3, 4),
+    out = {"workload": label or wl["name"], "frames_per_step": B, "settle_steps_run": settled,
+           "ms_per_step": round(elapsed / steps * 1e3, 4),
            "mpx_in_per_s": round(B * steps * h * w / elapsed / 1e6, 1),
            "algorithmic_bytes_per_frame": pipe.algorithmic_bytes_per_frame(),
            "whole_pass_frac_of_hbm_peak": round(whole / HBM_PEAK_GBS, 4),
            "dominant_kernel": dom["kernel"], "dominant_kernel_ms": round(dom["ms"], 4),
            "dominant_kernel_frac_of_hbm_peak": round(dom["bytes"] / (dom["ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}
     if wl["mode"] == "rgb":
+        out["streams"] = ("two (overlap=True): pyramid of batch n + 1 beside chain + keypoint tail of batch n" if pipe.overlap
+                          else "one: pyramid -> chain -> keypoint tail back to back")
         pipe.step(frames)
         pipe.wait()
         out["sparse_keypoint_tail"] = pipe.sparse_tail_stats()
@@ -356,17 +429,21 @@ def side_workload(torch, D, name, local, dev, rank, world, label=None, **over):
     return out
 
 
-def config3_variants(torch, D, local, dev, rank, world):
+def config3_variants(torch, D, local, dev, rank, world, cpu=True):
     """Config 3 on both output sets of SURVEY.md section 8d (line_end + keypoints; the same + the optional orientation map),
     on the bench's noise frames and -- the worst case for the sparse keypoint tail, which then hands most levels to the dense
     kernels -- with every frame a line drawing under the default 'ieee' policy."""
     out = {"config3": side_workload(torch, D, "config3", local, dev, rank, world),
+           "config3_one_stream": side_workload(torch, D, "config3", local, dev, rank, world, overlap=False,
+                                               label="config 3 on one stream (no overlap between consecutive steps)"),
            "config3_line_end_only": side_workload(torch, D, "config3", local, dev, rank, world,
                                                   label="config 3, SURVEY 8d output set: line_end + keypoints (no orientation map)",
                                                   orient_map=False),
            "config3_peak_value_map": side_workload(torch, D, "config3", local, dev, rank, world,
                                                    label="config 3 with the selection's peak-value map returned too (sparse tail + zero fill)",
                                                    peak_value_map=True)}
+    if cpu:   # the host number beside config 3's GPU number (C port on every core + NumPy / SciPy on 2 frames)
+        out["config3"]["cpu_baseline"] = cpu_baseline(WORKLOADS["config3"], D.broadcast_constants("rgb", 3, device=local))
     # the round-2 tail for comparison: the dense selection / count kernels on every level (SILENT_TUNE_RGB bit 5)
     from pysilent_amd import _lib, _runtime
     ctx = _runtime.get_context(local)
@@ -403,6 +480,11 @@ def emit_line(text):
         os.write(_REAL_STDOUT, (text + "\n").encode())
 
 
+def whole_job_mpx(frames_per_rank_per_step, world, steps, h, w, slowest_rank_seconds):
+    """The contract's ``value``: input megapixels ALL ranks processed in the timed region / the time of the SLOWEST rank."""
+    return frames_per_rank_per_step * world * steps * h * w / slowest_rank_seconds / 1e6
+
+
 def dist_record(D, rank, local, ident, own_ms):
     """all_gather of one record per rank -> the ``dist`` object of the JSON line; exits non-zero (every rank) when two
     ranks report the same GPU: N ranks must have seen N distinct devices."""
@@ -429,6 +511,10 @@ def dry_run(args):
     if os.environ.get("SILENT_BENCH_DRY_FAIL_RANK") == str(rank):
         print("dry run: rank %d fails on purpose" % rank, file=sys.stderr)
         sys.exit(7)
+    if os.environ.get("SILENT_BENCH_DRY_HANG_RANK") == str(rank):
+        print("dry run: rank %d (pid %d) hangs on purpose" % (rank, os.getpid()), file=sys.stderr, flush=True)
+        while True:
+            time.sleep(1.0)
     consts = D.broadcast_constants(wl["mode"], wl["n_orient"])
     mine = D.shard_frame_indices(4 * world, rank, world)
     D.barrier()
@@ -437,7 +523,11 @@ def dry_run(args):
     ident = {"device_name": "dry-run (no GPU)", "pci_bus_id": "dry:%02d" % (0 if same else rank), "uuid": "", "gcn_arch": ""}
     dist = dist_record(D, rank, local, ident, 1.0 + rank)
     if rank == 0:
-        emit_line(json.dumps({"metric": METRIC, "value": None, "dry_run": True, "n_gpus": world, "slowest_rank_time": slow,
+        h, w = wl["hw"]
+        # every rank "processed" 4 frames per step in (1 + rank) seconds: value = SUM of frames over ranks / MAX time
+        emit_line(json.dumps({"metric": METRIC, "value": whole_job_mpx(4, world, args.steps, h, w, slow), "dry_run": True,
+                              "steps": args.steps, "frames_per_rank_per_step": 4, "frame_hw": [h, w],
+                              "n_gpus": world, "slowest_rank_time": slow,
                               "frames_of_rank0": mine, "constants": sorted(consts), "dist": dist}))
     D.finalize()
 
@@ -486,6 +576,7 @@ def run_rank(args):
     frames = make_frames(torch, D, wl, B, rank, world, dev)
     torch.cuda.synchronize(dev)
 
+    settle_run, settle_ms = settle(torch, pipe, frames, dev)
     elapsed = timed_steps(torch, D, pipe, frames, args.steps, args.warmup, dev)
     own_ms = timed_steps.own / args.steps * 1e3
 
@@ -503,7 +594,7 @@ def run_rank(args):
         D.finalize()
         return
     total_frames = B * world * args.steps
-    mpx_in = total_frames * h * w / elapsed / 1e6
+    mpx_in = whole_job_mpx(B, world, args.steps, h, w, elapsed)
     whole = pipe.algorithmic_bytes_per_frame() * B * args.steps / elapsed / 1e9
     out = {
         "metric": METRIC if h == 1080 else "Mpx/s full pyramid line-end pass @4K",
@@ -512,6 +603,8 @@ def run_rank(args):
         "n_gpus": world,
         "steps": args.steps,
         "warmup": args.warmup,
+        "settle_steps_run": settle_run,
+        "settle_last_window_ms_per_step": round(settle_ms, 4),
         "ms_per_step": round(elapsed / args.steps * 1e3, 4),
         "higher_is_better": True,
         "scaling": "weak",
@@ -535,15 +628,16 @@ def run_rank(args):
         "steady_state": {"ms_per_step": round(steady / settle_steps * 1e3, 4), "steps": settle_steps,
                          "value": round(B * world * settle_steps * h * w / steady / 1e6, 2),
                          "whole_pass_frac_of_hbm_peak": round(pipe.algorithmic_bytes_per_frame() * B * settle_steps / steady / 1e9 / HBM_PEAK_GBS, 4),
-                         "note": "the same steps timed again right after the K timed ones: the first ~20 launches after an idle "
-                                 "period run inside a power-management transient (profiles/r02/launch_drift.txt)"},
+                         "note": "cross-check of the settle loop: the same steps timed again right after the K timed ones "
+                                 "(without a settle loop the first ~20 launches after an idle period run inside a power-management "
+                                 "transient, profiles/r02/launch_drift.txt)"},
     }
     del pipe, frames
     torch.cuda.empty_cache()
     if world == 1 and not args.no_side_workloads:
         out["other_workloads"] = {}
         if args.workload != "config3":
-            out["other_workloads"].update(config3_variants(torch, D, local, dev, rank, world))
+            out["other_workloads"].update(config3_variants(torch, D, local, dev, rank, world, cpu=not args.no_cpu_baseline))
         if args.workload != "config5":
             out["other_workloads"]["config5"] = side_workload(torch, D, "config5", local, dev, rank, world)
         if args.workload != "reference_layout":

@@ -10,13 +10,17 @@ import subprocess
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-_SO = os.path.join(_HERE, "libsilent_oracle.so")
+# SILENT_ORACLE_SO: another build of the same source (oracle/Makefile: `native` for bench.py's cpu_baseline leg on the box
+# that times it, `asan` for tests/test_sanitizers.py)
+_SO = os.environ.get("SILENT_ORACLE_SO") or os.path.join(_HERE, "libsilent_oracle.so")
 _lib = None
 
 _f = C.POINTER(C.c_float)
 
 
 def build(force=False):
+    if os.environ.get("SILENT_ORACLE_SO"):
+        return _SO
     if force or not os.path.exists(_SO) or os.path.getmtime(_SO) < os.path.getmtime(os.path.join(_HERE, "silent_oracle.c")):
         subprocess.check_call(["make", "-C", _HERE, "-s"] + (["-B"] if force else []))
     return _SO
@@ -44,6 +48,10 @@ def lib():
         L.so_gray_pass_frames.restype = C.c_double
         L.so_gray_pass_frames.argtypes = [_f, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int), C.c_int, _f, _f, C.c_int,
                                           C.c_float]
+        L.so_rgb_pass_frames.restype = C.c_int64
+        L.so_rgb_pass_frames.argtypes = [_f, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int), C.c_int, _f, _f, _f, _f, _f,
+                                         C.c_float, C.c_float, C.c_int, C.c_float, C.c_int, C.c_double,
+                                         C.POINTER(C.c_int64), C.c_int64, C.POINTER(C.c_int64)]
         _lib = L
     return _lib
 
@@ -159,3 +167,22 @@ def gray_pass_frames(frames, extents, cs_k, end_k, clip_hi=255.0):
     ext = np.ascontiguousarray(np.asarray(extents, dtype=np.int32).reshape(-1, 2))
     return lib().so_gray_pass_frames(_p(frames), B, H, W, ext.ctypes.data_as(C.POINTER(C.c_int)), ext.shape[0],
                                      _p(cs_k), _p(end_k), end_k.shape[-1], float(clip_hi))
+
+
+def rgb_pass_frames(frames, extents, kernels, flat_policy="ieee", top_percent=0.1, rv=1.0, root=0.1, clip_hi=255.0, pad=2,
+                    cap=0):
+    """BASELINE config 3 on a batch [B, H, W, 3] of frames, one frame per OpenMP thread: classic pyramid -> reference chain ->
+    top-percent -> NMS -> value -> per-region keypoint indices (region = half the level).  Returns (counts [B] int64, rows):
+    rows is None when cap == 0, else a list of int64 [K_f, 4] arrays (level, y, x, 0)."""
+    frames = _c32(frames)
+    B, H, W = frames.shape[:3]
+    ext = np.ascontiguousarray(np.asarray(extents, dtype=np.int32).reshape(-1, 2))
+    ks = [_c32(kernels[n]) for n in ("rgc", "rgby", "stripe", "blur", "end")]
+    counts = np.zeros(B, np.int64)
+    idx = np.empty((B, cap, 4), np.int64) if cap else None
+    lib().so_rgb_pass_frames(_p(frames), B, H, W, ext.ctypes.data_as(C.POINTER(C.c_int)), ext.shape[0], *[_p(k) for k in ks],
+                             float(rv), float(root), {"ieee": 0, "zero": 1}[flat_policy], float(clip_hi), int(pad),
+                             float(top_percent), idx.ctypes.data_as(C.POINTER(C.c_int64)) if cap else None, int(cap),
+                             counts.ctypes.data_as(C.POINTER(C.c_int64)))
+    rows = [idx[f, :min(int(counts[f]), cap)].copy() for f in range(B)] if cap else None
+    return counts, rows

@@ -337,3 +337,48 @@ SO_API double so_gray_pass_frames(const float* frames, int n_frames, int H, int 
     }
     return total;
 }
+
+/* BASELINE config 3 on a BATCH of frames, one frame per OpenMP thread (bench.py's cpu_baseline leg for the RGB workload; also
+ * checked against the per-op composition in tests/test_oracle.py): classic pyramid -> per level the reference graph
+ * recognition_testing.py:69-77 (rgc > rgby > stripe > regulate(blur 7x7, rv, root) > end > relu > clip > pad_inwards > value)
+ * -> top_value_points(p) (a-10) -> 3x3 NMS, product form (a-9) -> value (a-8) -> max_value_indices_region with
+ * region = (h / 2, w / 2) (a-11).  Rows (level, y, x, 0), levels in order, row-major inside a level, go to
+ * idx + f * cap * 4 when idx is not NULL (only the first cap of a frame); counts[f] = rows of frame f.  Returns the total. */
+SO_API int64_t so_rgb_pass_frames(const float* frames, int n_frames, int H, int W, const int* extents /* [L][2] */, int L,
+                                  const float* rgc, const float* rgby, const float* stripe, const float* blur,
+                                  const float* end, float rv, float root, int flat_policy, float clip_hi, int pad,
+                                  double top_percent, int64_t* idx, int64_t cap, int64_t* counts) {
+    int64_t total = 0;
+#pragma omp parallel for schedule(dynamic, 1) reduction(+ : total)
+    for (int f = 0; f < n_frames; ++f) {
+        const float* frame = frames + (size_t)f * H * W * 3;
+        int64_t n_rows = 0;
+        for (int l = 0; l < L; ++l) {
+            const int h = extents[2 * l], w = extents[2 * l + 1];
+            const size_t n3 = (size_t)h * w * 3;
+            float* a = (float*)malloc(sizeof(float) * (3 * n3 + (size_t)h * w));
+            float *b = a + n3, *c = b + n3, *v = c + n3;
+            so_zoom_level(frame, H, W, 3, 0, 0, H, W, h, w, h, w, a);
+            so_conv2d_same(a, 1, h, w, 3, rgc, 3, 3, 3, 1, 0.0f, b);
+            so_conv2d_same(b, 1, h, w, 3, rgby, 3, 3, 3, 1, 0.0f, a);
+            so_conv2d_same(a, 1, h, w, 3, stripe, 3, 3, 3, 1, 0.0f, b);
+            so_regulate(b, 1, h, w, 3, blur, 7, 7, rv, root, flat_policy, a);          /* orient */
+            so_conv2d_same(a, 1, h, w, 3, end, 3, 3, 3, 3, clip_hi, b);                /* line_end */
+            so_pad_inwards(b, 1, h, w, 3, pad, pad, pad, pad, a);                      /* padded */
+            so_value_from_color(a, (size_t)h * w, 3, v);
+            so_top_value_points(a, v, 1, h, w, 3, top_percent, b);
+            so_nms3x3(b, 1, h, w, 3, 0, c);
+            so_value_from_color(c, (size_t)h * w, 3, v);                               /* peak value */
+            int64_t* dst = idx ? idx + ((size_t)f * cap + (size_t)(n_rows < cap ? n_rows : cap)) * 4 : NULL;
+            const int64_t room = idx ? (n_rows < cap ? cap - n_rows : 0) : 0;
+            const int64_t got = so_max_value_indices_region(v, 1, h, w, h / 2 > 1 ? h / 2 : 1, w / 2 > 1 ? w / 2 : 1, dst, room);
+            if (dst)
+                for (int64_t r = 0; r < (got < room ? got : room); ++r) dst[r * 4] = l;
+            n_rows += got;
+            free(a);
+        }
+        if (counts) counts[f] = n_rows;
+        total += n_rows;
+    }
+    return total;
+}

@@ -109,8 +109,8 @@ def assert_close(got, want, rtol=1e-5, scale=None, what="", rel_floor=0.1, bound
         chain.  A float32 stencil whose taps cancel cannot be reproduced to 1e-5 of the RESULT by anyone (the reference's
         own TF kernels included); it can, and must, be reproduced to a few ulps of the TERMS.  Elements without a finite
         bound (the regulator's residue zone, NaN / inf reach) stay under (1); their share is reported.
-        Without ``bound`` (maps that are not sums of products of a known input, or two GPU evaluation orders compared with
-        each other): |a-b| <= rtol * |b| wherever |b| >= rel_floor * range (rel_floor=None: rule (1) only)."""
+    (3) Element-wise relative, with or without ``bound``: |a-b| <= rtol * |b| wherever |b| >= rel_floor * range
+        (rel_floor=None: not asserted -- callers that compare two float32 evaluation orders with a tolerance of their own)."""
     got, want = np.asarray(got), np.asarray(want)
     assert got.shape == want.shape, (what, got.shape, want.shape)
     nan_g, nan_w = np.isnan(got), np.isnan(want)
@@ -138,7 +138,8 @@ def assert_close(got, want, rtol=1e-5, scale=None, what="", rel_floor=0.1, bound
         ratio = float((err[has] / np.maximum(bound[has], 1e-300)).max()) if has.any() else 0.0
         old = WORST_BOUND.get(what, (0.0, 0.0))
         WORST_BOUND[what] = (max(old[0], ratio), max(old[1], 1.0 - float(has.mean()) if has.size else 0.0))
-        return
+        # (no return: a bound that has grown loose through the chain must not replace BASELINE's "1e-5 relative" -- the
+        # element-wise relative rule on the significant values below is asserted as well)
     worst = [0.0, 0.0]
     for k, floor in enumerate((rel_floor, 1e-3)):
         if floor is None:                  # caller compares two float32 evaluation orders with a tolerance of its own

@@ -96,6 +96,11 @@ def test_bench_launcher_spawns_its_own_ranks():
     out = json.loads(lines[0])
     assert out["n_gpus"] == 2 and out["dry_run"] is True
     assert out["slowest_rank_time"] == 2.0           # MAX over ranks of (1 + rank)
+    # the contract's `value`: the SUM over ranks of the frames they processed / the MAX over ranks of their times
+    h, w = out["frame_hw"]
+    frames_all_ranks = sum(out["frames_per_rank_per_step"] * out["steps"] for _ in out["dist"]["ranks"])
+    slowest_s = max(r["ms_per_step"] for r in out["dist"]["ranks"])          # (dry run: "ms_per_step" = 1 + rank seconds)
+    assert out["value"] == frames_all_ranks * h * w / slowest_s / 1e6
     assert out["frames_of_rank0"] == [0, 2, 4, 6]    # frame i -> rank i mod N
     assert out["constants"] == ["cs", "end"]
     # the scaling record proves itself: backend, world size, and per rank the device it ran on and its own time
@@ -138,3 +143,44 @@ def test_bench_launcher_reports_a_failed_rank():
                        stderr=subprocess.PIPE, text=True, timeout=300)
     assert p.returncode != 0
     assert "rank" in p.stderr
+
+
+def test_bench_launcher_stops_a_hung_rank(tmp_path):
+    """Rank 1 never reaches the rendezvous' first barrier: after SILENT_BENCH_LAUNCH_TIMEOUT the launcher exits 124, prints the
+    tails of the ranks still running, and leaves no process behind (rank 0 blocks in the barrier and is stopped too)."""
+    import re
+    import time
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT")}
+    env.update(SILENT_BENCH_DRY="1", SILENT_DIST_BACKEND="gloo", SILENT_BENCH_DRY_HANG_RANK="1",
+               SILENT_BENCH_LOG_DIR=str(tmp_path), SILENT_BENCH_LAUNCH_TIMEOUT="20")
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2"], env=env, stdout=subprocess.PIPE,
+                       stderr=subprocess.PIPE, text=True, timeout=300)
+    assert p.returncode == 124, p.stderr[-2000:]
+    assert not [l for l in p.stdout.splitlines() if l.startswith("{")]
+    assert "still running after" in p.stderr and "hangs on purpose" in p.stderr
+    pid = int(re.search(r"rank 1 \(pid (\d+)\) hangs", p.stderr).group(1))
+    for _ in range(50):                       # the launcher has waited for the processes it terminated
+        try:
+            os.kill(pid, 0)
+        except ProcessLookupError:
+            break
+        time.sleep(0.1)
+    else:
+        raise AssertionError("rank 1 (pid %d) is still alive after the launcher returned" % pid)
+
+
+def test_bench_launcher_survives_a_chatty_rank0(tmp_path):
+    """A library that prints far more than a pipe buffer to file descriptor 1 of rank 0 BEFORE bench.py has redirected it must
+    not block the launch: rank 0's stdout is a file, and the JSON line is still the last line relayed."""
+    import json
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT")}
+    site = tmp_path / "site"
+    site.mkdir()
+    (site / "sitecustomize.py").write_text("import os\nif os.environ.get('RANK') == '0':\n    os.write(1, b'x' * 300000 + b'\\n')\n")
+    env.update(SILENT_BENCH_DRY="1", SILENT_DIST_BACKEND="gloo", SILENT_BENCH_LOG_DIR=str(tmp_path),
+               PYTHONPATH=str(site) + os.pathsep + env.get("PYTHONPATH", ""))
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2"], env=env, stdout=subprocess.PIPE,
+                       stderr=subprocess.PIPE, text=True, timeout=300)
+    assert p.returncode == 0, p.stderr[-2000:]
+    last = p.stdout.strip().splitlines()[-1]
+    assert json.loads(last)["dry_run"] is True

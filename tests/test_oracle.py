@@ -455,3 +455,26 @@ def test_rounding_bound_of_a_single_convolution_and_of_the_gray_chain(kernels):
     # the pyramid's bound is a few ulps of the level itself
     lev = so.classic_pyramid(x[0], 2.0, 2)[1]
     assert np.all(eb.zoom(lev) <= 16 * 2.0 ** -24 * np.abs(lev) + 1e-11)
+
+
+@pytest.mark.parametrize("policy", ["ieee", "zero"])
+def test_c_rgb_pass_frames_equals_the_per_op_composition(kernels, policy):
+    """oracle/silent_oracle.c so_rgb_pass_frames (bench.py's CPU baseline for BASELINE config 3: one frame per OpenMP thread,
+    pyramid -> reference chain -> top 10 % -> NMS -> value -> per-region indices) gives the rows of the per-op composition the
+    GPU parity tests use (tests/kp_margin.py oracle_keypoints), frame by frame, in order."""
+    import c_oracle as co
+    import kp_margin as km
+    from conftest import margin_frame, noise_frame, structured_frame
+    h, w, levels = 96, 144, 3
+    frames = np.stack([noise_frame(3, h, w, 3), structured_frame(4, h, w, 3, n_lines=20), margin_frame(2, h, w),
+                       np.zeros((h, w, 3), np.float32)])
+    ks = {k: kernels[k].astype(np.float32) for k in ("rgc", "rgby", "stripe", "blur", "end")}
+    ext = so.classic_extents(h, w, 2.0, levels)
+    counts, rows = co.rgb_pass_frames(frames, ext, ks, policy, cap=2 * h * w)
+    for f in range(len(frames)):
+        want, _ = km.oracle_keypoints(frames[f], levels, ks, policy)
+        assert counts[f] == len(want)
+        np.testing.assert_array_equal(rows[f], want)
+    # counting only (what the timed baseline does) gives the same counts
+    counts2, none = co.rgb_pass_frames(frames, ext, ks, policy)
+    assert none is None and np.array_equal(counts, counts2)
