@@ -348,7 +348,10 @@ int silent_affine_clip_dev(silent_ctx* ctx, const float* in, size_t n_values, co
  *     out[p * out_stride + out_offset + k] = (float)in[p * in_stride + in_offset + k]      p < n_pixels, k < count
  * (strides / offsets in ELEMENTS).  in_dtype: SILENT_DT_*.  Widening (strides = count = channels), cutting plane c out of
  * an interleaved image (in_stride = C, in_offset = c, count = 1, out_stride = 1) and interleaving planes back are all
- * instances.  in and out must not overlap. */
+ * instances.  in and out must not overlap.  The conversion is the C cast: exact for uint8 / int16 / uint16 and for integers up to
+ * 2^24 in magnitude, round-to-nearest-even beyond (int32 / int64 / float64), like numpy's astype(float32).  Buffer sizes: `in`
+ * holds at least (n_pixels - 1) * in_stride + in_offset + count elements, `out` (n_pixels - 1) * out_stride + out_offset + count
+ * floats -- the last pixel needs no whole stride, and the host form copies exactly that much. */
 #define SILENT_DT_U8 0
 #define SILENT_DT_F32 1
 #define SILENT_DT_F64 2

@@ -156,13 +156,19 @@ def cast_interleave(src, out, in_stride, in_offset, count, out_stride, out_offse
 
 def as_float32(t):
     """A contiguous float32 GPU tensor with the values of ``t`` (np.asarray(frame, dtype=float32) of
-    recognition_testing.py:141 for device tensors).  float32 contiguous tensors pass through; any other dtype is widened
-    by the library's own cast kernel (no torch kernel on the path)."""
+    recognition_testing.py:141 for device tensors: any layout, any dtype).  float32 contiguous tensors pass through; contiguous
+    uint8 / int16 / uint16 / int32 / int64 / float64 tensors are widened by the library's own cast kernel (the fast path: no
+    torch kernel); anything else -- a strided view such as ``x.permute(...)`` or ``x[..., :3]``, float16 / bfloat16 / bool /
+    int8 -- is made contiguous float32 by torch first, like ``tensor.to(float32).contiguous()`` did before round 3."""
     import torch
     if t.dtype == torch.float32 and t.is_contiguous():
         return t
-    if not t.is_contiguous():
-        raise ValueError("GPU tensors must be contiguous (NHWC, C innermost)")
+    try:
+        code_ok = t.is_contiguous() and _torch_dtype_code(t) is not None
+    except TypeError:
+        code_ok = False
+    if not code_ok:
+        return t.to(torch.float32).contiguous()
     out = torch.empty(t.shape, dtype=torch.float32, device=t.device)
     if t.numel():
         cast_interleave(t, out, 1, 0, 1, 1, 0, t.numel())

@@ -11,6 +11,7 @@
 #include <string>
 #include <vector>
 
+#include "silent_host_shim.h"   // (inert unless SILENT_HOST_ONLY: the CPU container's sanitizer build of the host side)
 #include "silent_common.h"
 #include "silent_conv.h"
 #include "silent_peaks.h"
@@ -112,6 +113,34 @@ static int fail(silent_ctx* ctx, int code, const std::string& msg) {
     return code;
 }
 
+// ------------------------------------------------------------------------------------------ exception barrier
+// include/silent_hip.h promises that nothing throws or aborts across the ABI.  The host side allocates (std::vector, std::string):
+// every extern "C" entry point is a function-try-block whose handler turns std::bad_alloc into SILENT_E_NOMEM and anything else
+// into SILENT_E_INVALID (the message says what was thrown).  The handler itself must not throw: setting the message allocates.
+static int on_exception(silent_ctx* ctx, const char* who) noexcept {
+    int code = SILENT_E_INVALID;
+    try {
+        throw;
+    } catch (const std::bad_alloc&) {
+        code = SILENT_E_NOMEM;
+        try {
+            fail(ctx, code, std::string(who) + ": out of host memory");
+        } catch (...) {
+        }
+    } catch (const std::exception& e) {
+        try {
+            fail(ctx, code, std::string(who) + ": unexpected exception: " + e.what());
+        } catch (...) {
+        }
+    } catch (...) {
+        try {
+            fail(ctx, code, std::string(who) + ": unexpected exception");
+        } catch (...) {
+        }
+    }
+    return code;
+}
+
 #define HIP_TRY(ctx, call)                                                                            \
     do {                                                                                              \
         hipError_t e_ = (call);                                                                       \
@@ -155,12 +184,15 @@ static int workspace(silent_ctx* ctx, hipStream_t s, size_t bytes) {
     }
     ctx->ws_stream = s;
     ctx->ws_used = true;
+    // whoever lays the workspace out anew invalidates what silent_sparse_tail_stats would read back (silent_rgb_keypoints_dev
+    // sets the flag again AFTER its own layout)
+    ctx->sparse_ran = false;
     return grow(ctx, ctx->ws, bytes);
 }
 
 SILENT_EXPORT int silent_abi_version(void) { return SILENT_ABI_VERSION; }
 
-SILENT_EXPORT int silent_device_count(int* count) {
+SILENT_EXPORT int silent_device_count(int* count) try {
     if (!count) return fail(nullptr, SILENT_E_INVALID, "silent_device_count: count is NULL");
     int n = 0;
     hipError_t e = hipGetDeviceCount(&n);
@@ -171,9 +203,11 @@ SILENT_EXPORT int silent_device_count(int* count) {
     }
     *count = n;
     return SILENT_OK;
+} catch (...) {
+    return on_exception(nullptr, "silent_device_count");
 }
 
-SILENT_EXPORT int silent_create(int device, silent_ctx** out) {
+SILENT_EXPORT int silent_create(int device, silent_ctx** out) try {
     if (!out) return fail(nullptr, SILENT_E_INVALID, "silent_create: out is NULL");
     *out = nullptr;
     int n = 0;
@@ -201,22 +235,28 @@ SILENT_EXPORT int silent_create(int device, silent_ctx** out) {
         if (const char* e = std::getenv(names[i])) ctx->tune[i] = (unsigned)std::strtoul(e, nullptr, 0);
     *out = ctx;
     return SILENT_OK;
+} catch (...) {
+    return on_exception(nullptr, "silent_create");
 }
 
-SILENT_EXPORT int silent_set_tuning(silent_ctx* ctx, int which, unsigned value) {
+SILENT_EXPORT int silent_set_tuning(silent_ctx* ctx, int which, unsigned value) try {
     if (!ctx) return fail(nullptr, SILENT_E_INVALID, "silent_set_tuning: ctx is NULL");
     if (which < 0 || which >= SILENT_TUNE_COUNT) return fail(ctx, SILENT_E_INVALID, "silent_set_tuning: unknown knob");
     ctx->tune[which] = value;
     return SILENT_OK;
+} catch (...) {
+    return on_exception(ctx, "silent_set_tuning");
 }
 
-SILENT_EXPORT int silent_get_tuning(const silent_ctx* ctx, int which, unsigned* value) {
+SILENT_EXPORT int silent_get_tuning(const silent_ctx* ctx, int which, unsigned* value) try {
     if (!ctx || !value || which < 0 || which >= SILENT_TUNE_COUNT) return SILENT_E_INVALID;
     *value = ctx->tune[which];
     return SILENT_OK;
+} catch (...) {
+    return on_exception(nullptr, "silent_get_tuning");
 }
 
-SILENT_EXPORT void silent_destroy(silent_ctx* ctx) {
+SILENT_EXPORT void silent_destroy(silent_ctx* ctx) try {
     if (!ctx) return;
     DeviceGuard guard(ctx->device);
     if (ctx->arena.p) (void)hipFree(ctx->arena.p);
@@ -225,55 +265,67 @@ SILENT_EXPORT void silent_destroy(silent_ctx* ctx) {
         for (hipEvent_t e : pr)
             if (e) (void)hipEventDestroy(e);
     delete ctx;
+} catch (...) {
 }
 
 SILENT_EXPORT const char* silent_last_error(const silent_ctx* ctx) {
     return ctx ? ctx->err.c_str() : g_create_err.c_str();
 }
 
-SILENT_EXPORT int silent_device_name(const silent_ctx* ctx, char* buf, size_t len) {
+SILENT_EXPORT int silent_device_name(const silent_ctx* ctx, char* buf, size_t len) try {
     if (!ctx || !buf || len == 0) return SILENT_E_INVALID;
     std::snprintf(buf, len, "%s", ctx->name.c_str());
     return SILENT_OK;
+} catch (...) {
+    return on_exception(nullptr, "silent_device_name");
 }
 
 #define NEED_CTX(ctx)                  \
+    SILENT_FAULT_POINT();              \
     if (!(ctx)) return fail(nullptr, SILENT_E_INVALID, std::string(__func__) + ": ctx is NULL"); \
     DeviceGuard device_guard_((ctx)->device);                                                    \
     if (!device_guard_.ok) return fail(ctx, SILENT_E_HIP, std::string(__func__) + ": hipSetDevice failed")
 
-SILENT_EXPORT int silent_malloc(silent_ctx* ctx, size_t bytes, void** dptr) {
+SILENT_EXPORT int silent_malloc(silent_ctx* ctx, size_t bytes, void** dptr) try {
     NEED_CTX(ctx);
     if (!dptr) return fail(ctx, SILENT_E_INVALID, "silent_malloc: dptr is NULL");
     *dptr = nullptr;
     HIP_TRY(ctx, hipMalloc(dptr, bytes ? bytes : 1));
     return SILENT_OK;
+} catch (...) {
+    return on_exception(ctx, "silent_malloc");
 }
 
-SILENT_EXPORT int silent_free(silent_ctx* ctx, void* dptr) {
+SILENT_EXPORT int silent_free(silent_ctx* ctx, void* dptr) try {
     NEED_CTX(ctx);
     if (dptr) HIP_TRY(ctx, hipFree(dptr));
     return SILENT_OK;
+} catch (...) {
+    return on_exception(ctx, "silent_free");
 }
 
-SILENT_EXPORT int silent_memcpy_h2d(silent_ctx* ctx, void* dst, const void* src, size_t bytes, silent_stream stream) {
+SILENT_EXPORT int silent_memcpy_h2d(silent_ctx* ctx, void* dst, const void* src, size_t bytes, silent_stream stream) try {
     NEED_CTX(ctx);
     if (bytes && (!dst || !src)) return fail(ctx, SILENT_E_INVALID, "silent_memcpy_h2d: NULL pointer");
     HIP_TRY(ctx, hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, (hipStream_t)stream));
     HIP_TRY(ctx, hipStreamSynchronize((hipStream_t)stream));
     return SILENT_OK;
+} catch (...) {
+    return on_exception(ctx, "silent_memcpy_h2d");
 }
 
-SILENT_EXPORT int silent_memcpy_d2h(silent_ctx* ctx, void* dst, const void* src, size_t bytes, silent_stream stream) {
+SILENT_EXPORT int silent_memcpy_d2h(silent_ctx* ctx, void* dst, const void* src, size_t bytes, silent_stream stream) try {
     NEED_CTX(ctx);
     if (bytes && (!dst || !src)) return fail(ctx, SILENT_E_INVALID, "silent_memcpy_d2h: NULL pointer");
     HIP_TRY(ctx, hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, (hipStream_t)stream));
     HIP_TRY(ctx, hipStreamSynchronize((hipStream_t)stream));
     return SILENT_OK;
+} catch (...) {
+    return on_exception(ctx, "silent_memcpy_d2h");
 }
 
 SILENT_EXPORT int silent_gather_d2h(silent_ctx* ctx, void* dst_host, const void* const* src_dev, const size_t* bytes,
-                                    int n, silent_stream stream) {
+                                    int n, silent_stream stream) try {
     NEED_CTX(ctx);
     if (n < 0 || (n && (!dst_host || !src_dev || !bytes))) return fail(ctx, SILENT_E_INVALID, "silent_gather_d2h: NULL pointer");
     size_t total = 0;
@@ -297,12 +349,16 @@ SILENT_EXPORT int silent_gather_d2h(silent_ctx* ctx, void* dst_host, const void*
     }
     HIP_TRY(ctx, hipStreamSynchronize(s));
     return SILENT_OK;
+} catch (...) {
+    return on_exception(ctx, "silent_gather_d2h");
 }
 
-SILENT_EXPORT int silent_synchronize(silent_ctx* ctx, silent_stream stream) {
+SILENT_EXPORT int silent_synchronize(silent_ctx* ctx, silent_stream stream) try {
     NEED_CTX(ctx);
     HIP_TRY(ctx, hipStreamSynchronize((hipStream_t)stream));
     return SILENT_OK;
+} catch (...) {
+    return on_exception(ctx, "silent_synchronize");
 }
 
 // ------------------------------------------------------------------------------------------ tile tables
@@ -424,17 +480,19 @@ static int conv_dispatch(silent_ctx* ctx, const char* who, const float* in, cons
 
 SILENT_EXPORT int silent_conv2d_same_dev(silent_ctx* ctx, const float* in, const silent_extent* levels, int n_levels,
                                          int n_frames, int c_in, const float* kernel_hwio, int kh, int kw, int c_out,
-                                         unsigned flags, float clip_hi, float* out, silent_stream stream) {
+                                         unsigned flags, float clip_hi, float* out, silent_stream stream) try {
     NEED_CTX(ctx);
     Epilogue ep{flags, clip_hi, 0.f, 0.f, 0};
     return conv_dispatch(ctx, "silent_conv2d_same", in, levels, n_levels, n_frames, c_in, kernel_hwio, kh, kw, c_out,
                          false, ep, out, (hipStream_t)stream);
+} catch (...) {
+    return on_exception(ctx, "silent_conv2d_same_dev");
 }
 
 SILENT_EXPORT int silent_regulate_dev(silent_ctx* ctx, const float* in, const silent_extent* levels, int n_levels,
                                       int n_frames, int channels, const float* blur_hwio, int kh, int kw,
                                       float regulation_value, float regulation_root, int flat_policy, float* out,
-                                      silent_stream stream) {
+                                      silent_stream stream) try {
     NEED_CTX(ctx);
     if (flat_policy != SILENT_FLAT_IEEE && flat_policy != SILENT_FLAT_ZERO)
         return fail(ctx, SILENT_E_INVALID, "silent_regulate: flat_policy must be SILENT_FLAT_IEEE or SILENT_FLAT_ZERO");
@@ -462,6 +520,8 @@ SILENT_EXPORT int silent_regulate_dev(silent_ctx* ctx, const float* in, const si
     Epilogue ep{0u, 0.f, regulation_value, regulation_root, flat_policy};
     return conv_dispatch(ctx, "silent_regulate", in, levels, n_levels, n_frames, channels, blur_hwio, kh, kw, channels,
                          true, ep, out, (hipStream_t)stream);
+} catch (...) {
+    return on_exception(ctx, "silent_regulate_dev");
 }
 
 // ------------------------------------------------------------------------------------------ fused gray pass
@@ -504,17 +564,19 @@ static int launch_gray(silent_ctx* ctx, const char* who, const float* pyr, const
 SILENT_EXPORT int silent_gray_line_end_dev(silent_ctx* ctx, const float* pyr, const silent_extent* levels,
                                            int n_levels, int n_frames, const float* cs_kernel, const float* end_bank,
                                            int n_orient, float clip_hi, float* cs_out, float* end_out,
-                                           silent_stream stream) {
+                                           silent_stream stream) try {
     NEED_CTX(ctx);
     return launch_gray(ctx, "silent_gray_line_end", pyr, levels, n_levels, n_frames, cs_kernel, end_bank, n_orient,
                        clip_hi, cs_out, end_out, (hipStream_t)stream, nullptr);
+} catch (...) {
+    return on_exception(ctx, "silent_gray_line_end_dev");
 }
 
 // ------------------------------------------------------------------------------------------ pointwise / nms
 
 SILENT_EXPORT int silent_pad_inwards_dev(silent_ctx* ctx, const float* in, const silent_extent* levels, int n_levels,
                                          int n_frames, int channels, int pt, int pb, int pl, int pr, float* out,
-                                         silent_stream stream) {
+                                         silent_stream stream) try {
     NEED_CTX(ctx);
     const char* who = "silent_pad_inwards";
     if (!in || !out) return fail(ctx, SILENT_E_INVALID, std::string(who) + ": NULL pointer");
@@ -526,11 +588,13 @@ SILENT_EXPORT int silent_pad_inwards_dev(silent_ctx* ctx, const float* in, const
     hipLaunchKernelGGL(pad_inwards_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, in, out, tab,
                        channels, pt, pb, pl, pr);
     return check_launch(ctx, who);
+} catch (...) {
+    return on_exception(ctx, "silent_pad_inwards_dev");
 }
 
 SILENT_EXPORT int silent_value_from_color_dev(silent_ctx* ctx, const float* in, const silent_extent* levels,
                                               int n_levels, int n_frames, int channels, float* out,
-                                              silent_stream stream) {
+                                              silent_stream stream) try {
     NEED_CTX(ctx);
     const char* who = "silent_value_from_color";
     if (!in || !out) return fail(ctx, SILENT_E_INVALID, std::string(who) + ": NULL pointer");
@@ -543,11 +607,13 @@ SILENT_EXPORT int silent_value_from_color_dev(silent_ctx* ctx, const float* in, 
     hipLaunchKernelGGL(value_from_color_kernel, dim3((unsigned)grid), dim3(256), 0, (hipStream_t)stream, in, out, npx,
                        channels);
     return check_launch(ctx, who);
+} catch (...) {
+    return on_exception(ctx, "silent_value_from_color_dev");
 }
 
 SILENT_EXPORT int silent_bw_from_color_dev(silent_ctx* ctx, const float* in, const silent_extent* levels,
                                               int n_levels, int n_frames, int channels, float* out,
-                                              silent_stream stream) {
+                                              silent_stream stream) try {
     NEED_CTX(ctx);
     const char* who = "silent_bw_from_color";
     if (!in || !out) return fail(ctx, SILENT_E_INVALID, std::string(who) + ": NULL pointer");
@@ -560,10 +626,12 @@ SILENT_EXPORT int silent_bw_from_color_dev(silent_ctx* ctx, const float* in, con
     hipLaunchKernelGGL(bw_from_color_kernel, dim3((unsigned)grid), dim3(256), 0, (hipStream_t)stream, in, out, npx,
                        channels);
     return check_launch(ctx, who);
+} catch (...) {
+    return on_exception(ctx, "silent_bw_from_color_dev");
 }
 
 SILENT_EXPORT int silent_nms3x3_dev(silent_ctx* ctx, const float* in, const silent_extent* levels, int n_levels,
-                                    int n_frames, int channels, int mode, float* out, silent_stream stream) {
+                                    int n_frames, int channels, int mode, float* out, silent_stream stream) try {
     NEED_CTX(ctx);
     const char* who = "silent_nms3x3";
     if (!in || !out) return fail(ctx, SILENT_E_INVALID, std::string(who) + ": NULL pointer");
@@ -584,13 +652,15 @@ SILENT_EXPORT int silent_nms3x3_dev(silent_ctx* ctx, const float* in, const sile
     hipLaunchKernelGGL(nms3x3_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, in, out, tab, channels,
                        mode);
     return check_launch(ctx, who);
+} catch (...) {
+    return on_exception(ctx, "silent_nms3x3_dev");
 }
 
 // ------------------------------------------------------------------------------------------ top-percent threshold
 
 SILENT_EXPORT int silent_top_value_points_dev(silent_ctx* ctx, const float* color, const float* value,
                                               const silent_extent* levels, int n_levels, int n_frames, int channels,
-                                              double top_percent, float* out, silent_stream stream) {
+                                              double top_percent, float* out, silent_stream stream) try {
     NEED_CTX(ctx);
     const char* who = "silent_top_value_points";
     if (!color || !out) return fail(ctx, SILENT_E_INVALID, std::string(who) + ": NULL pointer");
@@ -613,12 +683,14 @@ SILENT_EXPORT int silent_top_value_points_dev(silent_ctx* ctx, const float* colo
     hipLaunchKernelGGL(top_value_points_kernel, dim3((unsigned)blocks), dim3(256), 0, s, color, value, out, tab,
                        channels, a, b, mm);
     return check_launch(ctx, who);
+} catch (...) {
+    return on_exception(ctx, "silent_top_value_points_dev");
 }
 
 SILENT_EXPORT int silent_select_peaks_dev(silent_ctx* ctx, const float* color, const float* value,
                                           const silent_extent* levels, int n_levels, int n_frames, int channels,
                                           double top_percent, float* top_out, float* peaks_out, float* peak_value_out,
-                                          silent_stream stream) {
+                                          silent_stream stream) try {
     NEED_CTX(ctx);
     const char* who = "silent_select_peaks";
     if (!color) return fail(ctx, SILENT_E_INVALID, std::string(who) + ": NULL pointer");
@@ -645,6 +717,8 @@ SILENT_EXPORT int silent_select_peaks_dev(silent_ctx* ctx, const float* color, c
         hipLaunchKernelGGL((select_peaks_kernel<1, false>), dim3((unsigned)blocks), dim3(256), 0, s, color, value, top_out,
                            peaks_out, peak_value_out, tab, a, b, mm, no_regions, nullptr, nullptr);
     return check_launch(ctx, who);
+} catch (...) {
+    return on_exception(ctx, "silent_select_peaks_dev");
 }
 
 // ------------------------------------------------------------------------------------------ keypoint indices
@@ -817,7 +891,7 @@ static void keypoint_passes(const float* value, const LevelTab& tab, long long b
 SILENT_EXPORT int silent_max_value_indices_region_dev(silent_ctx* ctx, const float* value, const silent_extent* levels,
                                                       int n_levels, int n_frames, const silent_extent* regions,
                                                       int64_t* idx, size_t cap_per_frame, int64_t* counts,
-                                                      silent_stream stream) {
+                                                      silent_stream stream) try {
     NEED_CTX(ctx);
     const char* who = "silent_max_value_indices_region";
     if (!value || !regions || !counts || (!idx && cap_per_frame))
@@ -840,6 +914,8 @@ SILENT_EXPORT int silent_max_value_indices_region_dev(silent_ctx* ctx, const flo
     }
     keypoint_passes(value, tab, blocks, rt, w, general, n_frames, idx, cap_per_frame, counts, s);
     return check_launch(ctx, who);
+} catch (...) {
+    return on_exception(ctx, "silent_max_value_indices_region_dev");
 }
 
 // SURVEY 8d config 3 as one call: top-percent -> NMS -> value -> per-region keypoint indices of the peak value.
@@ -946,7 +1022,7 @@ static int select_run(silent_ctx* ctx, const char* who, const float* color, cons
 SILENT_EXPORT int silent_select_keypoints_dev(silent_ctx* ctx, const float* color, const float* value,
                                               const silent_extent* levels, int n_levels, int n_frames, int channels,
                                               double top_percent, const silent_extent* regions, float* peak_value_out,
-                                              int64_t* idx, size_t cap_per_frame, int64_t* counts, silent_stream stream) {
+                                              int64_t* idx, size_t cap_per_frame, int64_t* counts, silent_stream stream) try {
     NEED_CTX(ctx);
     const char* who = "silent_select_keypoints";
     if (!color || !regions || !counts || (!idx && cap_per_frame))
@@ -956,6 +1032,8 @@ SILENT_EXPORT int silent_select_keypoints_dev(silent_ctx* ctx, const float* colo
     TRY(select_prepare(ctx, who, levels, n_levels, n_frames, regions, (hipStream_t)stream, &sp, 0, !peak_value_out));
     return select_run(ctx, who, color, value, levels, n_levels, n_frames, channels, top_percent, sp, false, peak_value_out, idx,
                       cap_per_frame, counts, (hipStream_t)stream);
+} catch (...) {
+    return on_exception(ctx, "silent_select_keypoints_dev");
 }
 
 // ------------------------------------------------------------------------------------------ centroids
@@ -984,7 +1062,7 @@ static int build_cell_tab(silent_ctx* ctx, const char* who, const silent_extent*
 
 SILENT_EXPORT int silent_centroids_dev(silent_ctx* ctx, const float* value, const silent_extent* levels, int n_levels,
                                        int n_frames, int region_h, int region_w, float* dist_out, float* total_out,
-                                       silent_stream stream) {
+                                       silent_stream stream) try {
     NEED_CTX(ctx);
     const char* who = "silent_centroids";
     if (!value || !dist_out || !total_out) return fail(ctx, SILENT_E_INVALID, std::string(who) + ": NULL pointer");
@@ -1002,6 +1080,8 @@ SILENT_EXPORT int silent_centroids_dev(silent_ctx* ctx, const float* value, cons
                        total_out, cxy);
     hipLaunchKernelGGL(centroid_dist_kernel, dim3((unsigned)blocks), dim3(256), 0, s, tab, ct, cxy, dist_out);
     return check_launch(ctx, who);
+} catch (...) {
+    return on_exception(ctx, "silent_centroids_dev");
 }
 
 // ------------------------------------------------------------------------------------------ boosting state
@@ -1024,7 +1104,7 @@ static int check_boost_params(silent_ctx* ctx, const silent_boosting_params* p, 
 
 SILENT_EXPORT int silent_boosting_step_dev(silent_ctx* ctx, const float* input, const silent_extent* levels,
                                            int n_levels, int n_frames, const silent_boosting_params* params,
-                                           float* energy, float* fired_out, float* energy_out, silent_stream stream) {
+                                           float* energy, float* fired_out, float* energy_out, silent_stream stream) try {
     NEED_CTX(ctx);
     const char* who = "silent_boosting_step";
     if (!input || !energy || !fired_out) return fail(ctx, SILENT_E_INVALID, std::string(who) + ": NULL pointer");
@@ -1042,12 +1122,14 @@ SILENT_EXPORT int silent_boosting_step_dev(silent_ctx* ctx, const float* input, 
     hipLaunchKernelGGL(boost_update_kernel, dim3((unsigned)blocks), dim3(256), 0, s, input, m, energy, fired_out,
                        energy_out, tab, bp);
     return check_launch(ctx, who);
+} catch (...) {
+    return on_exception(ctx, "silent_boosting_step_dev");
 }
 
 // ------------------------------------------------------------------------------------------ display-graph glue
 
 SILENT_EXPORT int silent_affine_clip_dev(silent_ctx* ctx, const float* in, size_t n_values,
-                                         const silent_affine_params* params, float* out, silent_stream stream) {
+                                         const silent_affine_params* params, float* out, silent_stream stream) try {
     NEED_CTX(ctx);
     const char* who = "silent_affine_clip";
     if (!in || !out || !params) return fail(ctx, SILENT_E_INVALID, std::string(who) + ": NULL pointer");
@@ -1057,6 +1139,8 @@ SILENT_EXPORT int silent_affine_clip_dev(silent_ctx* ctx, const float* in, size_
     hipLaunchKernelGGL(affine_clip_kernel, dim3((unsigned)((n_values + 2047) / 2048)), dim3(256), 0, (hipStream_t)stream,
                        in, out, (long long)n_values, ap);
     return check_launch(ctx, who);
+} catch (...) {
+    return on_exception(ctx, "silent_affine_clip_dev");
 }
 
 static size_t dtype_size(int dt) {
@@ -1071,7 +1155,7 @@ static size_t dtype_size(int dt) {
 
 SILENT_EXPORT int silent_cast_interleave_dev(silent_ctx* ctx, const void* in, int in_dtype, size_t n_pixels, int in_stride,
                                              int in_offset, int count, float* out, int out_stride, int out_offset,
-                                             silent_stream stream) {
+                                             silent_stream stream) try {
     NEED_CTX(ctx);
     const char* who = "silent_cast_interleave";
     if (!in || !out) return fail(ctx, SILENT_E_INVALID, std::string(who) + ": NULL pointer");
@@ -1096,11 +1180,13 @@ SILENT_EXPORT int silent_cast_interleave_dev(silent_ctx* ctx, const void* in, in
     }
 #undef CAST_CASE
     return check_launch(ctx, who);
+} catch (...) {
+    return on_exception(ctx, "silent_cast_interleave_dev");
 }
 
 SILENT_EXPORT int silent_resize_nearest_dev(silent_ctx* ctx, const float* in, const silent_extent* in_levels,
                                             int n_levels, int n_frames, int channels, const silent_extent* out_levels,
-                                            float* out, silent_stream stream) {
+                                            float* out, silent_stream stream) try {
     NEED_CTX(ctx);
     const char* who = "silent_resize_nearest";
     if (!in || !out) return fail(ctx, SILENT_E_INVALID, std::string(who) + ": NULL pointer");
@@ -1124,6 +1210,8 @@ SILENT_EXPORT int silent_resize_nearest_dev(silent_ctx* ctx, const float* in, co
     hipLaunchKernelGGL(resize_nearest_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, in, out, tab, rt,
                        channels);
     return check_launch(ctx, who);
+} catch (...) {
+    return on_exception(ctx, "silent_resize_nearest_dev");
 }
 
 // ------------------------------------------------------------------------------------------ RGB chain
@@ -1316,7 +1404,7 @@ static void pack_rgb_weights(const silent_rgb_chain_params* p, unsigned kopts, R
 }
 
 SILENT_EXPORT int silent_rgb_chain_stream(const silent_rgb_chain_params* params, unsigned knobs, float* stream, int* n_used,
-                                          int* variant) {
+                                          int* variant) try {
     if (!params || !stream || !n_used || !variant || !params->rgc || !params->rgby || !params->stripe || !params->blur || !params->end)
         return SILENT_E_INVALID;
     RgbW w;
@@ -1327,9 +1415,11 @@ SILENT_EXPORT int silent_rgb_chain_stream(const silent_rgb_chain_params* params,
     *n_used = rgb2_fill_stream(w, basic ? 0x111u : 0x1ffu, basic, two, two, stream, use_sym ? &sym : nullptr);
     *variant = use_sym ? 3 : two ? 2 : basic ? 1 : 0;
     return SILENT_OK;
+} catch (...) {
+    return on_exception(nullptr, "silent_rgb_chain_stream");
 }
 
-SILENT_EXPORT int silent_rgb_chain_structure(const silent_rgb_chain_params* params, unsigned* flags, unsigned* masks) {
+SILENT_EXPORT int silent_rgb_chain_structure(const silent_rgb_chain_params* params, unsigned* flags, unsigned* masks) try {
     if (!params || !flags || !params->rgc || !params->rgby || !params->stripe || !params->end) return SILENT_E_INVALID;
     RgbStructure r;
     analyze_rgb_chain(params, &r);
@@ -1341,6 +1431,8 @@ SILENT_EXPORT int silent_rgb_chain_structure(const silent_rgb_chain_params* para
             masks[3 + i] = r.end_two ? r.end_mask[i] : 0u;
         }
     return SILENT_OK;
+} catch (...) {
+    return on_exception(nullptr, "silent_rgb_chain_structure");
 }
 
 
@@ -1518,10 +1610,12 @@ static int rgb_chain_launch(silent_ctx* ctx, const char* who, const float* pyr, 
 
 SILENT_EXPORT int silent_rgb_line_end_dev(silent_ctx* ctx, const float* pyr, const silent_extent* levels, int n_levels,
                                           int n_frames, const silent_rgb_chain_params* p, float* orient_out,
-                                          float* line_end_out, float* value_out, silent_stream stream) {
+                                          float* line_end_out, float* value_out, silent_stream stream) try {
     NEED_CTX(ctx);
     return rgb_chain_launch(ctx, "silent_rgb_line_end", pyr, levels, n_levels, n_frames, p, orient_out, line_end_out, value_out,
                             nullptr, nullptr, stream);
+} catch (...) {
+    return on_exception(ctx, "silent_rgb_line_end_dev");
 }
 
 // Config 3 from the pyramid on in one call: silent_rgb_line_end + silent_select_keypoints on its line_end / value maps.
@@ -1532,7 +1626,7 @@ SILENT_EXPORT int silent_rgb_keypoints_dev(silent_ctx* ctx, const float* pyr, co
                                            int n_frames, const silent_rgb_chain_params* p, double top_percent,
                                            const silent_extent* regions, float* orient_out, float* line_end_out,
                                            float* value_out, float* peak_value_out, int64_t* idx, size_t cap_per_frame,
-                                           int64_t* counts, silent_stream stream) {
+                                           int64_t* counts, silent_stream stream) try {
     NEED_CTX(ctx);
     const char* who = "silent_rgb_keypoints";
     if (!pyr || !p || !regions || !line_end_out || !counts || (!idx && cap_per_frame))
@@ -1544,6 +1638,10 @@ SILENT_EXPORT int silent_rgb_keypoints_dev(silent_ctx* ctx, const float* pyr, co
         for (int io = 1; io < 9; ++io)
             if (p->blur[t * 9 + io] != p->blur[t * 9]) uniform_blur = false;
     hipStream_t s = (hipStream_t)stream;
+    if (!levels || n_levels < 1 || n_levels > kMaxLevels || n_frames < 1)
+        return fail(ctx, SILENT_E_INVALID, std::string(who) + ": bad levels / n_frames");
+    for (int l = 0; l < n_levels; ++l)
+        if (levels[l].h < 1 || levels[l].w < 1) return fail(ctx, SILENT_E_INVALID, std::string(who) + ": bad level extent");
     if (!uniform_blur) {
         TRY(rgb_chain_launch(ctx, who, pyr, levels, n_levels, n_frames, p, orient_out, line_end_out, value_out, nullptr, nullptr, stream));
         return silent_select_keypoints_dev(ctx, line_end_out, value_out, levels, n_levels, n_frames, 3, top_percent, regions,
@@ -1569,10 +1667,12 @@ SILENT_EXPORT int silent_rgb_keypoints_dev(silent_ctx* ctx, const float* pyr, co
     ctx->sparse_frames = n_frames;
     return select_run(ctx, who, line_end_out, mm_done ? nullptr : value_out, levels, n_levels, n_frames, 3, top_percent, sp, mm_done,
                       peak_value_out, idx, cap_per_frame, counts, s, sparse);
+} catch (...) {
+    return on_exception(ctx, "silent_rgb_keypoints_dev");
 }
 
 
-SILENT_EXPORT int silent_sparse_tail_stats(silent_ctx* ctx, int64_t* stats) {
+SILENT_EXPORT int silent_sparse_tail_stats(silent_ctx* ctx, int64_t* stats) try {
     NEED_CTX(ctx);
     if (!stats) return fail(ctx, SILENT_E_INVALID, "silent_sparse_tail_stats: stats is NULL");
     stats[0] = ctx->sparse_ran ? 1 : 0;
@@ -1587,6 +1687,8 @@ SILENT_EXPORT int silent_sparse_tail_stats(silent_ctx* ctx, int64_t* stats) {
     for (int f : flags) stats[4] += f == kTailZero ? 1 : 0;
     for (int c : cn) stats[3] += c;
     return SILENT_OK;
+} catch (...) {
+    return on_exception(ctx, "silent_sparse_tail_stats");
 }
 
 // ------------------------------------------------------------------------------------------ pyramid plan
@@ -1634,7 +1736,7 @@ static void axis_table(int n_in, int n_out, int* base, int* idx, float* wts) {
 
 SILENT_EXPORT int silent_pyramid_plan_create(silent_ctx* ctx, int frame_h, int frame_w, int channels,
                                              const silent_pyr_level* levels, int n_levels,
-                                             silent_pyramid_plan** out) {
+                                             silent_pyramid_plan** out) try {
     NEED_CTX(ctx);
     const char* who = "silent_pyramid_plan_create";
     if (!out || !levels) return fail(ctx, SILENT_E_INVALID, std::string(who) + ": NULL pointer");
@@ -2031,15 +2133,18 @@ SILENT_EXPORT int silent_pyramid_plan_create(silent_ctx* ctx, int frame_h, int f
     }
     *out = plan;
     return SILENT_OK;
+} catch (...) {
+    return on_exception(ctx, "silent_pyramid_plan_create");
 }
 
-SILENT_EXPORT void silent_pyramid_plan_destroy(silent_pyramid_plan* plan) {
+SILENT_EXPORT void silent_pyramid_plan_destroy(silent_pyramid_plan* plan) try {
     if (!plan) return;
     DeviceGuard guard(plan->ctx ? plan->ctx->device : 0);
     if (plan->tables) (void)hipFree(plan->tables);
     if (plan->stream_tables) (void)hipFree(plan->stream_tables);
     if (plan->walk_tables) (void)hipFree(plan->walk_tables);
     delete plan;
+} catch (...) {
 }
 
 template <int G, int PX>
@@ -2150,23 +2255,29 @@ static int launch_pyramid(silent_ctx* ctx, const char* who, const silent_pyramid
 }
 
 SILENT_EXPORT int silent_pyramid_dev(silent_ctx* ctx, const silent_pyramid_plan* plan, const float* frames,
-                                     int n_frames, float* pyr, silent_stream stream) {
+                                     int n_frames, float* pyr, silent_stream stream) try {
     NEED_CTX(ctx);
     return launch_pyramid(ctx, "silent_pyramid", plan, frames, n_frames, pyr, (hipStream_t)stream, true);
+} catch (...) {
+    return on_exception(ctx, "silent_pyramid_dev");
 }
 
 // ------------------------------------------------------------------------------------------ whole gray pass
 
-SILENT_EXPORT int silent_pyramid_plan_is_streamable(const silent_pyramid_plan* plan) {
+SILENT_EXPORT int silent_pyramid_plan_is_streamable(const silent_pyramid_plan* plan) try {
     return plan && plan->stream_ok ? 1 : 0;
+} catch (...) {
+    return on_exception(nullptr, "silent_pyramid_plan_is_streamable");
 }
 
-SILENT_EXPORT int silent_pyramid_plan_walk_plans(const silent_pyramid_plan* plan, int* pixels_per_wave) {
+SILENT_EXPORT int silent_pyramid_plan_walk_plans(const silent_pyramid_plan* plan, int* pixels_per_wave) try {
     if (pixels_per_wave) *pixels_per_wave = plan && plan->walk_pyr_ok ? plan->walk_px : 0;
     return plan && plan->walk_pyr_ok ? plan->walk.n_plans : 0;
+} catch (...) {
+    return on_exception(nullptr, "silent_pyramid_plan_walk_plans");
 }
 
-SILENT_EXPORT int silent_set_profiling(silent_ctx* ctx, int enable) {
+SILENT_EXPORT int silent_set_profiling(silent_ctx* ctx, int enable) try {
     NEED_CTX(ctx);
     if (enable < 0) return fail(ctx, SILENT_E_INVALID, "silent_set_profiling: enable must be >= 0");
     if (enable && !ctx->prof_ev[0][0])
@@ -2176,9 +2287,11 @@ SILENT_EXPORT int silent_set_profiling(silent_ctx* ctx, int enable) {
     ctx->prof_period = enable > 0 ? enable : 1;
     ctx->prof_calls = ctx->prof_recorded = 0;
     return SILENT_OK;
+} catch (...) {
+    return on_exception(ctx, "silent_set_profiling");
 }
 
-SILENT_EXPORT int silent_profile_elapsed_ms(silent_ctx* ctx, float* ms, int64_t* pixels) {
+SILENT_EXPORT int silent_profile_elapsed_ms(silent_ctx* ctx, float* ms, int64_t* pixels) try {
     NEED_CTX(ctx);
     if (!ms) return fail(ctx, SILENT_E_INVALID, "silent_profile_elapsed_ms: ms is NULL");
     if (!ctx->prof_recorded) return fail(ctx, SILENT_E_INVALID, "silent_profile_elapsed_ms: no profiled launch recorded");
@@ -2193,12 +2306,14 @@ SILENT_EXPORT int silent_profile_elapsed_ms(silent_ctx* ctx, float* ms, int64_t*
     *ms = (float)(sum / n);
     if (pixels) *pixels = ctx->prof_pixels;
     return SILENT_OK;
+} catch (...) {
+    return on_exception(ctx, "silent_profile_elapsed_ms");
 }
 
 SILENT_EXPORT int silent_gray_pass_dev(silent_ctx* ctx, const silent_pyramid_plan* plan, const float* frames,
                                        int n_frames, const float* cs_kernel, const float* end_bank, int n_orient,
                                        float clip_hi, float* pyr, float* cs_out, float* end_out,
-                                       silent_stream stream) {
+                                       silent_stream stream) try {
     NEED_CTX(ctx);
     const char* who = "silent_gray_pass";
     if (!plan || !frames || !pyr || !cs_kernel) return fail(ctx, SILENT_E_INVALID, std::string(who) + ": NULL pointer");
@@ -2294,6 +2409,8 @@ SILENT_EXPORT int silent_gray_pass_dev(silent_ctx* ctx, const silent_pyramid_pla
         TRY(launch_gray(ctx, who, pyr, plan->extents.data(), pt.n_levels, n_frames, cs_kernel, end_bank, n_orient,
                         clip_hi, cs_out, end_out, s, is_unit));
     return SILENT_OK;
+} catch (...) {
+    return on_exception(ctx, "silent_gray_pass_dev");
 }
 
 // ------------------------------------------------------------------------------------------ host-pointer twins
@@ -2338,7 +2455,7 @@ static int check_levels(silent_ctx* ctx, const char* who, const silent_extent* l
 
 SILENT_EXPORT int silent_conv2d_same(silent_ctx* ctx, const float* in, const silent_extent* levels, int n_levels,
                                      int n_frames, int c_in, const float* k, int kh, int kw, int c_out, unsigned flags,
-                                     float clip_hi, float* out) {
+                                     float clip_hi, float* out) try {
     NEED_CTX(ctx);
     if (!in || !out || !k) return fail(ctx, SILENT_E_INVALID, "silent_conv2d_same: NULL pointer");
     if (c_in < 1 || c_out < 1) return fail(ctx, SILENT_E_INVALID, "silent_conv2d_same: channels must be >= 1");
@@ -2353,11 +2470,13 @@ SILENT_EXPORT int silent_conv2d_same(silent_ctx* ctx, const float* in, const sil
                                clip_hi, st.ptr<float>(i_out), nullptr));
     TRY(sync0(ctx));
     return d2h(ctx, out, st.ptr<float>(i_out), bo);
+} catch (...) {
+    return on_exception(ctx, "silent_conv2d_same");
 }
 
 SILENT_EXPORT int silent_regulate(silent_ctx* ctx, const float* in, const silent_extent* levels, int n_levels,
                                   int n_frames, int channels, const float* blur, int kh, int kw, float rv, float root,
-                                  int flat_policy, float* out) {
+                                  int flat_policy, float* out) try {
     NEED_CTX(ctx);
     if (!in || !out || !blur) return fail(ctx, SILENT_E_INVALID, "silent_regulate: NULL pointer");
     if (channels < 1) return fail(ctx, SILENT_E_INVALID, "silent_regulate: channels must be >= 1");
@@ -2372,11 +2491,13 @@ SILENT_EXPORT int silent_regulate(silent_ctx* ctx, const float* in, const silent
                             flat_policy, st.ptr<float>(i_out), nullptr));
     TRY(sync0(ctx));
     return d2h(ctx, out, st.ptr<float>(i_out), b);
+} catch (...) {
+    return on_exception(ctx, "silent_regulate");
 }
 
 SILENT_EXPORT int silent_gray_line_end(silent_ctx* ctx, const float* pyr, const silent_extent* levels, int n_levels,
                                        int n_frames, const float* cs_kernel, const float* end_bank, int n_orient,
-                                       float clip_hi, float* cs_out, float* end_out) {
+                                       float clip_hi, float* cs_out, float* end_out) try {
     NEED_CTX(ctx);
     if (!pyr) return fail(ctx, SILENT_E_INVALID, "silent_gray_line_end: NULL pointer");
     if (n_orient < 1 || n_orient > 8) return fail(ctx, SILENT_E_UNSUPPORTED, "silent_gray_line_end: n_orient must be 3, 4 or 8");
@@ -2394,10 +2515,12 @@ SILENT_EXPORT int silent_gray_line_end(silent_ctx* ctx, const float* pyr, const 
     if (cs_out) TRY(d2h(ctx, cs_out, st.ptr<float>(i_cs), b1));
     if (end_out) TRY(d2h(ctx, end_out, st.ptr<float>(i_end), bk));
     return SILENT_OK;
+} catch (...) {
+    return on_exception(ctx, "silent_gray_line_end");
 }
 
 SILENT_EXPORT int silent_pad_inwards(silent_ctx* ctx, const float* in, const silent_extent* levels, int n_levels,
-                                     int n_frames, int channels, int pt, int pb, int pl, int pr, float* out) {
+                                     int n_frames, int channels, int pt, int pb, int pl, int pr, float* out) try {
     NEED_CTX(ctx);
     if (!in || !out) return fail(ctx, SILENT_E_INVALID, "silent_pad_inwards: NULL pointer");
     if (channels < 1) return fail(ctx, SILENT_E_INVALID, "silent_pad_inwards: channels must be >= 1");
@@ -2412,10 +2535,12 @@ SILENT_EXPORT int silent_pad_inwards(silent_ctx* ctx, const float* in, const sil
                                st.ptr<float>(i_out), nullptr));
     TRY(sync0(ctx));
     return d2h(ctx, out, st.ptr<float>(i_out), b);
+} catch (...) {
+    return on_exception(ctx, "silent_pad_inwards");
 }
 
 SILENT_EXPORT int silent_value_from_color(silent_ctx* ctx, const float* in, const silent_extent* levels, int n_levels,
-                                          int n_frames, int channels, float* out) {
+                                          int n_frames, int channels, float* out) try {
     NEED_CTX(ctx);
     if (!in || !out) return fail(ctx, SILENT_E_INVALID, "silent_value_from_color: NULL pointer");
     if (channels < 1) return fail(ctx, SILENT_E_INVALID, "silent_value_from_color: channels must be >= 1");
@@ -2430,10 +2555,12 @@ SILENT_EXPORT int silent_value_from_color(silent_ctx* ctx, const float* in, cons
                                     st.ptr<float>(i_out), nullptr));
     TRY(sync0(ctx));
     return d2h(ctx, out, st.ptr<float>(i_out), bo);
+} catch (...) {
+    return on_exception(ctx, "silent_value_from_color");
 }
 
 SILENT_EXPORT int silent_bw_from_color(silent_ctx* ctx, const float* in, const silent_extent* levels, int n_levels,
-                                          int n_frames, int channels, float* out) {
+                                          int n_frames, int channels, float* out) try {
     NEED_CTX(ctx);
     if (!in || !out) return fail(ctx, SILENT_E_INVALID, "silent_bw_from_color: NULL pointer");
     if (channels < 1) return fail(ctx, SILENT_E_INVALID, "silent_bw_from_color: channels must be >= 1");
@@ -2448,10 +2575,12 @@ SILENT_EXPORT int silent_bw_from_color(silent_ctx* ctx, const float* in, const s
                                     st.ptr<float>(i_out), nullptr));
     TRY(sync0(ctx));
     return d2h(ctx, out, st.ptr<float>(i_out), bo);
+} catch (...) {
+    return on_exception(ctx, "silent_bw_from_color");
 }
 
 SILENT_EXPORT int silent_nms3x3(silent_ctx* ctx, const float* in, const silent_extent* levels, int n_levels,
-                                int n_frames, int channels, int mode, float* out) {
+                                int n_frames, int channels, int mode, float* out) try {
     NEED_CTX(ctx);
     if (!in || !out) return fail(ctx, SILENT_E_INVALID, "silent_nms3x3: NULL pointer");
     if (channels < 1) return fail(ctx, SILENT_E_INVALID, "silent_nms3x3: channels must be >= 1");
@@ -2466,11 +2595,13 @@ SILENT_EXPORT int silent_nms3x3(silent_ctx* ctx, const float* in, const silent_e
                           nullptr));
     TRY(sync0(ctx));
     return d2h(ctx, out, st.ptr<float>(i_out), b);
+} catch (...) {
+    return on_exception(ctx, "silent_nms3x3");
 }
 
 SILENT_EXPORT int silent_top_value_points(silent_ctx* ctx, const float* color, const float* value,
                                           const silent_extent* levels, int n_levels, int n_frames, int channels,
-                                          double top_percent, float* out) {
+                                          double top_percent, float* out) try {
     NEED_CTX(ctx);
     if (!color || !out) return fail(ctx, SILENT_E_INVALID, "silent_top_value_points: NULL pointer");
     if (channels < 1) return fail(ctx, SILENT_E_INVALID, "silent_top_value_points: channels must be >= 1");
@@ -2486,11 +2617,13 @@ SILENT_EXPORT int silent_top_value_points(silent_ctx* ctx, const float* color, c
                                     n_frames, channels, top_percent, st.ptr<float>(i_o), nullptr));
     TRY(sync0(ctx));
     return d2h(ctx, out, st.ptr<float>(i_o), bc);
+} catch (...) {
+    return on_exception(ctx, "silent_top_value_points");
 }
 
 SILENT_EXPORT int silent_max_value_indices_region(silent_ctx* ctx, const float* value, const silent_extent* levels,
                                                   int n_levels, int n_frames, const silent_extent* regions,
-                                                  int64_t* idx, size_t cap_per_frame, int64_t* counts) {
+                                                  int64_t* idx, size_t cap_per_frame, int64_t* counts) try {
     NEED_CTX(ctx);
     if (!value || !counts) return fail(ctx, SILENT_E_INVALID, "silent_max_value_indices_region: NULL pointer");
     long long px;
@@ -2513,11 +2646,13 @@ SILENT_EXPORT int silent_max_value_indices_region(silent_ctx* ctx, const float* 
     }
     if (over) return fail(ctx, SILENT_E_CAPACITY, "silent_max_value_indices_region: cap_per_frame too small; counts hold the need");
     return SILENT_OK;
+} catch (...) {
+    return on_exception(ctx, "silent_max_value_indices_region");
 }
 
 SILENT_EXPORT int silent_rgb_line_end(silent_ctx* ctx, const float* pyr, const silent_extent* levels, int n_levels,
                                       int n_frames, const silent_rgb_chain_params* p, float* orient_out,
-                                      float* line_end_out, float* value_out) {
+                                      float* line_end_out, float* value_out) try {
     NEED_CTX(ctx);
     if (!pyr || !p) return fail(ctx, SILENT_E_INVALID, "silent_rgb_line_end: NULL pointer");
     long long px;
@@ -2535,12 +2670,14 @@ SILENT_EXPORT int silent_rgb_line_end(silent_ctx* ctx, const float* pyr, const s
     if (line_end_out) TRY(d2h(ctx, line_end_out, st.ptr<float>(i_l), b3));
     if (value_out) TRY(d2h(ctx, value_out, st.ptr<float>(i_v), b1));
     return SILENT_OK;
+} catch (...) {
+    return on_exception(ctx, "silent_rgb_line_end");
 }
 
 SILENT_EXPORT int silent_rgb_keypoints(silent_ctx* ctx, const float* pyr, const silent_extent* levels, int n_levels,
                                        int n_frames, const silent_rgb_chain_params* p, double top_percent,
                                        const silent_extent* regions, float* orient_out, float* line_end_out, float* value_out,
-                                       float* peak_value_out, int64_t* idx, size_t cap_per_frame, int64_t* counts) {
+                                       float* peak_value_out, int64_t* idx, size_t cap_per_frame, int64_t* counts) try {
     NEED_CTX(ctx);
     if (!pyr || !p || !regions || !counts || (!idx && cap_per_frame))
         return fail(ctx, SILENT_E_INVALID, "silent_rgb_keypoints: NULL pointer");
@@ -2564,10 +2701,12 @@ SILENT_EXPORT int silent_rgb_keypoints(silent_ctx* ctx, const float* pyr, const 
     if (peak_value_out) TRY(d2h(ctx, peak_value_out, st.ptr<float>(i_p), b1));
     if (cap_per_frame) TRY(d2h(ctx, idx, st.ptr<int64_t>(i_i), bi));
     return d2h(ctx, counts, st.ptr<int64_t>(i_n), bn);
+} catch (...) {
+    return on_exception(ctx, "silent_rgb_keypoints");
 }
 
 SILENT_EXPORT int silent_pyramid(silent_ctx* ctx, const silent_pyramid_plan* plan, const float* frames, int n_frames,
-                                 float* pyr) {
+                                 float* pyr) try {
     NEED_CTX(ctx);
     if (!plan || !frames || !pyr) return fail(ctx, SILENT_E_INVALID, "silent_pyramid: NULL pointer");
     if (n_frames < 1) return fail(ctx, SILENT_E_INVALID, "silent_pyramid: n_frames must be >= 1");
@@ -2580,11 +2719,13 @@ SILENT_EXPORT int silent_pyramid(silent_ctx* ctx, const silent_pyramid_plan* pla
     TRY(silent_pyramid_dev(ctx, plan, st.ptr<float>(i_in), n_frames, st.ptr<float>(i_out), nullptr));
     TRY(sync0(ctx));
     return d2h(ctx, pyr, st.ptr<float>(i_out), bo);
+} catch (...) {
+    return on_exception(ctx, "silent_pyramid");
 }
 
 SILENT_EXPORT int silent_gray_pass(silent_ctx* ctx, const silent_pyramid_plan* plan, const float* frames, int n_frames,
                                    const float* cs_kernel, const float* end_bank, int n_orient, float clip_hi,
-                                   float* pyr, float* cs_out, float* end_out) {
+                                   float* pyr, float* cs_out, float* end_out) try {
     NEED_CTX(ctx);
     if (!plan || !frames || !pyr) return fail(ctx, SILENT_E_INVALID, "silent_gray_pass: NULL pointer");
     if (n_frames < 1) return fail(ctx, SILENT_E_INVALID, "silent_gray_pass: n_frames must be >= 1");
@@ -2604,10 +2745,12 @@ SILENT_EXPORT int silent_gray_pass(silent_ctx* ctx, const silent_pyramid_plan* p
     if (cs_out) TRY(d2h(ctx, cs_out, st.ptr<float>(i_cs), b1));
     if (end_out) TRY(d2h(ctx, end_out, st.ptr<float>(i_end), bk));
     return SILENT_OK;
+} catch (...) {
+    return on_exception(ctx, "silent_gray_pass");
 }
 
 SILENT_EXPORT int silent_centroids(silent_ctx* ctx, const float* value, const silent_extent* levels, int n_levels,
-                                   int n_frames, int region_h, int region_w, float* dist_out, float* total_out) {
+                                   int n_frames, int region_h, int region_w, float* dist_out, float* total_out) try {
     NEED_CTX(ctx);
     if (!value || !dist_out || !total_out) return fail(ctx, SILENT_E_INVALID, "silent_centroids: NULL pointer");
     long long px;
@@ -2624,11 +2767,13 @@ SILENT_EXPORT int silent_centroids(silent_ctx* ctx, const float* value, const si
     TRY(sync0(ctx));
     TRY(d2h(ctx, dist_out, st.ptr<float>(i_d), bv));
     return d2h(ctx, total_out, st.ptr<float>(i_t), bt);
+} catch (...) {
+    return on_exception(ctx, "silent_centroids");
 }
 
 SILENT_EXPORT int silent_boosting_step(silent_ctx* ctx, const float* input, const silent_extent* levels, int n_levels,
                                        int n_frames, const silent_boosting_params* params, float* energy,
-                                       float* fired_out, float* energy_out) {
+                                       float* fired_out, float* energy_out) try {
     NEED_CTX(ctx);
     if (!input || !energy || !fired_out) return fail(ctx, SILENT_E_INVALID, "silent_boosting_step: NULL pointer");
     BoostP bp;
@@ -2647,10 +2792,12 @@ SILENT_EXPORT int silent_boosting_step(silent_ctx* ctx, const float* input, cons
     TRY(d2h(ctx, energy, st.ptr<float>(i_e), b1));
     TRY(d2h(ctx, fired_out, st.ptr<float>(i_f), bc));
     return energy_out ? d2h(ctx, energy_out, st.ptr<float>(i_o), bc) : SILENT_OK;
+} catch (...) {
+    return on_exception(ctx, "silent_boosting_step");
 }
 
 SILENT_EXPORT int silent_affine_clip(silent_ctx* ctx, const float* in, size_t n_values,
-                                     const silent_affine_params* params, float* out) {
+                                     const silent_affine_params* params, float* out) try {
     NEED_CTX(ctx);
     if (!in || !out || !params) return fail(ctx, SILENT_E_INVALID, "silent_affine_clip: NULL pointer");
     if (n_values == 0) return fail(ctx, SILENT_E_INVALID, "silent_affine_clip: empty tensor");
@@ -2662,17 +2809,23 @@ SILENT_EXPORT int silent_affine_clip(silent_ctx* ctx, const float* in, size_t n_
     TRY(silent_affine_clip_dev(ctx, st.ptr<float>(i_x), n_values, params, st.ptr<float>(i_x), nullptr));
     TRY(sync0(ctx));
     return d2h(ctx, out, st.ptr<float>(i_x), b);
+} catch (...) {
+    return on_exception(ctx, "silent_affine_clip");
 }
 
 SILENT_EXPORT int silent_cast_interleave(silent_ctx* ctx, const void* in, int in_dtype, size_t n_pixels, int in_stride,
-                                         int in_offset, int count, float* out, int out_stride, int out_offset) {
+                                         int in_offset, int count, float* out, int out_stride, int out_offset) try {
     NEED_CTX(ctx);
     if (!in || !out) return fail(ctx, SILENT_E_INVALID, "silent_cast_interleave: NULL pointer");
     const size_t es = dtype_size(in_dtype);
     if (!es) return fail(ctx, SILENT_E_UNSUPPORTED, "silent_cast_interleave: unknown in_dtype");
     if (n_pixels == 0 || in_stride < 1 || out_stride < 1) return fail(ctx, SILENT_E_INVALID, "silent_cast_interleave: empty tensor");
+    if (count < 1 || in_offset < 0 || out_offset < 0 || in_stride < in_offset + count || out_stride < out_offset + count)
+        return fail(ctx, SILENT_E_INVALID, "silent_cast_interleave: need 0 <= offset and offset + count <= stride on both sides");
     Stage st(ctx);
-    const size_t bi = n_pixels * (size_t)in_stride * es, bo = n_pixels * (size_t)out_stride * 4;
+    // the last pixel needs offset + count elements, not a whole stride: a caller's buffer may end with its last used element
+    const size_t bi = ((n_pixels - 1) * (size_t)in_stride + (size_t)(in_offset + count)) * es;
+    const size_t bo = ((n_pixels - 1) * (size_t)out_stride + (size_t)(out_offset + count)) * 4;
     const size_t i_x = st.add(bi), i_o = st.add(bo);
     TRY(st.commit());
     TRY(h2d(ctx, st.ptr<char>(i_x), in, bi));
@@ -2681,10 +2834,12 @@ SILENT_EXPORT int silent_cast_interleave(silent_ctx* ctx, const void* in, int in
                                    out_stride, out_offset, nullptr));
     TRY(sync0(ctx));
     return d2h(ctx, out, st.ptr<float>(i_o), bo);
+} catch (...) {
+    return on_exception(ctx, "silent_cast_interleave");
 }
 
 SILENT_EXPORT int silent_resize_nearest(silent_ctx* ctx, const float* in, const silent_extent* in_levels, int n_levels,
-                                        int n_frames, int channels, const silent_extent* out_levels, float* out) {
+                                        int n_frames, int channels, const silent_extent* out_levels, float* out) try {
     NEED_CTX(ctx);
     if (!in || !out) return fail(ctx, SILENT_E_INVALID, "silent_resize_nearest: NULL pointer");
     if (channels < 1) return fail(ctx, SILENT_E_INVALID, "silent_resize_nearest: channels must be >= 1");
@@ -2700,11 +2855,13 @@ SILENT_EXPORT int silent_resize_nearest(silent_ctx* ctx, const float* in, const 
                                   st.ptr<float>(i_o), nullptr));
     TRY(sync0(ctx));
     return d2h(ctx, out, st.ptr<float>(i_o), bo);
+} catch (...) {
+    return on_exception(ctx, "silent_resize_nearest");
 }
 
 SILENT_EXPORT int silent_select_peaks(silent_ctx* ctx, const float* color, const float* value, const silent_extent* levels,
                                       int n_levels, int n_frames, int channels, double top_percent, float* top_out,
-                                      float* peaks_out, float* peak_value_out) {
+                                      float* peaks_out, float* peak_value_out) try {
     NEED_CTX(ctx);
     if (!color) return fail(ctx, SILENT_E_INVALID, "silent_select_peaks: NULL pointer");
     if (!top_out && !peaks_out && !peak_value_out) return fail(ctx, SILENT_E_INVALID, "silent_select_peaks: all outputs are NULL");
@@ -2726,12 +2883,14 @@ SILENT_EXPORT int silent_select_peaks(silent_ctx* ctx, const float* color, const
     if (peaks_out) TRY(d2h(ctx, peaks_out, st.ptr<float>(i_p), bc));
     if (peak_value_out) TRY(d2h(ctx, peak_value_out, st.ptr<float>(i_o), bv));
     return SILENT_OK;
+} catch (...) {
+    return on_exception(ctx, "silent_select_peaks");
 }
 
 SILENT_EXPORT int silent_select_keypoints(silent_ctx* ctx, const float* color, const float* value, const silent_extent* levels,
                                           int n_levels, int n_frames, int channels, double top_percent,
                                           const silent_extent* regions, float* peak_value_out, int64_t* idx,
-                                          size_t cap_per_frame, int64_t* counts) {
+                                          size_t cap_per_frame, int64_t* counts) try {
     NEED_CTX(ctx);
     if (!color || !regions || !counts || (!idx && cap_per_frame))
         return fail(ctx, SILENT_E_INVALID, "silent_select_keypoints: NULL pointer");
@@ -2752,4 +2911,12 @@ SILENT_EXPORT int silent_select_keypoints(silent_ctx* ctx, const float* color, c
     if (peak_value_out) TRY(d2h(ctx, peak_value_out, st.ptr<float>(i_o), bv));
     if (cap_per_frame) TRY(d2h(ctx, idx, st.ptr<int64_t>(i_i), bi));
     return d2h(ctx, counts, st.ptr<int64_t>(i_n), bn);
+} catch (...) {
+    return on_exception(ctx, "silent_select_keypoints");
 }
+
+#ifdef SILENT_HOST_ONLY
+// fault injectors of the host-only sanitizer build (silent_host_shim.h); not part of include/silent_hip.h
+SILENT_EXPORT void silent_host_arm_fault(long countdown) { silent_host::fault_countdown() = countdown; }
+SILENT_EXPORT void silent_host_fail_new_after(long countdown) { silent_host::new_countdown() = countdown; }
+#endif

@@ -1098,8 +1098,8 @@ __global__ __launch_bounds__(256) void affine_clip_kernel(const float* __restric
 // np.asarray(frame, dtype=float32) (recognition_testing.py:141) and the per-colour-plane copies of image_to_zoom_tensor
 // (from_image.py:54-64) as one strided cast: out[p * out_stride + out_off + k] = float32(in[p * in_stride + in_off + k]),
 // k < count.  Widening uint8 / int / float64 camera frames, cutting a colour plane out of an interleaved image and
-// interleaving planes again are all instances.  The conversion is the C cast (exact for the integer types; float64 rounds
-// to nearest like NumPy's astype).
+// interleaving planes again are all instances.  The conversion is the C cast (exact up to 2^24 in magnitude, round-to-nearest
+// beyond for int32 / int64 / float64, like NumPy's astype).
 template <class T>
 __global__ __launch_bounds__(256) void cast_interleave_kernel(const T* __restrict__ in, float* __restrict__ out, long long n_px,
                                                               int in_stride, int in_off, int count, int out_stride, int out_off) {

@@ -316,8 +316,12 @@ def test_cast_interleave_and_device_frames_of_any_dtype(rt):
         np.testing.assert_array_equal(dev.cpu().numpy(), host)
         assert_close(host, so.zoom_from_image(img, ncol, (32, 24), 2.0), RTOL, scale=255.0, what="from_image %d colours" % ncol,
                      bound=eb.zoom(so.zoom_from_image(img, ncol, (32, 24), 2.0)))
-    with pytest.raises(ValueError):
-        rt.nms3x3(torch.from_numpy(img8[None].astype(np.float32)).cuda()[:, :, ::2], "fired")       # not contiguous
+    # layouts and dtypes outside the cast kernel's fast path (strided views, half precision, bool) are accepted like the
+    # reference's np.asarray(frame, dtype=float32) accepts them: same result as the contiguous float32 copy
+    f32 = torch.from_numpy(img8[None].astype(np.float32)).cuda()
+    for view in (f32[:, :, ::2], f32.permute(0, 2, 1, 3), f32[..., :2], f32.half(), f32.bfloat16(), f32 > 128, f32.to(torch.int8)):
+        want = rt.nms3x3(view.to(torch.float32).contiguous().cpu().numpy(), "fired")
+        np.testing.assert_array_equal(rt.nms3x3(view, "fired").cpu().numpy(), want)
 
 
 @pytest.mark.parametrize("shape,scale,n", [((135, 240, 1), 2.0, 5), ((135, 240, 3), 2.0, 4), ((270, 480, 1), math.e ** .5, 6),
