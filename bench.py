@@ -375,6 +375,49 @@ def dominant_kernel(torch, pipe, frames, wl, B, dev, launches=24):
             "pmc_name": "rgb_line_end2_kernel"}
 
 
+def ingest_record(torch, pipe, frames, wl, B, dev, steps=20):
+    """The ingest leg of the reference's per-frame path (recognition_testing.py:141-143: host frame -> float32 -> pyramid -> feed),
+    outside the timed region: LineEndPipeline.step_host on batches that sit in PINNED host memory (where a capture driver leaves
+    them), uint8 as a camera delivers them and float32 as the reference feeds them.  Reported: the host-to-device rate of the
+    copy alone, frames/s of the whole pass including the upload for both dtypes (two batches in flight: the copy of batch n + 1
+    overlaps the compute of batch n), the same from pageable NumPy arrays (one more host memcpy into the staging ring), and
+    overlap_frac = (t_copy + t_compute - t_pipelined) / min(t_copy, t_compute): 1 = the shorter leg is fully hidden."""
+    h, w = wl["hw"]
+    c = 1 if wl["mode"] == "gray" else 3
+
+    def wall(fn, n):
+        torch.cuda.synchronize(dev)
+        t0 = time.perf_counter()
+        for i in range(n):
+            fn(i)
+        torch.cuda.synchronize(dev)
+        return (time.perf_counter() - t0) / n
+
+    out = {"frames_per_step": B, "source": "pinned host memory, two alternating batches", "steps": steps}
+    t_comp = wall(lambda i: pipe.step(frames), steps)
+    for name, dtype in (("u8", torch.uint8), ("f32", torch.float32)):
+        host = [(torch.randint(0, 256, (B, h, w, c), dtype=torch.uint8) if dtype == torch.uint8
+                 else torch.randint(0, 256, (B, h, w, c), dtype=torch.uint8).to(torch.float32)).pin_memory() for _ in range(2)]
+        devbuf = torch.empty((B, h, w, c), dtype=dtype, device=dev)
+        wall(lambda i: devbuf.copy_(host[i & 1], non_blocking=True), 3)
+        t_copy = wall(lambda i: devbuf.copy_(host[i & 1], non_blocking=True), steps)
+        wall(lambda i: pipe.step_host(host[i & 1]), 4)
+        t_pipe = wall(lambda i: pipe.step_host(host[i & 1]), steps)
+        nbytes = host[0].numel() * host[0].element_size()
+        out["h2d_GBs" if name == "u8" else "h2d_GBs_f32"] = round(nbytes / t_copy / 1e9, 2)
+        out["frames_per_s_with_upload_" + name] = round(B / t_pipe, 1)
+        out["ms_per_step_with_upload_" + name] = round(t_pipe * 1e3, 4)
+        out["overlap_frac" if name == "u8" else "overlap_frac_f32"] = round((t_copy + t_comp - t_pipe) / min(t_copy, t_comp), 3)
+        if name == "u8":
+            pageable = [x.numpy().copy() for x in host]
+            wall(lambda i: pipe.step_host(pageable[i & 1]), 3)
+            out["frames_per_s_with_upload_u8_from_numpy"] = round(B / wall(lambda i: pipe.step_host(pageable[i & 1]), steps), 1)
+        del host, devbuf
+    out["frames_per_s_resident"] = round(B / t_comp, 1)
+    out["ms_per_step_resident"] = round(t_comp * 1e3, 4)
+    return out
+
+
 def roofline_of(dom, B):
     gbs = dom["bytes"] / (dom["ms"] * 1e-3) / 1e9
     roof = {"bound": "hbm", "kernel": dom["kernel"], "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
@@ -588,6 +631,7 @@ def run_rank(args):
     settle_steps = 60
     steady = timed_steps(torch, D, pipe, frames, settle_steps, 0, dev)
     dom = dominant_kernel(torch, pipe, frames, wl, B, dev)
+    ingest = ingest_record(torch, pipe, frames, wl, B, dev) if world == 1 and not args.no_ingest else None
     # the scaling record proves itself: backend, and per rank the device it ran on and its own step time
     dist = dist_record(D, rank, local, D.device_identity(local), own_ms)
     if rank != 0:
@@ -624,6 +668,7 @@ def run_rank(args):
                    "sharding": "frame i -> rank i mod N; one RCCL broadcast of constants at init",
                    "csrc_revision": csrc_revision()},
         "roofline": roofline_of(dom, B),
+        "ingest": ingest,
         "dist": dist,
         "steady_state": {"ms_per_step": round(steady / settle_steps * 1e3, 4), "steps": settle_steps,
                          "value": round(B * world * settle_steps * h * w / steady / 1e6, 2),
@@ -660,6 +705,7 @@ def main(argv=None):
     ap.add_argument("--workload", default="config2", choices=sorted(WORKLOADS))
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-side-workloads", action="store_true")
+    ap.add_argument("--no-ingest", action="store_true")
     args = ap.parse_args(argv)
     if args.gpus < 1:
         raise SystemExit("--gpus must be >= 1")

@@ -310,6 +310,14 @@ __global__ __launch_bounds__(256) void rgb_line_end_kernel(const RgbArgs args) {
             // ---- rgc: completes row yin - 1
             with_neighbours(cur[d], v);
             conv3_roll<RGC_PAIRS>(v, wp + 0 * 81, a1, b1, g);
+            if constexpr ((RGC_PAIRS & 0x1ffu) != 0x1ffu) {
+                // channel-diagonal rgc: the skipped 0 * x products of the reference's dense convolution are NaN for a NaN / inf
+                // pixel -- poison all three outputs where any channel's window holds one (silent_rgb2.h, rgc stage)
+                const float sg = (g[0] + g[1]) + g[2];
+                const float u = sg - sg;
+#pragma unroll
+                for (int c = 0; c < 3; ++c) g[c] = g[c] + u;
+            }
             {
                 const bool ok = yin - 1 >= 0 && yin - 1 < H && col_ok;
 #pragma unroll

@@ -455,6 +455,11 @@ __device__ __forceinline__ float relu_max3(float v) {   // relu_tf in one instru
     asm("v_maximum3_f32 %0, %1, 0, 0" : "=v"(r) : "v"(v));
     return r;
 }
+__device__ __forceinline__ float relu_max3_poisoned(float v, float u) {   // u: +0, or a NaN that the result must become
+    float r;
+    asm("v_maximum3_f32 %0, %1, 0, %2" : "=v"(r) : "v"(v), "v"(u));
+    return r;
+}
 
 // MM: also accumulate the per-level extrema of the value map (args.mm) -- a separate instantiation with a 3-waves/SIMD register
 // budget: the plain kernel sits at the 128-VGPR edge, and forced into that budget the extra pointer, masks and accumulators
@@ -463,6 +468,8 @@ template <unsigned RGC_PAIRS, bool STRIPE_SUM, unsigned RGBY_A, unsigned END_A0,
 __global__ __launch_bounds__(64 * kRgb2Waves) __attribute__((amdgpu_waves_per_eu(MM ? 3 : 4, 8))) void rgb_line_end2_kernel(const Rgb2Args args) {
     typedef Rgb2Layout<RGC_PAIRS, STRIPE_SUM, RGBY_A != kDense, END_A0 != kDense, SYM> L;
     static_assert(L::blocks * kRgb2Blk <= kRgb2StreamMax, "stream fits its kernarg array");
+    static_assert((RGC_PAIRS & 0x1ffu) == 0x1ffu || (RGC_PAIRS & 0x1ffu) == 0x111u, "rgc: dense or channel-diagonal");
+    constexpr bool kRgcDiag = (RGC_PAIRS & 0x1ffu) == 0x111u;   // zero weights skipped: the outputs are poisoned (rgc stage)
     const int R = args.th, NROWS = R + 2 * kRgb2RowHalo;
     const float* __restrict__ pyr = args.pyr;
     float* __restrict__ orient_out = args.orient_out;
@@ -590,6 +597,13 @@ __global__ __launch_bounds__(64 * kRgb2Waves) __attribute__((amdgpu_waves_per_eu
     const bool cols_ok = __builtin_amdgcn_readfirstlane(__all(col0 && col1 && padc0 && padc1) ? 1 : 0) != 0;
     const int in_hi = (H - prm.pad < H - 6 ? H - prm.pad : H - 6) - prm.pad;   // yout in [pad, pad + in_hi): rows yout .. yout + 6 in the level
     const unsigned in_len = (cols_ok && in_hi > 0) ? (unsigned)in_hi : 0u;
+    auto mask_stage = [&](f2 (&g)[3], int y, int outside) {
+        if (outside != 0) {
+            const bool rok = (unsigned)y < (unsigned)H;
+#pragma unroll
+            for (int c = 0; c < 3; ++c) g[c] = f2{(rok && col0) ? g[c].x : 0.0f, (rok && col1) ? g[c].y : 0.0f};
+        }
+    };
     auto relu_stage = [&](f2 (&g)[3], int y, int outside) {
         if constexpr (SYM) {
 #pragma unroll
@@ -598,11 +612,7 @@ __global__ __launch_bounds__(64 * kRgb2Waves) __attribute__((amdgpu_waves_per_eu
 #pragma unroll
             for (int c = 0; c < 3; ++c) g[c] = f2{relu_tf(g[c].x), relu_tf(g[c].y)};
         }
-        if (outside != 0) {
-            const bool rok = (unsigned)y < (unsigned)H;
-#pragma unroll
-            for (int c = 0; c < 3; ++c) g[c] = f2{(rok && col0) ? g[c].x : 0.0f, (rok && col1) ? g[c].y : 0.0f};
-        }
+        mask_stage(g, y, outside);
     };
     // one row step: `mine` holds this row; row + 2 is fetched into it as soon as the row has been taken
     auto step = [&](int row, i3 (&mine)[2]) {
@@ -640,7 +650,30 @@ __global__ __launch_bounds__(64 * kRgb2Waves) __attribute__((amdgpu_waves_per_eu
             conv3_roll2<RGC_PAIRS & 0x1ffu, L::b_rgc>(v, ws, a1, b1, g);
         }
         {
-            relu_stage(g, yin - 1, outside);
+            // The reference's rgc convolution is DENSE: its 54 zero weights (midget_rgc is channel-diagonal) still multiply, and
+            // 0 * x is NaN for a NaN / inf pixel -- a non-finite value in ONE channel of the 3 x 3 window makes ALL THREE outputs
+            // non-finite there.  The diagonal forms skip those products, so the outputs are "poisoned" instead: s = the sum of the
+            // three outputs is non-finite exactly where some channel's window holds a non-finite value (every tap of a channel's
+            // own 3 x 3 profile is non-zero), u = s - s is +0 there ... or NaN, and relu takes u along -- v_maximum3_f32(g, 0, u)
+            // = max(g, 0) for u = +0 and NaN for u = NaN (no instruction more than the plain relu; the non-SYM tiers add u first).
+            // The rgc map itself is not an output of this kernel; after the next stage (rgby: every product kept) the NaN / inf
+            // footprint is the reference's (tests/test_gpu_parity.py::test_rgb_chain_nonfinite_pixels_against_the_oracle).
+            if constexpr (kRgcDiag) {
+                const f2 sg = (g[0] + g[1]) + g[2];
+                const f2 u = sg - sg;
+                if constexpr (SYM) {
+#pragma unroll
+                    for (int c = 0; c < 3; ++c) g[c] = f2{relu_max3_poisoned(g[c].x, u.x), relu_max3_poisoned(g[c].y, u.y)};
+                } else {
+#pragma unroll
+                    for (int c = 0; c < 3; ++c) g[c] = g[c] + u;
+#pragma unroll
+                    for (int c = 0; c < 3; ++c) g[c] = f2{relu_tf(g[c].x), relu_tf(g[c].y)};
+                }
+                mask_stage(g, yin - 1, outside);
+            } else {
+                relu_stage(g, yin - 1, outside);
+            }
         }
         // ---- rgby: completes row yin - 2
         if constexpr (SYM) {

@@ -281,6 +281,76 @@ class LineEndPipeline(object):
             cur.wait_stream(self._chain_stream)
             cur.wait_stream(self._walk_stream)
 
+    # -- ingest: host frames -> pinned ring -> copy stream -> widening cast -> step -----------------------------
+    def _ingest_slot(self, dtype, pinned_source):
+        """Ring of two slots per dtype: [pinned staging buffer (None when the caller's frames are pinned already), device buffer
+        of the source dtype, float32 frame buffer, events].  Two batches are in flight: while batch n computes, batch n + 1 is
+        copied (and, for NumPy sources, batch n + 2 staged by the host)."""
+        torch = self.torch
+        ring = self._ingest.setdefault(dtype, {"slots": [], "next": 0})
+        if not ring["slots"]:
+            shape = (self.batch,) + self.frame_shape
+            for _ in range(2):
+                ring["slots"].append({
+                    "pinned": None,
+                    "raw": torch.empty(shape, dtype=dtype, device=self.tdev) if dtype != torch.float32 else None,
+                    "f32": torch.empty(shape, dtype=torch.float32, device=self.tdev),
+                    "h2d_done": torch.cuda.Event(), "raw_free": None, "f32_free": None})
+        slot = ring["slots"][ring["next"]]
+        ring["next"] ^= 1
+        if not pinned_source and slot["pinned"] is None:
+            slot["pinned"] = torch.empty((self.batch,) + self.frame_shape, dtype=dtype, pin_memory=True)
+        return slot
+
+    def step_host(self, frames):
+        """One pass over a batch of HOST frames -- the reference's per-call ingest, recognition_testing.py:141-143
+        (np.asarray(frame, float32) -> zoom.from_image -> session.run feed), batched: ``frames`` [batch, H, W, C] as a NumPy array
+        or a CPU torch tensor (uint8 as a camera delivers it, or int16 / uint16 / int32 / float32 / float64).  The batch goes
+        through a pinned staging buffer (skipped when ``frames`` is a pinned torch tensor already), an asynchronous host-to-device
+        copy on the pipeline's COPY stream, the library's widening cast (silent_cast_interleave_dev: uint8 -> float32 on the GPU,
+        a quarter of the PCIe bytes) and step().  Returns at once; two batches are in flight (ring of two slots), so the copy of
+        batch n + 1 overlaps the compute of batch n.  Results are bit-identical to step() on the same frames resident as float32."""
+        torch = self.torch
+        if isinstance(frames, np.ndarray):
+            src = torch.from_numpy(np.ascontiguousarray(frames))
+        else:
+            src = frames.contiguous()
+        if src.is_cuda or tuple(src.shape) != (self.batch,) + self.frame_shape:
+            raise ValueError("step_host takes host frames of shape %s" % ((self.batch,) + self.frame_shape,))
+        if src.dtype != torch.float32:
+            _runtime._torch_dtype_code(src)         # TypeError for dtypes the cast kernel does not take
+        if not hasattr(self, "_ingest"):
+            self._ingest, self._copy_stream = {}, torch.cuda.Stream(self.tdev)
+        pinned_source = src.is_pinned()
+        slot = self._ingest_slot(src.dtype, pinned_source)
+        cur = torch.cuda.current_stream(self.tdev)
+        cs = self._copy_stream
+        if not pinned_source:
+            slot["h2d_done"].synchronize()          # the staging buffer's previous copy has left the host
+            slot["pinned"].copy_(src)
+            src = slot["pinned"]
+        dst = slot["f32"] if slot["raw"] is None else slot["raw"]
+        for ev in ((slot["f32_free"],) if slot["raw"] is None else (slot["raw_free"],)):
+            if ev is not None:
+                cs.wait_event(ev)                   # the previous batch of this slot has been consumed on the device
+        with torch.cuda.stream(cs):
+            dst.copy_(src, non_blocking=True)
+        slot["h2d_done"].record(cs)
+        cur.wait_event(slot["h2d_done"])
+        if slot["raw"] is not None:
+            if slot["f32_free"] is not None:
+                cur.wait_event(slot["f32_free"])
+            c = self.channels
+            _runtime.cast_interleave(slot["raw"], slot["f32"], c, 0, c, c, 0, self.batch * self.frame_shape[0] * self.frame_shape[1])
+            if slot["raw_free"] is None:
+                slot["raw_free"] = torch.cuda.Event()
+            slot["raw_free"].record(cur)
+        self.step(slot["f32"])
+        # the float32 frames are read by the pyramid kernel only: on the walk stream with overlap, else on the caller's stream
+        if slot["f32_free"] is None:
+            slot["f32_free"] = torch.cuda.Event()
+        slot["f32_free"].record(self._walk_stream if self.overlap else cur)
+
     def step(self, frames):
         """One pass of the hot path over one batch of frames (asynchronous)."""
         if self.overlap:

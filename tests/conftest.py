@@ -94,6 +94,37 @@ def margin_frame(seed, h, w, c=3, n_weak=10, central=True):
     return img
 
 
+def ref_margin_frame(seed, h, w, center=(288, 192), scale=float(np.e) ** .5):
+    """Margin frame for the reference's nested-crop layout (zoom.from_image(frame, 3, center, scale)): level s looks at the
+    centre crop of size center * scale^s, so every level gets weak clutter and a few strong oblique segments INSIDE ITS OWN
+    ring (between the previous level's crop and its own), scaled with the level so that they survive the resampling."""
+    rng = np.random.default_rng(9000 + seed)
+    img = np.zeros((h, w, 3), np.float32)
+
+    def seg(x0, y0, ang, length, col, width=1):
+        for t in range(int(length)):
+            x, y = int(round(x0 + t * np.cos(ang))), int(round(y0 + t * np.sin(ang)))
+            img[max(0, y):min(h, y + width), max(0, x):min(w, x + width)] = col
+
+    cw, ch = center
+    n_levels = int(np.ceil(max(np.log(h / ch) / np.log(scale), np.log(w / cw) / np.log(scale))))
+    for s in range(max(n_levels, 1)):
+        f = scale ** s
+        bw, bh = min(cw * f, w), min(ch * f, h)                       # this level's crop
+        x0, y0 = (w - bw) / 2, (h - bh) / 2
+        thick = max(1, int(round(f)))
+        for _ in range(6):                                            # weak clutter
+            seg(x0 + rng.uniform(0.05, 0.95) * bw, y0 + rng.uniform(0.05, 0.95) * bh, rng.uniform(0, 2 * np.pi),
+                rng.integers(8, 30) * f, rng.integers(30, 100, 3).astype(np.float32), thick)
+        for k in range(2):                                            # strong segments, in the central box of the crop
+            col = ((255.0 - 35.0 * k - 10.0 * s) * rng.uniform(0.3, 1.0, 3)).astype(np.float32)
+            col[rng.integers(0, 3)] = 255.0 - 35.0 * k - 10.0 * s
+            ang = rng.uniform(0.2, np.pi / 2 - 0.2) + rng.integers(0, 4) * np.pi / 2
+            seg(x0 + rng.uniform(0.35, 0.65) * bw, y0 + rng.uniform(0.35, 0.65) * bh, ang, rng.uniform(0.12, 0.2) * bh, col,
+                thick * int(rng.integers(1, 3)))
+    return img
+
+
 WORST_REL = {}   # what -> (worst element-wise relative error at the asserted floor, same at the 1e-3 floor)
 
 

@@ -99,11 +99,19 @@ def level_margins(line, top_percent=0.1, tiny=1e-3):
     return out, pv
 
 
-def oracle_keypoints(frame, n_levels, kernels, flat_policy="ieee", top_percent=0.1, scale=2.0, keep=None):
-    """keep: optional list that receives (pyramid level, dict of the oracle's chain maps) of every level."""
+def oracle_keypoints(frame, n_levels, kernels, flat_policy="ieee", top_percent=0.1, scale=2.0, keep=None, center=None):
+    """keep: optional list that receives (pyramid level, dict of the oracle's chain maps) of every level.
+    center = (w, h): the reference's own layout instead of the classic one -- zoom.from_image(frame, 3, center, scale)
+    (util/zoom/from_image.py:10-69: nested centre crops resampled to one fixed size; n_levels is ignored, the level count follows
+    from the frame and the centre size like in the reference)."""
     h, w, _ = frame.shape
-    extents = so.classic_extents(h, w, scale, n_levels)
-    pyr = co.classic_pyramid(frame, extents)
+    if center is not None:
+        z = so.zoom_from_image(frame, 3, center, scale)
+        pyr = [np.ascontiguousarray(z[l:l + 1], dtype=F32) for l in range(z.shape[0])]
+        extents = [(int(center[1]), int(center[0]))] * len(pyr)
+    else:
+        extents = so.classic_extents(h, w, scale, n_levels)
+        pyr = co.classic_pyramid(frame, extents)
     rows, margins = [], []
     for l, lev in enumerate(pyr):
         chain = {}

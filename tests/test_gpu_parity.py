@@ -743,6 +743,43 @@ def test_rgb_symmetric_forms_against_the_two_group_kernel(rt, kernels, shape):
         assert_close(got["value"], want["value"], RTOL, scale=255.0, what="value " + policy, bound=bound["value"])
 
 
+@pytest.mark.parametrize("knob", [0, 64, 2, 1, 64 | 16, 2 | 16])
+@pytest.mark.parametrize("shape", [(2, 70, 131, 3), (1, 33, 448, 3), (1, 19, 5, 3), (1, 1, 1, 3), (1, 2, 3, 3), (1, 100, 113, 3)])
+def test_rgb_chain_nonfinite_pixels_against_the_oracle(rt, kernels, shape, knob):
+    """NaN / -NaN / +inf / -inf PIXELS through the fused chain, DIRECTLY against the oracle (the reference's dense convolutions:
+    every product is formed, so 0 * inf = NaN -- a non-finite value in one channel reaches all three outputs of midget_rgc's
+    channel-diagonal kernel; the diagonal forms of the fused kernels reproduce that with a poison term, csrc/silent_rgb2.h),
+    for every instantiation: the symmetric forms (0, the default on the reference's kernels), two-group (64), basic (2), dense (1)
+    and the one-pixel kernel (16).  Asserted: the same NaN pattern, the same infinities, finite values within the response
+    tolerance -- at corners, on edges, next to each other, in 1 x 1 and 2 x 3 levels, under both flat policies."""
+    n, h, w, _ = shape
+    rng = np.random.default_rng(h * 1000 + w + knob)
+    frames = np.stack([noise_frame(250 + i, h, w, 3) for i in range(n)])
+    if h > 8:
+        frames[0, 3:9, : max(1, w // 3)] = 0.0            # a flat region: 0 * inf under 'ieee'
+    bad = [np.nan, -np.nan, np.inf, -np.inf]
+    spots = [(0, 0), (h - 1, w - 1), (0, w // 2), (h // 2, 0)] + [(int(rng.integers(0, h)), int(rng.integers(0, w))) for _ in range(6)]
+    for k, (y, x) in enumerate(spots):
+        frames[0, y, x, k % 3] = bad[k % 4]
+    if h > 20 and w > 20:                                 # two different infinities next to each other, and a whole bad pixel
+        frames[0, 15, 15, 0], frames[0, 15, 16, 0] = np.inf, -np.inf
+        frames[0, 18, 5] = [np.inf, np.nan, -np.inf]
+    for policy in ("ieee", "zero"):
+        want = so.rgb_line_end_chain(frames, kernels, policy)
+        with rt.tuning(TUNE_RGB, knob):
+            got = rt.rgb_line_end(frames, kernels, flat_policy=policy)
+        for name, ref in (("orient", "orient"), ("line_end", "padded"), ("value", "value")):
+            a, b = got[name], want[ref]
+            assert np.array_equal(np.isnan(a), np.isnan(b)), "%s %s knob %d: NaN pattern differs (%d vs %d)" % (
+                name, policy, knob, np.isnan(a).sum(), np.isnan(b).sum())
+            inf = np.isinf(b)
+            assert np.array_equal(np.isinf(a), inf) and np.array_equal(a[inf], b[inf]), (name, policy, knob)
+            fin = np.isfinite(b)
+            if fin.any():
+                assert_close(np.where(fin, a, 0), np.where(fin, b, 0), RTOL, scale=max(float(np.abs(b[fin]).max()), 1.0),
+                             what="%s %s non-finite pixels, knob %d" % (name, policy, knob), rel_floor=None)
+
+
 def test_rgb_chain_output_subsets(rt, kernels):
     """NULL output pointers: the pair kernel gives an absent map a buffer resource of 0 records (every store of it is dropped
     by the range check); the maps that ARE requested must not change, and asking for nothing is an error."""

@@ -1,0 +1,86 @@
+"""The ingest leg of the per-frame path (recognition_testing.py:141-143: np.asarray(frame, float32) -> zoom.from_image -> feed),
+batched: LineEndPipeline.step_host (pinned ring, copy stream, widening cast on the GPU) against step() on the same frames
+resident as float32 -- bit-identical maps and keypoints, over several consecutive batches so that both ring slots are reused
+while the previous batch is still in flight; and overlap=True (two internal streams) against the one-stream step."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def _same(a, b, keys):
+    import torch
+    for k in keys:
+        assert torch.equal(a[k].data.view(torch.int32), b[k].data.view(torch.int32)), k
+    if "keypoints" in a:
+        np.testing.assert_array_equal(a["keypoint_counts"], b["keypoint_counts"])
+        for x, y in zip(a["keypoints"], b["keypoints"]):
+            np.testing.assert_array_equal(x, y)
+
+
+@pytest.mark.parametrize("mode,overlap", [("gray", False), ("rgb", False), ("rgb", True)])
+@pytest.mark.parametrize("source", ["numpy_u8", "pinned_u8", "numpy_f32", "numpy_i16"])
+def test_step_host_equals_the_resident_step(mode, overlap, source):
+    import torch
+    from pysilent_amd.pipeline import LineEndPipeline
+    h, w, B = 135, 240, 3
+    c = 1 if mode == "gray" else 3
+    kw = dict(selection=True, value_map=False, peak_value_map=False) if mode == "rgb" else {}
+    host = LineEndPipeline((h, w), mode=mode, n_levels=4, batch=B, overlap=overlap, **kw)
+    ref = LineEndPipeline((h, w), mode=mode, n_levels=4, batch=B, **kw)
+    keys = ("pyramid", "cs", "end") if mode == "gray" else ("pyramid", "orient", "line_end")
+    rng = np.random.default_rng(11)
+    batches = []
+    for _ in range(5):
+        u8 = rng.integers(0, 256, (B, h, w, c)).astype(np.uint8)
+        if source == "numpy_i16":
+            batches.append((u8.astype(np.int16) - 100))
+        elif source == "numpy_f32":
+            batches.append(u8.astype(np.float32) + np.float32(0.25))
+        else:
+            batches.append(u8)
+    srcs = [torch.from_numpy(b).pin_memory() for b in batches] if source == "pinned_u8" else batches
+    # all five batches enqueued back to back (two in flight at any time), only the last one's results are looked at ...
+    for s in srcs:
+        host.step_host(s)
+    ref.step(torch.from_numpy(batches[-1].astype(np.float32)).cuda())
+    torch.cuda.synchronize()
+    _same(host.outputs(), ref.outputs(), keys)
+    # ... and once more batch by batch with the results read in between
+    for s, b in zip(srcs[:2], batches[:2]):
+        host.step_host(s)
+        ref.step(torch.from_numpy(b.astype(np.float32)).cuda())
+        _same(host.outputs(), ref.outputs(), keys)
+
+
+def test_step_host_rejects_what_it_cannot_take():
+    import torch
+    from pysilent_amd.pipeline import LineEndPipeline
+    pipe = LineEndPipeline((32, 48), mode="gray", n_levels=2, batch=2)
+    with pytest.raises(ValueError):
+        pipe.step_host(np.zeros((1, 32, 48, 1), np.uint8))                  # wrong batch
+    with pytest.raises(ValueError):
+        pipe.step_host(torch.zeros((2, 32, 48, 1), dtype=torch.uint8).cuda())     # device frames go to step()
+    with pytest.raises(TypeError):
+        pipe.step_host(np.zeros((2, 32, 48, 1), np.complex64))
+
+
+@pytest.mark.parametrize("center", [None, (72, 48)])
+def test_overlap_mode_is_bit_identical_over_many_steps(center):
+    """overlap=True: pyramid of batch n + 1 on a second stream beside the chain + keypoint tail of batch n, double-buffered
+    pyramid.  Ten steps with DIFFERENT frames, results read after some of them, against the one-stream pipeline."""
+    import torch
+    from pysilent_amd.pipeline import LineEndPipeline
+    h, w, B = 216, 384, 4
+    kw = dict(selection=True, value_map=False, peak_value_map=False)
+    if center is not None:
+        kw.update(center_dimensions=center, scale=np.e ** .5)
+    a = LineEndPipeline((h, w), mode="rgb", n_levels=4, batch=B, overlap=True, **kw)
+    b = LineEndPipeline((h, w), mode="rgb", n_levels=4, batch=B, **kw)
+    rng = np.random.default_rng(3)
+    frames = [torch.from_numpy(rng.integers(0, 256, (B, h, w, 3)).astype(np.float32)).cuda() for _ in range(10)]
+    for i, f in enumerate(frames):
+        a.step(f)
+        b.step(f)
+        if i in (0, 3, 4, 9):
+            _same(a.outputs(), b.outputs(), ("pyramid", "orient", "line_end"))
