@@ -1537,6 +1537,11 @@ static int rgb_chain_launch(silent_ctx* ctx, const char* who, const float* pyr, 
             std::memset(a2.sum_off, 0, sizeof(a2.sum_off));
             std::memset(a2.ws, 0, sizeof(a2.ws));
             rgb2_fill_stream(a.w, basic ? 0x111u : 0x1ffu, basic, two, two, a2.ws, use_sym ? &sym : nullptr);
+            // 16-byte-per-lane stores of orient / line_end (ST4, silent_rgb2.h): every row of every map must start on a 16-byte
+            // boundary -- widths, level offsets and the frame stride multiples of 4 pixels, the map pointers 16-byte aligned (all
+            // BASELINE extents; anything else keeps the 12-byte form).  RGB knob bit 7: the 12-byte form regardless (A/B).
+            bool st4 = !(kopts & 128u) && tab.frame_px % 4 == 0 && (uintptr_t)orient_out % 16 == 0 && (uintptr_t)line_end_out % 16 == 0;
+            for (int l = 0; l < n_levels && st4; ++l) st4 = levels[l].w % 4 == 0 && tab.px_off[l] % 4 == 0;
             // silent_set_profiling: HIP events around THIS launch, on the stream it runs on (the fused RGB chain is the dominant
             // kernel of silent_rgb_line_end / silent_rgb_keypoints, like gray_stream_kernel is of silent_gray_pass)
             const bool prof = ctx->profiling && (ctx->prof_calls++ % ctx->prof_period) == 0;
@@ -1560,11 +1565,13 @@ static int rgb_chain_launch(silent_ctx* ctx, const char* who, const float* pyr, 
                     a2.sum_frame = st->frame_entries;
                     for (int l = 0; l < kMaxLevels; ++l) a2.sum_off[l] = st->off[l];
                 }
-                if (use_sym) hipLaunchKernelGGL((rgb_line_end2_kernel<0x111u, true, kRgbyA, kEndA0, kEndA1, kEndA2, true, true>), dim3((unsigned)blocks), dim3(64 * kRgb2Waves), 0, s, a2);
+                if (use_sym && st4) hipLaunchKernelGGL((rgb_line_end2_kernel<0x111u, true, kRgbyA, kEndA0, kEndA1, kEndA2, true, true, true>), dim3((unsigned)blocks), dim3(64 * kRgb2Waves), 0, s, a2);
+                else if (use_sym) hipLaunchKernelGGL((rgb_line_end2_kernel<0x111u, true, kRgbyA, kEndA0, kEndA1, kEndA2, true, true>), dim3((unsigned)blocks), dim3(64 * kRgb2Waves), 0, s, a2);
                 else hipLaunchKernelGGL((rgb_line_end2_kernel<0x111u, true, kRgbyA, kEndA0, kEndA1, kEndA2, true>), dim3((unsigned)blocks), dim3(64 * kRgb2Waves), 0, s, a2);
                 if (mm_done) *mm_done = true;
             } else
-            if (use_sym) hipLaunchKernelGGL((rgb_line_end2_kernel<0x111u, true, kRgbyA, kEndA0, kEndA1, kEndA2, false, true>), dim3((unsigned)blocks), dim3(64 * kRgb2Waves), 0, s, a2);
+            if (use_sym && st4) hipLaunchKernelGGL((rgb_line_end2_kernel<0x111u, true, kRgbyA, kEndA0, kEndA1, kEndA2, false, true, true>), dim3((unsigned)blocks), dim3(64 * kRgb2Waves), 0, s, a2);
+            else if (use_sym) hipLaunchKernelGGL((rgb_line_end2_kernel<0x111u, true, kRgbyA, kEndA0, kEndA1, kEndA2, false, true>), dim3((unsigned)blocks), dim3(64 * kRgb2Waves), 0, s, a2);
             else if (two) hipLaunchKernelGGL((rgb_line_end2_kernel<0x111u, true, kRgbyA, kEndA0, kEndA1, kEndA2>), dim3((unsigned)blocks), dim3(64 * kRgb2Waves), 0, s, a2);
             else if (basic) hipLaunchKernelGGL((rgb_line_end2_kernel<0x111u, true, kDense, kDense, kDense, kDense>), dim3((unsigned)blocks), dim3(64 * kRgb2Waves), 0, s, a2);
             else hipLaunchKernelGGL((rgb_line_end2_kernel<0x1ffu, false, kDense, kDense, kDense, kDense>), dim3((unsigned)blocks), dim3(64 * kRgb2Waves), 0, s, a2);

@@ -464,8 +464,12 @@ __device__ __forceinline__ float relu_max3_poisoned(float v, float u) {   // u: 
 // MM: also accumulate the per-level extrema of the value map (args.mm) -- a separate instantiation with a 3-waves/SIMD register
 // budget: the plain kernel sits at the 128-VGPR edge, and forced into that budget the extra pointer, masks and accumulators
 // spill to scratch (+16 %; with 3 waves +4 %)
-template <unsigned RGC_PAIRS, bool STRIPE_SUM, unsigned RGBY_A, unsigned END_A0, unsigned END_A1, unsigned END_A2, bool MM = false, bool SYM = false>
-__global__ __launch_bounds__(64 * kRgb2Waves) __attribute__((amdgpu_waves_per_eu(MM ? 3 : 4, 8))) void rgb_line_end2_kernel(const Rgb2Args args) {
+// ST4 (round 4): orient / line_end leave as 16-byte-per-lane stores (buffer_store_dwordx4), three per PAIR of rows instead of four
+// 12-byte ones -- see the store section below; host-checked: every level's width, pixel offset and the map pointers are
+// multiples of 4 pixels / 16 bytes (all BASELINE extents are).
+template <unsigned RGC_PAIRS, bool STRIPE_SUM, unsigned RGBY_A, unsigned END_A0, unsigned END_A1, unsigned END_A2, bool MM = false, bool SYM = false,
+          bool ST4 = false>
+__global__ __launch_bounds__(64 * kRgb2Waves) __attribute__((amdgpu_waves_per_eu((MM || ST4) ? 3 : 4, 8))) void rgb_line_end2_kernel(const Rgb2Args args) {
     typedef Rgb2Layout<RGC_PAIRS, STRIPE_SUM, RGBY_A != kDense, END_A0 != kDense, SYM> L;
     static_assert(L::blocks * kRgb2Blk <= kRgb2StreamMax, "stream fits its kernarg array");
     static_assert((RGC_PAIRS & 0x1ffu) == 0x1ffu || (RGC_PAIRS & 0x1ffu) == 0x111u, "rgc: dense or channel-diagonal");
@@ -550,7 +554,8 @@ __global__ __launch_bounds__(64 * kRgb2Waves) __attribute__((amdgpu_waves_per_eu
     const __amdgpu_buffer_rsrc_t r_sum = __builtin_amdgcn_make_buffer_rsrc(
         (void*)(args.sum + (long long)tc.frame * args.sum_frame + args.sum_off[tc.level] + (long long)tc.ty * gpt * nxp), 0, sum_bytes, 0x00020000);
     const int ssum = out0 ? (x0 >> 1) * 4 : kRgb2Out;
-    __shared__ float s_tr[kRgb2Waves][128 * 3];   // [wave][one output row of the wave's 128 columns x 3 channels]
+    // [wave][one output row of the wave's 128 columns x 3 channels]; ST4: [wave][map: orient, line_end][row A, row B][384]
+    __shared__ __attribute__((aligned(16))) float s_tr[kRgb2Waves][ST4 ? 4 * 384 : 384];
     float* const tr = s_tr[wave];
     // lane-major in AS HELD -- [lane][channel][half]: three 8-byte writes of the register pairs, no shuffling moves --, pixel-major
     // out: pixel p of the wave's 128 columns is half p & 1 of lane p >> 1, its channels 2 floats apart.  The reading lane j takes
@@ -566,6 +571,49 @@ __global__ __launch_bounds__(64 * kRgb2Waves) __attribute__((amdgpu_waves_per_eu
         const i3 db = {__float_as_int(tr_out[192]), __float_as_int(tr_out[194]), __float_as_int(tr_out[196])};
         __builtin_amdgcn_raw_buffer_store_b96(da, rsrc, (int)((unsigned)sta + (unsigned)ro), 0, kRgb2StoreAux);
         __builtin_amdgcn_raw_buffer_store_b96(db, rsrc, (int)((unsigned)stb + (unsigned)ro), 0, kRgb2StoreAux);
+    };
+    // ST4: a row of the wave's 128 columns is 1536 bytes = 96 sixteen-byte chunks, of which chunks 6 .. 89 (the 112 output columns;
+    // 4 pixels = 3 chunks and everything is a multiple of 4 pixels, so no chunk straddles a column bound) are stored.  84 chunks
+    // are 1.3 wave stores, so rows go out in PAIRS (A = the even row, B = A + 1): 168 chunks = three stores instead of four x3 ones
+    //   S1: lane j        -> row A chunk 6 + j
+    //   S2: lanes 0 .. 19 -> row A chunk 70 + j,   lanes 20 .. 63 -> row B chunk j - 14
+    //   S3: lanes 0 .. 39 -> row B chunk 50 + j    (lanes 40 .. 63 out of range)
+    // Row A waits one step in LDS: written PIXEL-MAJOR (float 3 P + c: three ds_write2_b32 of the register pairs as they lie),
+    // read back as one ds_read_b128 per lane and store.  Offsets are lane constant + row A's offset (row B = + one row, folded
+    // into the constant); rows outside the tile and chunks outside the columns are dropped by the range check as before.
+    typedef int i4v __attribute__((ext_vector_type(4)));
+    int st4_off[3] = {0, 0, 0}, st4_lds[3] = {0, 0, 0};
+    if constexpr (ST4) {
+        const int colb = (xw0 - kRgb2Halo) * 12;                       // byte offset of chunk 0 inside a row (a multiple of 16)
+        const int wend = (xw0 + kRgb2Cols < W ? xw0 + kRgb2Cols : W);  // one past the wave's last output column
+        auto chunk = [&](int q, int rowb, int ldsb, int& off, int& lds) {
+            const int x_last = xw0 - kRgb2Halo + (4 * q + 3) / 3;      // last pixel the chunk touches
+            const bool ok = q >= 6 && q < 90 && x_last < wend;
+            off = ok ? rowb + colb + 16 * q : kRgb2Out;
+            lds = ldsb + 16 * (q < 96 ? q : 95);
+        };
+        chunk(6 + lane, 0, 0, st4_off[0], st4_lds[0]);
+        if (lane < 20) chunk(70 + lane, 0, 0, st4_off[1], st4_lds[1]);
+        else chunk(lane - 14, rb, 1536, st4_off[1], st4_lds[1]);
+        chunk(lane < 40 ? 50 + lane : 95, rb, 1536, st4_off[2], st4_lds[2]);
+        if (lane >= 40) st4_off[2] = kRgb2Out;
+    }
+    // write this step's row of map `m` (0 orient, 1 line_end) into its pair slot; slot B completes the pair: three stores
+    auto st4_put = [&](const f2 (&val)[3], int m, int slot) {
+        float* const dst = tr + (m * 2 + slot) * 384 + lane * 6;
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            dst[c] = val[c].x;
+            dst[3 + c] = val[c].y;
+        }
+    };
+    auto st4_flush = [&](int m, __amdgpu_buffer_rsrc_t rsrc, int roA) {
+        const char* const base = reinterpret_cast<const char*>(tr + m * 2 * 384);
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            const i4v d = *reinterpret_cast<const i4v*>(base + st4_lds[k]);
+            __builtin_amdgcn_raw_buffer_store_b128(d, rsrc, (int)((unsigned)st4_off[k] + (unsigned)roA), 0, kRgb2StoreAux);
+        }
     };
 #pragma unroll
     for (int k = 0; k < 4; ++k)
@@ -615,7 +663,8 @@ __global__ __launch_bounds__(64 * kRgb2Waves) __attribute__((amdgpu_waves_per_eu
         mask_stage(g, y, outside);
     };
     // one row step: `mine` holds this row; row + 2 is fetched into it as soon as the row has been taken
-    auto step = [&](int row, i3 (&mine)[2]) {
+    auto step = [&](int row, i3 (&mine)[2], auto parity) {
+        constexpr int PAR = decltype(parity)::value;   // row & 1 (the loop is unrolled by two)
         const int yin = y0 - kRgb2RowHalo + row;  // input row of this step
         // 0 inside, -1 otherwise: kept as an INTEGER (both differences non-negative <=> inside) and compared where it is used -- a
         // bool that lives across blocks travels as a lane mask through a VGPR (v_cndmask + v_cmp per use)
@@ -880,7 +929,13 @@ __global__ __launch_bounds__(64 * kRgb2Waves) __attribute__((amdgpu_waves_per_eu
                 for (int c = 0; c < 3; ++c) o3[c] = f2{(rok && col0) ? o3[c].x : 0.0f, (rok && col1) ? o3[c].y : 0.0f};
             }
         }
-        store_row3(o3, r_orient, (t - y0) * rb);
+        if constexpr (ST4) {
+            // orient row t - y0 = row - 13: even on the odd steps (slot A), the pair completes on the even ones
+            st4_put(o3, 0, PAR == 1 ? 0 : 1);
+            if constexpr (PAR == 0) st4_flush(0, r_orient, (t - y0 - 1) * rb);
+        } else {
+            store_row3(o3, r_orient, (t - y0) * rb);
+        }
         // ---- end bank: completes row yout = yin - 7
 #pragma unroll
         for (int c = 0; c < 3; ++c) {
@@ -902,7 +957,13 @@ __global__ __launch_bounds__(64 * kRgb2Waves) __attribute__((amdgpu_waves_per_eu
 #pragma unroll
                 for (int c = 0; c < 3; ++c) le[c] = mk * le[c];
             }
-            store_row3(le, r_line, k * rb);
+            if constexpr (ST4) {
+                // line_end row k = row - 14: even on the even steps (slot A), the pair completes on the odd ones
+                st4_put(le, 1, PAR == 0 ? 0 : 1);
+                if constexpr (PAR == 1) st4_flush(1, r_line, (k - 1) * rb);
+            } else {
+                store_row3(le, r_line, k * rb);
+            }
             const f2 val = ((le[0] + le[1]) + le[2]) * inv3p;
             typedef int i2 __attribute__((ext_vector_type(2)));
             const int norow = (k | (rows_t - 1 - k)) >> 31;   // 0: an output row of this tile (wave-uniform, an integer like `outside`)
@@ -928,8 +989,8 @@ __global__ __launch_bounds__(64 * kRgb2Waves) __attribute__((amdgpu_waves_per_eu
     };
 #pragma unroll 1
     for (int row = 0; row < NROWS; row += 2) {   // th is even: whole pairs of rows
-        step(row, nb0);
-        step(row + 1, nb1);
+        step(row, nb0, ic<0>{});
+        step(row + 1, nb1, ic<1>{});
     }
     if constexpr (MM) {
         const float mx = wave_max(mm_mx), nmn = wave_max(mm_nmn);

@@ -780,6 +780,42 @@ def test_rgb_chain_nonfinite_pixels_against_the_oracle(rt, kernels, shape, knob)
                              what="%s %s non-finite pixels, knob %d" % (name, policy, knob), rel_floor=None)
 
 
+@pytest.mark.parametrize("extents", [[(90, 224), (45, 112), (23, 56), (12, 28)], [(270, 480)], [(7, 4)], [(91, 452), (33, 8), (1, 4)],
+                                     [(182, 228), (3, 116)]])
+def test_rgb_chain_16_byte_stores_are_bit_identical(rt, kernels, extents):
+    """ST4 (csrc/silent_rgb2.h): on levels whose rows start on 16-byte boundaries the chain writes orient / line_end with three
+    buffer_store_dwordx4 per pair of rows (row A parked in LDS for a step) instead of four 12-byte stores.  Pure data movement:
+    every bit must equal the 12-byte form (RGB knob bit 7) -- odd heights (a last pair with one row), tiles of one row, widths
+    that end inside a wave, inside a 4-pixel group never (widths are multiples of 4), several levels, NaN rows from the 'ieee'
+    policy, and the extrema instantiation behind silent_rgb_keypoints (maps + keypoints)."""
+    import torch
+    packed, levels = ragged_pyramid(rt, 77, extents, c=3, n_frames=2)
+    levels[0][0, : min(6, extents[0][0]), : extents[0][1] // 2] = 0.0      # 0 * inf under 'ieee'
+    packed = rt.PackedPyramid.from_levels(levels)
+    for tall in (0, 8):
+        with rt.tuning(TUNE_RGB, 128 | tall):
+            b = rt.rgb_line_end(packed, kernels)
+        with rt.tuning(TUNE_RGB, tall):
+            a = rt.rgb_line_end(packed, kernels)
+        for name in ("orient", "line_end", "value"):
+            np.testing.assert_array_equal(a[name].data.view(np.int32), b[name].data.view(np.int32), err_msg="%s tall %d" % (name, tall))
+    # the extrema instantiation (fused keypoints): device buffers, 16-byte aligned by the allocator
+    from pysilent_amd.pipeline import LineEndPipeline
+    h, w = 136, 240
+    frames = torch.from_numpy(np.stack([noise_frame(300 + i, h, w, 3) for i in range(3)])).cuda()
+    outs = []
+    for knob in (0, 128):
+        pipe = LineEndPipeline((h, w), mode="rgb", n_levels=4, batch=3, selection=True, value_map=False, peak_value_map=False)
+        with rt.tuning(TUNE_RGB, knob):
+            pipe.step(frames)
+            torch.cuda.synchronize()
+        outs.append(pipe.outputs())
+    for name in ("orient", "line_end"):
+        assert torch.equal(outs[0][name].data.view(torch.int32), outs[1][name].data.view(torch.int32)), name
+    for x, y in zip(outs[0]["keypoints"], outs[1]["keypoints"]):
+        np.testing.assert_array_equal(x, y)
+
+
 def test_rgb_chain_output_subsets(rt, kernels):
     """NULL output pointers: the pair kernel gives an absent map a buffer resource of 0 records (every store of it is dropped
     by the range check); the maps that ARE requested must not change, and asking for nothing is an error."""
