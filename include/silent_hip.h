@@ -185,8 +185,8 @@ int silent_profile_elapsed_ms(silent_ctx* ctx, float* ms, int64_t* pixels);
  * order, 2 32-row filter tiles, 8 32-row fused tiles, 16 no single-read stream kernel, 32 XCD order in the stream kernel;
  * RGB: 1 dense weights, 2 no two-group form, 8 no short tiles, 16 the one-pixel-per-lane chain kernel (default: two pixels
  * per lane on packed f32, same bits), 32 no sparse keypoint tail, 64 no symmetric forms (the two-group instantiation of the pair
- * kernel, bit-identical to the one-pixel kernel), 128 12-byte stores of orient / line_end even where rows are 16-byte aligned (default there:
- * 16-byte stores, same bits), bits 8-15 tile height / 2; PYRAMID: 1 no single-read pyramid
+ * kernel, bit-identical to the one-pixel kernel), 128 16-byte stores of orient / line_end where rows are 16-byte aligned (same bits as the default
+ * 12-byte form, same speed), bits 8-15 tile height / 2; PYRAMID: 1 no single-read pyramid
  * (gray stream kernel, RGB strip walk), 2 no RGB strip walk.  All variants give the same results (bit-identical, or within
  * the re-association tolerance for the RGB forms); the defaults are the fastest measured. */
 #define SILENT_TUNE_GRAY 0

@@ -1537,10 +1537,12 @@ static int rgb_chain_launch(silent_ctx* ctx, const char* who, const float* pyr, 
             std::memset(a2.sum_off, 0, sizeof(a2.sum_off));
             std::memset(a2.ws, 0, sizeof(a2.ws));
             rgb2_fill_stream(a.w, basic ? 0x111u : 0x1ffu, basic, two, two, a2.ws, use_sym ? &sym : nullptr);
-            // 16-byte-per-lane stores of orient / line_end (ST4, silent_rgb2.h): every row of every map must start on a 16-byte
-            // boundary -- widths, level offsets and the frame stride multiples of 4 pixels, the map pointers 16-byte aligned (all
-            // BASELINE extents; anything else keeps the 12-byte form).  RGB knob bit 7: the 12-byte form regardless (A/B).
-            bool st4 = !(kopts & 128u) && tab.frame_px % 4 == 0 && (uintptr_t)orient_out % 16 == 0 && (uintptr_t)line_end_out % 16 == 0;
+            // 16-byte-per-lane stores of orient / line_end (ST4, silent_rgb2.h; RGB knob bit 7 -- an alternating A/B on config 3 put
+            // it at 0.8063 against 0.8043 ms per launch for the 12-byte form, profiles/r04/evidence/ab_st4.txt: the store
+            // instructions are not what the kernel waits for, so the simpler form stays the default): every row of every map must
+            // start on a 16-byte boundary -- widths, level offsets and the frame stride multiples of 4 pixels, the map pointers
+            // 16-byte aligned (all BASELINE extents; anything else keeps the 12-byte form).
+            bool st4 = (kopts & 128u) && tab.frame_px % 4 == 0 && (uintptr_t)orient_out % 16 == 0 && (uintptr_t)line_end_out % 16 == 0;
             for (int l = 0; l < n_levels && st4; ++l) st4 = levels[l].w % 4 == 0 && tab.px_off[l] % 4 == 0;
             // silent_set_profiling: HIP events around THIS launch, on the stream it runs on (the fused RGB chain is the dominant
             // kernel of silent_rgb_line_end / silent_rgb_keypoints, like gray_stream_kernel is of silent_gray_pass)

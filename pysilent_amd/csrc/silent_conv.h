@@ -363,7 +363,14 @@ constexpr int kFusedCols = 56;
 // 5 waves (1120 bytes: tile edges off the line grid) 1.03, 8 waves 0.89
 constexpr int kFusedWaves = SILENT_FUSED_WAVES;
 constexpr int kFusedTW = kFusedWaves * kFusedCols;
-constexpr int kFusedTH = 16;
+#ifndef SILENT_FUSED_TH
+#define SILENT_FUSED_TH 32
+#endif
+// output rows per tile of the fused / stream kernels; a tile streams TH + 8 source rows.  32 since round 4: the stream kernel
+// fetches 40 rows per 32 produced instead of 24 per 16 (read amplification 1.43x instead of 1.79x with the column halo), at
+// 40 KB instead of 24 KB of LDS per block: -1.9 % on the config-2 step, -3.6 % on the kernel in three alternating A/Bs
+// (profiles/r04/evidence/ab_gray_tile_height.txt; 24 rows: no gain)
+constexpr int kFusedTH = SILENT_FUSED_TH;
 
 struct FusedLevel {  // the unit levels of a pyramid plan, as the kernel needs them
     int src_y0, src_x0, src_h, src_w;  // crop of the frame (mirror extension happens inside the crop)

@@ -464,9 +464,10 @@ __device__ __forceinline__ float relu_max3_poisoned(float v, float u) {   // u: 
 // MM: also accumulate the per-level extrema of the value map (args.mm) -- a separate instantiation with a 3-waves/SIMD register
 // budget: the plain kernel sits at the 128-VGPR edge, and forced into that budget the extra pointer, masks and accumulators
 // spill to scratch (+16 %; with 3 waves +4 %)
-// ST4 (round 4): orient / line_end leave as 16-byte-per-lane stores (buffer_store_dwordx4), three per PAIR of rows instead of four
-// 12-byte ones -- see the store section below; host-checked: every level's width, pixel offset and the map pointers are
-// multiples of 4 pixels / 16 bytes (all BASELINE extents are).
+// ST4 (round 4, opt-in by RGB knob bit 7): orient / line_end leave as 16-byte-per-lane stores (buffer_store_dwordx4), three per
+// PAIR of rows instead of four 12-byte ones -- see the store section below; host-checked: every level's width, pixel offset and
+// the map pointers are multiples of 4 pixels / 16 bytes (all BASELINE extents are).  Bit-identical and, measured, exactly as
+// fast as the 12-byte form (0.806 vs 0.804 ms per config-3 launch): not the default.
 template <unsigned RGC_PAIRS, bool STRIPE_SUM, unsigned RGBY_A, unsigned END_A0, unsigned END_A1, unsigned END_A2, bool MM = false, bool SYM = false,
           bool ST4 = false>
 __global__ __launch_bounds__(64 * kRgb2Waves) __attribute__((amdgpu_waves_per_eu((MM || ST4) ? 3 : 4, 8))) void rgb_line_end2_kernel(const Rgb2Args args) {

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Config 3 (32 x 1080p RGB, 6 levels), one stream: chain kernel alone (HIP events the library records around its launch),
 chain + keypoint tail, whole step, under alternating SILENT_TUNE_RGB knob values in one process (rounds of 10 steps, medians of 6
-rounds after one discarded).  Usage: ab_rgb_knobs2.py 0 128 [...]   (128: 12-byte stores instead of 16-byte ones)"""
+rounds after one discarded).  Usage: ab_rgb_knobs2.py 0 128 [...]   (128: 16-byte stores instead of the default 12-byte ones)"""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch

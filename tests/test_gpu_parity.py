@@ -785,7 +785,7 @@ def test_rgb_chain_nonfinite_pixels_against_the_oracle(rt, kernels, shape, knob)
 def test_rgb_chain_16_byte_stores_are_bit_identical(rt, kernels, extents):
     """ST4 (csrc/silent_rgb2.h): on levels whose rows start on 16-byte boundaries the chain writes orient / line_end with three
     buffer_store_dwordx4 per pair of rows (row A parked in LDS for a step) instead of four 12-byte stores.  Pure data movement:
-    every bit must equal the 12-byte form (RGB knob bit 7) -- odd heights (a last pair with one row), tiles of one row, widths
+    every bit must equal the default 12-byte form (ST4 = RGB knob bit 7) -- odd heights (a last pair with one row), tiles of one row, widths
     that end inside a wave, inside a 4-pixel group never (widths are multiples of 4), several levels, NaN rows from the 'ieee'
     policy, and the extrema instantiation behind silent_rgb_keypoints (maps + keypoints)."""
     import torch
