@@ -364,12 +364,15 @@ constexpr int kFusedCols = 56;
 constexpr int kFusedWaves = SILENT_FUSED_WAVES;
 constexpr int kFusedTW = kFusedWaves * kFusedCols;
 #ifndef SILENT_FUSED_TH
-#define SILENT_FUSED_TH 32
+#define SILENT_FUSED_TH 16
 #endif
-// output rows per tile of the fused / stream kernels; a tile streams TH + 8 source rows.  32 since round 4: the stream kernel
-// fetches 40 rows per 32 produced instead of 24 per 16 (read amplification 1.43x instead of 1.79x with the column halo), at
-// 40 KB instead of 24 KB of LDS per block: -1.9 % on the config-2 step, -3.6 % on the kernel in three alternating A/Bs
-// (profiles/r04/evidence/ab_gray_tile_height.txt; 24 rows: no gain)
+// output rows per tile of the fused / stream kernels; a tile streams TH + 8 source rows.  Round 4 tried 24 / 32 / 40 / 48 rows
+// (32: the stream kernel fetches 40 rows per 32 produced instead of 24 per 16 -- read amplification 1.43x instead of 1.79x with
+// the column halo -- at 40 KB instead of 24 KB of LDS per block, 4 instead of 6 waves / SIMD): in bursts of 5 steps on a fast box
+// 32 rows won 1.9 % of the config-2 step (profiles/r04/evidence/ab_gray_tile_height.txt), through bench.py's settled 30-step
+// windows on a slow box they LOST 8 % (step 1.154 against 1.066 ms, kernel 0.944 against 0.852; 40 rows the same, 48 rows 16 %;
+// config 5: +1 % / +9 % / +10 %; profiles/r04/evidence/ab_gray_tile_height_bench.txt).  16 stays: the contract number is the
+// settled one, and most boxes of the pool are of the slow kind.
 constexpr int kFusedTH = SILENT_FUSED_TH;
 
 struct FusedLevel {  // the unit levels of a pyramid plan, as the kernel needs them
