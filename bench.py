@@ -687,6 +687,9 @@ def run_rank(args):
             out["other_workloads"]["config5"] = side_workload(torch, D, "config5", local, dev, rank, world)
         if args.workload != "reference_layout":
             out["other_workloads"]["reference_layout"] = side_workload(torch, D, "reference_layout", local, dev, rank, world)
+            out["other_workloads"]["reference_layout_one_stream"] = side_workload(
+                torch, D, "reference_layout", local, dev, rank, world, overlap=False,
+                label="the reference's layout on one stream (no overlap between consecutive steps)")
     if world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(wl, consts)
     else:
