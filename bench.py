@@ -615,7 +615,7 @@ def run_rank(args):
     c = 1 if wl["mode"] == "gray" else 3
     # working set per rank well beyond the 256 MiB Infinity Cache (hard part 6)
     B = args.frames or wl["frames"]
-    pipe = make_pipeline(wl, B, local, consts)
+    pipe = make_pipeline(wl, B, local, consts, **({"overlap": False} if (args.one_stream and wl["mode"] == "rgb") else {}))
     frames = make_frames(torch, D, wl, B, rank, world, dev)
     torch.cuda.synchronize(dev)
 
@@ -709,6 +709,9 @@ def main(argv=None):
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-side-workloads", action="store_true")
     ap.add_argument("--no-ingest", action="store_true")
+    ap.add_argument("--one-stream", action="store_true",
+                    help="RGB workloads: pyramid -> chain -> tail back to back on one stream (no overlap=True); what the rocprofv3 "
+                         "per-kernel traces are taken with -- overlapped kernels stretch each other's durations")
     args = ap.parse_args(argv)
     if args.gpus < 1:
         raise SystemExit("--gpus must be >= 1")
