@@ -31,8 +31,9 @@ p = torch.cuda.get_device_properties(0)
 out = {"device": p.name, "cus": p.multi_processor_count, "gcn": getattr(p, "gcnArchName", ""),
        "pci": "%04x:%02x:%02x" % (getattr(p, "pci_domain_id", 0), getattr(p, "pci_bus_id", 0) & 0xff, getattr(p, "pci_device_id", 0)),
        "total_mem_GiB": round(p.total_memory / 2 ** 30, 1)}
-ident = smi_json("--showvbios", "--showcomputepartition", "--showmemorypartition", "--showperflevel", "--showmemvendor", "--showserial", "--showuniqueid")
-out["smi"] = {k: v for k, v in ident.items() if any(s in k.lower() for s in ("vbios", "partition", "perf", "vendor", "unique"))}
+ident = smi_json("--showvbios", "--showcomputepartition", "--showmemorypartition", "--showperflevel", "--showmemvendor", "--showserial", "--showuniqueid",
+                 "--showmaxpower")
+out["smi"] = {k: v for k, v in ident.items() if any(s in k.lower() for s in ("vbios", "partition", "perf", "vendor", "unique", "max"))}
 a = torch.empty(1 << 28, dtype=torch.float32, device=dev)
 b = torch.empty_like(a)
 ts = []
