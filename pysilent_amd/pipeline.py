@@ -53,6 +53,26 @@ def unpack_constants(blob, layout):
     return out
 
 
+_staging_pool = None
+
+
+def _staging_copy(dst, src, min_bytes=8 << 20, workers=16):
+    """Pageable host frames -> the pinned staging buffer.  One memcpy thread moves ~5 GB/s, a tenth of what the link then takes
+    away: batches above ``min_bytes`` are split along the batch axis over a small thread pool (NumPy releases the GIL in copyto)."""
+    global _staging_pool
+    nbytes = src.numel() * src.element_size()
+    n = min(workers, int(src.shape[0]))
+    if nbytes < min_bytes or n < 2:
+        dst.copy_(src)
+        return
+    if _staging_pool is None:
+        from concurrent.futures import ThreadPoolExecutor
+        _staging_pool = ThreadPoolExecutor(max_workers=workers, thread_name_prefix="silent-staging")
+    d, s_ = dst.numpy(), src.numpy()
+    step = -(-int(src.shape[0]) // n)
+    list(_staging_pool.map(lambda i: np.copyto(d[i:i + step], s_[i:i + step]), range(0, int(src.shape[0]), step)))
+
+
 class LineEndPipeline(object):
     def __init__(self, frame_hw, mode="gray", n_levels=5, scale=2.0, n_orient=4, batch=1, device=None,
                  constants=None, center_dimensions=None, clip_hi=255.0, flat_policy="ieee", pad=2,
@@ -327,7 +347,7 @@ class LineEndPipeline(object):
         cs = self._copy_stream
         if not pinned_source:
             slot["h2d_done"].synchronize()          # the staging buffer's previous copy has left the host
-            slot["pinned"].copy_(src)
+            _staging_copy(slot["pinned"], src)
             src = slot["pinned"]
         dst = slot["f32"] if slot["raw"] is None else slot["raw"]
         for ev in ((slot["f32_free"],) if slot["raw"] is None else (slot["raw_free"],)):
