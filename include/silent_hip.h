@@ -246,7 +246,7 @@ int silent_top_value_points_dev(silent_ctx* ctx, const float* color, const float
  * tf.where(value >= resize_nearest(max_pool(value, k=(H,W), strides=(rH,rW), SAME))) with the TF1
  * SAME / NEAREST index rules.  regions[l] = (rH, rW) of level l, any extents >= 1: up to
  * 4 x 4 windows per level (the reference uses 2 x 2) run a one-pass cell-maximum path, more windows the separable
- * prefix / suffix path (levels up to 16384 pixels wide); same results either way.
+ * prefix / suffix path (any level width: the row pass walks a row in chunks); same results either way.
  * idx: n_frames x cap_per_frame x 4 int64 rows (level, y, x, 0), ROW-MAJOR SORTED within a frame like
  * tf.where; counts[f] = number of rows frame f produced.  If any count exceeds cap_per_frame only the
  * first cap_per_frame rows of that frame are written and the host call returns SILENT_E_CAPACITY.

@@ -764,7 +764,6 @@ static int region_axis(int size, int stride, int* n_win, int* nseg, int* cut, in
 // than kMaxWin windows per axis: the cell tables (kernarg-resident) do not apply then and the separable prefix / suffix
 // path runs (region_rowmax_kernel / region_colmax_kernel) -- any region_shape the reference accepts
 // (slam_recognition/util/selection/top_value_points.py:32-45).
-constexpr int kRegionGeneralMaxW = 16384;   // the row pass stages one row twice in LDS
 static int build_region_tab(silent_ctx* ctx, const char* who, const silent_extent* levels, int n_levels,
                             const silent_extent* regions, RegionTab* rt, bool* general) {
     std::memset(rt, 0, sizeof(*rt));
@@ -787,11 +786,6 @@ static int build_region_tab(silent_ctx* ctx, const char* who, const silent_exten
     }
     rt->m1_per_frame = m1;
     rt->pooled_per_frame = pooled;
-    if (*general)
-        for (int l = 0; l < n_levels; ++l)
-            if (levels[l].w > kRegionGeneralMaxW)
-                return fail(ctx, SILENT_E_UNSUPPORTED, std::string(who) + ": more than " + std::to_string(kMaxWin) +
-                                                           " windows per axis on a level wider than " + std::to_string(kRegionGeneralMaxW));
     return SILENT_OK;
 }
 
@@ -857,13 +851,9 @@ static int region_window_maxima(silent_ctx* ctx, const char* who, const float* v
     LevelTab rowtab;
     long long rows;
     TRY(build_level_tab(ctx, who, levels, n_levels, n_frames, 1 << 30, 1, &rowtab, &rows));   // one tile per row
-    int maxw = 1;
     long long cols = 0;
-    for (int l = 0; l < n_levels; ++l) {
-        maxw = std::max(maxw, levels[l].w);
-        cols += rt.lv[l].ow;
-    }
-    hipLaunchKernelGGL(region_rowmax_kernel, dim3((unsigned)rows), dim3(256), sizeof(float) * 2 * (size_t)maxw, s, value, rowtab, rt, w.m1);
+    for (int l = 0; l < n_levels; ++l) cols += rt.lv[l].ow;
+    hipLaunchKernelGGL(region_rowmax_kernel, dim3((unsigned)rows), dim3(256), 0, s, value, rowtab, rt, w.m1);
     const long long threads = cols * n_frames;
     hipLaunchKernelGGL(region_colmax_kernel, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, s, w.m1, rowtab, rt, n_frames,
                        cols, w.pooled);

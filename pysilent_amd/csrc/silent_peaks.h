@@ -552,50 +552,65 @@ __device__ __forceinline__ float region_thr(int y, int x, const RegionLevel& rl,
 // separable prefix / suffix maxima: pass 1 gives every row its maxima over the column windows (M1[y][i]), pass 2 walks
 // each column of M1 down (prefix windows) and up (suffix windows).  max is exact and order-free (pool_max ignores NaN),
 // so the result is bit-identical to the cell path and to the oracle.
-// One block per (frame, level, row): the row is staged into LDS, prefix and suffix maxima by chunked scans.
+// One block per (frame, level, row).  The row is walked in CHUNKS of kRowChunk pixels staged in LDS -- left to right for the
+// prefix windows (a running prefix maximum is carried from chunk to chunk), right to left for the suffix windows -- so any
+// level width works (round 3 staged the whole row twice and refused levels wider than 16 384 pixels).  Inside a chunk: every
+// thread scans its slice, the slice totals are combined, and the windows whose last (prefix) / first (suffix) pixel lies in
+// the chunk are written.
+constexpr int kRowChunk = 8192;
 __global__ __launch_bounds__(256) void region_rowmax_kernel(const float* __restrict__ value, const LevelTab tab,
                                                             const RegionTab rt, float* __restrict__ m1) {
-    extern __shared__ float s_dyn_rows[];   // p[W] | s[W]
-    __shared__ float s_tot[2][256];
+    __shared__ float s_v[kRowChunk];
+    __shared__ float s_tot[256];
     const TileCoord tc = locate_tile(tab, blockIdx.x);   // tile = one row: ty = y
     const RegionLevel& rl = rt.lv[tc.level];
     const int W = tab.w[tc.level], y = tc.ty;
     const float* __restrict__ row = value + (long long)tc.frame * tab.frame_px + tab.px_off[tc.level] + (long long)y * W;
-    float* p = s_dyn_rows;
-    float* sfx = s_dyn_rows + W;
-    const int tid = threadIdx.x;
-    for (int x = tid; x < W; x += 256) {
-        const float v = pool_max(kPoolLowest, row[x]);
-        p[x] = v;
-        sfx[x] = v;
-    }
-    __syncthreads();
-    const int n = (W + 255) / 256, lo = min(tid * n, W), hi = min(lo + n, W);
-    float m = kPoolLowest;
-    for (int x = lo; x < hi; ++x) {
-        m = pool_max(m, p[x]);
-        p[x] = m;
-    }
-    s_tot[0][tid] = m;
-    m = kPoolLowest;
-    for (int x = hi - 1; x >= lo; --x) {
-        m = pool_max(m, sfx[x]);
-        sfx[x] = m;
-    }
-    s_tot[1][tid] = m;
-    __syncthreads();
-    float cp = kPoolLowest, cs = kPoolLowest;          // carries: maxima of the chunks before / after this one
-    for (int t = 0; t < tid; ++t) cp = pool_max(cp, s_tot[0][t]);
-    for (int t = tid + 1; t < 256; ++t) cs = pool_max(cs, s_tot[1][t]);
-    for (int x = lo; x < hi; ++x) {
-        p[x] = pool_max(cp, p[x]);
-        sfx[x] = pool_max(cs, sfx[x]);
-    }
-    __syncthreads();
     float* __restrict__ out = m1 + (long long)tc.frame * rt.m1_per_frame + rl.m1_off + (long long)y * rl.ow;
-    for (int i = tid; i < rl.ow; i += 256) {
-        const int a = i * rl.rx - rl.pad_x;
-        out[i] = a <= 0 ? p[min(a + W, W) - 1] : sfx[a];
+    const int tid = threadIdx.x;
+    const int n_chunks = (W + kRowChunk - 1) / kRowChunk;
+    for (int dir = 0; dir < 2; ++dir) {                 // 0: prefix maxima, chunks ascending; 1: suffix maxima, chunks descending
+        float carry = kPoolLowest;                      // maximum of everything before (after) the current chunk
+        for (int cc = 0; cc < n_chunks; ++cc) {
+            const int c = dir == 0 ? cc : n_chunks - 1 - cc;
+            const int x0 = c * kRowChunk, n = min(kRowChunk, W - x0);
+            for (int x = tid; x < n; x += 256) s_v[x] = pool_max(kPoolLowest, row[x0 + x]);   // a NaN never wins
+            __syncthreads();
+            const int per = (n + 255) / 256, lo = min(tid * per, n), hi = min(lo + per, n);
+            float m = kPoolLowest;
+            if (dir == 0) {
+                for (int x = lo; x < hi; ++x) {
+                    m = pool_max(m, s_v[x]);
+                    s_v[x] = m;
+                }
+            } else {
+                for (int x = hi - 1; x >= lo; --x) {
+                    m = pool_max(m, s_v[x]);
+                    s_v[x] = m;
+                }
+            }
+            s_tot[tid] = m;
+            __syncthreads();
+            float before = carry;                       // carry + the slices before (after) this thread's slice
+            if (dir == 0) {
+                for (int t = 0; t < tid; ++t) before = pool_max(before, s_tot[t]);
+            } else {
+                for (int t = tid + 1; t < 256; ++t) before = pool_max(before, s_tot[t]);
+            }
+            for (int x = lo; x < hi; ++x) s_v[x] = pool_max(before, s_v[x]);
+            float all = carry;
+            for (int t = 0; t < 256; ++t) all = pool_max(all, s_tot[t]);
+            __syncthreads();
+            // windows of max_pool(k = full extent, stride = region, SAME): start a = i * rx - pad_x; a <= 0: the prefix that ends
+            // at min(a + W, W) - 1, else the suffix that starts at a
+            for (int i = tid; i < rl.ow; i += 256) {
+                const int a = i * rl.rx - rl.pad_x;
+                const int key = a <= 0 ? min(a + W, W) - 1 : a;
+                if ((a <= 0) == (dir == 0) && key >= x0 && key < x0 + n) out[i] = s_v[key - x0];
+            }
+            carry = all;
+            __syncthreads();
+        }
     }
 }
 

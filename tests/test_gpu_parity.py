@@ -1448,7 +1448,9 @@ def test_entry_points_leave_the_callers_device_alone(rt):
                                           ((2, 40, 40, 3), (1, 1, 1, 3)),          # every pixel its own stride: 40 x 40 windows
                                           ((1, 64, 300, 1), (1, 64, 7, 1)),        # many windows on one axis only
                                           ((1, 135, 240, 1), (1, 9, 16, 1)),
-                                          ((3, 19, 27, 1), (1, 2, 27, 1))])
+                                          ((3, 19, 27, 1), (1, 2, 27, 1)),
+                                          ((1, 3, 20011, 1), (1, 2, 1501, 1)),     # a level wider than the row pass's 8192-pixel chunk
+                                          ((1, 2, 16400, 1), (1, 1, 3000, 1))])    # (round 3 refused levels wider than 16 384 px)
 def test_max_value_indices_region_with_many_windows(rt, shape, region):
     """More than 4 windows per axis (the kernarg cell tables of the fast path do not apply): separable prefix / suffix
     window maxima.  Bit-exact against the oracle, ties, zero plateaus and NaNs included, for NHWC tensors and packed levels."""
