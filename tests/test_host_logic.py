@@ -345,3 +345,16 @@ def test_generate_recovery_mirrors_the_reference_on_host_arrays():
     assert r.dtype == np.float32 and (r == 10.0).all() and r.shape == x.shape
     with pytest.raises(ValueError, match="You must choose a type of recovery"):
         generate_recovery(x, is_input_based=False, is_constant=False)
+
+
+def test_staging_copy_splits_a_batch_over_threads():
+    """LineEndPipeline.step_host's host leg for pageable sources: the batch is copied into the staging buffer by a small thread pool
+    (one memcpy thread is a tenth of the link rate); every byte arrives, for batch sizes that do not divide by the worker count."""
+    import torch
+    from pysilent_amd import pipeline as P
+    rng = np.random.default_rng(4)
+    for batch, dtype in ((1, np.uint8), (5, np.uint8), (16, np.float32), (37, np.int16)):
+        src = torch.from_numpy(rng.integers(0, 200, (batch, 33, 47, 3)).astype(dtype))
+        dst = torch.zeros_like(src)
+        P._staging_copy(dst, src, min_bytes=0, workers=4)
+        assert torch.equal(dst, src)
