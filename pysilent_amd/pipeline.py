@@ -284,6 +284,9 @@ class LineEndPipeline(object):
         self.run_pyramid(frames, C.c_void_p(ws.cuda_stream))
         self._pyr_ready[k].record(ws)
         cs.wait_event(self._pyr_ready[k])
+        # the caller's stream is ordered behind the READ of its frames (not behind the chain): whatever it enqueues next may
+        # overwrite them, exactly as after a one-stream step
+        torch.cuda.current_stream(self.tdev).wait_event(self._pyr_ready[k])
         s = C.c_void_p(cs.cuda_stream)
         if self.selection and not self.keep_selection_maps:
             self.run_filters_keypoints(s)
