@@ -18,7 +18,10 @@ steps = int(sys.argv[4]) if len(sys.argv) > 4 else 20
 dev = torch.device("cuda", 0)
 consts = None
 frames = bench.make_frames(torch, D, wl, B, 0, 1, dev)
-pipes = {"serial": bench.make_pipeline(wl, B, 0, consts), "overlap": bench.make_pipeline(wl, B, 0, consts, overlap=True)}
+pipes = {"serial": bench.make_pipeline(wl, B, 0, consts, overlap=False), "overlap": bench.make_pipeline(wl, B, 0, consts, overlap=True),
+         "overlap, equal stream priorities": bench.make_pipeline(wl, B, 0, consts, overlap=True, overlap_priorities=False),
+         "overlap, equal priorities, caller not ordered": bench.make_pipeline(wl, B, 0, consts, overlap=True, overlap_priorities=False)}
+pipes["overlap, equal priorities, caller not ordered"]._order_caller = False
 
 
 def run(pipe, n):
@@ -37,7 +40,7 @@ for rnd in range(rounds):
     for k, p in pipes.items():
         res[k].append(run(p, steps))
 for k in pipes:
-    print("%-8s ms per %d frames: %s  median %.4f" % (k, B, " ".join("%.4f" % t for t in res[k]), float(np.median(res[k]))))
+    print("%-50s ms per %d frames: %s  median %.4f" % (k, B, " ".join("%.4f" % t for t in res[k]), float(np.median(res[k]))))
 a, b = pipes["serial"].outputs(allow_truncated=True), pipes["overlap"].outputs(allow_truncated=True)
 same = True
 for key in ("pyramid", "orient", "line_end"):
