@@ -349,7 +349,10 @@ class LineEndPipeline(object):
         if src.dtype != torch.float32:
             _runtime._torch_dtype_code(src)         # TypeError for dtypes the cast kernel does not take
         if not hasattr(self, "_ingest"):
-            self._ingest, self._copy_stream = {}, torch.cuda.Stream(self.tdev)
+            # a stream of another priority than the compute stream gets a hardware queue of its own (two equal-priority streams
+            # may share one, and then copy and compute do not overlap): -1 beside a caller's normal stream; with overlap=True the
+            # chain stream holds -1 and the copies queue with the pyramid stream, which has to follow them anyway
+            self._ingest, self._copy_stream = {}, torch.cuda.Stream(self.tdev, priority=0 if self.overlap else -1)
         pinned_source = src.is_pinned()
         slot = self._ingest_slot(src.dtype, pinned_source)
         cur = torch.cuda.current_stream(self.tdev)
