@@ -285,7 +285,10 @@ def make_pipeline(wl, B, local, consts, **over):
         # beside the chain + keypoint tail of batch n; every step still enqueues the whole path of its batch)
         kw = {"selection": True, "value_map": False, "peak_value_map": False, "overlap": True}
     if "center" in wl:
-        kw.update(center_dimensions=wl["center"], scale=wl["scale"])
+        # (the reference's layout: a 0.4 ms step of twelve small launches.  scripts/ab_overlap.py measures overlap=True at -8 % on it,
+        # three bench lines in a row measured +10 % in this process, where it is the fifth pipeline with streams of its own: one
+        # stream by default here, the two-stream form beside it)
+        kw.update(center_dimensions=wl["center"], scale=wl["scale"], overlap=False)
     kw.update(over)
     # keypoint capacity = every pyramid pixel of a frame (the LineEndPipeline default): a window without a positive peak makes
     # every pixel mapped to it a keypoint (top_value_points.py:32-45), noise frames produce ~10^5 .. 10^6 rows, and a smaller
@@ -687,9 +690,9 @@ def run_rank(args):
             out["other_workloads"]["config5"] = side_workload(torch, D, "config5", local, dev, rank, world)
         if args.workload != "reference_layout":
             out["other_workloads"]["reference_layout"] = side_workload(torch, D, "reference_layout", local, dev, rank, world)
-            out["other_workloads"]["reference_layout_one_stream"] = side_workload(
-                torch, D, "reference_layout", local, dev, rank, world, overlap=False,
-                label="the reference's layout on one stream (no overlap between consecutive steps)")
+            out["other_workloads"]["reference_layout_two_streams"] = side_workload(
+                torch, D, "reference_layout", local, dev, rank, world, overlap=True,
+                label="the reference's layout with overlap=True (pyramid of batch n + 1 beside chain + tail of batch n)")
     if world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(wl, consts)
     else:
