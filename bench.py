@@ -283,12 +283,11 @@ def make_pipeline(wl, B, local, consts, **over):
         # peak-value map are intermediates the fused step never writes (silent_rgb_keypoints: extrema in the chain kernel,
         # sparse keypoint tail).  overlap: consecutive steps overlap on the pipeline's two streams (the pyramid of batch n + 1
         # beside the chain + keypoint tail of batch n; every step still enqueues the whole path of its batch)
-        kw = {"selection": True, "value_map": False, "peak_value_map": False, "overlap": True}
+        # "auto": the pipeline times a few stream pairs against its one-stream step when it is built and keeps what wins (which
+        # streams of the process's pool a pipeline draws decides whether two streams pay: scripts/ab_overlap_pool.py)
+        kw = {"selection": True, "value_map": False, "peak_value_map": False, "overlap": "auto"}
     if "center" in wl:
-        # (the reference's layout: a 0.4 ms step of twelve small launches.  scripts/ab_overlap.py measures overlap=True at -8 % on it,
-        # three bench lines in a row measured +10 % in this process, where it is the fifth pipeline with streams of its own: one
-        # stream by default here, the two-stream form beside it)
-        kw.update(center_dimensions=wl["center"], scale=wl["scale"], overlap=False)
+        kw.update(center_dimensions=wl["center"], scale=wl["scale"])
     kw.update(over)
     # keypoint capacity = every pyramid pixel of a frame (the LineEndPipeline default): a window without a positive peak makes
     # every pixel mapped to it a keypoint (top_value_points.py:32-45), noise frames produce ~10^5 .. 10^6 rows, and a smaller
@@ -457,8 +456,10 @@ def side_workload(torch, D, name, local, dev, rank, world, label=None, **over):
            "dominant_kernel": dom["kernel"], "dominant_kernel_ms": round(dom["ms"], 4),
            "dominant_kernel_frac_of_hbm_peak": round(dom["bytes"] / (dom["ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}
     if wl["mode"] == "rgb":
-        out["streams"] = ("two (overlap=True): pyramid of batch n + 1 beside chain + keypoint tail of batch n" if pipe.overlap
+        out["streams"] = ("two (overlap): pyramid of batch n + 1 beside chain + keypoint tail of batch n" if pipe.overlap
                           else "one: pyramid -> chain -> keypoint tail back to back")
+        if pipe.overlap_tuning:
+            out["overlap_tuning"] = pipe.overlap_tuning
         pipe.step(frames)
         pipe.wait()
         out["sparse_keypoint_tail"] = pipe.sparse_tail_stats()
@@ -690,9 +691,9 @@ def run_rank(args):
             out["other_workloads"]["config5"] = side_workload(torch, D, "config5", local, dev, rank, world)
         if args.workload != "reference_layout":
             out["other_workloads"]["reference_layout"] = side_workload(torch, D, "reference_layout", local, dev, rank, world)
-            out["other_workloads"]["reference_layout_two_streams"] = side_workload(
-                torch, D, "reference_layout", local, dev, rank, world, overlap=True,
-                label="the reference's layout with overlap=True (pyramid of batch n + 1 beside chain + tail of batch n)")
+            out["other_workloads"]["reference_layout_one_stream"] = side_workload(
+                torch, D, "reference_layout", local, dev, rank, world, overlap=False,
+                label="the reference's layout on one stream (no overlap between consecutive steps)")
     if world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(wl, consts)
     else:

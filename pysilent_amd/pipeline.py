@@ -53,6 +53,38 @@ def unpack_constants(blob, layout):
     return out
 
 
+def _spin_ms(torch, dev, streams, cycles):
+    """Wall time of one spin kernel (torch.cuda._sleep: a single thread counting clock cycles) on each of ``streams`` at once."""
+    import time
+    torch.cuda.synchronize(dev)
+    t0 = time.perf_counter()
+    for st in streams:
+        with torch.cuda.stream(st):
+            torch.cuda._sleep(cycles)
+    for st in streams:
+        st.synchronize()
+    return (time.perf_counter() - t0) * 1e3
+
+
+def pick_concurrent_stream(torch, dev, beside, priority=0, tries=10, cycles=1 << 20):
+    """A new stream whose work really runs CONCURRENTLY with the streams in ``beside``.  HIP multiplexes streams onto a few
+    hardware queues, and two streams that share one are served strictly in order -- "overlap" through such a pair is a loss
+    (cross-stream events, no concurrency), and which pairs share is a property of the process's stream pool, not of the
+    priorities (scripts/ab_overlap_pool.py: pipelines #2, #5 and #7 of a process lost 40 %, the others won 8 %).  So it is
+    measured: a spin kernel on the candidate and on every stream of ``beside`` at once must take about as long as one alone.
+    Returns (stream, verified); after ``tries`` candidates the last one is returned unverified."""
+    one = min(_spin_ms(torch, dev, beside[:1] or [torch.cuda.current_stream(dev)], cycles) for _ in range(2))
+    cand = None
+    keep = []                                  # rejected candidates stay alive until the choice is made (the pool hands out new ones)
+    for _ in range(tries):
+        cand = torch.cuda.Stream(dev, priority=priority)
+        together = min(_spin_ms(torch, dev, list(beside) + [cand], cycles) for _ in range(2))
+        if together < 1.5 * one:
+            return cand, True
+        keep.append(cand)
+    return cand, False
+
+
 _staging_pool = None
 
 
@@ -109,19 +141,18 @@ class LineEndPipeline(object):
         # kernel) runs beside the chain kernel and the small launches of the keypoint tail of batch n; the pyramid is then
         # double-buffered (pipeline.pyr = the last step's).  step() stays "enqueue the whole path for this batch", but on the
         # pipeline's own streams: wait() orders the caller's stream behind the results, outputs() does so itself.
+        self._overlap_auto = overlap == "auto" and mode == "rgb"
+        self._chain_priority = -1 if overlap_priorities else 0
         self.overlap = bool(overlap) and mode == "rgb"
+        self.overlap_tuning = None
         self._order_caller = True          # (A/B switch of scripts/ab_overlap.py: order the caller's stream behind the frame read)
         self._pyrs = [torch.empty(n * self.channels, **f32) for _ in range(2 if self.overlap else 1)]
         self.pyr = self._pyrs[0]
         if self.overlap:
             # the chain + tail of batch n are the critical path, the pyramid of batch n + 1 only has to be ready in time: the chain's
-            # stream gets the higher queue priority, so that the walk's blocks fill what the chain leaves free instead of competing
-            # with it for dispatch (without priorities the same A/B ran from -7 % to +12 % against one stream, box by box)
-            self._walk_stream = torch.cuda.Stream(self.tdev, priority=0)
-            self._chain_stream = torch.cuda.Stream(self.tdev, priority=-1 if overlap_priorities else 0)
-            self._pyr_ready = [torch.cuda.Event() for _ in range(2)]
-            self._pyr_free = [None, None]           # recorded behind the chain launch that read the buffer
-            self._steps = 0
+            # stream gets the higher queue priority, the pyramid's stream is checked to run concurrently with it -- and with
+            # overlap="auto" the pair is chosen by measurement (tune_overlap)
+            self._new_stream_pair()
         if mode == "gray":
             self.n_orient = int(self.consts["end"].shape[3])
             self.cs = torch.empty(n, **f32)
@@ -158,6 +189,73 @@ class LineEndPipeline(object):
                 *[self.consts[k].ctypes.data_as(fp) for k in ("rgc", "rgby", "stripe", "blur", "end")],
                 1.0, 0.1, {"ieee": _lib.FLAT_IEEE, "zero": _lib.FLAT_ZERO}[flat_policy], self.clip_hi, self.pad)
         self._lib = _lib.load()
+        if self._overlap_auto:
+            self.tune_overlap()
+
+    def _new_stream_pair(self):
+        torch = self.torch
+        self._chain_stream = torch.cuda.Stream(self.tdev, priority=self._chain_priority)
+        self._walk_stream, self.overlap_verified = pick_concurrent_stream(torch, self.tdev, [self._chain_stream])
+        self._pyr_ready = [torch.cuda.Event() for _ in range(2)]
+        self._pyr_free = [None, None]
+        self._steps = 0
+
+    def tune_overlap(self, frames=None, candidates=6, steps=10):
+        """overlap="auto": MEASURE whether two streams pay on this device, in this process, with these streams -- and with which.
+        HIP multiplexes streams onto hardware queues (and those onto the command processor's pipes); which pair of streams a
+        pipeline draws from the pool decides whether the pyramid of batch n + 1 really runs beside the chain of batch n (config 3:
+        -10 %) or mostly waits on it through the cross-stream events (+0 ... +40 % on the small reference layout), and no static
+        rule -- priorities, a concurrency check with independent spin kernels -- predicts it (scripts/ab_overlap_pool.py).  So a few
+        candidate pairs are timed on synthetic noise frames (``steps`` steps each, a fraction of a second once per pipeline) against
+        the one-stream step; the best pair is kept if it wins by more than 2 %, else the pipeline stays on one stream.  The
+        decision is in ``overlap_tuning``.  Results never depend on the choice (bit-identical paths)."""
+        import time
+        torch = self.torch
+        if self.mode != "rgb":
+            return None
+        if frames is None:
+            frames = torch.randint(0, 256, (self.batch,) + self.frame_shape, device=self.tdev).to(torch.float32)
+
+        def ms():
+            best = None
+            for _ in range(2):
+                torch.cuda.synchronize(self.tdev)
+                t0 = time.perf_counter()
+                for _ in range(steps):
+                    self.step(frames)
+                torch.cuda.synchronize(self.tdev)
+                t = (time.perf_counter() - t0) / steps * 1e3
+                best = t if best is None else min(best, t)
+            return best
+
+        if len(self._pyrs) < 2:
+            self._pyrs.append(torch.empty_like(self._pyrs[0]))
+        self.overlap = False
+        for _ in range(5):
+            self.step(frames)
+        serial = ms()
+        tried, best = [], (serial, None)
+        for _ in range(candidates):
+            self._new_stream_pair()
+            self.overlap = True
+            for _ in range(3):
+                self.step(frames)
+            t = ms()
+            tried.append(round(t, 4))
+            if t < best[0]:
+                best = (t, (self._chain_stream, self._walk_stream))
+            torch.cuda.synchronize(self.tdev)
+        if best[1] is not None and best[0] < 0.98 * serial:
+            self._new_stream_pair()
+            self._chain_stream, self._walk_stream = best[1]
+            self.overlap = True
+        else:
+            self.overlap = False
+            self.pyr = self._pyrs[0]
+        torch.cuda.synchronize(self.tdev)
+        self.overlap_tuning = {"one_stream_ms": round(serial, 4), "two_stream_candidates_ms": tried, "chosen": "two streams" if self.overlap else "one stream",
+                               "chosen_ms": round(best[0], 4) if self.overlap else round(serial, 4)}
+        return self.overlap_tuning
 
     # -- byte accounting (SURVEY.md section 8d) -------------------------------------------------------
     def algorithmic_bytes_per_frame(self):
@@ -352,7 +450,9 @@ class LineEndPipeline(object):
             # a stream of another priority than the compute stream gets a hardware queue of its own (two equal-priority streams
             # may share one, and then copy and compute do not overlap): -1 beside a caller's normal stream; with overlap=True the
             # chain stream holds -1 and the copies queue with the pyramid stream, which has to follow them anyway
-            self._ingest, self._copy_stream = {}, torch.cuda.Stream(self.tdev, priority=0 if self.overlap else -1)
+            self._ingest = {}
+            beside = [self._chain_stream, self._walk_stream] if self.overlap else [torch.cuda.current_stream(self.tdev)]
+            self._copy_stream, _ = pick_concurrent_stream(torch, self.tdev, beside, priority=0 if self.overlap else -1)
         pinned_source = src.is_pinned()
         slot = self._ingest_slot(src.dtype, pinned_source)
         cur = torch.cuda.current_stream(self.tdev)

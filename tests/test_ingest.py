@@ -84,3 +84,30 @@ def test_overlap_mode_is_bit_identical_over_many_steps(center):
         b.step(f)
         if i in (0, 3, 4, 9):
             _same(a.outputs(), b.outputs(), ("pyramid", "orient", "line_end"))
+
+
+def test_overlap_auto_measures_and_stays_bit_identical():
+    """overlap="auto": the pipeline times a few stream pairs against its one-stream step when it is built (which streams of the
+    process's pool a pipeline draws decides whether two streams pay) and keeps what wins; whatever it chose, the results are the
+    one-stream results, and step_host works on top."""
+    import torch
+    from pysilent_amd.pipeline import LineEndPipeline
+    h, w, B = 216, 384, 4
+    kw = dict(selection=True, value_map=False, peak_value_map=False)
+    a = LineEndPipeline((h, w), mode="rgb", n_levels=4, batch=B, overlap="auto", **kw)
+    b = LineEndPipeline((h, w), mode="rgb", n_levels=4, batch=B, **kw)
+    t = a.overlap_tuning
+    assert t and t["chosen"] in ("one stream", "two streams") and len(t["two_stream_candidates_ms"]) >= 1 and t["one_stream_ms"] > 0
+    assert a.overlap == (t["chosen"] == "two streams")
+    rng = np.random.default_rng(5)
+    for i in range(6):
+        u8 = rng.integers(0, 256, (B, h, w, 3)).astype(np.uint8)
+        f = torch.from_numpy(u8.astype(np.float32)).cuda()
+        if i % 2:
+            a.step_host(u8)
+        else:
+            a.step(f)
+        b.step(f)
+        if i in (0, 1, 5):
+            _same(a.outputs(), b.outputs(), ("pyramid", "orient", "line_end"))
+    assert LineEndPipeline((64, 96), mode="gray", n_levels=2, batch=1, overlap="auto").overlap is False      # gray: one stream
