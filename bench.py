@@ -277,7 +277,9 @@ def cpu_baseline(wl, consts, budget_s=12.0):
 def make_pipeline(wl, B, local, consts, **over):
     from pysilent_amd.pipeline import LineEndPipeline
     h, w = wl["hw"]
-    kw = {}
+    # "auto": the pipeline times a few stream pairs against its one-stream step when it is built and keeps what wins (gray: the
+    # stream kernel of batch n + 1 beside the filter kernel of batch n; rgb: the pyramid beside chain + tail)
+    kw = {"overlap": "auto"}
     if wl["mode"] == "rgb":
         # config 3 returns line_end + keypoints (+ orient, optional in SURVEY.md section 8d): the value map and the selection's
         # peak-value map are intermediates the fused step never writes (silent_rgb_keypoints: extrema in the chain kernel,
@@ -455,11 +457,11 @@ def side_workload(torch, D, name, local, dev, rank, world, label=None, **over):
            "whole_pass_frac_of_hbm_peak": round(whole / HBM_PEAK_GBS, 4),
            "dominant_kernel": dom["kernel"], "dominant_kernel_ms": round(dom["ms"], 4),
            "dominant_kernel_frac_of_hbm_peak": round(dom["bytes"] / (dom["ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}
+    out["streams"] = ("two (overlap): first half of batch n + 1 beside the second half of batch n" if pipe.overlap
+                      else "one: every launch of a step back to back")
+    if pipe.overlap_tuning:
+        out["overlap_tuning"] = pipe.overlap_tuning
     if wl["mode"] == "rgb":
-        out["streams"] = ("two (overlap): pyramid of batch n + 1 beside chain + keypoint tail of batch n" if pipe.overlap
-                          else "one: pyramid -> chain -> keypoint tail back to back")
-        if pipe.overlap_tuning:
-            out["overlap_tuning"] = pipe.overlap_tuning
         pipe.step(frames)
         pipe.wait()
         out["sparse_keypoint_tail"] = pipe.sparse_tail_stats()
@@ -619,7 +621,7 @@ def run_rank(args):
     c = 1 if wl["mode"] == "gray" else 3
     # working set per rank well beyond the 256 MiB Infinity Cache (hard part 6)
     B = args.frames or wl["frames"]
-    pipe = make_pipeline(wl, B, local, consts, **({"overlap": False} if (args.one_stream and wl["mode"] == "rgb") else {}))
+    pipe = make_pipeline(wl, B, local, consts, **({"overlap": False} if args.one_stream else {}))
     frames = make_frames(torch, D, wl, B, rank, world, dev)
     torch.cuda.synchronize(dev)
 
@@ -669,6 +671,9 @@ def run_rank(args):
                    # SURVEY.md section 8d quotes the fraction against the measured float4-copy peak as well
                    "whole_pass_frac_of_measured_copy_peak": round(whole / COPY_PEAK_GBS, 4),
                    "launches_per_step": pipe.launch_summary(),
+                   "streams": ("two (overlap): first half of batch n + 1 beside the second half of batch n" if pipe.overlap
+                               else "one: every launch of a step back to back"),
+                   "overlap_tuning": pipe.overlap_tuning,
                    "sharding": "frame i -> rank i mod N; one RCCL broadcast of constants at init",
                    "csrc_revision": csrc_revision()},
         "roofline": roofline_of(dom, B),
@@ -714,7 +719,7 @@ def main(argv=None):
     ap.add_argument("--no-side-workloads", action="store_true")
     ap.add_argument("--no-ingest", action="store_true")
     ap.add_argument("--one-stream", action="store_true",
-                    help="RGB workloads: pyramid -> chain -> tail back to back on one stream (no overlap=True); what the rocprofv3 "
+                    help="every launch of a step back to back on one stream (no overlap between consecutive steps); what the rocprofv3 "
                          "per-kernel traces are taken with -- overlapped kernels stretch each other's durations")
     args = ap.parse_args(argv)
     if args.gpus < 1:

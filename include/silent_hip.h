@@ -157,6 +157,17 @@ int silent_gray_pass(silent_ctx* ctx, const silent_pyramid_plan* plan, const flo
 int silent_gray_pass_dev(silent_ctx* ctx, const silent_pyramid_plan* plan, const float* frames, int n_frames,
                          const float* cs_kernel, const float* end_bank, int n_orient, float clip_hi, float* pyr,
                          float* cs_out, float* end_out, silent_stream stream);
+/* The same pass in two halves, for callers that overlap consecutive batches on two streams (the reference runs one frame per
+ * session.run, recognition_testing.py:132; a batched caller can run the second half of batch n beside the first half of batch
+ * n + 1).  parts bit 0 (SILENT_GRAY_PART_PYRAMID): the pyramid of every level + CS / end of the unit-zoom levels -- reads
+ * frames, writes pyr and the unit levels of cs_out / end_out; bit 1 (SILENT_GRAY_PART_FILTER): CS + end of the remaining
+ * levels -- reads pyr (as written by part 0 for the same frames), writes the other levels of cs_out / end_out.  parts = 3 is
+ * silent_gray_pass_dev.  The two parts of one batch must be ordered by the caller (same stream, or an event). */
+#define SILENT_GRAY_PART_PYRAMID 1u
+#define SILENT_GRAY_PART_FILTER 2u
+int silent_gray_pass_parts_dev(silent_ctx* ctx, const silent_pyramid_plan* plan, const float* frames, int n_frames,
+                               const float* cs_kernel, const float* end_bank, int n_orient, float clip_hi, float* pyr,
+                               float* cs_out, float* end_out, unsigned parts, silent_stream stream);
 
 /* 1 when silent_gray_pass runs this plan through the single-read stream kernel (one unit-zoom level and every
  * other level resampling the same crop with a step > 1.25: classic whole-frame pyramids), 0 when it falls

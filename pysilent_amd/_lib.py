@@ -29,6 +29,7 @@ RECOVERY_CONSTANT = 1
 RECOVERY_INPUT = 2
 MAX_LEVELS = 16
 TUNE_GRAY, TUNE_RGB, TUNE_PYRAMID = 0, 1, 2
+GRAY_PART_PYRAMID, GRAY_PART_FILTER = 1, 2
 DT_U8, DT_F32, DT_F64, DT_I32, DT_U16, DT_I16, DT_I64 = 0, 1, 2, 3, 4, 5, 6
 ABI_VERSION = 1
 
@@ -93,6 +94,7 @@ _SIGNATURES = {
     "silent_gray_line_end_dev": [_vp, _fp, _ep, _i, _i, _fp, _fp, _i, _f, _fp, _fp, _vp],
     "silent_gray_pass": [_vp, _vp, _fp, _i, _fp, _fp, _i, _f, _fp, _fp, _fp],
     "silent_gray_pass_dev": [_vp, _vp, _fp, _i, _fp, _fp, _i, _f, _fp, _fp, _fp, _vp],
+    "silent_gray_pass_parts_dev": [_vp, _vp, _fp, _i, _fp, _fp, _i, _f, _fp, _fp, _fp, _u, _vp],
     "silent_pyramid_plan_is_streamable": [_vp],
     "silent_pyramid_plan_walk_plans": [_vp, C.POINTER(C.c_int)],
     "silent_gather_d2h": [_vp, _vp, C.POINTER(C.c_void_p), C.POINTER(C.c_size_t), _i, _vp],

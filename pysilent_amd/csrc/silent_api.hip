@@ -2309,11 +2309,11 @@ SILENT_EXPORT int silent_profile_elapsed_ms(silent_ctx* ctx, float* ms, int64_t*
     return on_exception(ctx, "silent_profile_elapsed_ms");
 }
 
-SILENT_EXPORT int silent_gray_pass_dev(silent_ctx* ctx, const silent_pyramid_plan* plan, const float* frames,
-                                       int n_frames, const float* cs_kernel, const float* end_bank, int n_orient,
-                                       float clip_hi, float* pyr, float* cs_out, float* end_out,
-                                       silent_stream stream) try {
-    NEED_CTX(ctx);
+// parts: bit 0 = the pyramid of every level + CS / end of the unit levels (steps 1 and 2), bit 1 = CS + end of the remaining levels
+// (step 3, which reads the pyramid steps 1 and 2 wrote)
+static int gray_pass_parts(silent_ctx* ctx, const silent_pyramid_plan* plan, const float* frames, int n_frames,
+                           const float* cs_kernel, const float* end_bank, int n_orient, float clip_hi, float* pyr,
+                           float* cs_out, float* end_out, unsigned parts, silent_stream stream) {
     const char* who = "silent_gray_pass";
     if (!plan || !frames || !pyr || !cs_kernel) return fail(ctx, SILENT_E_INVALID, std::string(who) + ": NULL pointer");
     if (plan->ctx != ctx) return fail(ctx, SILENT_E_INVALID, std::string(who) + ": plan belongs to another context");
@@ -2329,7 +2329,8 @@ SILENT_EXPORT int silent_gray_pass_dev(silent_ctx* ctx, const silent_pyramid_pla
     const bool stream_path = plan->stream_ok && !(kopts & 16);
     // 1. non-unit levels of the pyramid: by the region kernel, unless the stream kernel of step 2 produces them
     //    from the same single read of the frame; plus the zero fill of canvases larger than their zoomed crop
-    TRY(launch_pyramid(ctx, who, plan, frames, n_frames, pyr, s, false, !stream_path));
+    if (!(parts & 3u)) return fail(ctx, SILENT_E_INVALID, std::string(who) + ": parts must name step 1 + 2 (bit 0) and / or step 3 (bit 1)");
+    if (parts & 1u) TRY(launch_pyramid(ctx, who, plan, frames, n_frames, pyr, s, false, !stream_path));
     // 2. unit levels: pyramid + CS + end in one kernel
     const int fth = (!stream_path && (kopts & 8)) ? 32 : kFusedTH;
     FusedTab ft;
@@ -2360,7 +2361,7 @@ SILENT_EXPORT int silent_gray_pass_dev(silent_ctx* ctx, const silent_pyramid_pla
     ft.frame_px = pt.frame_px_out;
     const long long blocks = tiles * n_frames;
     if (blocks > 0x7fffffffll) return fail(ctx, SILENT_E_INVALID, std::string(who) + ": too many tiles for one launch");
-    if (blocks) {
+    if (blocks && (parts & 1u)) {
         GrayW w;
         std::memset(&w, 0, sizeof(w));
         std::memcpy(w.cs, cs_kernel, sizeof(float) * 9);
@@ -2404,12 +2405,30 @@ SILENT_EXPORT int silent_gray_pass_dev(silent_ctx* ctx, const silent_pyramid_pla
         TRY(check_launch(ctx, who));
     }
     // 3. CS + end on the remaining levels (they read the pyramid written in step 1)
-    if (pt.n_general)
+    if (pt.n_general && (parts & 2u))
         TRY(launch_gray(ctx, who, pyr, plan->extents.data(), pt.n_levels, n_frames, cs_kernel, end_bank, n_orient,
                         clip_hi, cs_out, end_out, s, is_unit));
     return SILENT_OK;
+}
+
+SILENT_EXPORT int silent_gray_pass_dev(silent_ctx* ctx, const silent_pyramid_plan* plan, const float* frames,
+                                       int n_frames, const float* cs_kernel, const float* end_bank, int n_orient,
+                                       float clip_hi, float* pyr, float* cs_out, float* end_out,
+                                       silent_stream stream) try {
+    NEED_CTX(ctx);
+    return gray_pass_parts(ctx, plan, frames, n_frames, cs_kernel, end_bank, n_orient, clip_hi, pyr, cs_out, end_out, 3u, stream);
 } catch (...) {
     return on_exception(ctx, "silent_gray_pass_dev");
+}
+
+SILENT_EXPORT int silent_gray_pass_parts_dev(silent_ctx* ctx, const silent_pyramid_plan* plan, const float* frames,
+                                             int n_frames, const float* cs_kernel, const float* end_bank, int n_orient,
+                                             float clip_hi, float* pyr, float* cs_out, float* end_out, unsigned parts,
+                                             silent_stream stream) try {
+    NEED_CTX(ctx);
+    return gray_pass_parts(ctx, plan, frames, n_frames, cs_kernel, end_bank, n_orient, clip_hi, pyr, cs_out, end_out, parts, stream);
+} catch (...) {
+    return on_exception(ctx, "silent_gray_pass_parts_dev");
 }
 
 // ------------------------------------------------------------------------------------------ host-pointer twins

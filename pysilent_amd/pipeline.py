@@ -137,13 +137,14 @@ class LineEndPipeline(object):
         self.clip_hi, self.flat_policy, self.pad = float(clip_hi), flat_policy, int(pad)
         n = self.batch * self.frame_px
         f32 = dict(dtype=torch.float32, device=self.tdev)
-        # overlap=True (rgb): consecutive steps overlap on two internal streams -- the pyramid of batch n + 1 (latency-bound walk
-        # kernel) runs beside the chain kernel and the small launches of the keypoint tail of batch n; the pyramid is then
-        # double-buffered (pipeline.pyr = the last step's).  step() stays "enqueue the whole path for this batch", but on the
+        # overlap: consecutive steps overlap on two internal streams -- rgb: the pyramid of batch n + 1 (latency-bound walk kernel)
+        # beside the chain kernel and the small launches of the keypoint tail of batch n; gray: the single-read stream kernel of
+        # batch n + 1 beside the filter kernel of batch n's smaller levels.  The pyramid is then double-buffered (pipeline.pyr = the
+        # last step's).  step() stays "enqueue the whole path for this batch", but on the
         # pipeline's own streams: wait() orders the caller's stream behind the results, outputs() does so itself.
-        self._overlap_auto = overlap == "auto" and mode == "rgb"
+        self._overlap_auto = overlap == "auto"
         self._chain_priority = -1 if overlap_priorities else 0
-        self.overlap = bool(overlap) and mode == "rgb"
+        self.overlap = bool(overlap)
         self.overlap_tuning = None
         self._order_caller = True          # (A/B switch of scripts/ab_overlap.py: order the caller's stream behind the frame read)
         self._pyrs = [torch.empty(n * self.channels, **f32) for _ in range(2 if self.overlap else 1)]
@@ -211,8 +212,6 @@ class LineEndPipeline(object):
         decision is in ``overlap_tuning``.  Results never depend on the choice (bit-identical paths)."""
         import time
         torch = self.torch
-        if self.mode != "rgb":
-            return None
         if frames is None:
             frames = torch.randint(0, 256, (self.batch,) + self.frame_shape, device=self.tdev).to(torch.float32)
 
@@ -355,15 +354,16 @@ class LineEndPipeline(object):
         self.ctx.check(self._lib.silent_max_value_indices_region_dev(
             self.ctx.handle, p(value), *geom, self.regions, p(self.kp_idx), self.kp_cap, p(self.kp_counts), s))
 
-    def run_gray_pass(self, frames, stream=None):
+    def run_gray_pass(self, frames, stream=None, parts=3):
         """Whole grayscale hot path in one C-ABI call (silent_gray_pass_dev): region kernel for the non-unit
-        levels, fused pyramid + CS + end kernel for the unit levels, filter kernel for the rest."""
+        levels, fused pyramid + CS + end kernel for the unit levels, filter kernel for the rest.  ``parts``: 1 = pyramid + unit
+        levels only, 2 = the filter of the remaining levels only (silent_gray_pass_parts_dev; the halves of an overlapped step)."""
         self._check_frames(frames)
-        self.ctx.check(self._lib.silent_gray_pass_dev(
+        self.ctx.check(self._lib.silent_gray_pass_parts_dev(
             self.ctx.handle, self.plan.handle, C.c_void_p(frames.data_ptr()), self.batch,
             C.c_void_p(self.consts["cs"].ctypes.data), C.c_void_p(self.consts["end"].ctypes.data), self.n_orient,
             self.clip_hi, C.c_void_p(self.pyr.data_ptr()), C.c_void_p(self.cs.data_ptr()),
-            C.c_void_p(self.end.data_ptr()), stream or self._stream()))
+            C.c_void_p(self.end.data_ptr()), int(parts), stream or self._stream()))
 
     def set_profiling(self, every=1):
         """Bracket the dominant kernel with HIP events on every ``every``-th step (0 / False: off)."""
@@ -384,7 +384,10 @@ class LineEndPipeline(object):
         ws.wait_stream(torch.cuda.current_stream(self.tdev))     # the frames were produced on the caller's stream
         if self._pyr_free[k] is not None:
             ws.wait_event(self._pyr_free[k])                      # the chain of two steps ago has read this buffer
-        self.run_pyramid(frames, C.c_void_p(ws.cuda_stream))
+        if self.mode == "gray":
+            self.run_gray_pass(frames, C.c_void_p(ws.cuda_stream), parts=_lib.GRAY_PART_PYRAMID)
+        else:
+            self.run_pyramid(frames, C.c_void_p(ws.cuda_stream))
         self._pyr_ready[k].record(ws)
         cs.wait_event(self._pyr_ready[k])
         # the caller's stream is ordered behind the READ of its frames (not behind the chain): whatever it enqueues next may
@@ -392,7 +395,9 @@ class LineEndPipeline(object):
         if self._order_caller:
             torch.cuda.current_stream(self.tdev).wait_event(self._pyr_ready[k])
         s = C.c_void_p(cs.cuda_stream)
-        if self.selection and not self.keep_selection_maps:
+        if self.mode == "gray":
+            self.run_gray_pass(frames, s, parts=_lib.GRAY_PART_FILTER)
+        elif self.selection and not self.keep_selection_maps:
             self.run_filters_keypoints(s)
         else:
             self.run_filters(s)

@@ -18,7 +18,7 @@ def _same(a, b, keys):
             np.testing.assert_array_equal(x, y)
 
 
-@pytest.mark.parametrize("mode,overlap", [("gray", False), ("rgb", False), ("rgb", True)])
+@pytest.mark.parametrize("mode,overlap", [("gray", False), ("gray", True), ("rgb", False), ("rgb", True)])
 @pytest.mark.parametrize("source", ["numpy_u8", "pinned_u8", "numpy_f32", "numpy_i16"])
 def test_step_host_equals_the_resident_step(mode, overlap, source):
     import torch
@@ -110,4 +110,24 @@ def test_overlap_auto_measures_and_stays_bit_identical():
         b.step(f)
         if i in (0, 1, 5):
             _same(a.outputs(), b.outputs(), ("pyramid", "orient", "line_end"))
-    assert LineEndPipeline((64, 96), mode="gray", n_levels=2, batch=1, overlap="auto").overlap is False      # gray: one stream
+
+
+@pytest.mark.parametrize("overlap", [True, "auto"])
+@pytest.mark.parametrize("shape,levels,K", [((135, 240), 4, 4), ((216, 384), 5, 8), ((64, 96), 1, 3)])
+def test_gray_overlap_is_bit_identical(overlap, shape, levels, K):
+    """Gray pipelines on two streams: the stream kernel (pyramid + level 0's CS / line-end) of batch n + 1 beside the filter kernel
+    of batch n's smaller levels (silent_gray_pass_parts_dev), double-buffered pyramid -- eight different batches, results read in
+    between, against the one-call pass; a single-level pyramid (nothing for the second half to do) included."""
+    import torch
+    from pysilent_amd.pipeline import LineEndPipeline
+    h, w = shape
+    B = 3
+    a = LineEndPipeline((h, w), mode="gray", n_levels=levels, n_orient=K, batch=B, overlap=overlap)
+    b = LineEndPipeline((h, w), mode="gray", n_levels=levels, n_orient=K, batch=B)
+    rng = np.random.default_rng(8)
+    for i in range(8):
+        f = torch.from_numpy(rng.integers(0, 256, (B, h, w, 1)).astype(np.float32)).cuda()
+        a.step(f)
+        b.step(f)
+        if i in (0, 2, 3, 7):
+            _same(a.outputs(), b.outputs(), ("pyramid", "cs", "end"))
