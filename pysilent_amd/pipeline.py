@@ -201,7 +201,7 @@ class LineEndPipeline(object):
         self._pyr_free = [None, None]
         self._steps = 0
 
-    def tune_overlap(self, frames=None, candidates=6, steps=10):
+    def tune_overlap(self, frames=None, candidates=8, steps=10):
         """overlap="auto": MEASURE whether two streams pay on this device, in this process, with these streams -- and with which.
         HIP multiplexes streams onto hardware queues (and those onto the command processor's pipes); which pair of streams a
         pipeline draws from the pool decides whether the pyramid of batch n + 1 really runs beside the chain of batch n (config 3:
