@@ -66,13 +66,15 @@ def _spin_ms(torch, dev, streams, cycles):
     return (time.perf_counter() - t0) * 1e3
 
 
-def pick_concurrent_stream(torch, dev, beside, priority=0, tries=10, cycles=1 << 20):
+def pick_concurrent_stream(torch, dev, beside, priority=0, tries=10, cycles=1 << 17):
     """A new stream whose work really runs CONCURRENTLY with the streams in ``beside``.  HIP multiplexes streams onto a few
     hardware queues, and two streams that share one are served strictly in order -- "overlap" through such a pair is a loss
     (cross-stream events, no concurrency), and which pairs share is a property of the process's stream pool, not of the
     priorities (scripts/ab_overlap_pool.py: pipelines #2, #5 and #7 of a process lost 40 %, the others won 8 %).  So it is
-    measured: a spin kernel on the candidate and on every stream of ``beside`` at once must take about as long as one alone.
-    Returns (stream, verified); after ``tries`` candidates the last one is returned unverified."""
+    measured: a spin kernel on the candidate and on every stream of ``beside`` at once must take about as long as one alone
+    (about a millisecond each).  A NECESSARY check only: pairs that pass it can still stall each other through the real step's
+    cross-stream events -- tune_overlap times the real thing.  Returns (stream, verified); after ``tries`` candidates the last one
+    is returned unverified."""
     one = min(_spin_ms(torch, dev, beside[:1] or [torch.cuda.current_stream(dev)], cycles) for _ in range(2))
     cand = None
     keep = []                                  # rejected candidates stay alive until the choice is made (the pool hands out new ones)
