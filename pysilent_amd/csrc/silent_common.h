@@ -24,6 +24,8 @@ struct LevelTab {
     long long px_off[kMaxLevels];    // pixel offset of level l inside one pyramid
 };
 
+constexpr int kChunk = 1024;  // pixels per block for the 1-D (flattened level) kernels: 256 threads x 4
+
 struct TileCoord {
     int frame, level, ty, tx;
 };
@@ -97,5 +99,47 @@ __device__ __forceinline__ void relu_clip_tf(float (&v)[N], float hi) {
         for (int k = 0; k < N; ++k) v[k] = clip_hi_tf(relu_tf(v[k]), hi);
     }
 }
+
+// Value summary written by the fused RGB chain (rgb_line_end2_kernel, MM instantiation) for the sparse selection tail:
+// entry = max_pool(value) over one pixel PAIR x kSumRows rows of a chain tile.
+constexpr int kSumRowsLog2 = 4, kSumRows = 1 << kSumRowsLog2;
+// How the sparse tail (sparse_select_kernel, silent_peaks.h) settles a (frame, level): by its candidates alone (every window maximum > 0); candidates + a synthesised all-zero
+// map in the count pass (some window without a positive peak, but the level holds no NaN: every pixel mapped to such a window
+// is a keypoint); or the dense kernels (such a window AND NaNs in the level, or too many candidates)
+constexpr int kTailSparse = 0, kTailDense = 1, kTailZero = 2;
+
+// order-preserving float <-> uint map so that integer atomics give float max / min
+__device__ __forceinline__ unsigned f2ord(float f) {
+    const unsigned u = __float_as_uint(f);
+    return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+}
+__device__ __forceinline__ float ord2f(unsigned u) {
+    return __uint_as_float((u & 0x80000000u) ? (u & 0x7fffffffu) : ~u);
+}
+
+// tf.nn.max_pool as the reference's device path evaluates it.  The reference pins its graph to '/device:GPU:0'
+// (slam_recognition/recognition_testing.py:64); there TF 1.x runs MaxPoolForwardNHWC (`maxval = lowest(); if (x > maxval)
+// maxval = x`) or cuDNN with CUDNN_NOT_PROPAGATE_NAN (TF_ENABLE_MAXPOOL_NANPROP defaults to false): a NaN never wins, the
+// result is independent of the tap order, a window with nothing above lowest() yields lowest() = -FLT_MAX.
+// Every maximum in silent_peaks.h (3x3 NMS, per-level max / min, window and cell maxima) goes through pool_max with the
+// RUNNING maximum as first argument, so an accumulator is never a NaN and atomics only ever see ordered floats.
+// Oracle: pool_max in oracle/silent_oracle.py.
+constexpr float kPoolLowest = -3.402823466e+38f;
+__device__ __forceinline__ float pool_max(float m, float v) { return v > m ? v : m; }
+__device__ __forceinline__ unsigned pool_lowest_ord() { return f2ord(kPoolLowest); }
+
+// v must already be NaN-free (a pool_max accumulator)
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = pool_max(v, __shfl_xor(v, o));
+    return v;
+}
+
+// Geometry of that value summary (host: build_sum_tab in silent_peaks_api.hip)
+struct SumTab {
+    int th, gpt;                       // tile height of the chain launch, groups per tile = ceil(th / kSumRows)
+    long long frame_entries;
+    long long off[kMaxLevels + 1];     // entry offset of level l inside a frame (off[n_levels] = frame_entries)
+};
 
 }  // namespace silent

@@ -4,7 +4,7 @@
 //
 // Not a product path and never shipped as one: every kernel launch is compiled out (outputs are whatever the "device" buffers
 // held), device memory is host memory, streams and events are inert.  What it keeps is every line of host code of
-// silent_api.hip, run under -fsanitize=address,undefined with extents / crops / regions fuzzed from Python, plus two fault
+// the six translation units (silent_unity.hip), run under -fsanitize=address,undefined with extents / crops / regions fuzzed from Python, plus two fault
 // injectors for the exception barrier of the ABI:
 //   silent_host_arm_fault(n)       the n-th NEED_CTX passed from now on throws std::bad_alloc (every entry point has one)
 //   silent_host_fail_new_after(n)  the n-th operator new of this library from now on throws std::bad_alloc (vectors of the planners)

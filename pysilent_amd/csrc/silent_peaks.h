@@ -5,43 +5,6 @@
 
 namespace silent {
 
-constexpr int kChunk = 1024;  // pixels per block for the 1-D (flattened level) kernels: 256 threads x 4
-
-// Value summary written by the fused RGB chain (rgb_line_end2_kernel, MM instantiation) for the sparse selection tail:
-// entry = max_pool(value) over one pixel PAIR x kSumRows rows of a chain tile.
-constexpr int kSumRowsLog2 = 4, kSumRows = 1 << kSumRowsLog2;
-// How the sparse tail (sparse_select_kernel, below) settles a (frame, level): by its candidates alone (every window maximum > 0); candidates + a synthesised all-zero
-// map in the count pass (some window without a positive peak, but the level holds no NaN: every pixel mapped to such a window
-// is a keypoint); or the dense kernels (such a window AND NaNs in the level, or too many candidates)
-constexpr int kTailSparse = 0, kTailDense = 1, kTailZero = 2;
-
-// order-preserving float <-> uint map so that integer atomics give float max / min
-__device__ __forceinline__ unsigned f2ord(float f) {
-    const unsigned u = __float_as_uint(f);
-    return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
-}
-__device__ __forceinline__ float ord2f(unsigned u) {
-    return __uint_as_float((u & 0x80000000u) ? (u & 0x7fffffffu) : ~u);
-}
-
-// tf.nn.max_pool as the reference's device path evaluates it.  The reference pins its graph to '/device:GPU:0'
-// (slam_recognition/recognition_testing.py:64); there TF 1.x runs MaxPoolForwardNHWC (`maxval = lowest(); if (x > maxval)
-// maxval = x`) or cuDNN with CUDNN_NOT_PROPAGATE_NAN (TF_ENABLE_MAXPOOL_NANPROP defaults to false): a NaN never wins, the
-// result is independent of the tap order, a window with nothing above lowest() yields lowest() = -FLT_MAX.
-// Every maximum in this file (3x3 NMS, per-level max / min, window and cell maxima) goes through pool_max with the
-// RUNNING maximum as first argument, so an accumulator is never a NaN and atomics only ever see ordered floats.
-// Oracle: pool_max in oracle/silent_oracle.py.
-constexpr float kPoolLowest = -3.402823466e+38f;
-__device__ __forceinline__ float pool_max(float m, float v) { return v > m ? v : m; }
-__device__ __forceinline__ unsigned pool_lowest_ord() { return f2ord(kPoolLowest); }
-
-// v must already be NaN-free (a pool_max accumulator)
-__device__ __forceinline__ float wave_max(float v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v = pool_max(v, __shfl_xor(v, o));
-    return v;
-}
-
 // ---- a-7 pad_inwards: out = mask * in (multiplication, like the reference: 0 * NaN stays NaN)
 __global__ __launch_bounds__(256) void pad_inwards_kernel(const float* __restrict__ in, float* __restrict__ out,
                                                           const LevelTab tab, int C, int pt, int pb, int pl,
@@ -727,11 +690,6 @@ __global__ __launch_bounds__(256) void region_count_kernel(const float* __restri
 // exits at once -- and turns the candidates that reach their window maximum into hit bits + chunk counts, the form the
 // count pass leaves them in, so that scan and ordered write run unchanged (row-major order like tf.where by construction).
 constexpr int kCandCap = 16384;   // candidates per frame; more -> the frame runs the dense kernels
-struct SumTab {
-    int th, gpt;                       // tile height of the chain launch, groups per tile = ceil(th / kSumRows)
-    long long frame_entries;
-    long long off[kMaxLevels + 1];     // entry offset of level l inside a frame (off[n_levels] = frame_entries)
-};
 struct Candidate {
     int level, y, x;
     float pv;

@@ -313,6 +313,7 @@ __global__ __launch_bounds__(256) void pyramid_region_kernel(const float* __rest
 }
 
 // ------------------------------------------------------------------------------------------ ZERO FILL
+template <int C>
 __global__ __launch_bounds__(256) void pyramid_zero_kernel(float* __restrict__ pyr, const PyrTab tab) {
     const unsigned bid = blockIdx.x;
     const int frame = (int)(bid / (unsigned)tab.zero_chunks_per_frame);
@@ -323,14 +324,14 @@ __global__ __launch_bounds__(256) void pyramid_zero_kernel(float* __restrict__ p
         if (i < tab.n_levels && rem >= tab.zero_chunk_start[i]) l = i;
     rem -= tab.zero_chunk_start[l];
     const PyrLevelDev& lv = tab.lv[l];
-    float* __restrict__ dst = pyr + ((long long)frame * tab.frame_px_out + tab.px_off[l]) * tab.C;
+    float* __restrict__ dst = pyr + ((long long)frame * tab.frame_px_out + tab.px_off[l]) * C;
     const int npx = lv.out_h * lv.out_w;
     for (int k = 0; k < 4; ++k) {
         const int p = rem * 1024 + k * 256 + threadIdx.x;
         if (p >= npx) break;
         const int y = p / lv.out_w, x = p - y * lv.out_w;
         if (y >= lv.zoom_h || x >= lv.zoom_w)
-            for (int ch = 0; ch < tab.C; ++ch) dst[(long long)p * tab.C + ch] = 0.0f;
+            for (int ch = 0; ch < C; ++ch) dst[(long long)p * C + ch] = 0.0f;
     }
 }
 

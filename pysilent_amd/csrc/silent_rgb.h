@@ -55,7 +55,7 @@ constexpr int kRgbTH = 90;                   // round 1's fixed tile height (50 
 // Round 2: the tile height is a launch parameter (RgbArgs::th, even, kRgbTHMin .. kRgbTHMax).  Launches of about one round of
 // resident tiles or less get the height that minimises ceil(tiles / resident tiles) x (th + 14) row steps -- short tiles, the
 // generalisation of round 1's 18-row instantiation; launches that fill the chip several times keep 90 rows (the sweep in
-// silent_api.hip: +-4 % without a trend).
+// silent_rgb_api.hip: +-4 % without a trend).
 constexpr int kRgbTHMin = 18, kRgbTHMax = 160;
 constexpr int kRgbChunk = 2;                 // input rows per prefetch chunk; (TH + 14) % chunk == 0
 // A wave walks its TH + 14 rows one after the other (~1.8 us per row when it has a SIMD to itself), so a launch with

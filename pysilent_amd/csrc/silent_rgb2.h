@@ -25,7 +25,6 @@
 // History and leave-one-out measurements: profiles/r02/rgb_pair_kernel.txt, profiles/r03_experiments.txt, DESIGN.md 4.5.
 #pragma once
 
-#include "silent_peaks.h"
 #include "silent_rgb.h"
 
 namespace silent {
@@ -61,7 +60,7 @@ constexpr int kRgb2StreamMax = SILENT_RGB_STREAM_MAX;  // 4 x 81 + 49 = 373 floa
 
 constexpr int rgb2_popc(unsigned v) { return v ? (int)(v & 1u) + rgb2_popc(v >> 1) : 0; }
 
-// The "symmetric" forms (SYM instantiation; host-checked structure of the weights, silent_api.hip analyze_rgb_chain):
+// The "symmetric" forms (SYM instantiation; host-checked structure of the weights, silent_rgb_api.hip analyze_rgb_chain):
 //   rgc   channel-diagonal, every channel's 3x3 kernel mirror-symmetric in both axes (midget_rgc: a centre-surround profile):
 //         per channel [corner, edge_h (above / below the centre), edge_v (left / right), centre];
 //   rgby  K[t][i][o] = S[t] * A[i][o] for the 8 taps around the centre, S mirror-symmetric in both axes, + B[i][o] at the centre

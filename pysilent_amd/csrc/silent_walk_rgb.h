@@ -31,7 +31,7 @@
 #include <type_traits>
 
 #include "silent_common.h"
-#include "silent_conv.h"
+#include "silent_gray.h"
 
 namespace silent {
 

@@ -1,5 +1,5 @@
 """Worker of tests/test_sanitizers.py: runs INSIDE a python started with LD_PRELOAD=<asan runtime> and
-SILENT_LIB_PATH=pysilent_amd/lib/libsilent_hostonly_asan.so (the host side of silent_api.hip, kernel launches compiled out,
+SILENT_LIB_PATH=pysilent_amd/lib/libsilent_hostonly_asan.so (the host side of the library, silent_unity.hip, kernel launches compiled out,
 device memory = host memory; pysilent_amd/csrc/silent_host_shim.h).  No GPU, no oracle: what is checked is that every line of
 host code -- validation, tile / region / tap tables, row programs, walk plans, weight-stream packing, workspace layout, staging
 of the host-pointer twins -- runs clean under AddressSanitizer + UndefinedBehaviorSanitizer for fuzzed geometries, that bad
