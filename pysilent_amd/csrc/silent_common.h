@@ -77,6 +77,41 @@ __device__ __forceinline__ int mirror_near(int i, int n) {
     return min(max(i, 0), n - 1);
 }
 
+// The horizontal taps of a unit (zoom 1) level for one streamed row of a lane-per-column wave.  scipy.ndimage.zoom(order=5)
+// (from_image.py:55-59) evaluates SIX taps, x - 2 .. x + 3; at zoom 1 the sixth weight is what double arithmetic leaves of
+// 1 - (1 + 26 + 66 + 26 + 1) / 120 = 2^-53: nothing next to finite neighbours, but a NaN / inf pixel reaches the outputs three
+// to its left (and three above it) as well, and a lone bright pixel leaves 2^-53 of itself there.  The sixth tap of lane 61 is
+// the column right of the wave's 64: `edge` carries it (wave-uniform: one lane of a per-tile load, unit_edge_column) and enters
+// as what lane 63 "receives from lane 64" in the first shift (a DPP shift without bound_ctrl keeps the destination's old value
+// in the lane that has no source), so r2 of lane 62 and r3 of lane 61 see it too.
+// EDGE = false: lane 61 is no output's tap (kernels whose halo lanes already cover x + 3).
+template <bool EDGE = true>
+__device__ __forceinline__ float unit_taps6(float c0, float edge, const float (&w)[6]) {
+    const float l1 = from_lane_below(c0), l2 = from_lane_below(l1);
+    float r1;
+    if constexpr (EDGE)
+        r1 = __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(edge), __float_as_int(c0), 0x130 /* wave_shl:1 */, 0xf, 0xf, false));
+    else
+        r1 = from_lane_above(c0);
+    const float r2 = from_lane_above(r1), r3 = from_lane_above(r2);
+    float h = w[0] * l2;
+    h = __builtin_fmaf(w[1], l1, h);
+    h = __builtin_fmaf(w[2], c0, h);
+    h = __builtin_fmaf(w[3], r1, h);
+    h = __builtin_fmaf(w[4], r2, h);
+    return __builtin_fmaf(w[5], r3, h);
+}
+// Stream row i of the column `col` (level coordinates, mirrored inside the crop like every tap; px_stride floats per pixel) in lane i: ONE load per tile
+// for the sixth taps of a wave's last smoothing lane; row i is read back with unit_edge(xcol, i).
+__device__ __forceinline__ float unit_edge_column(const float* __restrict__ src, long long row_stride, int col, int src_w, int src_x0,
+                                                  int y_first, int n_rows, int src_h, int src_y0, int lane, int px_stride = 1) {
+    const long long sx = (long long)(mirror_near(col, src_w) + src_x0) * px_stride;
+    return src[(long long)(mirror_near(y_first + min(lane, n_rows - 1), src_h) + src_y0) * row_stride + sx];
+}
+__device__ __forceinline__ float unit_edge(float xcol, int i) {
+    return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(xcol), i));
+}
+
 // tf.maximum(x, [0]) with Eigen's CPU functor: a NaN stays a NaN (oracle: relu_tf).
 __device__ __forceinline__ float relu_tf(float v) { return v < 0.0f ? 0.0f : v; }
 __device__ __forceinline__ float clip_hi_tf(float v, float hi) { return v > hi ? hi : v; }

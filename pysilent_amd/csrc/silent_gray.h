@@ -207,7 +207,7 @@ struct FusedLevel {  // the unit levels of a pyramid plan, as the kernel needs t
 struct FusedTab {
     int n, tiles_per_frame, H, W;
     long long frame_px;                // pixels of one whole pyramid (all levels)
-    float wx[5], wy[5];
+    float wx[6], wy[6];                // scipy's SIX taps of a zoom-1 level: [1, 26, 66, 26, 1] / 120 and 2^-53 (unit_taps6)
     FusedLevel lv[kMaxLevels];
 };
 
@@ -240,16 +240,18 @@ __global__ __launch_bounds__(64 * kFusedWaves) void gray_unit_fused_kernel(const
 
     // scipy 'mirror' inside the crop, then the crop's offset in the frame
     const long long sx = mirror_near(ox, lv.src_w) + lv.src_x0;
-    float in[R + 8];
+    float in[R + 9];                                                  // stream rows y0 - 4 .. y0 + R + 4 (the sixth tap: + 1 row)
 #pragma unroll
-    for (int i = 0; i < R + 8; ++i)
+    for (int i = 0; i < R + 9; ++i)
         in[i] = src[(long long)(mirror_near(y0 - 4 + i, lv.src_h) + lv.src_y0) * W + sx];
+    float xcol = unit_edge_column(src, W, xw0 + 60, lv.src_w, lv.src_x0, y0 - 4, R + 9, lv.src_h, lv.src_y0, lane);
 #pragma unroll
-    for (int i = 0; i < R + 8; ++i) asm volatile("" ::"v"(in[i]));  // retire loads before the first store
+    for (int i = 0; i < R + 9; ++i) asm volatile("" ::"v"(in[i]));  // retire loads before the first store
+    asm volatile("" : "+v"(xcol));
 
     const bool col_in = ox >= 0 && ox < lv.out_w;                  // inside the level (SAME padding is 0 outside)
     const bool out_lane = lane >= 4 && lane < 4 + kFusedCols && ox < lv.out_w;
-    float hw[5] = {0, 0, 0, 0, 0};
+    float hw[6] = {0, 0, 0, 0, 0, 0};
     float iw[3][3], cw[3][3];
 #pragma unroll
     for (int a = 0; a < 3; ++a)
@@ -257,27 +259,20 @@ __global__ __launch_bounds__(64 * kFusedWaves) void gray_unit_fused_kernel(const
         for (int b = 0; b < 3; ++b) iw[a][b] = cw[a][b] = 0.0f;
 
 #pragma unroll
-    for (int i = 0; i < R + 8; ++i) {
-        // ---- horizontal 5 taps of source row y0 - 4 + i
+    for (int i = 0; i < R + 9; ++i) {
+        // ---- horizontal taps of source row y0 - 4 + i
         {
-            const float c0 = in[i];
-            const float l1 = from_lane_below(c0), l2 = from_lane_below(l1);
-            const float r1 = from_lane_above(c0), r2 = from_lane_above(r1);
-            float h = tab.wx[0] * l2;
-            h = __builtin_fmaf(tab.wx[1], l1, h);
-            h = __builtin_fmaf(tab.wx[2], c0, h);
-            h = __builtin_fmaf(tab.wx[3], r1, h);
-            h = __builtin_fmaf(tab.wx[4], r2, h);
+            const float h = unit_taps6(in[i], unit_edge(xcol, i), tab.wx);
 #pragma unroll
-            for (int j = 0; j < 4; ++j) hw[j] = hw[j + 1];
-            hw[4] = h;
+            for (int j = 0; j < 5; ++j) hw[j] = hw[j + 1];
+            hw[5] = h;
         }
-        if (i >= 4) {
-            // ---- pyramid row p = y0 + i - 6 (vertical 5 taps)
-            const int p = y0 + i - 6;
+        if (i >= 5) {
+            // ---- pyramid row p = y0 + i - 7 (vertical taps p - 2 .. p + 3)
+            const int p = y0 + i - 7;
             float v = tab.wy[0] * hw[0];
 #pragma unroll
-            for (int j = 1; j < 5; ++j) v = __builtin_fmaf(tab.wy[j], hw[j], v);
+            for (int j = 1; j < 6; ++j) v = __builtin_fmaf(tab.wy[j], hw[j], v);
             v = (p < lv.zoom_h && ox < lv.zoom_w) ? v : 0.0f;                 // canvas beyond the zoomed crop
             if (p >= y0 && p < y0 + R && p < lv.out_h && out_lane) pyr[base_px + (long long)p * lv.out_w + ox] = v;
             v = (p >= 0 && p < lv.out_h && col_in) ? v : 0.0f;                // SAME zero padding of the first conv
@@ -290,9 +285,9 @@ __global__ __launch_bounds__(64 * kFusedWaves) void gray_unit_fused_kernel(const
             iw[2][0] = from_lane_below(v);
             iw[2][2] = from_lane_above(v);
         }
-        if (i >= 6) {
-            // ---- CS row c = y0 + i - 7
-            const int c = y0 + i - 7;
+        if (i >= 7) {
+            // ---- CS row c = y0 + i - 8
+            const int c = y0 + i - 8;
             float acc = 0.0f;
 #pragma unroll
             for (int dy = 0; dy < 3; ++dy)
@@ -309,9 +304,9 @@ __global__ __launch_bounds__(64 * kFusedWaves) void gray_unit_fused_kernel(const
             cw[2][0] = from_lane_below(cs);
             cw[2][2] = from_lane_above(cs);
         }
-        if (i >= 8) {
-            // ---- output row y = y0 + i - 8
-            const int y = y0 + i - 8;
+        if (i >= 9) {
+            // ---- output row y = y0 + i - 9
+            const int y = y0 + i - 9;
             if (y < lv.out_h) {  // wave-uniform
                 const long long px = base_px + (long long)y * lv.out_w + ox;
                 if (cs_out && out_lane) cs_out[px] = cw[1][1];  // (non-temporal here: 6 % SLOWER, unlike in gray_stream_kernel)
@@ -419,6 +414,7 @@ __global__ __launch_bounds__(64 * kFusedWaves) void gray_stream_kernel(const flo
     // request the 24 frame rows and the per-level column records of this lane (output j of the wave's run = lane j)
     const long long sx = mirror_near(ox, lv.src_w) + lv.src_x0;
     float in[R + 8];
+    float in_last = 0.0f, xcol = 0.0f;   // pass 1's sixth taps: stream row R + 8 and the column right of the wave's 64 (unit_taps6)
     int gx0[G], gn[G], glane[G];
     float gw[G][6];
 #pragma unroll
@@ -433,6 +429,8 @@ __global__ __launch_bounds__(64 * kFusedWaves) void gray_stream_kernel(const flo
 #pragma unroll
         for (int i = 0; i < R + 8; ++i)
             in[i] = src[(long long)(mirror_near(y0 - 4 + i, lv.src_h) + lv.src_y0) * W + sx];
+        in_last = src[(long long)(mirror_near(y0 + R + 4, lv.src_h) + lv.src_y0) * W + sx];
+        xcol = unit_edge_column(src, W, xw0 + 60, lv.src_w, lv.src_x0, y0 - 4, R + 9, lv.src_h, lv.src_y0, lane);
 #pragma unroll
         for (int g = 0; g < G; ++g) {
             const int gg = min(g, st.G - 1);
@@ -453,6 +451,7 @@ __global__ __launch_bounds__(64 * kFusedWaves) void gray_stream_kernel(const flo
     if (!live) return;
 #pragma unroll
     for (int i = 0; i < R + 8; ++i) asm volatile("" ::"v"(in[i]));  // retire loads before the first store
+    asm volatile("" : "+v"(in_last), "+v"(xcol));
 #pragma unroll
     for (int g = 0; g < G; ++g) {
         asm volatile("" ::"v"(glane[g]));
@@ -521,10 +520,10 @@ __global__ __launch_bounds__(64 * kFusedWaves) void gray_stream_kernel(const flo
     // instruction, scripts/ubench/valu_rate.hip), and the ~50 SGPRs they would take no longer force reloads of
     // the weights from the kernarg segment in every row.
     constexpr bool VW = K <= 4;
-    float wv[5], csw[9], endw[VW ? 9 * K : 1];
+    float wv[6], csw[9], endw[VW ? 9 * K : 1];
 #pragma unroll
-    for (int j = 0; j < 5; ++j) {
-        wv[j] = tab.wx[j];  // the unit level's taps are the same on both axes ([1,26,66,26,1]/120)
+    for (int j = 0; j < 6; ++j) {
+        wv[j] = tab.wx[j];  // the unit level's taps are the same on both axes ([1,26,66,26,1]/120 and scipy's sixth, 2^-53)
         if constexpr (VW) asm volatile("" : "+v"(wv[j]));
     }
 #pragma unroll
@@ -554,32 +553,26 @@ __global__ __launch_bounds__(64 * kFusedWaves) void gray_stream_kernel(const flo
     // is not VALU-bound any more.  Parking 4 finished rows of the 1-channel maps in consumed LDS rows and writing them with one
     // global_store_dwordx4 per 4 rows -- 24 instead of 48 stores per tile -- was 3.5 % slower in an alternating A/B.)
     {
-        float hw[5] = {0, 0, 0, 0, 0};
+        float hw[6] = {0, 0, 0, 0, 0, 0};
         float iw[3][3], cw[3][3];
 #pragma unroll
         for (int a = 0; a < 3; ++a)
 #pragma unroll
             for (int b = 0; b < 3; ++b) iw[a][b] = cw[a][b] = 0.0f;
 #pragma unroll
-        for (int i = 0; i < R + 8; ++i) {
+        for (int i = 0; i < R + 9; ++i) {
             {
-                const float c0 = s_rows[wave][i][lane];
-                const float l1 = from_lane_below(c0), l2 = from_lane_below(l1);
-                const float r1 = from_lane_above(c0), r2 = from_lane_above(r1);
-                float h = wv[0] * l2;
-                h = __builtin_fmaf(wv[1], l1, h);
-                h = __builtin_fmaf(wv[2], c0, h);
-                h = __builtin_fmaf(wv[3], r1, h);
-                h = __builtin_fmaf(wv[4], r2, h);
+                const float c0 = i < R + 8 ? s_rows[wave][i < R + 8 ? i : 0][lane] : in_last;   // (the last row stayed in a register)
+                const float h = unit_taps6(c0, unit_edge(xcol, i), wv);
 #pragma unroll
-                for (int j = 0; j < 4; ++j) hw[j] = hw[j + 1];
-                hw[4] = h;
+                for (int j = 0; j < 5; ++j) hw[j] = hw[j + 1];
+                hw[5] = h;
             }
-            if (i >= 4) {
-                const int p = y0 + i - 6;
+            if (i >= 5) {
+                const int p = y0 + i - 7;
                 float v = wv[0] * hw[0];
 #pragma unroll
-                for (int j = 1; j < 5; ++j) v = __builtin_fmaf(wv[j], hw[j], v);
+                for (int j = 1; j < 6; ++j) v = __builtin_fmaf(wv[j], hw[j], v);
                 v = (p >= 0 && p < eff_h && col_eff) ? v : 0.0f;
                 if (p >= y0 && p < y0 + R && p < lv.out_h) {  // wave-uniform
                     float* __restrict__ prow = pyr + (wave_px + (long long)p * lv.out_w);
@@ -594,8 +587,8 @@ __global__ __launch_bounds__(64 * kFusedWaves) void gray_stream_kernel(const flo
                 iw[2][0] = from_lane_below(v);
                 iw[2][2] = from_lane_above(v);
             }
-            if (i >= 6) {
-                const int c = y0 + i - 7;
+            if (i >= 7) {
+                const int c = y0 + i - 8;
                 float acc = 0.0f;
 #pragma unroll
                 for (int dy = 0; dy < 3; ++dy)
@@ -612,8 +605,8 @@ __global__ __launch_bounds__(64 * kFusedWaves) void gray_stream_kernel(const flo
                 cw[2][0] = from_lane_below(cs);
                 cw[2][2] = from_lane_above(cs);
             }
-            if (i >= 8) {
-                const int y = y0 + i - 8;
+            if (i >= 9) {
+                const int y = y0 + i - 9;
                 if (y < lv.out_h) {  // wave-uniform
                     const long long row_px = wave_px + (long long)y * lv.out_w;
                     if (cs_out) {
@@ -773,26 +766,20 @@ __global__ __launch_bounds__(64 * kFusedWaves) void pyramid_stream_kernel(const 
             }
         }
 
-        // ---- pass 1: the unit level (same fma order as pyramid_unit_kernel)
-        float hw[5] = {0, 0, 0, 0, 0};
+        // ---- pass 1: the unit level (same fma order as pyramid_unit_kernel).  The tile's 24 rows and the wave's 4 halo lanes per
+        // side hold scipy's sixth taps (row p + 3, column x + 3) of every output without extra loads: no edge column here
+        float hw[6] = {0, 0, 0, 0, 0, 0};
 #pragma unroll
         for (int i = 0; i < R + 8; ++i) {
-            const float c0 = s_rows[wave][i][lane];
-            const float l1 = from_lane_below(c0), l2 = from_lane_below(l1);
-            const float r1 = from_lane_above(c0), r2 = from_lane_above(r1);
-            float h = tab.wx[0] * l2;
-            h = __builtin_fmaf(tab.wx[1], l1, h);
-            h = __builtin_fmaf(tab.wx[2], c0, h);
-            h = __builtin_fmaf(tab.wx[3], r1, h);
-            h = __builtin_fmaf(tab.wx[4], r2, h);
+            const float h = unit_taps6<false>(s_rows[wave][i][lane], 0.0f, tab.wx);
 #pragma unroll
-            for (int j = 0; j < 4; ++j) hw[j] = hw[j + 1];
-            hw[4] = h;
-            if (i >= 6 && i < R + 6) {
-                const int p = y0 + i - 6;
+            for (int j = 0; j < 5; ++j) hw[j] = hw[j + 1];
+            hw[5] = h;
+            if (i >= 7 && i < R + 7) {
+                const int p = y0 + i - 7;
                 float v = tab.wy[0] * hw[0];
 #pragma unroll
-                for (int j = 1; j < 5; ++j) v = __builtin_fmaf(tab.wy[j], hw[j], v);
+                for (int j = 1; j < 6; ++j) v = __builtin_fmaf(tab.wy[j], hw[j], v);
                 v = (p < eff_h && col_eff) ? v : 0.0f;
                 if (p < lv.out_h && out_lane) pyr[(base_px + (long long)p * lv.out_w + ox) * C + ch] = v;
             }

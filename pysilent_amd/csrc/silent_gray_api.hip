@@ -85,7 +85,7 @@ static int gray_pass_parts(silent_ctx* ctx, const silent_pyramid_plan* plan, con
         if (d.kind != kPyrUnit) continue;
         is_unit[l] = true;
         if (ft.n == 0)
-            for (int j = 0; j < 5; ++j) {  // every unit level has the same [1,26,66,26,1]/120 taps
+            for (int j = 0; j < 6; ++j) {  // every unit level has the same taps ([1,26,66,26,1]/120 and the sixth, 2^-53)
                 ft.wx[j] = plan->unit_w[j];
                 ft.wy[j] = plan->unit_w[j];
             }

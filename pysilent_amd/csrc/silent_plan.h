@@ -12,7 +12,7 @@ struct silent_pyramid_plan {
     silent::PyrTab tab{};
     std::vector<silent_extent> extents;
     void* tables = nullptr;
-    float unit_w[5] = {0, 0, 0, 0, 0};  // taps of a unit-zoom level ([1,26,66,26,1]/120 as float32)
+    float unit_w[6] = {0, 0, 0, 0, 0, 0};  // scipy's six taps of a unit-zoom level ([1,26,66,26,1]/120 and 2^-53, as float32)
     // single-read "stream" path (gray_stream_kernel): row programs + column records, when the plan is eligible
     bool stream_ok = false;
     void* stream_tables = nullptr;

@@ -83,8 +83,8 @@ __device__ __forceinline__ int mirror_index(int i, int n) {
 
 // ------------------------------------------------------------------------------------------ UNIT
 // A wave owns 64 source columns (60 outputs) and walks down kUnitTH rows: per row one coalesced load of
-// its own column (all rows requested up front), four DPP shifts for the +-1 / +-2 neighbours, 5 horizontal
-// FMAs, a 5-row register window, 5 vertical FMAs, one store.
+// its own column (all rows requested up front), DPP shifts for the neighbours x - 2 .. x + 3, 6 horizontal
+// FMAs, a 6-row register window, 6 vertical FMAs, one store (scipy's six taps at zoom 1: unit_taps6, silent_gray.h).
 template <int C>
 __global__ __launch_bounds__(256) void pyramid_unit_kernel(const float* __restrict__ frames,
                                                            float* __restrict__ pyr, const PyrTab tab) {
@@ -111,50 +111,49 @@ __global__ __launch_bounds__(256) void pyramid_unit_kernel(const float* __restri
     const float* __restrict__ src = frames + (long long)frame * tab.H * W * C;
     float* __restrict__ dst = pyr + ((long long)frame * tab.frame_px_out + tab.px_off[l]) * C;
 
-    float wx[5], wy[5];
+    float wx[6], wy[6];
 #pragma unroll
-    for (int i = 0; i < 5; ++i) {
+    for (int i = 0; i < 6; ++i) {
         wx[i] = tab.xw[(long long)lv.xtab_off * 6 + i];
         wy[i] = tab.yw[(long long)lv.ytab_off * 6 + i];
     }
     const long long sx = (long long)(mirror_near(ox, lv.src_w) + lv.src_x0) * C;
-    float in[R + 4][C];
+    float in[R + 5][C];                                   // stream rows y0 - 2 .. y0 + R + 2
+    float xcol[C];                                        // the column right of the wave's 64: lane 61's sixth tap, row i in lane i
 #pragma unroll
-    for (int i = 0; i < R + 4; ++i) {
+    for (int i = 0; i < R + 5; ++i) {
         const long long sy = mirror_near(y0 - 2 + i, lv.src_h) + lv.src_y0;
 #pragma unroll
         for (int ch = 0; ch < C; ++ch) in[i][ch] = src[sy * W * C + sx + ch];
     }
+#pragma unroll
+    for (int ch = 0; ch < C; ++ch)
+        xcol[ch] = unit_edge_column(src + ch, (long long)W * C, xw0 + 62, lv.src_w, lv.src_x0, y0 - 2, R + 5, lv.src_h, lv.src_y0, lane, C);
     // retire the loads before the first store (see gray_line_end_kernel)
 #pragma unroll
-    for (int i = 0; i < R + 4; ++i)
+    for (int i = 0; i < R + 5; ++i)
 #pragma unroll
         for (int ch = 0; ch < C; ++ch) asm volatile("" ::"v"(in[i][ch]));
+#pragma unroll
+    for (int ch = 0; ch < C; ++ch) asm volatile("" : "+v"(xcol[ch]));
 
     const bool out_lane = lane >= 2 && lane < 2 + kUnitCols && ox < lv.out_w;
-    float hw[5][C];
+    float hw[6][C];
 #pragma unroll
-    for (int j = 0; j < 5; ++j)
+    for (int j = 0; j < 6; ++j)
 #pragma unroll
         for (int ch = 0; ch < C; ++ch) hw[j][ch] = 0.0f;
 #pragma unroll
-    for (int i = 0; i < R + 4; ++i) {
+    for (int i = 0; i < R + 5; ++i) {
 #pragma unroll
         for (int ch = 0; ch < C; ++ch) {
-            const float c0 = in[i][ch];
-            const float l1 = from_lane_below(c0), l2 = from_lane_below(l1);
-            const float r1 = from_lane_above(c0), r2 = from_lane_above(r1);
-            float h = wx[0] * l2;
-            h = __builtin_fmaf(wx[1], l1, h);
-            h = __builtin_fmaf(wx[2], c0, h);
-            h = __builtin_fmaf(wx[3], r1, h);
-            h = __builtin_fmaf(wx[4], r2, h);
+            const float h = unit_taps6(in[i][ch], unit_edge(xcol[ch], i), wx);
 #pragma unroll
-            for (int j = 0; j < 4; ++j) hw[j][ch] = hw[j + 1][ch];
-            hw[4][ch] = h;
+            for (int j = 0; j < 5; ++j) hw[j][ch] = hw[j + 1][ch];
+            hw[5][ch] = h;
         }
-        if (i >= 4) {
-            const int oy = y0 + i - 4;
+        if (i >= 5) {
+            const int oy = y0 + i - 5;
             if (oy < lv.out_h && out_lane) {
                 const bool live = oy < lv.zoom_h && ox < lv.zoom_w;
                 float* __restrict__ po = dst + ((long long)oy * lv.out_w + ox) * C;
@@ -162,7 +161,7 @@ __global__ __launch_bounds__(256) void pyramid_unit_kernel(const float* __restri
                 for (int ch = 0; ch < C; ++ch) {
                     float v = wy[0] * hw[0][ch];
 #pragma unroll
-                    for (int j = 1; j < 5; ++j) v = __builtin_fmaf(wy[j], hw[j][ch], v);
+                    for (int j = 1; j < 6; ++j) v = __builtin_fmaf(wy[j], hw[j][ch], v);
                     po[ch] = live ? v : 0.0f;
                 }
             }

@@ -2,6 +2,8 @@
 // (float64 tap tables, scipy-identical; row programs and column records of the single-read kernels) and their launches.
 #include "silent_plan.h"
 
+#include <limits>
+
 using namespace silent;
 
 // ------------------------------------------------------------------------------------------ pyramid plan
@@ -41,7 +43,12 @@ static void axis_table(int n_in, int n_out, int* base, int* idx, float* wts) {
         if (c >= 0.0 && c <= (double)(n_in - 1)) spline5_weights(c - (double)b, w);
         base[o] = (int)b;
         for (int j = 0; j < 6; ++j) {
-            wts[6 * o + j] = (float)w[j];
+            // a weight that is not 0 in scipy's double arithmetic must not become 0 in float32: an outer tap's (1 - t)^5 / 120 falls
+            // below 2^-149 when t rounds to just under 1, and 0 * inf = NaN where scipy has tiny * inf = inf.  The smallest float32
+            // magnitude keeps the sign and the non-finite arithmetic; next to finite pixels it is as invisible as the true weight
+            float f = (float)w[j];
+            if (w[j] != 0.0 && f == 0.0f) f = std::copysign(std::numeric_limits<float>::denorm_min(), (float)(w[j] < 0.0 ? -1.0 : 1.0));
+            wts[6 * o + j] = f;
             idx[6 * o + j] = host_mirror(b - 2 + j, n_in);
         }
     }
@@ -120,10 +127,17 @@ SILENT_EXPORT int silent_pyramid_plan_create(silent_ctx* ctx, int frame_h, int f
         d.yreg_off = (int)yreg.size();
         if (unit) {
             unit_tiles += (long long)tab.unit_tiles_x[l] * ((d.out_h + kUnitTH - 1) / kUnitTH);
-            for (int j = 0; j < 5; ++j) plan->unit_w[j] = xwl[j];
+            for (int j = 0; j < 6; ++j) plan->unit_w[j] = xwl[j];
             continue;
         }
         ++tab.n_general;
+        // scipy's mode-'constant' artefact: the last output coordinate (n_out - 1) * step can round to just above n_in - 1, and the
+        // whole row / column is then cval = 0 WITHOUT a pixel being read (axis_table leaves its six weights 0) -- a NaN / inf pixel
+        // under it stays out of the level.  0 * NaN would not: such a row / column leaves the resampler and joins the zero fill of
+        // "canvas beyond the zoomed crop" (pyramid_zero_kernel); d.zoom_* from here on = the outputs the resampler produces
+        auto dead = [](const float* w6) { return w6[0] == 0.0f && w6[1] == 0.0f && w6[2] == 0.0f && w6[3] == 0.0f && w6[4] == 0.0f && w6[5] == 0.0f; };
+        if (d.zoom_w > 1 && dead(xwl + (size_t)(d.zoom_w - 1) * 6)) --d.zoom_w;
+        if (d.zoom_h > 1 && dead(ywl + (size_t)(d.zoom_h - 1) * 6)) --d.zoom_h;
         // outputs are owned by the region that holds their ANCHOR = floor(source coordinate), frame coordinates
         const int zc = std::min(d.zoom_w, d.out_w), zr = std::min(d.zoom_h, d.out_h);
         int o = 0;
@@ -437,7 +451,7 @@ SILENT_EXPORT int silent_pyramid_plan_create(silent_ctx* ctx, int frame_h, int f
             wa.W = tab.W;
             wa.n_plans = (int)hp.size();
             wa.frame_px = tab.frame_px_out;
-            for (int j = 0; j < 5; ++j) wa.wx[j] = plan->unit_w[j];
+            for (int j = 0; j < 6; ++j) wa.wx[j] = plan->unit_w[j];
             plan->walk = wa;
             plan->walk_px = px;
             plan->walk_G = Gp;
@@ -527,7 +541,7 @@ int launch_pyramid(silent_ctx* ctx, const char* who, const silent_pyramid_plan* 
         FusedTab ft;
         std::memset(&ft, 0, sizeof(ft));
         ft.n = 1;
-        for (int j = 0; j < 5; ++j) ft.wx[j] = ft.wy[j] = plan->unit_w[j];
+        for (int j = 0; j < 6; ++j) ft.wx[j] = ft.wy[j] = plan->unit_w[j];
         FusedLevel& f = ft.lv[0];
         f.src_y0 = d.src_y0; f.src_x0 = d.src_x0; f.src_h = d.src_h; f.src_w = d.src_w;
         f.zoom_h = d.zoom_h; f.zoom_w = d.zoom_w; f.out_h = d.out_h; f.out_w = d.out_w;

@@ -56,7 +56,7 @@ struct WalkTab {
     int out_h, out_w, eff_h, eff_w;      // canvas, and the part of it the zoomed crop covers
     int strips_x, segs_y, seg_rows;      // decomposition: block = (frame, segment of seg_rows output rows, strip)
     long long frame_px, px_off;          // pixels of one pyramid, offset of the unit level in it
-    float wx[5];                         // [1, 26, 66, 26, 1] / 120 as float32 (both axes)
+    float wx[6];                         // [1, 26, 66, 26, 1] / 120 and scipy's sixth tap, 2^-53, as float32 (both axes)
 };
 
 // compile-time loop: the body gets its index as an integral constant
@@ -109,7 +109,7 @@ struct Walk3Args {
     int H, W;                            // frame extents
     int n_plans, blocks_per_frame;
     long long frame_px;                  // pixels of one pyramid
-    float wx[5];                         // [1, 26, 66, 26, 1] / 120 as float32 (both axes)
+    float wx[6];                         // [1, 26, 66, 26, 1] / 120 and scipy's sixth tap, 2^-53, as float32 (both axes)
     Walk3Plan plan[kW3MaxPlans];
 };
 // row record of the walk: [meta(0) .. meta(Gp-1)] [6 weights of level 0] ... [6 weights of level Gp-1], padded to a multiple
@@ -197,7 +197,9 @@ __global__ __launch_bounds__(kW3Threads) void pyramid_walk3_kernel(const float* 
     // across the lanes: the ring reads and the line writes are free of bank conflicts (floats 2 lane, 2 lane + 1 gave 2-way
     // conflicts on every ds_read_b32: SQ_LDS_BANK_CONFLICT was 1.6x the LDS instruction cycles), and a store instruction writes
     // 256 contiguous bytes without any alignment condition on the level
-    int off[2][5];                                              // ring offsets of the 5 horizontal taps (pixel - 2 .. + 2) of each float
+    // ring offsets (in floats, < kW3RowF) of the 6 horizontal taps (pixel - 2 .. + 3) of each float, two per register: six taps in
+    // the registers five took (at 7 waves / SIMD the kernel has 72)
+    unsigned offp[2][3];
     int px[2];
 #pragma unroll
     for (int k = 0; k < 2; ++k) {
@@ -205,8 +207,11 @@ __global__ __launch_bounds__(kW3Threads) void pyramid_walk3_kernel(const float* 
         const int p = wx0 - kW3TileL + i / 3, c = i % 3;
         px[k] = p;
 #pragma unroll
-        for (int d = 0; d < 5; ++d)
-            off[k][d] = min(max((mirror_near(p + d - 2, tab.src_w) - R0) * 3 + c + tab.shift, 0), kW3RowF - 1);
+        for (int d = 0; d < 6; d += 2) {
+            const int lo = min(max((mirror_near(p + d - 2, tab.src_w) - R0) * 3 + c + tab.shift, 0), kW3RowF - 1);
+            const int hi = min(max((mirror_near(p + d - 1, tab.src_w) - R0) * 3 + c + tab.shift, 0), kW3RowF - 1);
+            offp[k][d >> 1] = (unsigned)lo | ((unsigned)hi << 16);
+        }
     }
     const bool out0 = px[0] >= wx0 && px[0] < wx0 + kW3Px && px[0] < tab.out_w;
     const bool out1 = px[1] >= wx0 && px[1] < wx0 + kW3Px && px[1] < tab.out_w && lane + 64 < kW3TileF;
@@ -240,9 +245,9 @@ __global__ __launch_bounds__(kW3Threads) void pyramid_walk3_kernel(const float* 
     }
     const int gj = lane / 3, gc = lane - 3 * gj;               // gather role: output pixel gj, channel gc
 
-    float hw[5][2];                                             // horizontally smoothed rows y-4 .. y of the two floats
+    float hw[6][2];                                             // horizontally smoothed rows y-5 .. y of the two floats
 #pragma unroll
-    for (int j = 0; j < 5; ++j) hw[j][0] = hw[j][1] = 0.0f;
+    for (int j = 0; j < 6; ++j) hw[j][0] = hw[j][1] = 0.0f;
 
     int slot = 0;
     for (int c = 0; c < n_chunks; ++c) {
@@ -254,11 +259,14 @@ __global__ __launch_bounds__(kW3Threads) void pyramid_walk3_kernel(const float* 
                 const int s = c * kW3CH + r;                  // stream row; source row y = seg_y0 - 4 + s
                 if (s >= n_rows) break;                         // wave-uniform
                 const float* __restrict__ row = &s_ring[slot * kW3CH + r][0];
-                float t[2][5];
+                float t[2][6];
 #pragma unroll
-                for (int k = 0; k < 2; ++k)
+                for (int k = 0; k < 2; ++k) {
 #pragma unroll
-                    for (int d = 0; d < 5; ++d) t[k][d] = row[off[k][d]];
+                    for (int j = 0; j < 3; ++j) asm volatile("" : "+v"(offp[k][j]));   // (unpacked here, per row: hoisted, the halves take 12 registers again)
+#pragma unroll
+                    for (int d = 0; d < 6; ++d) t[k][d] = row[(offp[k][d >> 1] >> ((d & 1) * 16)) & 0xffffu];
+                }
                 const int* __restrict__ prow = s_prog + (slot * kW3CH + r) * PR;
                 int meta_v[(G + 3) / 4 * 4];
 #pragma unroll
@@ -266,7 +274,8 @@ __global__ __launch_bounds__(kW3Threads) void pyramid_walk3_kernel(const float* 
                     const int4 q = reinterpret_cast<const int4*>(prow)[e];   // every lane reads the same record (LDS broadcast)
                     meta_v[4 * e] = q.x; meta_v[4 * e + 1] = q.y; meta_v[4 * e + 2] = q.z; meta_v[4 * e + 3] = q.w;
                 }
-                // ---- unit level: horizontal 5 taps (same fma order as pyramid_unit_kernel), then the vertical window
+                // ---- unit level: scipy's six horizontal taps x - 2 .. x + 3 (same fma order as pyramid_unit_kernel / unit_taps6:
+                // the sixth, 2^-53, carries a NaN / inf pixel to the outputs three to its left and above), then the vertical window
                 if (has_unit) {
 #pragma unroll
                 for (int k = 0; k < 2; ++k) {
@@ -275,16 +284,17 @@ __global__ __launch_bounds__(kW3Threads) void pyramid_walk3_kernel(const float* 
                     h = __builtin_fmaf(args.wx[2], t[k][2], h);
                     h = __builtin_fmaf(args.wx[3], t[k][3], h);
                     h = __builtin_fmaf(args.wx[4], t[k][4], h);
+                    h = __builtin_fmaf(args.wx[5], t[k][5], h);
 #pragma unroll
-                    for (int j = 0; j < 4; ++j) hw[j][k] = hw[j + 1][k];
-                    hw[4][k] = h;
+                    for (int j = 0; j < 5; ++j) hw[j][k] = hw[j + 1][k];
+                    hw[5][k] = h;
                 }
                 }
-                const int p = seg_y0 + s - 6;                   // level-0 row that completes with source row y = p + 2
+                const int p = seg_y0 + s - 7;                   // level-0 row that completes with source row y = p + 3
                 if (has_unit && p >= seg_y0 && p < seg_y0 + seg_h) {        // wave-uniform (rows above are warm-up)
                     float v0 = args.wx[0] * hw[0][0], v1 = args.wx[0] * hw[0][1];
 #pragma unroll
-                    for (int j = 1; j < 5; ++j) {
+                    for (int j = 1; j < 6; ++j) {
                         v0 = __builtin_fmaf(args.wx[j], hw[j][0], v0);
                         v1 = __builtin_fmaf(args.wx[j], hw[j][1], v1);
                     }

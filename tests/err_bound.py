@@ -125,6 +125,6 @@ def gray_chain(level, cs_kernel, end_bank, cs_map, e_x=None):
 def zoom(level, extra=4):
     """Bound for a pyramid level: the quintic B-spline's 36 weights are >= 0, so S = sum w |x| is the zoom of |x| -- for the
     non-negative frames of this path the level itself; 6 + 6 separable taps and the float32 weights: c = 12 + extra."""
-    # (+ 1e-12: at zoom 1 the kernels drop the sixth tap, whose float64 weight is a ~1e-18 residue of the partition of unity
-    # that SciPy still multiplies: differences of ~1e-16 on a black pixel next to a bright one)
-    return np.minimum((12 + extra) * U * np.abs(np.nan_to_num(np.asarray(level, np.float64), nan=BIG, posinf=BIG, neginf=BIG)) + 1e-12, BIG)
+    # (no absolute slack: at zoom 1 the kernels evaluate scipy's sixth tap too -- its weight, 2^-53, is what a black pixel three
+    # left of / above a bright one holds in the reference)
+    return np.minimum((12 + extra) * U * np.abs(np.nan_to_num(np.asarray(level, np.float64), nan=BIG, posinf=BIG, neginf=BIG)), BIG)

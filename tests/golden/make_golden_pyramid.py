@@ -10,7 +10,8 @@ was written against -- and whose `empty` is zero-filled, so that canvas pixels t
 (they are uninitialised in the reference; the oracle and the product define them as 0).  scipy.ndimage.zoom itself is
 the real one.  Inert `tensorflow` modules as in make_golden.py (the package imports it at module scope).
 
-Stores float32 inputs and float64 outputs for a few small cases in tests/golden/pyramid.npz.
+Stores float32 inputs and float64 outputs for a few small cases in tests/golden/pyramid.npz (two of them with NaN / inf pixels:
+the reference's own outputs pin the footprint of a non-finite pixel, scipy's six taps per axis at zoom 1).
 Usage:  PYTHONDONTWRITEBYTECODE=1 python tests/golden/make_golden_pyramid.py
 """
 import importlib
@@ -83,6 +84,29 @@ def main():
         out[name + "_out"] = np.asarray(z, np.float64)
         out[name + "_par"] = np.array([center[0], center[1], scale], np.float64)
         print("%-14s in %s -> %s" % (name, img.shape, z.shape))
+    # Non-finite pixels (round 5): NaN / -NaN / +-inf at the corners, on the edges and inside the innermost crop (level 0 is that crop
+    # at zoom 1: scipy's SIX taps carry each of them to a 6 x 6 block of outputs, rows / columns p - 3 .. p + 2), next to each other,
+    # and outside it (only the outer levels see those).  Own generator: the cases above keep their values.
+    rng2 = np.random.default_rng(12)
+    neg_nan = np.frombuffer(np.uint32(0xffc00000).tobytes(), np.float32)[0]
+    for name, (h, w, c, center, scale) in {"nonfinite_rgb": (60, 80, 3, (36, 24), math.e ** 0.5),
+                                            "nonfinite_gray": (50, 70, 1, (20, 15), 1.5)}.items():
+        img = rng2.integers(0, 256, (h, w, c)).astype(np.float32)
+        y0, x0 = int(max((h - center[1]) / 2, 0)), int(max((w - center[0]) / 2, 0))   # the innermost crop (from_image.py:50-51)
+        y1, x1 = int((h + center[1]) / 2) - 1, int((w + center[0]) / 2) - 1
+        spots = [(y0, x0, np.nan), (y0, x1, np.inf), (y1, x0, -np.inf), (y1, x1, neg_nan),            # its four corners
+                 (y0, (x0 + x1) // 2, np.inf), ((y0 + y1) // 2, x1, np.nan),                          # edges
+                 ((y0 + y1) // 2, (x0 + x1) // 2, -np.inf), ((y0 + y1) // 2, (x0 + x1) // 2 + 1, np.inf),   # neighbours, opposite signs
+                 (y0 + 4, x0 + 5, np.nan), (y1 - 3, x1 - 3, np.inf),                                  # 3 from the far edges: the sixth tap's reach
+                 (1, 2, np.nan), (h - 2, w - 3, np.inf)]                                              # outside the innermost crop
+        for i, (y, x, v) in enumerate(spots):
+            img[y, x, i % c] = v
+        with np.errstate(invalid="ignore"):
+            z = mod.image_to_zoom_tensor(img.view(OldIndexing), c, list(center), scale)
+        out[name + "_in"] = img
+        out[name + "_out"] = np.asarray(z, np.float64)
+        out[name + "_par"] = np.array([center[0], center[1], scale], np.float64)
+        print("%-14s in %s -> %s, %d non-finite outputs in level 0" % (name, img.shape, z.shape, int((~np.isfinite(z[0])).sum())))
     # zoom_tensor_to_image_list (util/zoom/to_image_list.py:7-15), same indexing idiom, same shim: the display glue of f-3
     tl = importlib.import_module("slam_recognition.util.zoom.to_image_list")
     tl.np = mod.np

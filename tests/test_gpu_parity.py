@@ -1161,34 +1161,100 @@ def test_gray_pass_tiny_and_tile_boundary_frames(rt, kernels, shape, n):
                                 kernels["end4"], "tiny %d" % l)
 
 
-def test_gray_pass_nan_and_inf_propagate_like_the_oracle(rt, kernels):
-    """Non-finite values: a NaN stays a NaN through relu / clip (Eigen's (x < 0) ? 0 : x), +inf clips to 255, and the
-    single-read kernel agrees with the two-step path bit for bit (NaN payloads aside).
-    Documented deviation: at zoom 1 scipy still multiplies the exactly-zero 6th spline tap, so a
-    non-finite FRAME pixel poisons a 6 x 6 neighbourhood there and 5 x 5 here."""
+def _nonfinite_frame(seed, h, w, c):
+    """Noise frame with NaN / -NaN / +-inf pixels where the unit-level kernels' sixth taps come from somewhere special: the frame's
+    corners and edges (mirrored taps: the pixel 3 from the far edge is the last output's sixth tap), the column right of a wave's 64
+    lanes and the row below a tile's 24 streamed rows (gray_stream_kernel: 56-column wave tiles, 16-row tiles), neighbours of
+    opposite sign (inf - inf), and a 2^-53 leak: a lone huge pixel on a black patch."""
+    img = noise_frame(seed, h, w, c)
+    neg_nan = np.frombuffer(np.uint32(0xffc00000).tobytes(), np.float32)[0]
+    spots = [(0, 0, np.nan), (0, w - 1, np.inf), (h - 1, 0, -np.inf), (h - 1, w - 1, neg_nan), (h - 4, w - 4, np.inf), (3, 3, -np.inf),
+             (h // 2, 0, np.nan), (0, w // 2, np.inf), (h // 2, w - 1, -np.inf), (h - 1, w // 2, np.nan)]
+    for x in (55, 56, 59, 60, 61, 116, 224 + 60):        # around the edge column of the first waves / the first block
+        if x < w - 8:
+            spots.append((min(h - 6, 9 + (x % 7)), x, np.inf if x % 2 else np.nan))
+    for y in (15, 16, 19, 20, 21, 36):                   # around the extra streamed row of the first tile rows
+        if y < h - 8 and w > 40:
+            spots.append((y, 30 + (y % 5), -np.inf if y % 2 else np.nan))
+    if h > 60 and w > 100:
+        spots += [(h // 2 + 7, w // 2, np.inf), (h // 2 + 7, w // 2 + 1, -np.inf)]
+        img[h // 2 - 20:h // 2 - 8, 20:36] = 0.0
+        spots.append((h // 2 - 14, 30, 3e38))
+    for i, (y, x, v) in enumerate(spots):
+        img[y, x, i % c] = v
+    return img
+
+
+@pytest.mark.parametrize("shape,scale,n,K", [((96, 160, 1), 2.0, 3, 4), ((135, 300, 1), 2.0, 8, 8), ((135, 300, 1), math.e ** .5, 5, 3),
+                                             ((100, 260, 1), 1.2, 3, 8),
+                                             ((109, 216, 1), 2.0, 4, 4)])   # levels whose last row / column is scipy's mode-'constant' artefact
+def test_gray_pass_nonfinite_pixels_reach_scipys_six_taps(rt, kernels, shape, scale, n, K):
+    """A NaN / inf FRAME pixel poisons what it poisons in the reference: at zoom 1 scipy.ndimage.zoom(order=5) multiplies SIX taps per
+    axis (from_image.py:55-59; the sixth weight is 2^-53), so the pixel reaches the level-0 outputs p - 3 .. p + 2 of both axes, and
+    everything downstream of them.  Whole maps against the oracle (scipy itself + the filters): same NaN pattern, same infinities,
+    finite values inside their bounds -- on the single-read stream kernel <K, 4> / <K, 7>, the unit-fused + region path (zoom step
+    1.2) and the two-step path, which must agree with each other bit for bit."""
     from pysilent_amd.util.zoom.from_image import classic_levels
-    frame = noise_frame(3, 96, 160, 1)
-    bad = frame.copy()
-    bad[10, 20, 0] = np.nan
-    bad[50, 100, 0] = np.inf
-    bad[70, 5, 0] = -np.inf
-    plan = rt.PyramidPlan(96, 160, 1, classic_levels((96, 160), 2.0, 3))
-    assert plan.streamable
-    got = plan.gray_pass(bad[None], kernels["cs_gray"], kernels["end4"])
+    bad = _nonfinite_frame(3, *shape)
+    plan = rt.PyramidPlan(shape[0], shape[1], 1, classic_levels(shape[:2], scale, n))
+    assert plan.streamable == (scale > 1.25)
+    bank = kernels["end%d" % K]
+    got = plan.gray_pass(bad[None], kernels["cs_gray"], bank)
     pyr2 = plan.run(bad[None])
-    two = (pyr2,) + tuple(rt.gray_line_end(pyr2, kernels["cs_gray"], kernels["end4"]))
+    two = (pyr2,) + tuple(rt.gray_line_end(pyr2, kernels["cs_gray"], bank))
     for a, b in zip(got, two):
         np.testing.assert_array_equal(np.isnan(a.data), np.isnan(b.data))
         np.testing.assert_array_equal(np.nan_to_num(a.data, nan=-1.0), np.nan_to_num(b.data, nan=-1.0))
-    want = so.classic_pyramid(bad, 2.0, 3)
-    far = np.ones((96, 160), bool)                 # outside scipy's 6 x 6 footprint (outputs p-3 .. p+2) of each bad pixel
-    for y, x in ((10, 20), (50, 100), (70, 5)):
-        far[max(y - 3, 0):y + 3, max(x - 3, 0):x + 3] = False
+    with rt.tuning(TUNE_PYRAMID, 1):                     # unit + region kernels instead of pyramid_stream_kernel
+        pyr3 = plan.run(bad[None])
+    np.testing.assert_array_equal(np.nan_to_num(pyr3.data, nan=-1.0), np.nan_to_num(pyr2.data, nan=-1.0))
+    with np.errstate(invalid="ignore", over="ignore"):
+        want = so.classic_pyramid(bad, scale, n)
+        chain = so.gray_line_end_pass(want, kernels["cs_gray"], bank)
+    # the footprint itself, spelled out on the isolated interior NaNs: outputs p - 3 .. p + 2 on both axes, in scipy and here
     g0, w0 = got[0].level(0)[0, :, :, 0], want[0][0, :, :, 0]
-    assert np.isfinite(g0[far]).all() and np.isfinite(w0[far]).all()
-    assert_close(g0[far], w0[far], RTOL, scale=255.0, what="level 0 away from the bad pixels")
-    assert np.isnan(g0[8:13, 18:23]).all() and np.isnan(w0[7:13, 17:23]).all()   # 5 x 5 here, 6 x 6 in scipy
-    assert np.isposinf(g0[48:53, 98:103]).all()
+    nonfin = ~np.isfinite(bad[:, :, 0])
+    seen = 0
+    for y, x in zip(*np.nonzero(np.isnan(bad[:, :, 0]))):
+        if 8 <= y < shape[0] - 8 and 8 <= x < shape[1] - 8 and nonfin[y - 7:y + 8, x - 7:x + 8].sum() == 1:
+            for m in (g0, w0):
+                assert np.isnan(m[y - 3:y + 3, x - 3:x + 3]).all() and np.isfinite(m[y - 4:y + 4, x - 4]).all()
+                assert np.isfinite(m[y - 4, x - 4:x + 4]).all() and np.isfinite(m[y + 3, x - 4:x + 4]).all() and np.isfinite(m[y - 4:y + 4, x + 3]).all()
+            seen += 1
+    assert seen >= 2
+    for l, (wcs, wend) in enumerate(chain):
+        with np.errstate(invalid="ignore", over="ignore"):
+            assert_gray_level_close(got[0].level(l)[0:1], got[1].level(l)[0:1], got[2].level(l)[0:1], want[l], wcs, wend,
+                                    kernels["cs_gray"], bank, "nonfinite %d" % l)
+
+
+def test_rgb_pyramids_nonfinite_pixels_reach_scipys_six_taps(rt):
+    """The same on three channels: the strip-walk kernel (classic pyramid: 36 pixels per wave; zoom step e^0.5: 32) and the unit +
+    region kernels agree bit for bit and show scipy's footprint."""
+    from pysilent_amd.util.zoom.from_image import classic_levels
+    # (135 x 240 at e^0.5: an outer weight of the last column underflows float32 -- the host keeps it non-zero so that inf * w stays
+    # inf; 109 x 220: level 1's last column and level 2 / 3's last rows are scipy's mode-'constant' artefact, exactly 0 whatever the
+    # pixels under them hold)
+    for shape, scale, n in (((96, 160, 3), 2.0, 4), ((135, 240, 3), math.e ** .5, 5), ((109, 220, 3), 2.0, 4)):
+        bad = _nonfinite_frame(5, *shape)
+        plan = rt.PyramidPlan(shape[0], shape[1], 3, classic_levels(shape[:2], scale, n))
+        assert plan.walk_plans[0] == 1
+        pyr = plan.run(bad[None])
+        with rt.tuning(TUNE_PYRAMID, 2):
+            pyr2 = plan.run(bad[None])
+        np.testing.assert_array_equal(np.nan_to_num(pyr.data, nan=-1.0), np.nan_to_num(pyr2.data, nan=-1.0))
+        with np.errstate(invalid="ignore", over="ignore"):
+            want = so.classic_pyramid(bad, scale, n)
+            for l in range(n):
+                assert_close(pyr.level(l)[0:1], want[l], RTOL, scale=255.0, what="rgb nonfinite pyramid %d" % l, bound=eb.zoom(want[l]))
+
+
+def test_gray_filters_nan_and_inf_propagate_like_the_oracle(rt, kernels):
+    """Non-finite values injected into a finite pyramid: a NaN stays a NaN through relu / clip (Eigen's (x < 0) ? 0 : x), +inf clips
+    to 255 -- every level, against the oracle."""
+    from pysilent_amd.util.zoom.from_image import classic_levels
+    frame = noise_frame(3, 96, 160, 1)
+    plan = rt.PyramidPlan(96, 160, 1, classic_levels((96, 160), 2.0, 3))
     # the filters themselves: non-finite values injected into a finite pyramid, every level, against the oracle
     pyr = plan.run(frame[None])
     levels = [np.array(pyr.level(l)) for l in range(3)]
