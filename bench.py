@@ -274,20 +274,35 @@ def cpu_baseline(wl, consts, budget_s=12.0):
 
 # ------------------------------------------------------------------------------------------ one rank
 
+def overlap_policy(world):
+    """Whether consecutive steps may overlap on two streams: SILENT_OVERLAP=off|on|auto.  Default: "auto" on one GPU (the pipeline
+    measures stream pairs against its one-stream step and keeps what wins), "off" on N > 1 -- every rank then runs the same,
+    deterministic one-stream step, and N tuners do not time their candidates beside each other on a shared host.  "on" = "auto"
+    (a pair is never kept unmeasured)."""
+    v = os.environ.get("SILENT_OVERLAP", "").strip().lower()
+    if v in ("off", "0", "false", "no"):
+        return False
+    if v in ("on", "auto", "1", "true", "yes"):
+        return "auto"
+    return "auto" if world == 1 else False
+
+
+def placement_policy():
+    """SILENT_PLACEMENT=off: keep the first allocation of the maps; default: LineEndPipeline.tune_placement draws a few."""
+    return os.environ.get("SILENT_PLACEMENT", "").strip().lower() not in ("off", "0", "false", "no")
+
+
 def make_pipeline(wl, B, local, consts, **over):
+    """The pipeline of a workload, UNTUNED (one stream, first allocation): tune_pipeline() does the measuring once the caller's
+    frames are resident."""
     from pysilent_amd.pipeline import LineEndPipeline
     h, w = wl["hw"]
-    # "auto": the pipeline times a few stream pairs against its one-stream step when it is built and keeps what wins (gray: the
-    # stream kernel of batch n + 1 beside the filter kernel of batch n; rgb: the pyramid beside chain + tail)
-    kw = {"overlap": "auto"}
+    kw = {}
     if wl["mode"] == "rgb":
         # config 3 returns line_end + keypoints (+ orient, optional in SURVEY.md section 8d): the value map and the selection's
         # peak-value map are intermediates the fused step never writes (silent_rgb_keypoints: extrema in the chain kernel,
-        # sparse keypoint tail).  overlap: consecutive steps overlap on the pipeline's two streams (the pyramid of batch n + 1
-        # beside the chain + keypoint tail of batch n; every step still enqueues the whole path of its batch)
-        # "auto": the pipeline times a few stream pairs against its one-stream step when it is built and keeps what wins (which
-        # streams of the process's pool a pipeline draws decides whether two streams pay: scripts/ab_overlap_pool.py)
-        kw = {"selection": True, "value_map": False, "peak_value_map": False, "overlap": "auto"}
+        # sparse keypoint tail)
+        kw = {"selection": True, "value_map": False, "peak_value_map": False}
     if "center" in wl:
         kw.update(center_dimensions=wl["center"], scale=wl["scale"])
     kw.update(over)
@@ -296,6 +311,18 @@ def make_pipeline(wl, B, local, consts, **over):
     # cap would drop rows inside the timed region (round 3's 1 << 16 did)
     return LineEndPipeline((h, w), mode=wl["mode"], n_levels=wl["n_levels"], n_orient=wl["n_orient"], batch=B,
                            device=local, constants=consts, **kw)
+
+
+def tune_pipeline(pipe, frames, overlap, placement=True):
+    """Outside every timed region, once per pipeline: (1) placement -- the maps are allocated a few times and the fastest set is
+    kept (the physical pages an allocation lands on move the same kernel by up to 20 %: LineEndPipeline.tune_placement,
+    profiles/r05/placement.md); (2) overlap="auto" -- candidate stream pairs against the one-stream step, consecutive batches
+    overlap on two streams only where that measurably pays (gray: the stream kernel of batch n + 1 beside the filter kernel of
+    batch n; rgb: the pyramid beside chain + tail).  Both leave their record on the pipeline; results never depend on either."""
+    if placement:
+        pipe.tune_placement(frames)
+    if overlap:
+        pipe.tune_overlap(frames)
 
 
 def make_frames(torch, D, wl, B, rank, world, dev):
@@ -439,9 +466,11 @@ def side_workload(torch, D, name, local, dev, rank, world, label=None, **over):
     wl = WORKLOADS[name]
     B = wl["frames"]
     consts = D.broadcast_constants(wl["mode"], wl["n_orient"], device=local)
+    overlap = over.pop("overlap", overlap_policy(world))
     pipe = make_pipeline(wl, B, local, consts, **over)
     frames = make_frames(torch, D, wl, B, rank, world, dev)
     torch.cuda.synchronize(dev)
+    tune_pipeline(pipe, frames, overlap, placement_policy())
     # settle first: building the pipeline and the synthetic frames leaves the GPU idle for a second or two, and the
     # first ~20 launches after an idle period run inside the power-management transient (profiles/r02/launch_drift.txt)
     steps = 30
@@ -461,6 +490,7 @@ def side_workload(torch, D, name, local, dev, rank, world, label=None, **over):
                       else "one: every launch of a step back to back")
     if pipe.overlap_tuning:
         out["overlap_tuning"] = pipe.overlap_tuning
+    out["placement_tuning"] = pipe.placement_tuning
     if wl["mode"] == "rgb":
         pipe.step(frames)
         pipe.wait()
@@ -534,10 +564,12 @@ def whole_job_mpx(frames_per_rank_per_step, world, steps, h, w, slowest_rank_sec
     return frames_per_rank_per_step * world * steps * h * w / slowest_rank_seconds / 1e6
 
 
-def dist_record(D, rank, local, ident, own_ms):
+def dist_record(D, rank, local, ident, own_ms, **extra):
     """all_gather of one record per rank -> the ``dist`` object of the JSON line; exits non-zero (every rank) when two
-    ranks report the same GPU: N ranks must have seen N distinct devices."""
+    ranks report the same GPU: N ranks must have seen N distinct devices.  ``extra``: what this rank's tuners decided (streams,
+    placement) and how long it settled."""
     rec = dict(rank=rank, local_rank=local, host=socket.gethostname(), pid=os.getpid(), ms_per_step=round(own_ms, 4), **ident)
+    rec.update(extra)
     recs = sorted(D.gather_records(rec), key=lambda r: r["rank"])
     dup = D.duplicate_devices(recs) if os.environ.get("SILENT_BENCH_SHARE_GPU") != "1" else []
     out = {"backend": D.backend_name(), "world_size": len(recs), "distinct_devices": len({r["pci_bus_id"] for r in recs}),
@@ -570,7 +602,8 @@ def dry_run(args):
     slow = D.max_over_ranks(1.0 + rank)
     same = os.environ.get("SILENT_BENCH_DRY_SAME_BUS") == "1"
     ident = {"device_name": "dry-run (no GPU)", "pci_bus_id": "dry:%02d" % (0 if same else rank), "uuid": "", "gcn_arch": ""}
-    dist = dist_record(D, rank, local, ident, 1.0 + rank)
+    dist = dist_record(D, rank, local, ident, 1.0 + rank, settle_steps_run=0, streams="one", overlap_policy=str(overlap_policy(world)),
+                       placement_chosen_ms=None, placement_tries_ms=None)
     if rank == 0:
         h, w = wl["hw"]
         # every rank "processed" 4 frames per step in (1 + rank) seconds: value = SUM of frames over ranks / MAX time
@@ -621,9 +654,10 @@ def run_rank(args):
     c = 1 if wl["mode"] == "gray" else 3
     # working set per rank well beyond the 256 MiB Infinity Cache (hard part 6)
     B = args.frames or wl["frames"]
-    pipe = make_pipeline(wl, B, local, consts, **({"overlap": False} if args.one_stream else {}))
+    pipe = make_pipeline(wl, B, local, consts)
     frames = make_frames(torch, D, wl, B, rank, world, dev)
     torch.cuda.synchronize(dev)
+    tune_pipeline(pipe, frames, False if args.one_stream else overlap_policy(world), placement_policy() and not args.no_placement)
 
     settle_run, settle_ms = settle(torch, pipe, frames, dev)
     elapsed = timed_steps(torch, D, pipe, frames, args.steps, args.warmup, dev)
@@ -639,7 +673,11 @@ def run_rank(args):
     dom = dominant_kernel(torch, pipe, frames, wl, B, dev)
     ingest = ingest_record(torch, pipe, frames, wl, B, dev) if world == 1 and not args.no_ingest else None
     # the scaling record proves itself: backend, and per rank the device it ran on and its own step time
-    dist = dist_record(D, rank, local, D.device_identity(local), own_ms)
+    dist = dist_record(D, rank, local, D.device_identity(local), own_ms,
+                       settle_steps_run=settle_run, streams="two" if pipe.overlap else "one",
+                       overlap_policy=str(False if args.one_stream else overlap_policy(world)),
+                       placement_chosen_ms=(pipe.placement_tuning or {}).get("chosen_ms"),
+                       placement_tries_ms=(pipe.placement_tuning or {}).get("tries_ms"))
     if rank != 0:
         D.finalize()
         return
@@ -674,6 +712,8 @@ def run_rank(args):
                    "streams": ("two (overlap): first half of batch n + 1 beside the second half of batch n" if pipe.overlap
                                else "one: every launch of a step back to back"),
                    "overlap_tuning": pipe.overlap_tuning,
+                   "overlap_policy": "SILENT_OVERLAP=%s -> %s" % (os.environ.get("SILENT_OVERLAP", "(unset)"), False if args.one_stream else overlap_policy(world)),
+                   "placement_tuning": pipe.placement_tuning,
                    "sharding": "frame i -> rank i mod N; one RCCL broadcast of constants at init",
                    "csrc_revision": csrc_revision()},
         "roofline": roofline_of(dom, B),
@@ -718,6 +758,7 @@ def main(argv=None):
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-side-workloads", action="store_true")
     ap.add_argument("--no-ingest", action="store_true")
+    ap.add_argument("--no-placement", action="store_true", help="keep the first allocation of the maps (no tune_placement)")
     ap.add_argument("--one-stream", action="store_true",
                     help="every launch of a step back to back on one stream (no overlap between consecutive steps); what the rocprofv3 "
                          "per-kernel traces are taken with -- overlapped kernels stretch each other's durations")

@@ -37,7 +37,7 @@
 extern "C" {
 #endif
 
-#define SILENT_ABI_VERSION 1
+#define SILENT_ABI_VERSION 2
 #define SILENT_MAX_LEVELS 16
 #define SILENT_MAX_KERNEL_FLOATS 784 /* kh*kw*C_in*C_out limit (weights travel as kernel arguments) */
 
@@ -91,6 +91,10 @@ int silent_memcpy_d2h(silent_ctx* ctx, void* dst_host, const void* src_dev, size
 int silent_gather_d2h(silent_ctx* ctx, void* dst_host, const void* const* src_dev, const size_t* bytes, int n,
                       silent_stream stream);
 int silent_synchronize(silent_ctx* ctx, silent_stream stream);
+/* Occupies `stream` for about `microseconds` (one wavefront polling the constant-rate clock; <= 1 s): the probe a host
+ * uses to find out whether two streams really run side by side (pysilent_amd.pipeline.pick_concurrent_stream).  No
+ * counterpart in the reference (it has one stream: tf.device('/device:GPU:0'), recognition_testing.py:64). */
+int silent_busy_wait_dev(silent_ctx* ctx, unsigned microseconds, silent_stream stream);
 
 /* ---------------------------------------------------------------------------- a-1 pyramid
  * Replaces image_to_zoom_tensor, slam_recognition/util/zoom/from_image.py:10-69: per level a crop of

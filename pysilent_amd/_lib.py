@@ -31,7 +31,7 @@ MAX_LEVELS = 16
 TUNE_GRAY, TUNE_RGB, TUNE_PYRAMID = 0, 1, 2
 GRAY_PART_PYRAMID, GRAY_PART_FILTER = 1, 2
 DT_U8, DT_F32, DT_F64, DT_I32, DT_U16, DT_I16, DT_I64 = 0, 1, 2, 3, 4, 5, 6
-ABI_VERSION = 1
+ABI_VERSION = 2
 
 
 class Extent(C.Structure):
@@ -84,6 +84,7 @@ _SIGNATURES = {
     "silent_memcpy_h2d": [_vp, _vp, _vp, _sz, _vp],
     "silent_memcpy_d2h": [_vp, _vp, _vp, _sz, _vp],
     "silent_synchronize": [_vp, _vp],
+    "silent_busy_wait_dev": [_vp, _u, _vp],
     "silent_pyramid_plan_create": [_vp, _i, _i, _i, C.POINTER(PyrLevel), _i, C.POINTER(_vp)],
     "silent_pyramid_plan_destroy": [_vp],
     "silent_pyramid": [_vp, _vp, _fp, _i, _fp],

@@ -265,6 +265,27 @@ SILENT_EXPORT int silent_profile_elapsed_ms(silent_ctx* ctx, float* ms, int64_t*
     return on_exception(ctx, "silent_profile_elapsed_ms");
 }
 
+// One wavefront polling the constant-rate clock (100 MHz on gfx950: s_memrealtime) until `ticks` have passed.  Bounded by the
+// host (<= 1 s), so every wave reaches its exit.
+__global__ __launch_bounds__(64) void busy_wait_kernel(unsigned long long ticks) {
+    const unsigned long long t0 = wall_clock64();
+    while (wall_clock64() - t0 < ticks) __builtin_amdgcn_s_sleep(32);
+}
+
+SILENT_EXPORT int silent_busy_wait_dev(silent_ctx* ctx, unsigned microseconds, silent_stream stream) try {
+    NEED_CTX(ctx);
+    if (microseconds > 1000000u) return fail(ctx, SILENT_E_INVALID, "silent_busy_wait: at most 1 000 000 microseconds");
+    int khz = 100000;   // wall_clock64 ticks per millisecond
+    if (hipDeviceGetAttribute(&khz, hipDeviceAttributeWallClockRate, ctx->device) != hipSuccess || khz <= 0) {
+        (void)hipGetLastError();
+        khz = 100000;
+    }
+    hipLaunchKernelGGL(busy_wait_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, (unsigned long long)microseconds * (unsigned long long)khz / 1000ull);
+    return check_launch(ctx, "silent_busy_wait");
+} catch (...) {
+    return on_exception(ctx, "silent_busy_wait_dev");
+}
+
 // ------------------------------------------------------------------------------------------ tile tables
 
 // tile_h == 0 selects the 1-D "chunk" decomposition (kChunk flattened pixels per block; tile_w > 0: that many).

@@ -385,6 +385,35 @@ struct StreamTab {
     int out_w[8];
 };
 
+// A lane's column record of general level g: where its run of outputs starts, how many outputs the wave has, and for output
+// `lane` of the run the lane that holds tap 0 (as a ds_bpermute byte index) + the 6 horizontal weights.
+struct StreamCol {
+    int x0, n, lane4;
+    float w[6];
+};
+__device__ __forceinline__ StreamCol stream_col(const StreamTab& st, int g, int wx_tile, int lane) {
+    const int gg = min(g, st.G - 1);
+    const int* __restrict__ h = st.col_hdr + ((long long)gg * st.waves_x + wx_tile) * 2;
+    const int4* __restrict__ rec = reinterpret_cast<const int4*>(st.col_rec + (((long long)gg * st.waves_x + wx_tile) * 64 + lane) * 8);
+    const int4 a = rec[0], b = rec[1];
+    StreamCol c;
+    c.x0 = h[0];
+    c.n = g < st.G ? h[1] : 0;
+    c.lane4 = a.x * 4;
+    c.w[0] = __int_as_float(a.y);
+    c.w[1] = __int_as_float(a.z);
+    c.w[2] = __int_as_float(a.w);
+    c.w[3] = __int_as_float(b.x);
+    c.w[4] = __int_as_float(b.y);
+    c.w[5] = __int_as_float(b.z);
+    return c;
+}
+// The first kStreamRegLevels general levels keep their column records in registers for the whole tile (a row of level 0 completes
+// every other stream row); the smaller levels -- one completed row per 2, 4, 8 tiles -- fetch theirs when a row completes.  With all
+// seven resident the <K, 7> instantiations sat at 125 VGPRs = 4 waves / SIMD (63 registers of records); now they run at the <K, 4>
+// instantiations' 5 - 6 waves (profiles/r05_config5/README.md).
+constexpr int kStreamRegLevels = 3;
+
 template <int K, int G>
 __global__ __launch_bounds__(64 * kFusedWaves) void gray_stream_kernel(const float* __restrict__ frames, float* __restrict__ pyr,
                                                           float* __restrict__ cs_out, float* __restrict__ end_out,
@@ -415,15 +444,15 @@ __global__ __launch_bounds__(64 * kFusedWaves) void gray_stream_kernel(const flo
     const long long sx = mirror_near(ox, lv.src_w) + lv.src_x0;
     float in[R + 8];
     float in_last = 0.0f, xcol = 0.0f;   // pass 1's sixth taps: stream row R + 8 and the column right of the wave's 64 (unit_taps6)
-    int gx0[G], gn[G], glane[G];
-    float gw[G][6];
+    constexpr int GR = G < kStreamRegLevels ? G : kStreamRegLevels;
+    StreamCol col[GR];
 #pragma unroll
     for (int i = 0; i < R + 8; ++i) in[i] = 0.0f;
 #pragma unroll
-    for (int g = 0; g < G; ++g) {
-        gx0[g] = gn[g] = glane[g] = 0;
+    for (int g = 0; g < GR; ++g) {
+        col[g].x0 = col[g].n = col[g].lane4 = 0;
 #pragma unroll
-        for (int j = 0; j < 6; ++j) gw[g][j] = 0.0f;
+        for (int j = 0; j < 6; ++j) col[g].w[j] = 0.0f;
     }
     if (live) {
 #pragma unroll
@@ -432,31 +461,17 @@ __global__ __launch_bounds__(64 * kFusedWaves) void gray_stream_kernel(const flo
         in_last = src[(long long)(mirror_near(y0 + R + 4, lv.src_h) + lv.src_y0) * W + sx];
         xcol = unit_edge_column(src, W, xw0 + 60, lv.src_w, lv.src_x0, y0 - 4, R + 9, lv.src_h, lv.src_y0, lane);
 #pragma unroll
-        for (int g = 0; g < G; ++g) {
-            const int gg = min(g, st.G - 1);
-            const int* __restrict__ h = st.col_hdr + ((long long)gg * st.waves_x + wx_tile) * 2;
-            gx0[g] = h[0];
-            gn[g] = g < st.G ? h[1] : 0;
-            const int4* __restrict__ rec = reinterpret_cast<const int4*>(st.col_rec + (((long long)gg * st.waves_x + wx_tile) * 64 + lane) * 8);
-            const int4 a = rec[0], b = rec[1];
-            glane[g] = a.x * 4;  // byte index for ds_bpermute
-            gw[g][0] = __int_as_float(a.y);
-            gw[g][1] = __int_as_float(a.z);
-            gw[g][2] = __int_as_float(a.w);
-            gw[g][3] = __int_as_float(b.x);
-            gw[g][4] = __int_as_float(b.y);
-            gw[g][5] = __int_as_float(b.z);
-        }
+        for (int g = 0; g < GR; ++g) col[g] = stream_col(st, g, wx_tile, lane);
     }
     if (!live) return;
 #pragma unroll
     for (int i = 0; i < R + 8; ++i) asm volatile("" ::"v"(in[i]));  // retire loads before the first store
     asm volatile("" : "+v"(in_last), "+v"(xcol));
 #pragma unroll
-    for (int g = 0; g < G; ++g) {
-        asm volatile("" ::"v"(glane[g]));
+    for (int g = 0; g < GR; ++g) {
+        asm volatile("" ::"v"(col[g].lane4));
 #pragma unroll
-        for (int j = 0; j < 6; ++j) asm volatile("" ::"v"(gw[g][j]));
+        for (int j = 0; j < 6; ++j) asm volatile("" ::"v"(col[g].w[j]));
     }
 #pragma unroll
     for (int i = 0; i < R + 8; ++i) s_rows[wave][i][lane] = in[i];
@@ -502,11 +517,12 @@ __global__ __launch_bounds__(64 * kFusedWaves) void gray_stream_kernel(const flo
 #pragma unroll
                 for (int k = 1; k < stream_slots(g); ++k) v = done == k ? vacc[g][k] : v;
                 const int vbits = __float_as_int(v);
-                float acc = gw[g][0] * __int_as_float(__builtin_amdgcn_ds_bpermute(glane[g], vbits));
+                const StreamCol cr = g < GR ? col[g < GR ? g : 0] : stream_col(st, g, wx_tile, lane);   // (g is a constant here)
+                float acc = cr.w[0] * __int_as_float(__builtin_amdgcn_ds_bpermute(cr.lane4, vbits));
 #pragma unroll
                 for (int t = 1; t < 6; ++t)
-                    acc = __builtin_fmaf(gw[g][t], __int_as_float(__builtin_amdgcn_ds_bpermute(glane[g] + 4 * t, vbits)), acc);
-                if (lane < gn[g]) pyr[frame_px0 + st.px_off[g] + (long long)oy * st.out_w[g] + gx0[g] + lane] = acc;
+                    acc = __builtin_fmaf(cr.w[t], __int_as_float(__builtin_amdgcn_ds_bpermute(cr.lane4 + 4 * t, vbits)), acc);
+                if (lane < cr.n) pyr[frame_px0 + st.px_off[g] + (long long)oy * st.out_w[g] + cr.x0 + lane] = acc;
             }
         }
 #pragma unroll
@@ -681,24 +697,10 @@ __global__ __launch_bounds__(64 * kFusedWaves) void pyramid_stream_kernel(const 
     const long long base_px = frame_px0 + lv.px_off;
     const long long sx = (long long)(mirror_near(ox, lv.src_w) + lv.src_x0) * C;
 
-    int gx0[G], gn[G], glane[G];
-    float gw[G][6];
+    constexpr int GR = G < kStreamRegLevels ? G : kStreamRegLevels;
+    StreamCol col[GR];
 #pragma unroll
-    for (int g = 0; g < G; ++g) {
-        const int gg = min(g, st.G - 1);
-        const int* __restrict__ h = st.col_hdr + ((long long)gg * st.waves_x + wx_tile) * 2;
-        gx0[g] = h[0];
-        gn[g] = g < st.G ? h[1] : 0;
-        const int4* __restrict__ rec = reinterpret_cast<const int4*>(st.col_rec + (((long long)gg * st.waves_x + wx_tile) * 64 + lane) * 8);
-        const int4 a = rec[0], b = rec[1];
-        glane[g] = a.x * 4;
-        gw[g][0] = __int_as_float(a.y);
-        gw[g][1] = __int_as_float(a.z);
-        gw[g][2] = __int_as_float(a.w);
-        gw[g][3] = __int_as_float(b.x);
-        gw[g][4] = __int_as_float(b.y);
-        gw[g][5] = __int_as_float(b.z);
-    }
+    for (int g = 0; g < GR; ++g) col[g] = stream_col(st, g, wx_tile, lane);
     const int eff_h = min(lv.zoom_h, lv.out_h), eff_w = min(lv.zoom_w, lv.out_w);
     const bool col_eff = ox >= 0 && ox < eff_w;
     const bool out_lane = lane >= 4 && lane < 4 + kFusedCols && ox < lv.out_w;
@@ -752,12 +754,13 @@ __global__ __launch_bounds__(64 * kFusedWaves) void pyramid_stream_kernel(const 
 #pragma unroll
                         for (int k = 1; k < stream_slots(g); ++k) v = done == k ? vacc[g][k] : v;
                         const int vbits = __float_as_int(v);
-                        float acc = gw[g][0] * __int_as_float(__builtin_amdgcn_ds_bpermute(glane[g], vbits));
+                        const StreamCol cr = g < GR ? col[g < GR ? g : 0] : stream_col(st, g, wx_tile, lane);   // (g is a constant here)
+                        float acc = cr.w[0] * __int_as_float(__builtin_amdgcn_ds_bpermute(cr.lane4, vbits));
 #pragma unroll
                         for (int q = 1; q < 6; ++q)
-                            acc = __builtin_fmaf(gw[g][q], __int_as_float(__builtin_amdgcn_ds_bpermute(glane[g] + 4 * q, vbits)), acc);
-                        if (lane < gn[g])
-                            pyr[(frame_px0 + st.px_off[g] + (long long)oy * st.out_w[g] + gx0[g] + lane) * C + ch] = acc;
+                            acc = __builtin_fmaf(cr.w[q], __int_as_float(__builtin_amdgcn_ds_bpermute(cr.lane4 + 4 * q, vbits)), acc);
+                        if (lane < cr.n)
+                            pyr[(frame_px0 + st.px_off[g] + (long long)oy * st.out_w[g] + cr.x0 + lane) * C + ch] = acc;
                     }
                 }
 #pragma unroll

@@ -96,6 +96,7 @@ void __hipUnregisterFatBinary(void**) {}
 #undef hipGetDeviceProperties
 #define hipGetDeviceProperties(p, d) silent_host::Props(p)
 #define hipOccupancyMaxActiveBlocksPerMultiprocessor(out, ...) (*(out) = 5, hipSuccess)
+#define hipDeviceGetAttribute(v, a, d) (*(v) = 100000, hipSuccess)
 #define hipEventCreate(e) (*(e) = (hipEvent_t)(size_t)1, hipSuccess)
 #define hipEventDestroy(e) ((void)(e), hipSuccess)
 #define hipEventRecord(e, s) ((void)(e), (void)(s), hipSuccess)

@@ -53,20 +53,21 @@ def unpack_constants(blob, layout):
     return out
 
 
-def _spin_ms(torch, dev, streams, cycles):
-    """Wall time of one spin kernel (torch.cuda._sleep: a single thread counting clock cycles) on each of ``streams`` at once."""
+def _spin_ms(torch, dev, streams, microseconds):
+    """Wall time of one busy-wait kernel (silent_busy_wait_dev: one wavefront polling the clock) on each of ``streams`` at once."""
     import time
+    ctx = _runtime.get_context(dev.index)
+    lib = _lib.load()
     torch.cuda.synchronize(dev)
     t0 = time.perf_counter()
     for st in streams:
-        with torch.cuda.stream(st):
-            torch.cuda._sleep(cycles)
+        ctx.check(lib.silent_busy_wait_dev(ctx.handle, int(microseconds), C.c_void_p(st.cuda_stream)))
     for st in streams:
         st.synchronize()
     return (time.perf_counter() - t0) * 1e3
 
 
-def pick_concurrent_stream(torch, dev, beside, priority=0, tries=10, cycles=1 << 17):
+def pick_concurrent_stream(torch, dev, beside, priority=0, tries=10, microseconds=400):
     """A new stream whose work really runs CONCURRENTLY with the streams in ``beside``.  HIP multiplexes streams onto a few
     hardware queues, and two streams that share one are served strictly in order -- "overlap" through such a pair is a loss
     (cross-stream events, no concurrency), and which pairs share is a property of the process's stream pool, not of the
@@ -74,13 +75,13 @@ def pick_concurrent_stream(torch, dev, beside, priority=0, tries=10, cycles=1 <<
     measured: a spin kernel on the candidate and on every stream of ``beside`` at once must take about as long as one alone
     (about a millisecond each).  A NECESSARY check only: pairs that pass it can still stall each other through the real step's
     cross-stream events -- tune_overlap times the real thing.  Returns (stream, verified); after ``tries`` candidates the last one
-    is returned unverified."""
-    one = min(_spin_ms(torch, dev, beside[:1] or [torch.cuda.current_stream(dev)], cycles) for _ in range(2))
+    is returned unverified (callers keep the flag: LineEndPipeline.overlap_verified)."""
+    one = min(_spin_ms(torch, dev, beside[:1] or [torch.cuda.current_stream(dev)], microseconds) for _ in range(2))
     cand = None
     keep = []                                  # rejected candidates stay alive until the choice is made (the pool hands out new ones)
     for _ in range(tries):
         cand = torch.cuda.Stream(dev, priority=priority)
-        together = min(_spin_ms(torch, dev, list(beside) + [cand], cycles) for _ in range(2))
+        together = min(_spin_ms(torch, dev, list(beside) + [cand], microseconds) for _ in range(2))
         if together < 1.5 * one:
             return cand, True
         keep.append(cand)
@@ -111,7 +112,7 @@ class LineEndPipeline(object):
     def __init__(self, frame_hw, mode="gray", n_levels=5, scale=2.0, n_orient=4, batch=1, device=None,
                  constants=None, center_dimensions=None, clip_hi=255.0, flat_policy="ieee", pad=2,
                  max_keypoints_per_frame=None, selection=False, top_percent=0.1, keep_selection_maps=False, value_map=True,
-                 peak_value_map=True, orient_map=True, overlap=False, overlap_priorities=True):
+                 peak_value_map=True, orient_map=True, overlap=False, overlap_priorities=True, placement=None):
         import torch
         self.torch = torch
         self.mode = mode
@@ -139,36 +140,34 @@ class LineEndPipeline(object):
         self.clip_hi, self.flat_policy, self.pad = float(clip_hi), flat_policy, int(pad)
         n = self.batch * self.frame_px
         f32 = dict(dtype=torch.float32, device=self.tdev)
+        self.placement_tuning = None
         # overlap: consecutive steps overlap on two internal streams -- rgb: the pyramid of batch n + 1 (latency-bound walk kernel)
         # beside the chain kernel and the small launches of the keypoint tail of batch n; gray: the single-read stream kernel of
         # batch n + 1 beside the filter kernel of batch n's smaller levels.  The pyramid is then double-buffered (pipeline.pyr = the
         # last step's).  step() stays "enqueue the whole path for this batch", but on the
         # pipeline's own streams: wait() orders the caller's stream behind the results, outputs() does so itself.
-        self._overlap_auto = overlap == "auto"
+        # overlap=True and overlap="auto" both MEASURE (tune_overlap): a pair of streams that does not pay -- some pairs of a
+        # process's stream pool lose 30 - 40 % -- is never kept on faith.  overlap="force": the first pair, unmeasured (tests of
+        # the overlapped path's bit-identity, A/B scripts)
+        if overlap not in (False, True, None, "auto", "force"):
+            raise ValueError("overlap must be False, True, 'auto' or 'force'")
+        self._overlap_auto = overlap in (True, "auto")
         self._chain_priority = -1 if overlap_priorities else 0
-        self.overlap = bool(overlap)
+        self.overlap = False
+        self.overlap_verified = None
         self.overlap_tuning = None
         self._order_caller = True          # (A/B switch of scripts/ab_overlap.py: order the caller's stream behind the frame read)
-        self._pyrs = [torch.empty(n * self.channels, **f32) for _ in range(2 if self.overlap else 1)]
-        self.pyr = self._pyrs[0]
-        if self.overlap:
-            # the chain + tail of batch n are the critical path, the pyramid of batch n + 1 only has to be ready in time: the chain's
-            # stream gets the higher queue priority, the pyramid's stream is checked to run concurrently with it -- and with
-            # overlap="auto" the pair is chosen by measurement (tune_overlap)
-            self._new_stream_pair()
+        self._chain_stream = self._walk_stream = self._copy_stream = None
         if mode == "gray":
             self.n_orient = int(self.consts["end"].shape[3])
-            self.cs = torch.empty(n, **f32)
-            self.end = torch.empty(n * self.n_orient, **f32)
         else:
             # orient_map=False: SURVEY.md section 8d config 3 returns line_end + keypoints, the orientation map is optional
             self.orient_map = bool(orient_map)
-            self.orient = torch.empty(n * 3, **f32) if self.orient_map else None
-            self.line_end = torch.empty(n * 3, **f32)
             # value_map=False: the value map (a-8 of the line-end map) is not kept -- with selection the fused step needs it
             # nowhere (silent_rgb_keypoints), and BASELINE config 3 returns line_end + keypoints (+ orient) only
             self.value_map = bool(value_map) or not selection or bool(keep_selection_maps)
-            self.value = torch.empty(n, **f32) if self.value_map else None
+        self._adopt_maps(self._alloc_maps())
+        if mode != "gray":
             self.regions = (_lib.Extent * self.n_levels)(*[_lib.Extent(max(eh // 2, 1), max(ew // 2, 1))
                                                            for eh, ew in self.extents])
             # selection=True: SURVEY.md section 8d config 3 -- top-percent threshold (a-10, p = 0.1), 3x3 NMS (a-9),
@@ -192,8 +191,129 @@ class LineEndPipeline(object):
                 *[self.consts[k].ctypes.data_as(fp) for k in ("rgc", "rgby", "stripe", "blur", "end")],
                 1.0, 0.1, {"ieee": _lib.FLAT_IEEE, "zero": _lib.FLAT_ZERO}[flat_policy], self.clip_hi, self.pad)
         self._lib = _lib.load()
-        if self._overlap_auto:
+        if placement not in (None, False, "auto"):
+            raise ValueError("placement must be None or 'auto'")
+        if placement == "auto":
+            self.tune_placement()
+        if overlap == "force":
+            self._pyrs.append(torch.empty_like(self._pyrs[0]))
+            # the chain + tail of batch n are the critical path, the pyramid of batch n + 1 only has to be ready in time: the chain's
+            # stream gets the higher queue priority, the pyramid's stream is checked to run concurrently with it
+            self._new_stream_pair()
+            self.overlap = True
+        elif self._overlap_auto:
             self.tune_overlap()
+
+    # -- the maps a step streams through: pyramid + every dense output ---------------------------------
+    def _alloc_maps(self):
+        """Fresh device buffers for the pyramid and the dense maps (one allocation each; the keypoint rows and the optional
+        selection maps are not part of it)."""
+        torch = self.torch
+        n = self.batch * self.frame_px
+        f32 = dict(dtype=torch.float32, device=self.tdev)
+        m = {"pyr": torch.empty(n * self.channels, **f32)}
+        if self.mode == "gray":
+            m["cs"] = torch.empty(n, **f32)
+            m["end"] = torch.empty(n * self.n_orient, **f32)
+        else:
+            m["orient"] = torch.empty(n * 3, **f32) if self.orient_map else None
+            m["line_end"] = torch.empty(n * 3, **f32)
+            m["value"] = torch.empty(n, **f32) if self.value_map else None
+        return m
+
+    def _adopt_maps(self, m):
+        self._pyrs = [m["pyr"]] + list(getattr(self, "_pyrs", [])[1:])
+        self.pyr = self._pyrs[0]
+        for k, v in m.items():
+            if k != "pyr":
+                setattr(self, k, v)
+
+    def _time_step(self, frames, steps, windows=2):
+        import time
+        torch = self.torch
+        best = None
+        for _ in range(windows):
+            torch.cuda.synchronize(self.tdev)
+            t0 = time.perf_counter()
+            for _ in range(steps):
+                self.step(frames)
+            torch.cuda.synchronize(self.tdev)
+            t = (time.perf_counter() - t0) / steps * 1e3
+            best = t if best is None else min(best, t)
+        return best
+
+    def tune_placement(self, frames=None, tries=6, steps=10, budget_s=4.0, good_enough=None):
+        """Pick the physical placement of the maps by measurement.  The same kernel on the same buffers AT THE SAME VIRTUAL
+        ADDRESSES takes 1.23 ... 1.49 ms (config 5) from one allocation to the next: which physical pages the driver hands out
+        decides how the dozen concurrent write streams of a step fall onto the HBM channels, and nothing an unprivileged process
+        can see predicts it -- not the addresses, not the copy rate of any single buffer, not the TLB counters
+        (profiles/r05/placement.md).  So it is drawn a few times: allocate the maps, time ``steps`` steps (after a warm-up), keep
+        the fastest set, return the others to the allocator.  ``frames``: the caller's resident batch (its placement is part
+        of what is measured); default: synthetic noise.  Bounded by ``tries`` and by ``budget_s`` seconds.  Results never depend
+        on the choice.  The decision is in ``placement_tuning``."""
+        import time
+        torch = self.torch
+        if frames is None:
+            frames = torch.randint(0, 256, (self.batch,) + self.frame_shape, device=self.tdev).to(torch.float32)
+        was = self.overlap
+        self.overlap = False
+        t_start = time.perf_counter()
+        for _ in range(30):                        # past the idle -> load transient of the chip
+            self.step(frames)
+        cur = {"pyr": self._pyrs[0]}
+        cur.update({k: getattr(self, k) for k in (("cs", "end") if self.mode == "gray" else ("orient", "line_end", "value"))})
+        best = (self._time_step(frames, steps), cur)
+        tried = [round(best[0], 4)]
+        held = []                                  # the losers stay allocated while there is room: a freed block comes straight back
+        for _ in range(tries - 1):                 # from the caching allocator -- the same pages, the same time
+            if time.perf_counter() - t_start > budget_s:
+                break
+            free, total = torch.cuda.mem_get_info(self.tdev)
+            if free < total // 4:
+                held.clear()
+                torch.cuda.synchronize(self.tdev)
+                torch.cuda.empty_cache()
+            cand = self._alloc_maps()
+            self._adopt_maps(cand)
+            for _ in range(5):
+                self.step(frames)
+            t = self._time_step(frames, steps)
+            tried.append(round(t, 4))
+            if t < best[0]:
+                held.append(best[1])
+                best = (t, cand)
+            else:
+                held.append(cand)
+            torch.cuda.synchronize(self.tdev)
+            del cand
+        self._adopt_maps(best[1])
+        held.clear()
+        del cur
+        self.overlap = was
+        torch.cuda.synchronize(self.tdev)
+        torch.cuda.empty_cache()                   # the losing sets go back to the driver
+        self.placement_tuning = {"tries_ms": tried, "chosen_ms": round(best[0], 4), "seconds": round(time.perf_counter() - t_start, 2)}
+        return self.placement_tuning
+
+    def close(self):
+        """Order the caller's stream and the host behind everything the pipeline has in flight on its own streams (overlap, ingest)
+        before its buffers go back to the allocator: they were allocated on the constructor's stream, and the caching allocator
+        would hand them to the next tensor of that stream while a side stream still writes them."""
+        torch = getattr(self, "torch", None)
+        if torch is None:
+            return
+        for st in (self._chain_stream, self._walk_stream, self._copy_stream):
+            if st is not None:
+                try:
+                    st.synchronize()
+                except Exception:          # (interpreter shutdown: the runtime may be gone)
+                    pass
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
 
     def _new_stream_pair(self, flip=False):
         """flip: the FIRST half's stream (pyramid / stream kernel) at the higher priority instead of the second half's."""
@@ -205,62 +325,74 @@ class LineEndPipeline(object):
         self._pyr_free = [None, None]
         self._steps = 0
 
-    def tune_overlap(self, frames=None, candidates=8, steps=10):
-        """overlap="auto": MEASURE whether two streams pay on this device, in this process, with these streams -- and with which.
+    def tune_overlap(self, frames=None, candidates=8, steps=10, budget_s=3.0):
+        """MEASURE whether two streams pay on this device, in this process, with these streams -- and with which.
         HIP multiplexes streams onto hardware queues (and those onto the command processor's pipes); which pair of streams a
         pipeline draws from the pool decides whether the pyramid of batch n + 1 really runs beside the chain of batch n (config 3:
         -10 %) or mostly waits on it through the cross-stream events (+0 ... +40 % on the small reference layout), and no static
-        rule -- priorities, a concurrency check with independent spin kernels -- predicts it (scripts/ab_overlap_pool.py).  So a few
-        candidate pairs are timed on synthetic noise frames (``steps`` steps each, a fraction of a second once per pipeline) against
-        the one-stream step; the best pair is kept if it wins by more than 2 %, else the pipeline stays on one stream.  The
-        decision is in ``overlap_tuning``.  Results never depend on the choice (bit-identical paths)."""
+        rule -- priorities, a concurrency check with independent busy-wait kernels -- predicts it (scripts/ab_overlap_pool.py).  So
+        up to ``candidates`` pairs are timed on synthetic noise frames (``steps`` steps each, at most ``budget_s`` seconds in all)
+        against the one-stream step; then the best pair and the one-stream step are timed AGAIN, alternately, three windows each
+        (the minimum of eight candidates against a baseline timed twice is biased towards two streams), and the pair is kept only
+        if that second measurement still wins by more than 2 %.  Otherwise the pipeline stays on one stream and the second
+        pyramid buffer is released.  The decision is in ``overlap_tuning``.  Results never depend on the choice (bit-identical
+        paths)."""
         import time
         torch = self.torch
         if frames is None:
             frames = torch.randint(0, 256, (self.batch,) + self.frame_shape, device=self.tdev).to(torch.float32)
-
-        def ms():
-            best = None
-            for _ in range(2):
-                torch.cuda.synchronize(self.tdev)
-                t0 = time.perf_counter()
-                for _ in range(steps):
-                    self.step(frames)
-                torch.cuda.synchronize(self.tdev)
-                t = (time.perf_counter() - t0) / steps * 1e3
-                best = t if best is None else min(best, t)
-            return best
-
+        t_start = time.perf_counter()
         if len(self._pyrs) < 2:
             self._pyrs.append(torch.empty_like(self._pyrs[0]))
         self.overlap = False
         for _ in range(30):                        # (past the idle -> load transient of the chip: a cold baseline flatters every candidate)
             self.step(frames)
-        serial = ms()
-        tried, best = [], (serial, None)
+        serial = self._time_step(frames, steps)
+        tried, best = [], (None, None)
         for i in range(candidates):
+            if time.perf_counter() - t_start > budget_s:
+                break
             self._new_stream_pair(flip=bool(i & 1))         # (every other candidate with the priorities the other way round)
             self.overlap = True
             for _ in range(3):
                 self.step(frames)
-            t = ms()
+            t = self._time_step(frames, steps)
             tried.append(round(t, 4))
-            if t < best[0]:
-                best = (t, (self._chain_stream, self._walk_stream))
+            if best[0] is None or t < best[0]:
+                best = (t, (self._chain_stream, self._walk_stream, self.overlap_verified))
             torch.cuda.synchronize(self.tdev)
+        # the decision: winner and baseline once more, alternately
         self.overlap = False
         self.pyr = self._pyrs[0]
-        serial = min(serial, ms())                 # the one-stream step once more, now that the chip has been busy for a while
+        again_one, again_two = [], []
         if best[1] is not None and best[0] < 0.98 * serial:
-            self._new_stream_pair()
-            self._chain_stream, self._walk_stream = best[1]
+            for _ in range(3):
+                self.overlap = False
+                self.pyr = self._pyrs[0]
+                again_one.append(self._time_step(frames, steps, windows=1))
+                self._new_stream_pair()
+                self._chain_stream, self._walk_stream, self.overlap_verified = best[1]
+                self.overlap = True
+                for _ in range(3):
+                    self.step(frames)
+                again_two.append(self._time_step(frames, steps, windows=1))
+                torch.cuda.synchronize(self.tdev)
+            serial = min(again_one)
+        keep = bool(again_two) and min(again_two) < 0.98 * min(again_one)
+        if keep:
             self.overlap = True
         else:
             self.overlap = False
             self.pyr = self._pyrs[0]
+            del self._pyrs[1:]                     # one stream: the second pyramid buffer (0.7 GB at config 2) is not held for nothing
+            self._chain_stream = self._walk_stream = None
         torch.cuda.synchronize(self.tdev)
-        self.overlap_tuning = {"one_stream_ms": round(serial, 4), "two_stream_candidates_ms": tried, "chosen": "two streams" if self.overlap else "one stream",
-                               "chosen_ms": round(best[0], 4) if self.overlap else round(serial, 4)}
+        self.overlap_tuning = {"one_stream_ms": round(serial, 4), "two_stream_candidates_ms": tried,
+                               "remeasured_ms": {"one_stream": [round(t, 4) for t in again_one], "two_streams": [round(t, 4) for t in again_two]},
+                               "chosen": "two streams" if self.overlap else "one stream",
+                               "chosen_ms": round(min(again_two), 4) if self.overlap else round(serial, 4),
+                               "stream_pair_verified_concurrent": self.overlap_verified if self.overlap else None,
+                               "seconds": round(time.perf_counter() - t_start, 2)}
         return self.overlap_tuning
 
     # -- byte accounting (SURVEY.md section 8d) -------------------------------------------------------
@@ -464,7 +596,7 @@ class LineEndPipeline(object):
             # chain stream holds -1 and the copies queue with the pyramid stream, which has to follow them anyway
             self._ingest = {}
             beside = [self._chain_stream, self._walk_stream] if self.overlap else [torch.cuda.current_stream(self.tdev)]
-            self._copy_stream, _ = pick_concurrent_stream(torch, self.tdev, beside, priority=0 if self.overlap else -1)
+            self._copy_stream, self.copy_stream_verified = pick_concurrent_stream(torch, self.tdev, beside, priority=0 if self.overlap else -1)
         pinned_source = src.is_pinned()
         slot = self._ingest_slot(src.dtype, pinned_source)
         cur = torch.cuda.current_stream(self.tdev)
@@ -539,7 +671,7 @@ class LineEndPipeline(object):
                 raise ValueError("keypoint capacity exceeded: frame %d produced %d rows, max_keypoints_per_frame is %d "
                                  "(only the first %d were written; pass allow_truncated=True to take them)"
                                  % (int(np.argmax(counts)), int(counts.max()), self.kp_cap, self.kp_cap))
-            idx = self.kp_idx.cpu().numpy()
-            out["keypoints"] = [idx[f, :min(int(counts[f]), self.kp_cap)].copy() for f in range(self.batch)]
+            # (only the rows each frame produced: the buffer holds kp_cap rows per frame -- every pyramid pixel by default)
+            out["keypoints"] = [self.kp_idx[f, :min(int(counts[f]), self.kp_cap)].cpu().numpy() for f in range(self.batch)]
             out["keypoint_counts"] = counts
         return out

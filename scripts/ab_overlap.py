@@ -19,7 +19,7 @@ dev = torch.device("cuda", 0)
 consts = None
 frames = bench.make_frames(torch, D, wl, B, 0, 1, dev)
 pipes = {"serial": bench.make_pipeline(wl, B, 0, consts, overlap=False), "overlap": bench.make_pipeline(wl, B, 0, consts, overlap="auto"),
-         "overlap, first stream pair unmeasured": bench.make_pipeline(wl, B, 0, consts, overlap=True)}
+         "overlap, first stream pair unmeasured": bench.make_pipeline(wl, B, 0, consts, overlap="force")}
 print("overlap_tuning:", pipes["overlap"].overlap_tuning)
 
 

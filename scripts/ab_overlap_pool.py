@@ -30,7 +30,7 @@ print("spin kernel: one stream %.3f ms, two streams %.3f ms" % (_spin_ms(torch, 
 serial = bench.make_pipeline(wl, B, 0, None, overlap=False)
 run(serial, 40)
 for k in range(7):
-    p = bench.make_pipeline(wl, B, 0, None, overlap=os.environ.get("AB_OVERLAP", "1") == "auto" and "auto" or True)
+    p = bench.make_pipeline(wl, B, 0, None, overlap=os.environ.get("AB_OVERLAP", "1") == "auto" and "auto" or "force")
     run(p, 40)
     t_o = float(np.median([run(p, 30) for _ in range(3)]))
     t_s = float(np.median([run(serial, 30) for _ in range(3)]))

@@ -113,6 +113,43 @@ def test_bench_launcher_spawns_its_own_ranks():
         assert set(r) >= {"rank", "local_rank", "device_name", "pci_bus_id", "ms_per_step", "host", "pid"}
 
 
+def test_bench_launcher_eight_ranks_dry_run():
+    """The driver's N = 8 case rehearsed on the CPU: eight fresh rank processes, one gloo rendezvous on 127.0.0.1, the broadcast of
+    the constants, frame i -> rank i mod 8, MAX over ranks -- and every rank's record says what its tuners would run with: on N > 1
+    the overlap policy is "off" (one deterministic one-stream step per rank, no eight tuners timing candidates beside each other)
+    unless SILENT_OVERLAP says otherwise."""
+    import json
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT", "SILENT_OVERLAP")}
+    env.update(SILENT_BENCH_DRY="1", SILENT_DIST_BACKEND="gloo", SILENT_BENCH_LAUNCH_TIMEOUT="240", OMP_NUM_THREADS="1")
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "8", "--steps", "2", "--warmup", "1"],
+                       env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=400)
+    assert p.returncode == 0, p.stderr[-3000:]
+    out = json.loads([l for l in p.stdout.splitlines() if l.startswith("{")][0])
+    d = out["dist"]
+    assert out["n_gpus"] == 8 and d["world_size"] == 8 and d["distinct_devices"] == 8
+    assert [r["rank"] for r in d["ranks"]] == list(range(8)) and len({r["pid"] for r in d["ranks"]}) == 8
+    assert out["slowest_rank_time"] == 8.0 and out["frames_of_rank0"] == [0, 8, 16, 24]
+    h, w = out["frame_hw"]
+    assert out["value"] == 8 * out["frames_per_rank_per_step"] * out["steps"] * h * w / 8.0 / 1e6
+    for r in d["ranks"]:
+        assert r["overlap_policy"] == "False" and r["streams"] == "one" and "settle_steps_run" in r and "placement_chosen_ms" in r
+
+
+def test_overlap_policy_is_one_decision():
+    """SILENT_OVERLAP=off|on|auto; unset: measured ("auto") on one GPU, off on N > 1."""
+    import bench
+    old = os.environ.pop("SILENT_OVERLAP", None)
+    try:
+        assert bench.overlap_policy(1) == "auto" and bench.overlap_policy(2) is False and bench.overlap_policy(8) is False
+        for v, want in (("off", False), ("on", "auto"), ("auto", "auto"), ("0", False)):
+            os.environ["SILENT_OVERLAP"] = v
+            assert bench.overlap_policy(1) == want and bench.overlap_policy(8) == want
+    finally:
+        os.environ.pop("SILENT_OVERLAP", None)
+        if old is not None:
+            os.environ["SILENT_OVERLAP"] = old
+
+
 def test_bench_refuses_two_ranks_on_one_device():
     """Two ranks that report the same PCI bus id: exit non-zero, no JSON line."""
     env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT")}
