@@ -449,6 +449,38 @@ def ingest_record(torch, pipe, frames, wl, B, dev, steps=20):
     return out
 
 
+def latency_record():
+    """The reference's per-frame path (LineEndDisplayer.callback, recognition_testing.py:136-144: ONE camera frame per call -- host
+    uint8 frame in, the six fetched tensors in host memory out), outside every timed region: wall time per call, p50 / p99, for
+    the native displayer (silent_displayer_step: one library call, a replayed HIP graph per frame), the per-op path eager and with
+    torch's graph capture, and the device time of the native frame (events around its graph: upload to download)."""
+    from pysilent_amd.recognition_testing import LineEndDisplayer
+    out = {}
+    for name, (h, w) in (("640x480", (480, 640)), ("1920x1080", (1080, 1920))):
+        frames = [np.random.default_rng(s_).integers(0, 256, (h, w, 3)).astype(np.uint8) for s_ in range(4)]
+        rec = {"frame": "%s x 3 uint8 -> six float32 maps on the host" % name}
+        for label, kw, n in (("native", {}, 300), ("eager", {"native": False}, 60), ("graph", {"native": False, "use_graph": True}, 60)):
+            disp = LineEndDisplayer(**kw)
+            for i in range(10):
+                res = disp.callback(frames[i & 3])
+            ts, busy = [], []
+            for i in range(n):
+                t0 = time.perf_counter()
+                res = disp.callback(frames[i & 3])
+                ts.append((time.perf_counter() - t0) * 1e3)
+                if label == "native":
+                    busy.append(disp._native[1].gpu_ms)
+            rec["%s_ms_p50" % label] = round(float(np.percentile(ts, 50)), 4)
+            rec["%s_ms_p99" % label] = round(float(np.percentile(ts, 99)), 4)
+            if label == "native":
+                rec["gpu_busy_ms"] = round(float(np.median(busy)), 4)
+                rec["levels"] = len(res[1])
+                rec["result_bytes"] = int(sum(np.stack(r).nbytes for r in res[1:]))
+            del disp, res
+        out[name] = rec
+    return out
+
+
 def roofline_of(dom, B):
     gbs = dom["bytes"] / (dom["ms"] * 1e-3) / 1e9
     roof = {"bound": "hbm", "kernel": dom["kernel"], "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
@@ -672,6 +704,7 @@ def run_rank(args):
     steady = timed_steps(torch, D, pipe, frames, settle_steps, 0, dev)
     dom = dominant_kernel(torch, pipe, frames, wl, B, dev)
     ingest = ingest_record(torch, pipe, frames, wl, B, dev) if world == 1 and not args.no_ingest else None
+    latency = latency_record() if world == 1 and not args.no_latency else None
     # the scaling record proves itself: backend, and per rank the device it ran on and its own step time
     dist = dist_record(D, rank, local, D.device_identity(local), own_ms,
                        settle_steps_run=settle_run, streams="two" if pipe.overlap else "one",
@@ -718,6 +751,7 @@ def run_rank(args):
                    "csrc_revision": csrc_revision()},
         "roofline": roofline_of(dom, B),
         "ingest": ingest,
+        "latency": latency,
         "dist": dist,
         "steady_state": {"ms_per_step": round(steady / settle_steps * 1e3, 4), "steps": settle_steps,
                          "value": round(B * world * settle_steps * h * w / steady / 1e6, 2),
@@ -758,6 +792,7 @@ def main(argv=None):
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-side-workloads", action="store_true")
     ap.add_argument("--no-ingest", action="store_true")
+    ap.add_argument("--no-latency", action="store_true")
     ap.add_argument("--no-placement", action="store_true", help="keep the first allocation of the maps (no tune_placement)")
     ap.add_argument("--one-stream", action="store_true",
                     help="every launch of a step back to back on one stream (no overlap between consecutive steps); what the rocprofv3 "

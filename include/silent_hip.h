@@ -37,7 +37,7 @@
 extern "C" {
 #endif
 
-#define SILENT_ABI_VERSION 2
+#define SILENT_ABI_VERSION 3
 #define SILENT_MAX_LEVELS 16
 #define SILENT_MAX_KERNEL_FLOATS 784 /* kh*kw*C_in*C_out limit (weights travel as kernel arguments) */
 
@@ -460,6 +460,36 @@ int silent_rgb_line_end(silent_ctx* ctx, const float* pyr, const silent_extent* 
 int silent_rgb_line_end_dev(silent_ctx* ctx, const float* pyr, const silent_extent* levels, int n_levels,
                             int n_frames, const silent_rgb_chain_params* params, float* orient_out,
                             float* line_end_out, float* value_out, silent_stream stream);
+
+/* ---------------------------------------------------------------------------- one camera frame, one call
+ * LineEndDisplayer.callback + run, slam_recognition/recognition_testing.py:106-144: a frame in host memory ->
+ * np.asarray(frame, float32) (:141) -> zoom.from_image(frame, 3, output_size, zoom_ratio) (:142) -> the graph of compile()
+ * (:60-100) -> the six tensors session.run fetches (:99-100, :132), in host memory:
+ *   0 orient [L,h,w,3]   1 255 - centroids * 255 [L,h,w,1]   2 255 - centroids2 * 255 [L,h2,w2,1] (h2 = int(h / e ** .5))
+ *   3 fired * 255 [L,ch,cw,C]   4 update_importances [L,ch,cw,C]   5 padded line_end [L,h,w,3]      (ch = ceil(h / region_h);
+ *                                                                                      C = 3 with boosting.visualize, else 1)
+ * The reference pays a feed, a session.run and six fetches per frame; the displayer replays ONE HIP graph per frame (upload,
+ * ~20 kernels, download) on a stream of its own and owns every buffer, a private context and the boosting state
+ * (energy_values, :56; 8 everywhere at creation).  levels: the host's geometry of image_to_zoom_tensor (from_image.py:45-64),
+ * every level on the same canvas extent.  Not thread-safe; frames of one camera must come to one displayer, in order. */
+typedef struct silent_displayer silent_displayer;
+typedef struct silent_displayer_params {
+    int32_t frame_h, frame_w;        /* camera frame [frame_h, frame_w, 3] */
+    int32_t frame_dtype;             /* SILENT_DT_U8 (a camera's) ... SILENT_DT_F32 */
+    int32_t centroid_region_h, centroid_region_w;   /* centroid_region_shape[1:3] = 3, 3 (recognition_testing.py:38) */
+    silent_rgb_chain_params chain;   /* kernels are copied at creation */
+    silent_boosting_params boosting; /* get_boosting(..., 1, 1, recovery, True): visualize = 1 in the reference (:86) */
+} silent_displayer_params;
+int silent_displayer_create(silent_ctx* ctx, const silent_displayer_params* params, const silent_pyr_level* levels, int n_levels,
+                            silent_displayer** out);
+void silent_displayer_destroy(silent_displayer* d);
+/* shape7 = {L, h, w, ch, cw, h2, w2}; out_floats6 (may be NULL): floats of each of the six results */
+int silent_displayer_shape(const silent_displayer* d, int32_t* shape7, size_t* out_floats6);
+/* Synchronous.  results[0..5]: pointers INTO the displayer's pinned result slot, valid until the SECOND next step (two slots
+ * alternate).  gpu_ms (may be NULL): device time of the frame, upload to download. */
+int silent_displayer_step(silent_displayer* d, const void* frame_host, const float** results, float* gpu_ms);
+int silent_displayer_get_state(silent_displayer* d, float* energy_host);       /* [L, ch, cw] */
+int silent_displayer_set_state(silent_displayer* d, const float* energy_host);
 
 #ifdef __cplusplus
 }

@@ -31,7 +31,7 @@ MAX_LEVELS = 16
 TUNE_GRAY, TUNE_RGB, TUNE_PYRAMID = 0, 1, 2
 GRAY_PART_PYRAMID, GRAY_PART_FILTER = 1, 2
 DT_U8, DT_F32, DT_F64, DT_I32, DT_U16, DT_I16, DT_I64 = 0, 1, 2, 3, 4, 5, 6
-ABI_VERSION = 2
+ABI_VERSION = 3
 
 
 class Extent(C.Structure):
@@ -58,6 +58,12 @@ class BoostingParams(C.Structure):
 class AffineParams(C.Structure):
     _fields_ = [("mul", C.c_float), ("div", C.c_float), ("add", C.c_float), ("lo", C.c_float), ("hi", C.c_float),
                 ("post_add", C.c_float)]
+
+
+class DisplayerParams(C.Structure):
+    """silent_displayer_params (include/silent_hip.h)."""
+    _fields_ = [("frame_h", C.c_int32), ("frame_w", C.c_int32), ("frame_dtype", C.c_int32), ("centroid_region_h", C.c_int32),
+                ("centroid_region_w", C.c_int32), ("chain", RgbChainParams), ("boosting", BoostingParams)]
 
 
 class SilentLibraryError(RuntimeError):
@@ -138,8 +144,14 @@ _SIGNATURES = {
     "silent_rgb_chain_stream": [C.POINTER(RgbChainParams), C.c_uint, _fp, C.POINTER(C.c_int), C.POINTER(C.c_int)],
     "silent_rgb_line_end": [_vp, _fp, _ep, _i, _i, C.POINTER(RgbChainParams), _fp, _fp, _fp],
     "silent_rgb_line_end_dev": [_vp, _fp, _ep, _i, _i, C.POINTER(RgbChainParams), _fp, _fp, _fp, _vp],
+    "silent_displayer_create": [_vp, C.POINTER(DisplayerParams), C.POINTER(PyrLevel), _i, C.POINTER(_vp)],
+    "silent_displayer_destroy": [_vp],
+    "silent_displayer_shape": [_vp, C.POINTER(C.c_int32), C.POINTER(_sz)],
+    "silent_displayer_step": [_vp, _vp, C.POINTER(_vp), C.POINTER(_f)],
+    "silent_displayer_get_state": [_vp, _fp],
+    "silent_displayer_set_state": [_vp, _fp],
 }
-_RESTYPES = {"silent_destroy": None, "silent_pyramid_plan_destroy": None, "silent_last_error": C.c_char_p}
+_RESTYPES = {"silent_destroy": None, "silent_pyramid_plan_destroy": None, "silent_displayer_destroy": None, "silent_last_error": C.c_char_p}
 
 EXPORTED_SYMBOLS = tuple(sorted(_SIGNATURES))
 

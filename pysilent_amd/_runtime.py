@@ -596,6 +596,86 @@ def rgb_line_end(x, kernels, regulation_value=1.0, regulation_root=0.1, flat_pol
 
 # ----------------------------------------------------------------------------- pyramid plans
 
+class FrameDisplayer(object):
+    """silent_displayer: one camera frame -> the six fetched tensors of the reference's graph, ONE library call per frame
+    (recognition_testing.py:106-144 as a replayed HIP graph; include/silent_hip.h).  ``frame_shape`` (H, W, 3), ``dtype`` the
+    frames' NumPy dtype, ``output_size`` (w, h) and ``zoom_ratio`` as PyramidDisplayer takes them."""
+
+    _DT = {"uint8": _lib.DT_U8, "float32": _lib.DT_F32, "float64": _lib.DT_F64, "int32": _lib.DT_I32, "uint16": _lib.DT_U16,
+           "int16": _lib.DT_I16, "int64": _lib.DT_I64}
+
+    def __init__(self, frame_shape, dtype, output_size, zoom_ratio, kernels, centroid_region=(3, 3), recovery_mode=_lib.RECOVERY_CONSTANT,
+                 flat_policy="ieee", clip_hi=255.0, pad=2, device=None):
+        from .util.zoom.from_image import reference_levels
+        h, w, c = (int(v) for v in frame_shape)
+        if c != 3:
+            raise ValueError("FrameDisplayer takes [H, W, 3] frames")
+        self.dtype = np.dtype(dtype)
+        if self.dtype.name not in self._DT:
+            raise TypeError("frames of dtype %s are not supported" % self.dtype)
+        self.frame_shape = (h, w, 3)
+        self.ctx = get_context(device)
+        levels = reference_levels((h, w), output_size, zoom_ratio)
+        if not levels:
+            raise ValueError("the frame is not larger than output_size: image_to_zoom_tensor has no level (from_image.py:45-46)")
+        arr = (_lib.PyrLevel * len(levels))(*[_lib.PyrLevel(*[int(v) for v in l]) for l in levels])
+        self._kernels = {k: np.ascontiguousarray(kernels[k], np.float32) for k in ("rgc", "rgby", "stripe", "blur", "end")}
+        fp = C.POINTER(C.c_float)
+        chain = _lib.RgbChainParams(*[self._kernels[k].ctypes.data_as(fp) for k in ("rgc", "rgby", "stripe", "blur", "end")],
+                                    1.0, 0.1, {"ieee": _lib.FLAT_IEEE, "zero": _lib.FLAT_ZERO}[flat_policy], float(clip_hi), int(pad))
+        boost = _lib.BoostingParams(1.0, 1.0, int(recovery_mode), 10.0, 0.8, 1)
+        prm = _lib.DisplayerParams(h, w, self._DT[self.dtype.name], int(centroid_region[0]), int(centroid_region[1]), chain, boost)
+        self.handle = C.c_void_p()
+        lib = self._lib = _lib.load()
+        self.ctx.check(lib.silent_displayer_create(self.ctx.handle, C.byref(prm), arr, len(levels), C.byref(self.handle)))
+        shape, floats = (C.c_int32 * 7)(), (C.c_size_t * 6)()
+        self.ctx.check(lib.silent_displayer_shape(self.handle, shape, floats))
+        L, lh, lw, ch, cw, hh, hw = (int(v) for v in shape)
+        self.shapes = [(L, lh, lw, 3), (L, lh, lw, 1), (L, hh, hw, 1), (L, ch, cw, 3), (L, ch, cw, 3), (L, lh, lw, 3)]
+        self.state_shape = (L, ch, cw, 1)
+        assert [int(np.prod(sh)) for sh in self.shapes] == [int(f) for f in floats]
+        self._res = (C.c_void_p * 6)()
+        self._ms = C.c_float(0)
+        self.gpu_ms = 0.0
+
+    def step(self, frame):
+        """frame: [H, W, 3] ndarray of the displayer's dtype.  Returns the six float32 arrays as VIEWS of the displayer's pinned
+        result slot -- valid until the second next step (two slots alternate); copy what has to live longer."""
+        if not isinstance(frame, np.ndarray) or frame.dtype != self.dtype or tuple(frame.shape) != self.frame_shape:
+            raise ValueError("frame must be a %s ndarray of shape %s" % (self.dtype, self.frame_shape,))
+        f = np.ascontiguousarray(frame)
+        self.ctx.check(self._lib.silent_displayer_step(self.handle, C.c_void_p(f.ctypes.data), self._res, C.byref(self._ms)))
+        self.gpu_ms = float(self._ms.value)
+        out = []
+        for ptr, sh in zip(self._res, self.shapes):
+            buf = (C.c_float * int(np.prod(sh))).from_address(ptr)
+            buf._owner = self               # the views keep the displayer (and with it the pinned slot) alive
+            out.append(np.frombuffer(buf, np.float32).reshape(sh))
+        return out
+
+    def get_state(self):
+        st = np.empty(self.state_shape, np.float32)
+        self.ctx.check(self._lib.silent_displayer_get_state(self.handle, C.c_void_p(st.ctypes.data)))
+        return st
+
+    def set_state(self, state):
+        st = np.ascontiguousarray(state, np.float32)
+        if tuple(st.shape) != self.state_shape:
+            raise ValueError("state shape %s does not match the compiled pyramid %s" % (st.shape, self.state_shape))
+        self.ctx.check(self._lib.silent_displayer_set_state(self.handle, C.c_void_p(st.ctypes.data)))
+
+    def close(self):
+        if getattr(self, "handle", None):
+            self._lib.silent_displayer_destroy(self.handle)
+            self.handle = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
 class PyramidPlan(object):
     """Tap tables of one (frame size, level geometry) on the device.  ``levels`` is a list of dicts / tuples
     (src_y0, src_x0, src_h, src_w, zoom_h, zoom_w, out_h, out_w)."""

@@ -19,7 +19,7 @@ import time
 HERE = os.path.dirname(os.path.abspath(__file__))
 PKG = os.path.dirname(HERE)
 OUT = os.path.join(PKG, "lib", "libsilent_hip.so")
-UNITS = ["silent_core", "silent_conv_api", "silent_gray_api", "silent_peaks_api", "silent_rgb_api", "silent_pyramid_api"]
+UNITS = ["silent_core", "silent_conv_api", "silent_gray_api", "silent_peaks_api", "silent_rgb_api", "silent_pyramid_api", "silent_displayer_api"]
 HOST_ASAN_OUT = os.path.join(PKG, "lib", "libsilent_hostonly_asan.so")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fvisibility=hidden", "-ffp-contract=off", "-fno-slp-vectorize",
          "-Wall", "-Wextra", "-Wno-unused-parameter"]

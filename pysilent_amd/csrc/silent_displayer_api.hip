@@ -1,0 +1,280 @@
+// libsilent_hip.so -- the reference's application graph for ONE camera frame as one call (include/silent_hip.h,
+// silent_displayer_*): LineEndDisplayer.callback + run, slam_recognition/recognition_testing.py:106-144 -- frame in host memory ->
+// np.asarray(float32) -> zoom.from_image -> the graph of compile() (:60-100) -> the six fetched tensors in host memory.  The
+// reference pays a feed, a session.run and six fetches per frame; here the whole frame is one HIP graph: an upload node, ~20
+// kernel nodes (every one a kernel of the other translation units, enqueued through their *_dev entry points while the stream
+// captures), a download node.  The object owns its buffers, its stream, a context of its own (nobody else regrows the workspace
+// the graph's nodes point into) and the boosting state (energy_values, recognition_testing.py:56).
+#include "silent_internal.h"
+
+using namespace silent;
+
+struct silent_displayer {
+    silent_ctx* owner = nullptr;          // the caller's context (errors are reported there)
+    silent_ctx* ctx = nullptr;            // private context: workspace of the graph's nodes
+    silent_pyramid_plan* plan = nullptr;
+    hipStream_t stream = nullptr;
+    hipGraph_t graph[2] = {nullptr, nullptr};        // one per result slot (the download nodes point into the slot)
+    hipGraphExec_t exec[2] = {nullptr, nullptr};
+    hipEvent_t ev[2] = {nullptr, nullptr};
+    silent_displayer_params prm{};
+    float kernels[4 * 81 + 441];          // private copy of the chain's constant kernels (the caller's arrays may go away)
+    int L = 0, h = 0, w = 0, ch = 0, cw = 0, hh = 0, hw = 0;
+    size_t in_bytes = 0;
+    // device
+    void* slab = nullptr;
+    void* d_raw = nullptr;
+    float *d_frame = nullptr, *d_pyr = nullptr, *d_orient = nullptr, *d_line = nullptr, *d_value = nullptr, *d_g = nullptr, *d_dist1 = nullptr,
+          *d_tot1 = nullptr, *d_imp = nullptr, *d_im2 = nullptr, *d_im2n = nullptr, *d_dist2 = nullptr, *d_tot2 = nullptr, *d_fired = nullptr,
+          *d_update = nullptr, *d_energy = nullptr, *d_out1 = nullptr, *d_out2 = nullptr, *d_out3 = nullptr;
+    // pinned host: the frame, and two result slots (the results of step n stay valid until step n + 2)
+    void* h_in = nullptr;
+    float* h_out[2] = {nullptr, nullptr};
+    size_t out_floats[6] = {0, 0, 0, 0, 0, 0}, out_total = 0;
+    int slot = 0;
+    long long steps = 0;
+};
+
+static size_t dt_size(int dt) {
+    switch (dt) {
+        case SILENT_DT_U8: return 1;
+        case SILENT_DT_U16: case SILENT_DT_I16: return 2;
+        case SILENT_DT_F32: case SILENT_DT_I32: return 4;
+        case SILENT_DT_F64: case SILENT_DT_I64: return 8;
+        default: return 0;
+    }
+}
+
+static void displayer_free(silent_displayer* d) {
+    if (!d) return;
+    for (hipGraphExec_t e : d->exec)
+        if (e) (void)hipGraphExecDestroy(e);
+    for (hipGraph_t g : d->graph)
+        if (g) (void)hipGraphDestroy(g);
+    for (hipEvent_t e : d->ev)
+        if (e) (void)hipEventDestroy(e);
+    if (d->stream) (void)hipStreamDestroy(d->stream);
+    if (d->slab) (void)hipFree(d->slab);
+    if (d->h_in) (void)hipHostFree(d->h_in);
+    for (float* p : d->h_out)
+        if (p) (void)hipHostFree(p);
+    if (d->plan) silent_pyramid_plan_destroy(d->plan);
+    if (d->ctx) silent_destroy(d->ctx);
+    delete d;
+}
+
+// the kernels of one frame on d->stream, between the upload and the download (recognition_testing.py:141-142, :69-100)
+static int displayer_enqueue(silent_displayer* d, int slot) {
+    silent_ctx* c = d->ctx;
+    silent_stream s = (silent_stream)d->stream;
+    const int L = d->L;
+    const size_t px = (size_t)L * d->h * d->w, cells = (size_t)L * d->ch * d->cw, px2 = (size_t)L * d->hh * d->hw;
+    const silent_extent lev = {d->h, d->w}, half = {d->hh, d->hw}, cell = {d->ch, d->cw};
+    HIP_TRY(d->owner, hipMemcpyAsync(d->d_raw, d->h_in, d->in_bytes, hipMemcpyHostToDevice, d->stream));
+    // np.asarray(frame, dtype=float32) (:141)
+    if (d->prm.frame_dtype != SILENT_DT_F32)
+        TRY(silent_cast_interleave_dev(c, d->d_raw, d->prm.frame_dtype, (size_t)d->prm.frame_h * d->prm.frame_w, 3, 0, 3, d->d_frame, 3, 0, s));
+    // zoom.from_image (:142)
+    TRY(silent_pyramid_dev(c, d->plan, d->prm.frame_dtype == SILENT_DT_F32 ? (const float*)d->d_raw : d->d_frame, 1, d->d_pyr, s));
+    // rgc -> rgby -> orientation -> line-end -> clip -> pad_inwards; get_value_from_color (:69-77): the pyramid's levels are the batch
+    silent_rgb_chain_params cp = d->prm.chain;
+    cp.rgc = d->kernels; cp.rgby = d->kernels + 81; cp.stripe = d->kernels + 162; cp.end = d->kernels + 243; cp.blur = d->kernels + 324;
+    TRY(silent_rgb_line_end_dev(c, d->d_pyr, &lev, 1, L, &cp, d->d_orient, d->d_line, d->d_value, s));
+    // centroids of gray / 255 (:79-80), importances (:81); the same on the nearest-neighbour half-size map (:82-84)
+    const silent_affine_params by255 = {1.f, 255.f, 0.f, -INFINITY, INFINITY, 0.f};
+    TRY(silent_affine_clip_dev(c, d->d_value, px, &by255, d->d_g, s));
+    TRY(silent_centroids_dev(c, d->d_g, &lev, 1, L, d->prm.centroid_region_h, d->prm.centroid_region_w, d->d_dist1, d->d_tot1, s));
+    const silent_affine_params imp = {255.f / 4.0f, 1.f, 0.f, 1.f, 256.f, -1.f};
+    TRY(silent_affine_clip_dev(c, d->d_tot1, cells, &imp, d->d_imp, s));
+    TRY(silent_resize_nearest_dev(c, d->d_value, &lev, 1, L, 1, &half, d->d_im2, s));
+    TRY(silent_affine_clip_dev(c, d->d_im2, px2, &by255, d->d_im2n, s));
+    TRY(silent_centroids_dev(c, d->d_im2n, &half, 1, L, d->prm.centroid_region_h, d->prm.centroid_region_w, d->d_dist2, d->d_tot2, s));
+    // get_boosting (:86): advances energy_values
+    TRY(silent_boosting_step_dev(c, d->d_imp, &cell, 1, L, &d->prm.boosting, d->d_energy, d->d_fired, d->d_update, s));
+    // what the reference fetches (:99-100): orient, 255 - centroids * 255, 255 - centroids2 * 255, fired * 255, update, padded line_end
+    const silent_affine_params inv = {-255.f, 1.f, 255.f, -INFINITY, INFINITY, 0.f}, x255 = {255.f, 1.f, 0.f, -INFINITY, INFINITY, 0.f};
+    TRY(silent_affine_clip_dev(c, d->d_dist1, px, &inv, d->d_out1, s));
+    TRY(silent_affine_clip_dev(c, d->d_dist2, px2, &inv, d->d_out2, s));
+    TRY(silent_affine_clip_dev(c, d->d_fired, cells * (d->prm.boosting.visualize ? 3 : 1), &x255, d->d_out3, s));
+    const float* src[6] = {d->d_orient, d->d_out1, d->d_out2, d->d_out3, d->d_update, d->d_line};
+    float* dst = d->h_out[slot];
+    for (int i = 0; i < 6; ++i) {
+        HIP_TRY(d->owner, hipMemcpyAsync(dst, src[i], d->out_floats[i] * 4, hipMemcpyDeviceToHost, d->stream));
+        dst += d->out_floats[i];
+    }
+    return SILENT_OK;
+}
+
+SILENT_EXPORT int silent_displayer_create(silent_ctx* ctx, const silent_displayer_params* p, const silent_pyr_level* levels, int n_levels,
+                                          silent_displayer** out) try {
+    NEED_CTX(ctx);
+    const char* who = "silent_displayer_create";
+    if (!p || !levels || !out) return fail(ctx, SILENT_E_INVALID, std::string(who) + ": NULL pointer");
+    *out = nullptr;
+    if (!p->chain.rgc || !p->chain.rgby || !p->chain.stripe || !p->chain.blur || !p->chain.end)
+        return fail(ctx, SILENT_E_INVALID, std::string(who) + ": a kernel pointer in params is NULL");
+    if (!dt_size(p->frame_dtype)) return fail(ctx, SILENT_E_UNSUPPORTED, std::string(who) + ": unknown frame_dtype");
+    if (p->frame_h < 1 || p->frame_w < 1 || n_levels < 1 || n_levels > kMaxLevels || p->centroid_region_h < 1 || p->centroid_region_w < 1)
+        return fail(ctx, SILENT_E_INVALID, std::string(who) + ": bad extents");
+    for (int l = 0; l < n_levels; ++l)
+        if (levels[l].out_h != levels[0].out_h || levels[l].out_w != levels[0].out_w)
+            return fail(ctx, SILENT_E_INVALID, std::string(who) + ": the reference's pyramid has ONE canvas extent for every level");
+    struct Guard {
+        silent_displayer* d;
+        ~Guard() { displayer_free(d); }
+    } g{new silent_displayer()};
+    silent_displayer* d = g.d;
+    d->owner = ctx;
+    d->prm = *p;
+    std::memcpy(d->kernels, p->chain.rgc, 81 * 4);
+    std::memcpy(d->kernels + 81, p->chain.rgby, 81 * 4);
+    std::memcpy(d->kernels + 162, p->chain.stripe, 81 * 4);
+    std::memcpy(d->kernels + 243, p->chain.end, 81 * 4);
+    std::memcpy(d->kernels + 324, p->chain.blur, 441 * 4);
+    int rc = silent_create(ctx->device, &d->ctx);
+    if (rc != SILENT_OK) return fail(ctx, rc, std::string(who) + ": " + silent_last_error(nullptr));
+    for (int i = 0; i < SILENT_TUNE_COUNT; ++i) d->ctx->tune[i] = ctx->tune[i];
+    rc = silent_pyramid_plan_create(d->ctx, p->frame_h, p->frame_w, 3, levels, n_levels, &d->plan);
+    if (rc != SILENT_OK) return fail(ctx, rc, std::string(who) + ": " + silent_last_error(d->ctx));
+    d->L = n_levels;
+    d->h = levels[0].out_h;
+    d->w = levels[0].out_w;
+    d->ch = (d->h + p->centroid_region_h - 1) / p->centroid_region_h;
+    d->cw = (d->w + p->centroid_region_w - 1) / p->centroid_region_w;
+    // tf.image.resize_images(gray, [int(h / e ** .5), int(w / e ** .5)]) with the float32 arithmetic of recognition_testing.py:82
+    const float root_e = (float)std::exp(0.5);
+    d->hh = std::max(1, (int)((float)d->h / root_e));
+    d->hw = std::max(1, (int)((float)d->w / root_e));
+    const size_t px = (size_t)d->L * d->h * d->w, cells = (size_t)d->L * d->ch * d->cw, px2 = (size_t)d->L * d->hh * d->hw;
+    const int vis = p->boosting.visualize ? 3 : 1;
+    d->in_bytes = (size_t)p->frame_h * p->frame_w * 3 * dt_size(p->frame_dtype);
+    const size_t want[] = {d->in_bytes, (size_t)p->frame_h * p->frame_w * 12, px * 12, px * 12, px * 12, px * 4, px * 4, px * 4, cells * 4, cells * 4,
+                           px2 * 4, px2 * 4, px2 * 4, cells * 4, cells * 4 * vis, cells * 4 * vis, cells * 4, px * 4, px2 * 4, cells * 4 * vis};
+    size_t total = 0;
+    for (size_t b : want) total += align_up(b);
+    HIP_TRY(ctx, hipMalloc(&d->slab, total));
+    char* at = (char*)d->slab;
+    auto take = [&](size_t b) { char* r = at; at += align_up(b); return r; };
+    d->d_raw = take(want[0]);
+    float** f[] = {&d->d_frame, &d->d_pyr, &d->d_orient, &d->d_line, &d->d_value, &d->d_g, &d->d_dist1, &d->d_tot1, &d->d_imp, &d->d_im2,
+                   &d->d_im2n, &d->d_dist2, &d->d_tot2, &d->d_fired, &d->d_update, &d->d_energy, &d->d_out1, &d->d_out2, &d->d_out3};
+    for (size_t i = 0; i < sizeof(f) / sizeof(f[0]); ++i) *f[i] = (float*)take(want[i + 1]);
+    const size_t outs[6] = {px * 3, px, px2, cells * vis, cells * vis, px * 3};
+    for (int i = 0; i < 6; ++i) {
+        d->out_floats[i] = outs[i];
+        d->out_total += outs[i];
+    }
+    HIP_TRY(ctx, hipHostMalloc(&d->h_in, d->in_bytes, hipHostMallocDefault));
+    for (float*& hp : d->h_out) HIP_TRY(ctx, hipHostMalloc((void**)&hp, d->out_total * 4, hipHostMallocDefault));
+    HIP_TRY(ctx, hipStreamCreateWithFlags(&d->stream, hipStreamNonBlocking));
+    for (hipEvent_t& e : d->ev) HIP_TRY(ctx, hipEventCreate(&e));
+    // initialize_boosting: 8 everywhere (boosting.py:6-7, recognition_testing.py:56)
+    std::vector<float> eight(cells, 8.0f);
+    HIP_TRY(ctx, hipMemcpy(d->d_energy, eight.data(), cells * 4, hipMemcpyHostToDevice));
+    *out = d;
+    g.d = nullptr;
+    return SILENT_OK;
+} catch (...) {
+    return on_exception(ctx, "silent_displayer_create");
+}
+
+SILENT_EXPORT void silent_displayer_destroy(silent_displayer* d) try {
+    if (!d) return;
+    DeviceGuard guard(d->owner ? d->owner->device : 0);
+    if (d->stream) (void)hipStreamSynchronize(d->stream);
+    displayer_free(d);
+} catch (...) {
+}
+
+SILENT_EXPORT int silent_displayer_shape(const silent_displayer* d, int32_t* shape7, size_t* out_floats6) try {
+    if (!d || !shape7) return SILENT_E_INVALID;
+    const int32_t s[7] = {d->L, d->h, d->w, d->ch, d->cw, d->hh, d->hw};
+    std::memcpy(shape7, s, sizeof(s));
+    if (out_floats6)
+        for (int i = 0; i < 6; ++i) out_floats6[i] = d->out_floats[i];
+    return SILENT_OK;
+} catch (...) {
+    return on_exception(nullptr, "silent_displayer_shape");
+}
+
+static int displayer_fail(silent_displayer* d, int rc, const char* who) {
+    // (a failing *_dev call left its message in the private context)
+    if (!d->ctx->err.empty()) return fail(d->owner, rc, std::string(who) + ": " + d->ctx->err);
+    return rc;
+}
+
+// frame_host: the camera frame [frame_h, frame_w, 3] of the dtype the displayer was created for.  results[0 .. 5]: pointers INTO
+// the displayer's pinned result slot (layouts: silent_displayer_shape), valid until the second next step.  gpu_ms (may be NULL):
+// device time of the frame, upload to download, from events around the graph.  Synchronous.
+SILENT_EXPORT int silent_displayer_step(silent_displayer* d, const void* frame_host, const float** results, float* gpu_ms) try {
+    if (!d) return fail(nullptr, SILENT_E_INVALID, "silent_displayer_step: displayer is NULL");
+    silent_ctx* ctx = d->owner;
+    NEED_CTX(ctx);
+    const char* who = "silent_displayer_step";
+    if (!frame_host || !results) return fail(ctx, SILENT_E_INVALID, std::string(who) + ": NULL pointer");
+    std::memcpy(d->h_in, frame_host, d->in_bytes);
+    const int slot = d->slot;
+    d->ctx->err.clear();
+    HIP_TRY(ctx, hipEventRecord(d->ev[0], d->stream));
+    if (d->steps == 0) {
+        // the first frame runs eagerly: the private context's workspace grows to its final size outside any capture
+        const int rc = displayer_enqueue(d, slot);
+        if (rc != SILENT_OK) return displayer_fail(d, rc, who);
+    } else {
+        if (!d->exec[slot]) {
+            // the same sequence under stream capture, once per result slot (the download nodes point into the slot)
+            HIP_TRY(ctx, hipStreamBeginCapture(d->stream, hipStreamCaptureModeRelaxed));
+            const int rc = displayer_enqueue(d, slot);
+            hipGraph_t g = nullptr;
+            const hipError_t e = hipStreamEndCapture(d->stream, &g);
+            if (rc != SILENT_OK) {
+                if (g) (void)hipGraphDestroy(g);
+                (void)hipGetLastError();
+                return displayer_fail(d, rc, who);
+            }
+            if (e != hipSuccess) {
+                (void)hipGetLastError();
+                return fail(ctx, SILENT_E_HIP, std::string(who) + ": hipStreamEndCapture: " + hipGetErrorString(e));
+            }
+            d->graph[slot] = g;
+            HIP_TRY(ctx, hipGraphInstantiate(&d->exec[slot], g, nullptr, nullptr, 0));
+        }
+        HIP_TRY(ctx, hipGraphLaunch(d->exec[slot], d->stream));
+    }
+    HIP_TRY(ctx, hipEventRecord(d->ev[1], d->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(d->stream));
+    if (gpu_ms) HIP_TRY(ctx, hipEventElapsedTime(gpu_ms, d->ev[0], d->ev[1]));
+    const float* r = d->h_out[slot];
+    for (int i = 0; i < 6; ++i) {
+        results[i] = r;
+        r += d->out_floats[i];
+    }
+    d->slot ^= 1;
+    ++d->steps;
+    return SILENT_OK;
+} catch (...) {
+    return on_exception(d ? d->owner : nullptr, "silent_displayer_step");
+}
+
+// The boosting state (energy_values, recognition_testing.py:56): [levels, ceil(h / region_h), ceil(w / region_w)] float32.
+SILENT_EXPORT int silent_displayer_get_state(silent_displayer* d, float* energy_host) try {
+    if (!d || !energy_host) return fail(d ? d->owner : nullptr, SILENT_E_INVALID, "silent_displayer_get_state: NULL pointer");
+    silent_ctx* ctx = d->owner;
+    NEED_CTX(ctx);
+    HIP_TRY(ctx, hipStreamSynchronize(d->stream));
+    HIP_TRY(ctx, hipMemcpy(energy_host, d->d_energy, (size_t)d->L * d->ch * d->cw * 4, hipMemcpyDeviceToHost));
+    return SILENT_OK;
+} catch (...) {
+    return on_exception(d ? d->owner : nullptr, "silent_displayer_get_state");
+}
+
+SILENT_EXPORT int silent_displayer_set_state(silent_displayer* d, const float* energy_host) try {
+    if (!d || !energy_host) return fail(d ? d->owner : nullptr, SILENT_E_INVALID, "silent_displayer_set_state: NULL pointer");
+    silent_ctx* ctx = d->owner;
+    NEED_CTX(ctx);
+    HIP_TRY(ctx, hipStreamSynchronize(d->stream));
+    HIP_TRY(ctx, hipMemcpy(d->d_energy, energy_host, (size_t)d->L * d->ch * d->cw * 4, hipMemcpyHostToDevice));
+    return SILENT_OK;
+} catch (...) {
+    return on_exception(d ? d->owner : nullptr, "silent_displayer_set_state");
+}

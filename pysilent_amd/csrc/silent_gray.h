@@ -412,7 +412,10 @@ __device__ __forceinline__ StreamCol stream_col(const StreamTab& st, int g, int 
 // every other stream row); the smaller levels -- one completed row per 2, 4, 8 tiles -- fetch theirs when a row completes.  With all
 // seven resident the <K, 7> instantiations sat at 125 VGPRs = 4 waves / SIMD (63 registers of records); now they run at the <K, 4>
 // instantiations' 5 - 6 waves (profiles/r05_config5/README.md).
-constexpr int kStreamRegLevels = 3;
+#ifndef SILENT_STREAM_REG_LEVELS
+#define SILENT_STREAM_REG_LEVELS 3
+#endif
+constexpr int kStreamRegLevels = SILENT_STREAM_REG_LEVELS;
 
 template <int K, int G>
 __global__ __launch_bounds__(64 * kFusedWaves) void gray_stream_kernel(const float* __restrict__ frames, float* __restrict__ pyr,
@@ -445,7 +448,7 @@ __global__ __launch_bounds__(64 * kFusedWaves) void gray_stream_kernel(const flo
     float in[R + 8];
     float in_last = 0.0f, xcol = 0.0f;   // pass 1's sixth taps: stream row R + 8 and the column right of the wave's 64 (unit_taps6)
     constexpr int GR = G < kStreamRegLevels ? G : kStreamRegLevels;
-    StreamCol col[GR];
+    StreamCol col[GR > 0 ? GR : 1];
 #pragma unroll
     for (int i = 0; i < R + 8; ++i) in[i] = 0.0f;
 #pragma unroll
@@ -698,7 +701,7 @@ __global__ __launch_bounds__(64 * kFusedWaves) void pyramid_stream_kernel(const 
     const long long sx = (long long)(mirror_near(ox, lv.src_w) + lv.src_x0) * C;
 
     constexpr int GR = G < kStreamRegLevels ? G : kStreamRegLevels;
-    StreamCol col[GR];
+    StreamCol col[GR > 0 ? GR : 1];
 #pragma unroll
     for (int g = 0; g < GR; ++g) col[g] = stream_col(st, g, wx_tile, lane);
     const int eff_h = min(lv.zoom_h, lv.out_h), eff_w = min(lv.zoom_w, lv.out_w);

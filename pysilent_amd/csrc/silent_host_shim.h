@@ -97,6 +97,16 @@ void __hipUnregisterFatBinary(void**) {}
 #define hipGetDeviceProperties(p, d) silent_host::Props(p)
 #define hipOccupancyMaxActiveBlocksPerMultiprocessor(out, ...) (*(out) = 5, hipSuccess)
 #define hipDeviceGetAttribute(v, a, d) (*(v) = 100000, hipSuccess)
+#define hipHostMalloc(p, n, f) silent_host::Malloc((void**)(p), (n))
+#define hipHostFree(p) silent_host::Free((void*)(p))
+#define hipStreamCreateWithFlags(s, f) (*(s) = (hipStream_t)(size_t)8, hipSuccess)
+#define hipStreamDestroy(s) ((void)(s), hipSuccess)
+#define hipStreamBeginCapture(s, m) ((void)(s), hipSuccess)
+#define hipStreamEndCapture(s, g) ((void)(s), *(g) = (hipGraph_t)(size_t)1, hipSuccess)
+#define hipGraphInstantiate(e, g, a, b, c) (*(e) = (hipGraphExec_t)(size_t)1, hipSuccess)
+#define hipGraphLaunch(e, s) ((void)(e), (void)(s), hipSuccess)
+#define hipGraphDestroy(g) ((void)(g), hipSuccess)
+#define hipGraphExecDestroy(e) ((void)(e), hipSuccess)
 #define hipEventCreate(e) (*(e) = (hipEvent_t)(size_t)1, hipSuccess)
 #define hipEventDestroy(e) ((void)(e), hipSuccess)
 #define hipEventRecord(e, s) ((void)(e), (void)(s), hipSuccess)

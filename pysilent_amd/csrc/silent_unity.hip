@@ -6,3 +6,4 @@
 #include "silent_peaks_api.hip"
 #include "silent_rgb_api.hip"
 #include "silent_pyramid_api.hip"
+#include "silent_displayer_api.hip"

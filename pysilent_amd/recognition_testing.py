@@ -24,12 +24,19 @@ from .util.energy.recovery import recovery_mode
 
 
 class LineEndDisplayer(PyramidDisplayer):
-    def __init__(self, n_dimensions=2, use_graph=False, **argv):
-        """``use_graph``: capture the ~20 launches of one frame into a HIP graph the first time a pyramid shape is
+    def __init__(self, n_dimensions=2, use_graph=False, native=True, **argv):
+        """``native`` (default): ``callback`` hands the camera frame to ONE library call (silent_displayer_step: upload, cast,
+        pyramid, the whole graph, download -- a HIP graph replayed per frame, buffers and boosting state owned by the library;
+        _runtime.FrameDisplayer).  The arrays it returns are views of a pinned result slot that stay valid until the second
+        next frame -- the reference returns fresh arrays from session.run; copy what has to live longer.  ``native=False``: the
+        per-op path below (``run`` / ``run_device`` always take it: they start from a pyramid, not from a frame).
+        ``use_graph`` (per-op path): capture the ~20 launches of one frame into a HIP graph the first time a pyramid shape is
         seen and replay it per frame (torch.cuda.CUDAGraph is only the capture / replay plumbing; every node is one
         of this library's kernels)."""
         super(LineEndDisplayer, self).__init__(**argv)
         self.use_graph = bool(use_graph)
+        self.native = bool(native)
+        self._native = None                 # (frame shape, dtype) -> FrameDisplayer
         self._graph = None
         self._ctx = None        # graph mode: a private silent_ctx, so that no other caller regrows the captured workspace
         if n_dimensions != 2:
@@ -56,10 +63,14 @@ class LineEndDisplayer(PyramidDisplayer):
 
     def get_state(self):
         """Host copy of the boosting state (checkpoint); None before the first run."""
+        if self._native is not None:
+            return self._native[1].get_state()
         return None if self.energy_values is None else self.energy_values.cpu().numpy()
 
     def set_state(self, state):
         import torch
+        if self._native is not None:
+            return self._native[1].set_state(state)
         state = np.ascontiguousarray(state, np.float32)
         if self.energy_values is None or tuple(state.shape) != tuple(self.energy_values.shape):
             raise ValueError("state shape %s does not match the compiled pyramid" % (state.shape,))
@@ -136,8 +147,23 @@ class LineEndDisplayer(PyramidDisplayer):
             o += t.numel()
         return res
 
+    def _native_for(self, frame):
+        key = (tuple(frame.shape), frame.dtype.str)
+        if self._native is None or self._native[0] != key:
+            # (like the reference, recognition_testing.py:108-117: a new frame shape compiles anew and re-initialises the state)
+            if self._native is not None:
+                self._native[1].close()
+            self._native = (key, _runtime.FrameDisplayer(
+                frame.shape, frame.dtype, self.output_size, self.zoom_ratio, self.kernels, self.centroid_region_shape[1:],
+                recovery_mode(self.input_based_recovery, self.constant_recovery), device=self.device_index))
+        return self._native[1]
+
     def callback(self, frame, cam_id=None, depth=2):
         import torch
+        if self.native and isinstance(frame, np.ndarray) and frame.ndim == 3 and frame.shape[2] == 3 and self.output_colors == 3 \
+                and frame.dtype.name in _runtime.FrameDisplayer._DT:
+            tensors = self._native_for(frame).step(frame)
+            return [frame] + [[tensors[x][y] for y in range(len(tensors[x]))] for x in range(6)]
         # frame -> GPU once; the zoom pyramid stays on the device between from_image and the graph
         dev = torch.device("cuda", self.device_index)
         if isinstance(frame, np.ndarray) and frame.dtype == np.uint8:

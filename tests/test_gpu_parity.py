@@ -589,9 +589,30 @@ def test_line_end_displayer_three_frames(rt, kernels):
             scale = 255.0 * (64 + 96) if i < 2 else 255.0
             assert_close(got[1 + i], tail[i], RTOL, scale=scale, what="%s, frame %d" % (name, step))
         assert_close(disp.get_state(), want_state, RTOL, what="state, frame %d" % step)
-    # the same three frames through a captured HIP graph: bit-identical outputs and state
-    eager = LineEndDisplayer(output_size=(96, 64))
-    graphed = LineEndDisplayer(output_size=(96, 64), use_graph=True)
+    # (above: the default, native path -- one library call per frame, silent_displayer_step.)  The per-op path gives the same bits,
+    # over six frames: the native displayer's first frame runs eagerly, the next two capture one graph per result slot, the rest replay
+    assert disp.native and disp._native is not None
+    native, per_op = LineEndDisplayer(output_size=(96, 64)), LineEndDisplayer(output_size=(96, 64), native=False)
+    held = []
+    for step in range(6):
+        frame = structured_frame(60 + step, 150, 230, 3)
+        a, b = native.callback(frame), per_op.callback(frame)
+        for i in range(1, 7):
+            np.testing.assert_array_equal(np.stack(a[i]), np.stack(b[i]), err_msg="native vs per-op, frame %d, output %d" % (step, i))
+        np.testing.assert_array_equal(native.get_state(), per_op.get_state())
+        held.append((np.stack(a[1]).copy(), a[1]))
+        if step >= 1:       # the previous frame's views are still intact (two result slots alternate)
+            np.testing.assert_array_equal(held[step - 1][0], np.stack(held[step - 1][1]))
+    st = native.get_state()
+    native.set_state(st * 0 + 3.0)
+    per_op.set_state(st * 0 + 3.0)
+    frame = structured_frame(70, 150, 230, 3)
+    a, b = native.callback(frame), per_op.callback(frame)
+    for i in range(1, 7):
+        np.testing.assert_array_equal(np.stack(a[i]), np.stack(b[i]))
+    # the same three frames through a captured HIP graph (per-op path): bit-identical outputs and state
+    eager = LineEndDisplayer(output_size=(96, 64), native=False)
+    graphed = LineEndDisplayer(output_size=(96, 64), native=False, use_graph=True)
     for step in range(3):
         frame = structured_frame(40 + step, 150, 230, 3)
         a, b = eager.callback(frame), graphed.callback(frame)
