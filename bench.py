@@ -48,6 +48,9 @@ WORKLOADS = {
     # e ** .5; util/zoom/from_image.py:45-64: nested centre crops resampled to one fixed size) on batched 1080p RGB frames
     "reference_layout": dict(hw=(1080, 1920), mode="rgb", n_levels=4, n_orient=3, frames=32, center=(288, 192), scale=math.e ** .5,
                              name="1080p RGB, the reference's layout: 4 levels of 288x192 (centre crops, zoom e^-s/2), chain + keypoints"),
+    # the same layout on one channel (PyramidDisplayer(output_colors=1), pyramid_displayer.py:22) with the gray chain of config 2
+    "reference_layout_gray": dict(hw=(1080, 1920), mode="gray", n_levels=4, n_orient=4, frames=64, center=(288, 192), scale=math.e ** .5,
+                                  name="1080p gray, the reference's layout: 4 levels of 288x192 (centre crops, zoom e^-s/2), CS + 4-orientation line-end"),
     # configs[4]: 4K, 8-level pyramid, 8-orientation bank
     "config5": dict(hw=(2160, 3840), mode="gray", n_levels=8, n_orient=8, frames=16,
                     name="4K gray, 8-level pyramid (scale 2), CS + 8-orientation line-end"),
@@ -770,6 +773,7 @@ def run_rank(args):
             out["other_workloads"]["config5"] = side_workload(torch, D, "config5", local, dev, rank, world)
         if args.workload != "reference_layout":
             out["other_workloads"]["reference_layout"] = side_workload(torch, D, "reference_layout", local, dev, rank, world)
+            out["other_workloads"]["reference_layout_gray"] = side_workload(torch, D, "reference_layout_gray", local, dev, rank, world)
             out["other_workloads"]["reference_layout_one_stream"] = side_workload(
                 torch, D, "reference_layout", local, dev, rank, world, overlap=False,
                 label="the reference's layout on one stream (no overlap between consecutive steps)")
