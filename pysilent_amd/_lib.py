@@ -9,7 +9,7 @@ import importlib.util
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-# SILENT_LIB_PATH: load another build of the same library (kernel experiments, scripts/experiment_builds.sh)
+# SILENT_LIB_PATH: load another build of the same library (kernel experiments: build.py --out ... -D..., scripts/ab_same_buffers.py)
 LIB_PATH = os.environ.get("SILENT_LIB_PATH") or os.path.join(_HERE, "lib", "libsilent_hip.so")
 
 SILENT_OK = 0

@@ -35,8 +35,7 @@
 
 namespace silent {
 
-// ---- shared strip-walk declarations (the gray strip-walk kernels of round 2 that also used them are not part of the product:
-// scripts/ubench/walk_kernels/, profiles/r02/walk_kernel.txt)
+// ---- strip-walk declarations
 constexpr int kWalkCH = 8;                          // rows per record chunk the host pads the row program to
 constexpr int kWalkSlots = 3;                       // chunks in the ring
 
@@ -48,15 +47,6 @@ struct WalkPyr {
     const int* col_rec;           // [waves_x][w3_rec_total(Gp)][8]: float index of tap 0 in the wave's line, 6 weights, pad
     long long px_off[8];          // pixel offset of level g inside one pyramid
     int out_w[8];
-};
-
-struct WalkTab {
-    int H, W;                            // frame extents
-    int src_y0, src_x0, src_h, src_w;    // crop the unit level resamples (zoom 1)
-    int out_h, out_w, eff_h, eff_w;      // canvas, and the part of it the zoomed crop covers
-    int strips_x, segs_y, seg_rows;      // decomposition: block = (frame, segment of seg_rows output rows, strip)
-    long long frame_px, px_off;          // pixels of one pyramid, offset of the unit level in it
-    float wx[6];                         // [1, 26, 66, 26, 1] / 120 and scipy's sixth tap, 2^-53, as float32 (both axes)
 };
 
 // compile-time loop: the body gets its index as an integral constant
@@ -77,6 +67,8 @@ constexpr int kW3MaxPlans = 8;                  // walk plans per launch
 constexpr int kW3TileL = 2;                     // a wave's line starts 2 pixels left of its first pixel ...
 constexpr int kW3TileF = 124;                   // ... and holds 124 floats (41 pixels + 1 float): taps -2 .. +3 of its anchors
 constexpr int kW3RowF = 456;                    // floats per ring row ((144 + 7) * 3 = 453 used, + up to 3 of alignment shift)
+constexpr int kW3RingTail = 16;                 // floats behind the ring's last row: a lane's six taps are tap 0 + 0, 3 .. 15 floats, and the
+                                                // idle tail lanes of a wave's line read up to 12 floats past their row (into the next one)
 constexpr int kW3Threads = (kW3NC + 1) * 64;
 constexpr int kW3CH = 4;                        // rows per chunk: a 12-row ring (22 KB) instead of 24 rows -- the loader is far from
                                                 // being the limit (all loads alone: 0.14 ms), the consumers are latency-bound and
@@ -124,7 +116,8 @@ __global__ __launch_bounds__(kW3Threads) void pyramid_walk3_kernel(const float* 
     constexpr int kW3Px = PX, kW3StripPx = kW3NC * PX;
     constexpr int PR = w3_prog_row(G);
     constexpr int kRecTotal = w3_rec_total(PX, G);
-    __shared__ __attribute__((aligned(16))) float s_ring[kWalkSlots * kW3CH][kW3RowF];          // 43.8 KB
+    __shared__ __attribute__((aligned(16))) float s_ring_f[kWalkSlots * kW3CH * kW3RowF + kW3RingTail];
+    float (*s_ring)[kW3RowF] = reinterpret_cast<float (*)[kW3RowF]>(s_ring_f);
     __shared__ __attribute__((aligned(16))) int s_prog[kWalkSlots * kW3CH * PR];                // row records of the ring's chunks
     __shared__ __attribute__((aligned(16))) float s_line[kW3NC * 128];                            // a completed row, per wave
     __shared__ __attribute__((aligned(16))) int s_rec[kW3NC * kRecTotal * 8];                     // column records, per wave
@@ -177,12 +170,37 @@ __global__ __launch_bounds__(kW3Threads) void pyramid_walk3_kernel(const float* 
                 if (lane < NV - 64) __builtin_amdgcn_global_load_lds((walk_glb_ptr)(rp + 256), (walk_lds_ptr)(dst + 256), 16, 0, 0);
             }
         };
+        // scipy mirrors every tap at the CROP's edge (d c b | a b c d | c b a).  The ring row of a strip at the crop's left / right
+        // edge holds whatever lies beside the crop in the frame (or a clamped address): the loader writes the mirrored pixels over
+        // those halo positions -- up to 4 pixels left (q = -4 .. -1 <- -q) and 3 right (q = n .. n + 2 <- 2 (n - 1) - q) -- once per
+        // chunk, so that the consumers read every tap at a fixed offset from tap 0 (no per-tap offsets, no mirror arithmetic)
+        int fix_dst = 0, fix_src = 0;
+        bool fix = false;
+        {
+            const int n = tab.src_w;
+            const int q = lane < 12 ? -4 + lane / 3 : n + (lane - 12) / 3;
+            const int ch = lane < 12 ? lane % 3 : (lane - 12) % 3;
+            const int qs = lane < 12 ? -q : 2 * (n - 1) - q;
+            fix = lane < 21 && q - R0 >= 0 && q - R0 < kW3StripPx + kW3HaloL + kW3HaloR && qs - R0 >= 0 && qs - R0 < kW3StripPx + kW3HaloL + kW3HaloR;
+            fix_dst = (q - R0) * 3 + ch + tab.shift;
+            fix_src = (qs - R0) * 3 + ch + tab.shift;
+        }
+        const bool any_fix = __any(fix);                        // wave-uniform: an edge strip
         issue(0, 0);
         if (n_chunks > 1) issue(1, 1);
-        int slot2 = 2;
+        int slot2 = 2, slot0 = 0;
         for (int c = 0; c < n_chunks; ++c) {
             if (c + 1 < n_chunks) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * kW3CH + (kW3CH * PR / 4 > 64 ? 2 : 1)) : "memory");
             else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            if (any_fix) {
+#pragma unroll
+                for (int r = 0; r < kW3CH; ++r) {
+                    float* row = &s_ring[slot0 * kW3CH + r][0];
+                    if (fix) row[fix_dst] = row[fix_src];
+                }
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            }
+            slot0 = slot0 == kWalkSlots - 1 ? 0 : slot0 + 1;
             __builtin_amdgcn_s_barrier();
             if (c + 2 < n_chunks) issue(c + 2, slot2);
             slot2 = slot2 == kWalkSlots - 1 ? 0 : slot2 + 1;
@@ -197,21 +215,16 @@ __global__ __launch_bounds__(kW3Threads) void pyramid_walk3_kernel(const float* 
     // across the lanes: the ring reads and the line writes are free of bank conflicts (floats 2 lane, 2 lane + 1 gave 2-way
     // conflicts on every ds_read_b32: SQ_LDS_BANK_CONFLICT was 1.6x the LDS instruction cycles), and a store instruction writes
     // 256 contiguous bytes without any alignment condition on the level
-    // ring offsets (in floats, < kW3RowF) of the 6 horizontal taps (pixel - 2 .. + 3) of each float, two per register: six taps in
-    // the registers five took (at 7 waves / SIMD the kernel has 72)
-    unsigned offp[2][3];
+    // ring offset (in floats) of tap 0 (pixel - 2) of each float; tap d is 3 d floats further (the loader has mirrored the crop's
+    // edges into the ring): one address per float, the six taps as immediate offsets (pairs of them share a ds_read2_b32)
+    int tap0[2];
     int px[2];
 #pragma unroll
     for (int k = 0; k < 2; ++k) {
         const int i = lane + 64 * k;
         const int p = wx0 - kW3TileL + i / 3, c = i % 3;
         px[k] = p;
-#pragma unroll
-        for (int d = 0; d < 6; d += 2) {
-            const int lo = min(max((mirror_near(p + d - 2, tab.src_w) - R0) * 3 + c + tab.shift, 0), kW3RowF - 1);
-            const int hi = min(max((mirror_near(p + d - 1, tab.src_w) - R0) * 3 + c + tab.shift, 0), kW3RowF - 1);
-            offp[k][d >> 1] = (unsigned)lo | ((unsigned)hi << 16);
-        }
+        tap0[k] = min(max((p - 2 - R0) * 3 + c + tab.shift, 0), kW3RowF - 1);
     }
     const bool out0 = px[0] >= wx0 && px[0] < wx0 + kW3Px && px[0] < tab.out_w;
     const bool out1 = px[1] >= wx0 && px[1] < wx0 + kW3Px && px[1] < tab.out_w && lane + 64 < kW3TileF;
@@ -261,12 +274,9 @@ __global__ __launch_bounds__(kW3Threads) void pyramid_walk3_kernel(const float* 
                 const float* __restrict__ row = &s_ring[slot * kW3CH + r][0];
                 float t[2][6];
 #pragma unroll
-                for (int k = 0; k < 2; ++k) {
+                for (int k = 0; k < 2; ++k)
 #pragma unroll
-                    for (int j = 0; j < 3; ++j) asm volatile("" : "+v"(offp[k][j]));   // (unpacked here, per row: hoisted, the halves take 12 registers again)
-#pragma unroll
-                    for (int d = 0; d < 6; ++d) t[k][d] = row[(offp[k][d >> 1] >> ((d & 1) * 16)) & 0xffffu];
-                }
+                    for (int d = 0; d < 6; ++d) t[k][d] = row[tap0[k] + 3 * d];
                 const int* __restrict__ prow = s_prog + (slot * kW3CH + r) * PR;
                 int meta_v[(G + 3) / 4 * 4];
 #pragma unroll
