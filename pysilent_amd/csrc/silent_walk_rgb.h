@@ -37,7 +37,10 @@ namespace silent {
 
 // ---- strip-walk declarations
 constexpr int kWalkCH = 8;                          // rows per record chunk the host pads the row program to
-constexpr int kWalkSlots = 3;                       // chunks in the ring
+#ifndef SILENT_W3_SLOTS
+#define SILENT_W3_SLOTS 3
+#endif
+constexpr int kWalkSlots = SILENT_W3_SLOTS;         // chunks in the ring (the loader runs kWalkSlots - 1 chunks ahead of the consumers)
 
 // tables of the in-walk pyramid (device memory owned by the plan)
 struct WalkPyr {
@@ -70,7 +73,10 @@ constexpr int kW3RowF = 456;                    // floats per ring row ((144 + 7
 constexpr int kW3RingTail = 16;                 // floats behind the ring's last row: a lane's six taps are tap 0 + 0, 3 .. 15 floats, and the
                                                 // idle tail lanes of a wave's line read up to 12 floats past their row (into the next one)
 constexpr int kW3Threads = (kW3NC + 1) * 64;
-constexpr int kW3CH = 4;                        // rows per chunk: a 12-row ring (22 KB) instead of 24 rows -- the loader is far from
+#ifndef SILENT_W3_CH
+#define SILENT_W3_CH 4
+#endif
+constexpr int kW3CH = SILENT_W3_CH;             // rows per chunk: a 12-row ring (22 KB) instead of 24 rows -- the loader is far from
                                                 // being the limit (all loads alone: 0.14 ms), the consumers are latency-bound and
                                                 // want waves: 31 KB of LDS per block = 4 blocks (16 consumer waves) per CU instead of 3
 // column records per wave tile and level: output PIXELS anchored in a wave's PX pixels (36: zoom steps >= 1.875 ^ (g + 1);
@@ -186,11 +192,13 @@ __global__ __launch_bounds__(kW3Threads) void pyramid_walk3_kernel(const float* 
             fix_src = (qs - R0) * 3 + ch + tab.shift;
         }
         const bool any_fix = __any(fix);                        // wave-uniform: an edge strip
+        static_assert(kWalkSlots == 2 || kWalkSlots == 3, "");
         issue(0, 0);
-        if (n_chunks > 1) issue(1, 1);
-        int slot2 = 2, slot0 = 0;
+        if (kWalkSlots == 3 && n_chunks > 1) issue(1, 1);
+        int slot2 = kWalkSlots - 1, slot0 = 0;
         for (int c = 0; c < n_chunks; ++c) {
-            if (c + 1 < n_chunks) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * kW3CH + (kW3CH * PR / 4 > 64 ? 2 : 1)) : "memory");
+            // chunk c has landed when at most the next chunk's loads (three slots: one chunk in flight behind it) are outstanding
+            if (kWalkSlots == 3 && c + 1 < n_chunks) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * kW3CH + (kW3CH * PR / 4 > 64 ? 2 : 1)) : "memory");
             else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             if (any_fix) {
 #pragma unroll
@@ -202,7 +210,7 @@ __global__ __launch_bounds__(kW3Threads) void pyramid_walk3_kernel(const float* 
             }
             slot0 = slot0 == kWalkSlots - 1 ? 0 : slot0 + 1;
             __builtin_amdgcn_s_barrier();
-            if (c + 2 < n_chunks) issue(c + 2, slot2);
+            if (c + kWalkSlots - 1 < n_chunks) issue(c + kWalkSlots - 1, slot2);
             slot2 = slot2 == kWalkSlots - 1 ? 0 : slot2 + 1;
         }
         return;
