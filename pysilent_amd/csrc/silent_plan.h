@@ -26,6 +26,7 @@ struct silent_pyramid_plan {
     int walk_G = 4;                      // general levels the kernel is instantiated for (4 or 7)
     void* walk_tables = nullptr;
     silent::Walk3Args walk{};                    // everything but the per-launch decomposition (strips / segments / block0)
+    silent::BorderTab walk_border{};             // union plans: the inner levels' border outputs (pyramid_border_kernel); n = 0: none
 };
 
 // (silent_pyramid_api.hip) with_unit: also the unit levels (the gray pass produces them itself); with_region: also the general levels

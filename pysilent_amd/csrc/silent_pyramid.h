@@ -311,6 +311,78 @@ __global__ __launch_bounds__(256) void pyramid_region_kernel(const float* __rest
     }
 }
 
+// ------------------------------------------------------------------------------------------ BORDER
+// The reference's layout (image_to_zoom_tensor, from_image.py:45-64) resamples NESTED centre crops.  pyramid_walk3_kernel reads the
+// outermost crop once and serves the inner levels from the same rows wherever an output's 6 x 6 taps lie inside ITS level's crop
+// (silent_pyramid_api.hip, "union" plans).  What is left is each inner level's frame of outputs whose taps scipy mirrors at that
+// level's own crop edge -- the first / last output row and column, a few thousand pixels per frame: one thread per (pixel, channel),
+// taps straight from the frame through the plan's mirrored tap tables, in the walk's order of operations (vertical 6 fmas from
+// fmaf(w0, x0, 0), then w0 * v0 and 5 fmas): bit-identical to what the level's own plan produced.
+struct BorderLevel {
+    int level;                         // index into PyrTab::lv
+    int oy_lo, oy_hi, ox_lo, ox_hi;    // interior outputs [oy_lo, oy_hi) x [ox_lo, ox_hi): served by the union walk
+    int zr, zc;                        // outputs the resampler produces (min(zoom, canvas))
+    int start;                         // first border pixel of this level among one frame's border pixels
+};
+struct BorderTab {
+    int n, per_frame;
+    BorderLevel lv[kMaxLevels];
+};
+
+template <int C>
+__global__ __launch_bounds__(256) void pyramid_border_kernel(const float* __restrict__ frames, float* __restrict__ pyr, const PyrTab tab,
+                                                             const BorderTab bt, int n_frames) {
+    const long long gid = (long long)blockIdx.x * 256 + threadIdx.x;
+    const long long per_frame = (long long)bt.per_frame * C;
+    if (gid >= per_frame * n_frames) return;
+    const int frame = (int)(gid / per_frame);
+    int k = (int)(gid - (long long)frame * per_frame);
+    const int ch = k % C;
+    k /= C;
+    int bi = 0;
+#pragma unroll
+    for (int i = 1; i < kMaxLevels; ++i)
+        if (i < bt.n && k >= bt.lv[i].start) bi = i;
+    const BorderLevel& b = bt.lv[bi];
+    k -= b.start;
+    // border pixels in this order: the rows above the interior, the rows below it, then per interior row the columns left / right of it
+    const int top = b.oy_lo * b.zc, bottom = (b.zr - b.oy_hi) * b.zc, ih = b.oy_hi - b.oy_lo, side = b.ox_lo + (b.zc - b.ox_hi);
+    int oy, ox;
+    if (k < top) {
+        oy = k / b.zc;
+        ox = k - oy * b.zc;
+    } else if (k < top + bottom) {
+        const int q = k - top;
+        oy = b.oy_hi + q / b.zc;
+        ox = q - (q / b.zc) * b.zc;
+    } else {
+        const int q = k - top - bottom;
+        oy = b.oy_lo + q / side;
+        const int r = q - (q / side) * side;
+        ox = r < b.ox_lo ? r : b.ox_hi + (r - b.ox_lo);
+    }
+    (void)ih;
+    const PyrLevelDev& lv = tab.lv[b.level];
+    const float* __restrict__ src = frames + (long long)frame * tab.H * tab.W * C;
+    const int* __restrict__ yi = tab.yidx + (long long)(lv.ytab_off + oy) * 6;
+    const int* __restrict__ xi = tab.xidx + (long long)(lv.xtab_off + ox) * 6;
+    const float* __restrict__ wy = tab.yw + (long long)(lv.ytab_off + oy) * 6;
+    const float* __restrict__ wx = tab.xw + (long long)(lv.xtab_off + ox) * 6;
+    float v[6];
+#pragma unroll
+    for (int j = 0; j < 6; ++j) {
+        const long long col = (long long)(xi[j] + lv.src_x0) * C + ch;
+        float a = __builtin_fmaf(wy[0], src[(long long)(yi[0] + lv.src_y0) * tab.W * C + col], 0.0f);
+#pragma unroll
+        for (int i = 1; i < 6; ++i) a = __builtin_fmaf(wy[i], src[(long long)(yi[i] + lv.src_y0) * tab.W * C + col], a);
+        v[j] = a;
+    }
+    float acc = wx[0] * v[0];
+#pragma unroll
+    for (int j = 1; j < 6; ++j) acc = __builtin_fmaf(wx[j], v[j], acc);
+    pyr[((long long)frame * tab.frame_px_out + tab.px_off[b.level] + (long long)oy * lv.out_w + ox) * C + ch] = acc;
+}
+
 // ------------------------------------------------------------------------------------------ ZERO FILL
 template <int C>
 __global__ __launch_bounds__(256) void pyramid_zero_kernel(float* __restrict__ pyr, const PyrTab tab) {

@@ -310,15 +310,19 @@ SILENT_EXPORT int silent_pyramid_plan_create(silent_ctx* ctx, int frame_h, int f
         }
     }
     // ---- walk plans of pyramid_walk3_kernel (3 channels).  Classic pyramid (one unit level whose crop every other level
-    // resamples): one plan.  Anything else (the reference's nested centre crops): one plan per level -- a unit level alone, or a
-    // general level alone on its own crop.  Per plan: a row program (one record per source row of the crop: "an output row of
-    // level g completes here" + its 6 vertical weights) and column records per PX-pixel wave tile.
+    // resamples): one plan.  Anything else (the reference's nested centre crops): a unit level alone; and the general levels
+    // either as ONE "union" plan -- the walk over the OUTERMOST crop serves every level whose crop lies inside it, wherever an
+    // output's 6 x 6 taps stay inside that level's own crop (no mirroring: the frame pixels ARE the taps); the inner levels' first /
+    // last output rows and columns go to pyramid_border_kernel -- or, where that is not eligible, one plan per level on its own crop.
+    // Per plan: a row program (one record per source row of the crop: "an output row of level g completes here" + its 6 vertical
+    // weights) and column records per PX-pixel wave tile.
     if (channels == 3 && tab.W % 4 == 0 && n_levels <= 7 + kW3MaxPlans) {
         struct HostPlan {
             int unit;                 // level index of the plan's unit level, or -1
-            std::vector<int> gen;     // its general levels
+            int crop;                 // the level whose crop the plan walks
+            std::vector<int> gen;     // its general levels (union plans: finest first; those other than `crop` interior-only)
         };
-        std::vector<HostPlan> hp;
+        std::vector<std::vector<HostPlan>> candidates;
         {
             int unit = -1, n_unit = 0;
             for (int l = 0; l < n_levels; ++l)
@@ -334,128 +338,177 @@ SILENT_EXPORT int silent_pyramid_plan_create(silent_ctx* ctx, int frame_h, int f
                 }
             }
             if (same_crop) {
-                HostPlan h{unit, {}};
+                HostPlan h{unit, unit, {}};
                 for (int l = 0; l < n_levels; ++l)
                     if (tab.lv[l].kind == kPyrGeneral) h.gen.push_back(l);
-                hp.push_back(h);
+                candidates.push_back({h});
             } else {
+                std::vector<HostPlan> units, singles;
+                std::vector<int> gens;
                 for (int l = 0; l < n_levels; ++l) {
-                    if (tab.lv[l].kind == kPyrUnit) hp.push_back(HostPlan{l, {}});
-                    else if (tab.lv[l].kind == kPyrGeneral) hp.push_back(HostPlan{-1, {l}});
+                    if (tab.lv[l].kind == kPyrUnit) units.push_back(HostPlan{l, l, {}});
+                    else if (tab.lv[l].kind == kPyrGeneral) { singles.push_back(HostPlan{-1, l, {l}}); gens.push_back(l); }
                 }
-            }
-        }
-        bool usable = !hp.empty() && (int)hp.size() <= kW3MaxPlans;
-        for (const HostPlan& h : hp) {
-            if (h.unit >= 0) {
-                const PyrLevelDev& u = tab.lv[h.unit];   // canvas at least as large as the crop
-                if (u.out_h < u.src_h || u.out_w < u.src_w) usable = false;
-            }
-            const PyrLevelDev& c = tab.lv[h.unit >= 0 ? h.unit : h.gen[0]];
-            if (c.src_w < 8) usable = false;
-        }
-        int maxg = 0;
-        for (const HostPlan& h : hp) maxg = std::max(maxg, (int)h.gen.size());
-        const int Gp = stream_pad_levels(std::max(maxg, 1)), PR = w3_prog_row(Gp);
-        for (int px : {36, 32}) {
-            if (!usable || plan->walk_pyr_ok) break;
-            const int rec_total = w3_rec_total(px, Gp);
-            std::vector<int> blob;                        // all tables of all plans, offsets in ints
-            struct Off { size_t prog, hdr, rec; };
-            std::vector<Off> offs;
-            bool ok = true;
-            Walk3Args wa;
-            std::memset(&wa, 0, sizeof(wa));
-            for (size_t pi = 0; pi < hp.size() && ok; ++pi) {
-                const HostPlan& h = hp[pi];
-                const PyrLevelDev& c = tab.lv[h.unit >= 0 ? h.unit : h.gen[0]];
-                const int walk_h = h.unit >= 0 ? c.out_h : c.src_h, walk_w = h.unit >= 0 ? c.out_w : c.src_w;
-                const int G = (int)h.gen.size();
-                const int waves_x = ((walk_w + kW3NC * px - 1) / (kW3NC * px)) * kW3NC;
-                const size_t n_rec = (size_t)walk_h + 8;                 // stream rows y = -4 .. walk_h + 3 at index y + 4
-                const size_t n_rec_pad = n_rec + 2 * kWalkCH;            // the loader fetches whole chunks of records
-                std::vector<int> prog(n_rec_pad * PR, 0), hdr((size_t)std::max(G, 1) * waves_x * 2, 0), rec((size_t)waves_x * rec_total * 8, 0);
-                Walk3Plan& wp3 = wa.plan[pi];
-                for (int g = 0; g < G && ok; ++g) {
-                    const PyrLevelDev& d = tab.lv[h.gen[g]];
-                    const int zc = std::min(d.zoom_w, d.out_w), zr = std::min(d.zoom_h, d.out_h);
-                    const int* yb = ybase.data() + d.ytab_off;
-                    const int* xb = xbase.data() + d.xtab_off;
-                    for (int oy = 0; oy < zr && ok; ++oy) {
-                        // one record entry per COMPLETING row: flag + output row, 6 weights
-                        if (yb[oy] < 0 || yb[oy] >= walk_h) { ok = false; break; }
-                        const size_t r = (size_t)(yb[oy] + 7);           // the last tap sits on stream row y = yb + 3, index y + 4
-                        if (r >= n_rec) { ok = false; break; }
-                        int* pr = prog.data() + r * PR;
-                        if (pr[g] & 1) { ok = false; break; }             // two rows of one level completing together: step < 1
-                        pr[g] = 1 | (oy << 8);
-                        std::memcpy(pr + Gp + 6 * g, &yw[(size_t)(d.ytab_off + oy) * 6], 24);
+                // the union: an outermost general level whose crop holds every other general level's crop
+                int outer = -1;
+                for (int o : gens) {
+                    bool holds = true;
+                    for (int l : gens) {
+                        const PyrLevelDev &a = tab.lv[o], &d = tab.lv[l];
+                        holds = holds && d.src_y0 >= a.src_y0 && d.src_x0 >= a.src_x0 && d.src_y0 + d.src_h <= a.src_y0 + a.src_h &&
+                                d.src_x0 + d.src_w <= a.src_x0 + a.src_w;
                     }
-                    int ox = 0;
-                    for (int wx = 0; wx < waves_x && ok; ++wx) {
-                        const int xw0 = wx * px;
-                        while (ox < zc && xb[ox] < xw0) ++ox;
-                        int n = 0;
-                        while (ox + n < zc && xb[ox + n] < xw0 + px) ++n;
-                        if (n > w3_rec_cap(px, g)) { ok = false; break; }  // outputs per wave tile (the gather takes <= 21)
-                        hdr[((size_t)g * waves_x + wx) * 2] = ox;
-                        hdr[((size_t)g * waves_x + wx) * 2 + 1] = n;
-                        for (int j = 0; j < n; ++j) {
-                            int* r = rec.data() + ((size_t)wx * rec_total + w3_rec_base(px, g) + j) * 8;
-                            r[0] = (xb[ox + j] - xw0) * 3;               // FLOAT index of tap 0, channel 0 (line starts at pixel xw0 - 2)
-                            if (r[0] < 0 || r[0] + 2 + 15 > kW3TileF - 1) { ok = false; break; }
-                            std::memcpy(r + 1, &xw[(size_t)(d.xtab_off + ox + j) * 6], 24);
+                    if (holds) { outer = o; break; }
+                }
+                if (outer >= 0 && gens.size() >= 2 && gens.size() <= 7 && !(ctx->tune[SILENT_TUNE_PYRAMID] & 4u)) {
+                    // finest level first: the column records' capacity per wave tile shrinks with the position (w3_rec_cap)
+                    std::vector<int> order = gens;
+                    std::stable_sort(order.begin(), order.end(), [&](int x, int y) {
+                        return (double)tab.lv[x].zoom_w / tab.lv[x].src_w > (double)tab.lv[y].zoom_w / tab.lv[y].src_w;
+                    });
+                    std::vector<HostPlan> u2 = units;
+                    u2.push_back(HostPlan{-1, outer, order});
+                    candidates.push_back(u2);
+                }
+                std::vector<HostPlan> per_level = units;
+                per_level.insert(per_level.end(), singles.begin(), singles.end());
+                candidates.push_back(per_level);
+            }
+        }
+        for (const std::vector<HostPlan>& hp : candidates) {
+            if (plan->walk_pyr_ok) break;
+            bool usable = !hp.empty() && (int)hp.size() <= kW3MaxPlans;
+            for (const HostPlan& h : hp) {
+                if (h.unit >= 0) {
+                    const PyrLevelDev& u = tab.lv[h.unit];   // canvas at least as large as the crop
+                    if (u.out_h < u.src_h || u.out_w < u.src_w) usable = false;
+                }
+                if (tab.lv[h.crop].src_w < 8) usable = false;
+            }
+            int maxg = 0;
+            for (const HostPlan& h : hp) maxg = std::max(maxg, (int)h.gen.size());
+            const int Gp = stream_pad_levels(std::max(maxg, 1)), PR = w3_prog_row(Gp);
+            for (int px : {36, 32}) {
+                if (!usable || plan->walk_pyr_ok) break;
+                const int rec_total = w3_rec_total(px, Gp);
+                std::vector<int> blob;                        // all tables of all plans, offsets in ints
+                struct Off { size_t prog, hdr, rec; };
+                std::vector<Off> offs;
+                bool ok = true;
+                Walk3Args wa;
+                std::memset(&wa, 0, sizeof(wa));
+                BorderTab bt;
+                std::memset(&bt, 0, sizeof(bt));
+                for (size_t pi = 0; pi < hp.size() && ok; ++pi) {
+                    const HostPlan& h = hp[pi];
+                    const PyrLevelDev& c = tab.lv[h.crop];
+                    const int walk_h = h.unit >= 0 ? c.out_h : c.src_h, walk_w = h.unit >= 0 ? c.out_w : c.src_w;
+                    const int G = (int)h.gen.size();
+                    const int waves_x = ((walk_w + kW3NC * px - 1) / (kW3NC * px)) * kW3NC;
+                    const size_t n_rec = (size_t)walk_h + 8;                 // stream rows y = -4 .. walk_h + 3 at index y + 4
+                    const size_t n_rec_pad = n_rec + 2 * kWalkCH;            // the loader fetches whole chunks of records
+                    std::vector<int> prog(n_rec_pad * PR, 0), hdr((size_t)std::max(G, 1) * waves_x * 2, 0), rec((size_t)waves_x * rec_total * 8, 0);
+                    Walk3Plan& wp3 = wa.plan[pi];
+                    for (int g = 0; g < G && ok; ++g) {
+                        const PyrLevelDev& d = tab.lv[h.gen[g]];
+                        const int zc = std::min(d.zoom_w, d.out_w), zr = std::min(d.zoom_h, d.out_h);
+                        const int* yb = ybase.data() + d.ytab_off;
+                        const int* xb = xbase.data() + d.xtab_off;
+                        // a level on ANOTHER crop than the walk's: offset of its crop inside the walk, and the outputs whose taps
+                        // (rows / columns base - 2 .. base + 3) stay inside its own crop
+                        const int dy = d.src_y0 - c.src_y0, dx = d.src_x0 - c.src_x0;
+                        int oy_lo = 0, oy_hi = zr, ox_lo = 0, ox_hi = zc;
+                        if (h.unit < 0 && h.gen[g] != h.crop) {
+                            while (oy_lo < zr && yb[oy_lo] - 2 < 0) ++oy_lo;
+                            while (oy_hi > oy_lo && yb[oy_hi - 1] + 3 > d.src_h - 1) --oy_hi;
+                            while (ox_lo < zc && xb[ox_lo] - 2 < 0) ++ox_lo;
+                            while (ox_hi > ox_lo && xb[ox_hi - 1] + 3 > d.src_w - 1) --ox_hi;
+                            if (oy_hi <= oy_lo || ox_hi <= ox_lo || bt.n >= kMaxLevels) { ok = false; break; }
+                            BorderLevel& bl = bt.lv[bt.n++];
+                            bl.level = h.gen[g];
+                            bl.oy_lo = oy_lo; bl.oy_hi = oy_hi; bl.ox_lo = ox_lo; bl.ox_hi = ox_hi;
+                            bl.zr = zr; bl.zc = zc;
+                            bl.start = bt.per_frame;
+                            bt.per_frame += zr * zc - (oy_hi - oy_lo) * (ox_hi - ox_lo);
                         }
-                        ox += n;
+                        for (int oy = oy_lo; oy < oy_hi && ok; ++oy) {
+                            // one record entry per COMPLETING row: flag + output row, 6 weights
+                            const int y = yb[oy] + dy;
+                            if (y < 0 || y >= walk_h) { ok = false; break; }
+                            const size_t r = (size_t)(y + 7);                // the last tap sits on stream row y + 3, index y + 4
+                            if (r >= n_rec) { ok = false; break; }
+                            int* pr = prog.data() + r * PR;
+                            if (pr[g] & 1) { ok = false; break; }             // two rows of one level completing together: step < 1
+                            pr[g] = 1 | (oy << 8);
+                            std::memcpy(pr + Gp + 6 * g, &yw[(size_t)(d.ytab_off + oy) * 6], 24);
+                        }
+                        int ox = ox_lo;
+                        for (int wx = 0; wx < waves_x && ok; ++wx) {
+                            const int xw0 = wx * px;
+                            while (ox < ox_hi && xb[ox] + dx < xw0) ++ox;
+                            int n = 0;
+                            while (ox + n < ox_hi && xb[ox + n] + dx < xw0 + px) ++n;
+                            if (n > w3_rec_cap(px, g)) { ok = false; break; }  // outputs per wave tile (the gather takes <= 21)
+                            hdr[((size_t)g * waves_x + wx) * 2] = ox;
+                            hdr[((size_t)g * waves_x + wx) * 2 + 1] = n;
+                            for (int j = 0; j < n; ++j) {
+                                int* r = rec.data() + ((size_t)wx * rec_total + w3_rec_base(px, g) + j) * 8;
+                                r[0] = (xb[ox + j] + dx - xw0) * 3;          // FLOAT index of tap 0, channel 0 (line starts at pixel xw0 - 2)
+                                if (r[0] < 0 || r[0] + 2 + 15 > kW3TileF - 1) { ok = false; break; }
+                                std::memcpy(r + 1, &xw[(size_t)(d.xtab_off + ox + j) * 6], 24);
+                            }
+                            ox += n;
+                        }
+                        wp3.pyr.px_off[g] = tab.px_off[h.gen[g]];
+                        wp3.pyr.out_w[g] = d.out_w;
                     }
-                    wp3.pyr.px_off[g] = tab.px_off[h.gen[g]];
-                    wp3.pyr.out_w[g] = d.out_w;
+                    if (!ok) break;
+                    wp3.src_y0 = c.src_y0; wp3.src_x0 = c.src_x0; wp3.src_h = c.src_h; wp3.src_w = c.src_w;
+                    wp3.shift = (c.src_x0 * 3) % 4;
+                    wp3.has_unit = h.unit >= 0 ? 1 : 0;
+                    wp3.out_h = walk_h; wp3.out_w = walk_w;
+                    wp3.eff_h = h.unit >= 0 ? std::min(c.zoom_h, c.out_h) : walk_h;
+                    wp3.eff_w = h.unit >= 0 ? std::min(c.zoom_w, c.out_w) : walk_w;
+                    wp3.px_off = h.unit >= 0 ? tab.px_off[h.unit] : 0;
+                    wp3.pyr.G = G;
+                    auto put = [&](const std::vector<int>& v) {
+                        while (blob.size() % 64) blob.push_back(0);          // 256-byte aligned tables
+                        const size_t at = blob.size();
+                        blob.insert(blob.end(), v.begin(), v.end());
+                        return at;
+                    };
+                    Off o;
+                    o.prog = put(prog);
+                    o.hdr = put(hdr);
+                    o.rec = put(rec);
+                    offs.push_back(o);
                 }
-                if (!ok) break;
-                wp3.src_y0 = c.src_y0; wp3.src_x0 = c.src_x0; wp3.src_h = c.src_h; wp3.src_w = c.src_w;
-                wp3.shift = (c.src_x0 * 3) % 4;
-                wp3.has_unit = h.unit >= 0 ? 1 : 0;
-                wp3.out_h = walk_h; wp3.out_w = walk_w;
-                wp3.eff_h = h.unit >= 0 ? std::min(c.zoom_h, c.out_h) : walk_h;
-                wp3.eff_w = h.unit >= 0 ? std::min(c.zoom_w, c.out_w) : walk_w;
-                wp3.px_off = h.unit >= 0 ? tab.px_off[h.unit] : 0;
-                wp3.pyr.G = G;
-                auto put = [&](const std::vector<int>& v) {
-                    while (blob.size() % 64) blob.push_back(0);          // 256-byte aligned tables
-                    const size_t at = blob.size();
-                    blob.insert(blob.end(), v.begin(), v.end());
-                    return at;
-                };
-                Off o;
-                o.prog = put(prog);
-                o.hdr = put(hdr);
-                o.rec = put(rec);
-                offs.push_back(o);
+                if (!ok) continue;
+                hipError_t se = hipMalloc(&plan->walk_tables, blob.size() * 4);
+                if (se == hipSuccess) se = hipMemcpy(plan->walk_tables, blob.data(), blob.size() * 4, hipMemcpyHostToDevice);
+                if (se != hipSuccess) {
+                    (void)hipGetLastError();
+                    if (plan->walk_tables) (void)hipFree(plan->walk_tables);
+                    plan->walk_tables = nullptr;
+                    break;
+                }
+                const int* base = (const int*)plan->walk_tables;
+                for (size_t pi = 0; pi < hp.size(); ++pi) {
+                    wa.plan[pi].pyr.row_prog = base + offs[pi].prog;
+                    wa.plan[pi].pyr.col_hdr = base + offs[pi].hdr;
+                    wa.plan[pi].pyr.col_rec = base + offs[pi].rec;
+                }
+                wa.H = tab.H;
+                wa.W = tab.W;
+                wa.n_plans = (int)hp.size();
+                wa.frame_px = tab.frame_px_out;
+                for (int j = 0; j < 6; ++j) wa.wx[j] = plan->unit_w[j];
+                plan->walk = wa;
+                plan->walk_border = bt;
+                plan->walk_px = px;
+                plan->walk_G = Gp;
+                plan->walk_pyr_ok = true;
             }
-            if (!ok) continue;
-            hipError_t se = hipMalloc(&plan->walk_tables, blob.size() * 4);
-            if (se == hipSuccess) se = hipMemcpy(plan->walk_tables, blob.data(), blob.size() * 4, hipMemcpyHostToDevice);
-            if (se != hipSuccess) {
-                (void)hipGetLastError();
-                if (plan->walk_tables) (void)hipFree(plan->walk_tables);
-                plan->walk_tables = nullptr;
-                break;
-            }
-            const int* base = (const int*)plan->walk_tables;
-            for (size_t pi = 0; pi < hp.size(); ++pi) {
-                wa.plan[pi].pyr.row_prog = base + offs[pi].prog;
-                wa.plan[pi].pyr.col_hdr = base + offs[pi].hdr;
-                wa.plan[pi].pyr.col_rec = base + offs[pi].rec;
-            }
-            wa.H = tab.H;
-            wa.W = tab.W;
-            wa.n_plans = (int)hp.size();
-            wa.frame_px = tab.frame_px_out;
-            for (int j = 0; j < 6; ++j) wa.wx[j] = plan->unit_w[j];
-            plan->walk = wa;
-            plan->walk_px = px;
-            plan->walk_G = Gp;
-            plan->walk_pyr_ok = true;
         }
     }
     *out = plan;
@@ -570,6 +623,11 @@ int launch_pyramid(silent_ctx* ctx, const char* who, const silent_pyramid_plan* 
             else WALK3(7, 32);
         }
 #undef WALK3
+        if (plan->walk_border.n > 0) {   // union plans: the inner levels' first / last output rows and columns
+            const long long threads = (long long)plan->walk_border.per_frame * 3 * n_frames;
+            if ((threads + 255) / 256 > 0x7fffffffll) return fail(ctx, SILENT_E_INVALID, std::string(who) + ": too many border pixels for one launch");
+            hipLaunchKernelGGL(pyramid_border_kernel<3>, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, s, frames, pyr, tab, plan->walk_border, n_frames);
+        }
     } else if (tab.C == 1) {
         if (b_unit) hipLaunchKernelGGL(pyramid_unit_kernel<1>, dim3((unsigned)b_unit), dim3(256), 0, s, frames, pyr, tab);
         if (b_region) hipLaunchKernelGGL(pyramid_region_kernel<1>, dim3((unsigned)b_region), dim3(256), 0, s, frames, pyr, tab);

@@ -1751,23 +1751,39 @@ def test_rgb_pyramid_walk_is_bit_identical_to_unit_plus_region_kernels(rt, shape
                                                   ((97, 132, 3), (32, 24), 1.7, 1)])
 def test_rgb_pyramid_walk_on_the_references_crop_layout(rt, shape, center, scale, B):
     """The reference's own pyramid layout (image_to_zoom_tensor, from_image.py:45-64: nested centre crops resampled to one
-    fixed size) through ONE launch of the strip-walk kernel, one walk plan per level, each mirroring at its own crop's edge
-    like scipy does on the cropped array: every level equal bit for bit to the unit + region kernels (PYRAMID knob 2), and
-    both within tolerance of the oracle (which calls scipy.ndimage.zoom like the reference)."""
+    fixed size) through ONE launch of the strip-walk kernel.  Round 5: a plan for the unit level and ONE "union" plan for the other
+    levels -- the walk over the outermost crop serves every inner level wherever its taps stay inside that level's crop, the inner
+    levels' first / last output rows and columns (scipy mirrors them at the level's OWN crop edge) come from pyramid_border_kernel;
+    PYRAMID knob 4 at plan creation: round 3's one plan per level.  Every level equal bit for bit between the union plans, the
+    per-level plans and the unit + region kernels (PYRAMID knob 2), with NaN / inf pixels on the corners of every crop, and within
+    tolerance of the oracle (which calls scipy.ndimage.zoom like the reference)."""
     from pysilent_amd.util.zoom.from_image import reference_levels
     levels = reference_levels(shape[:2], center, scale)
     frames = np.stack([noise_frame(80 + s_, *shape) for s_ in range(B)])
     frames[0, shape[0] // 2, shape[1] // 2, 1] = np.nan          # inside every crop
     frames[B - 1, shape[0] // 2 - 3, shape[1] // 2 + 5, 0] = np.inf
+    for k, (y0, x0, ch, cw) in enumerate(l[:4] for l in levels):  # the corners and edges of every crop: border outputs and mirrored taps
+        frames[0, y0, x0, k % 3] = np.inf
+        frames[0, y0 + ch - 1, x0 + cw - 1, (k + 1) % 3] = np.nan
+        frames[B - 1, y0 + ch // 2, x0, (k + 2) % 3] = -np.inf
+        frames[B - 1, y0 + ch - 1, x0 + cw // 3, k % 3] = np.nan
     plan = rt.PyramidPlan(shape[0], shape[1], 3, levels)
     n_plans, px = plan.walk_plans
-    assert n_plans == len(levels) and px in (32, 36), (n_plans, px)
+    assert n_plans == (2 if len(levels) >= 3 else len(levels)) and px in (32, 36), (n_plans, px)
+    with rt.tuning(TUNE_PYRAMID, 4):
+        per_level = rt.PyramidPlan(shape[0], shape[1], 3, levels)
+    assert per_level.walk_plans[0] == len(levels)
     got = plan.run(frames)
     with rt.tuning(TUNE_PYRAMID, 2):
         two = plan.run(frames)
-    a, b = np.asarray(got.data), np.asarray(two.data)
-    assert np.array_equal(np.isnan(a), np.isnan(b))
+    a, b, c = np.asarray(got.data), np.asarray(two.data), np.asarray(per_level.run(frames).data)
+    assert np.array_equal(np.isnan(a), np.isnan(b)) and np.array_equal(np.isnan(a), np.isnan(c))
     np.testing.assert_array_equal(np.nan_to_num(a, nan=7.0), np.nan_to_num(b, nan=7.0))
+    np.testing.assert_array_equal(np.nan_to_num(a, nan=7.0), np.nan_to_num(c, nan=7.0))
+    with np.errstate(invalid="ignore", over="ignore"):
+        bad_want = so.zoom_from_image(frames[0], 3, center, scale)
+        assert_close(a.reshape((B,) + bad_want.shape)[0], bad_want, RTOL, scale=255.0, what="reference layout, non-finite pixels on the crop corners",
+                     bound=eb.zoom(bad_want))
     clean = noise_frame(98, *shape)
     want = so.zoom_from_image(clean, 3, center, scale)
     res = plan.run(clean[None])
