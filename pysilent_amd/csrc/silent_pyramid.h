@@ -384,6 +384,13 @@ __global__ __launch_bounds__(256) void pyramid_border_kernel(const float* __rest
 }
 
 // ------------------------------------------------------------------------------------------ ZERO FILL
+// Canvas pixels the resampler does not produce -- rows zoom_h .. out_h - 1 over the full width, columns zoom_w .. out_w - 1 of the
+// rows above them (a canvas larger than its zoomed crop; scipy's mode-'constant' artefact row / column) -- and only those: the
+// chunks of 1024 enumerate exactly that L-shaped set (host: the same count in silent_pyramid_plan_create).
+__host__ __device__ inline long long pyramid_zero_count(int zoom_h, int zoom_w, int out_h, int out_w) {
+    const int zh = zoom_h < out_h ? zoom_h : out_h, zw = zoom_w < out_w ? zoom_w : out_w;
+    return (long long)(out_h - zh) * out_w + (long long)zh * (out_w - zw);
+}
 template <int C>
 __global__ __launch_bounds__(256) void pyramid_zero_kernel(float* __restrict__ pyr, const PyrTab tab) {
     const unsigned bid = blockIdx.x;
@@ -396,13 +403,22 @@ __global__ __launch_bounds__(256) void pyramid_zero_kernel(float* __restrict__ p
     rem -= tab.zero_chunk_start[l];
     const PyrLevelDev& lv = tab.lv[l];
     float* __restrict__ dst = pyr + ((long long)frame * tab.frame_px_out + tab.px_off[l]) * C;
-    const int npx = lv.out_h * lv.out_w;
+    const int zh = min(lv.zoom_h, lv.out_h), zw = min(lv.zoom_w, lv.out_w);
+    const int n_below = (lv.out_h - zh) * lv.out_w, wide = lv.out_w - zw, n_right = zh * wide;
     for (int k = 0; k < 4; ++k) {
         const int p = rem * 1024 + k * 256 + threadIdx.x;
-        if (p >= npx) break;
-        const int y = p / lv.out_w, x = p - y * lv.out_w;
-        if (y >= lv.zoom_h || x >= lv.zoom_w)
-            for (int ch = 0; ch < C; ++ch) dst[(long long)p * C + ch] = 0.0f;
+        if (p >= n_below + n_right) break;
+        int y, x;
+        if (p < n_below) {
+            y = zh + p / lv.out_w;
+            x = p - (p / lv.out_w) * lv.out_w;
+        } else {
+            const int q = p - n_below;
+            y = q / wide;
+            x = zw + (q - y * wide);
+        }
+        const long long px = (long long)y * lv.out_w + x;
+        for (int ch = 0; ch < C; ++ch) dst[px * C + ch] = 0.0f;
     }
 }
 

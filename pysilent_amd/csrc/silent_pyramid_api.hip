@@ -167,7 +167,7 @@ SILENT_EXPORT int silent_pyramid_plan_create(silent_ctx* ctx, int frame_h, int f
                 if (p < 0 || p >= RH + kRegionHaloT + kRegionHaloB) tap_range_ok = false;
             }
         }
-        if (d.out_h > d.zoom_h || d.out_w > d.zoom_w) zero_chunks += ((long long)d.out_h * d.out_w + 1023) / 1024;
+        zero_chunks += (pyramid_zero_count(d.zoom_h, d.zoom_w, d.out_h, d.out_w) + 1023) / 1024;   // (exactly the pixels the resampler leaves)
     }
     tab.unit_tile_start[n_levels] = (int)unit_tiles;
     tab.unit_tiles_per_frame = (int)unit_tiles;
