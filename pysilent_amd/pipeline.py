@@ -242,7 +242,7 @@ class LineEndPipeline(object):
             best = t if best is None else min(best, t)
         return best
 
-    def tune_placement(self, frames=None, tries=6, steps=10, budget_s=4.0, good_enough=None):
+    def tune_placement(self, frames=None, tries=6, steps=10, budget_s=4.0, spacer_gib=8.0):
         """Pick the physical placement of the maps by measurement.  The same kernel on the same buffers AT THE SAME VIRTUAL
         ADDRESSES takes 1.23 ... 1.49 ms (config 5) from one allocation to the next: which physical pages the driver hands out
         decides how the dozen concurrent write streams of a step fall onto the HBM channels, and nothing an unprivileged process
@@ -250,7 +250,8 @@ class LineEndPipeline(object):
         (profiles/r05/placement.md).  So it is drawn a few times: allocate the maps, time ``steps`` steps (after a warm-up), keep
         the fastest set, return the others to the allocator.  ``frames``: the caller's resident batch (its placement is part
         of what is measured); default: synthetic noise.  Bounded by ``tries`` and by ``budget_s`` seconds.  Results never depend
-        on the choice.  The decision is in ``placement_tuning``."""
+        on the choice.  The decision is in ``placement_tuning``.  ``spacer_gib``: device memory allocated (and held until the end)
+        between two draws, so that they sample different stretches of the physical memory."""
         import time
         torch = self.torch
         if frames is None:
@@ -273,6 +274,13 @@ class LineEndPipeline(object):
                 held.clear()
                 torch.cuda.synchronize(self.tdev)
                 torch.cuda.empty_cache()
+                free, total = torch.cuda.mem_get_info(self.tdev)
+            # the fast and the slow stretches of physical memory are tens of GiB long (profiles/r05/placement.md, experiment 8):
+            # consecutive draws land in the same one.  A spacer between the draws -- held like the losers, freed at the end -- moves
+            # the next draw on by ``spacer_gib`` (while a third of the device stays free)
+            spacer = int(spacer_gib * (1 << 30))
+            if spacer and free - spacer > total // 3:
+                held.append(torch.empty(spacer, dtype=torch.uint8, device=self.tdev))
             cand = self._alloc_maps()
             self._adopt_maps(cand)
             for _ in range(5):
