@@ -164,6 +164,20 @@ def rgb_keypoints_host(ext, n_frames, cap=None):
     assert rc in (_lib.SILENT_OK, _lib.SILENT_E_CAPACITY), _lib.last_error(ctx.handle)
 
 
+def displayer_frames(n_frames=3, native_dtype=None):
+    """silent_displayer_*: one camera frame per call -- create, a few steps (eager, two captures, a replay), state, destroy."""
+    h, w = int(rng.integers(40, 120)), int(rng.integers(40, 160))
+    dt = native_dtype or [np.uint8, np.float32, np.uint16][int(rng.integers(3))]
+    out = (int(rng.integers(8, w // 2)), int(rng.integers(8, h // 2)))
+    d = rt.FrameDisplayer((h, w, 3), dt, out, float(rng.choice([math.e ** .5, 2.0, 1.6])), RGB, device=0)
+    for _ in range(n_frames):
+        res = d.step((rng.random((h, w, 3)) * 255).astype(dt))
+        assert len(res) == 6 and res[0].shape == d.shapes[0]
+    st = d.get_state()
+    d.set_state(st)
+    d.close()
+
+
 def bad_arguments():
     """Every one of these must come back as an error code (ValueError / TypeError in Python), never as a crash."""
     ext = [(9, 11)]
@@ -231,6 +245,8 @@ def exception_barrier():
         "malloc": lambda: ctx.check(lib.silent_malloc(ctx.handle, 64, C.byref(C.c_void_p()))),
         "synchronize": lambda: ctx.check(lib.silent_synchronize(ctx.handle, None)),
         "sparse_tail_stats": lambda: ctx.check(lib.silent_sparse_tail_stats(ctx.handle, (C.c_int64 * 5)())),
+        "busy_wait": lambda: ctx.check(lib.silent_busy_wait_dev(ctx.handle, 5, None)),
+        "displayer": lambda: displayer_frames(4, np.uint8),
     }
     for name, call in calls.items():
         call()                                   # works
@@ -249,7 +265,7 @@ def exception_barrier():
         call()                                   # and works again afterwards
     # (b) real allocation failures, one after the other, through plan creation (tap tables, row programs, walk plans) and
     # through a keypoint call (region tables, std::string of error paths): NOMEM or success, nothing else, and no crash
-    for what in ("plan3", "plan1", "keypoints"):
+    for what in ("plan3", "plan1", "keypoints", "displayer"):
         for k in range(1, 400):
             lib.silent_host_fail_new_after(k)
             try:
@@ -257,6 +273,8 @@ def exception_barrier():
                     rt.PyramidPlan(64, 96, 3, classic_levels((64, 96), 2.0, 4), 0).close()
                 elif what == "plan1":
                     rt.PyramidPlan(64, 96, 1, reference_levels((64, 96), (24, 16), math.e ** .5), 0).close()
+                elif what == "displayer":
+                    displayer_frames(2, np.uint8)
                 else:
                     rt.max_value_indices_region(x1, [(2, 2), (1, 1)])
                 done = True
@@ -300,7 +318,10 @@ bad_arguments()
 exception_barrier()
 while time.time() - t0 < budget:
     try:
-        if rng.random() < 0.35:
+        r = rng.random()
+        if r < 0.04:
+            displayer_frames()
+        elif r < 0.37:
             one_plan()
         else:
             one_op()
