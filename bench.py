@@ -479,6 +479,16 @@ def latency_record():
                 rec["gpu_busy_ms"] = round(float(np.median(busy)), 4)
                 rec["levels"] = len(res[1])
                 rec["result_bytes"] = int(sum(np.stack(r).nbytes for r in res[1:]))
+                # the same with the frame captured INTO the displayer's pinned buffer (no staging copy on the host)
+                fd = disp._native[1]
+                np.copyto(fd.frame_buffer, frames[0])
+                ts = []
+                for i in range(n):
+                    t0 = time.perf_counter()
+                    fd.step(fd.frame_buffer)
+                    ts.append((time.perf_counter() - t0) * 1e3)
+                rec["native_in_place_ms_p50"] = round(float(np.percentile(ts, 50)), 4)
+                rec["native_in_place_ms_p99"] = round(float(np.percentile(ts, 99)), 4)
             del disp, res
         out[name] = rec
     return out

@@ -37,7 +37,7 @@
 extern "C" {
 #endif
 
-#define SILENT_ABI_VERSION 3
+#define SILENT_ABI_VERSION 4
 #define SILENT_MAX_LEVELS 16
 #define SILENT_MAX_KERNEL_FLOATS 784 /* kh*kw*C_in*C_out limit (weights travel as kernel arguments) */
 
@@ -488,6 +488,9 @@ int silent_displayer_shape(const silent_displayer* d, int32_t* shape7, size_t* o
 /* Synchronous.  results[0..5]: pointers INTO the displayer's pinned result slot, valid until the SECOND next step (two slots
  * alternate).  gpu_ms (may be NULL): device time of the frame, upload to download. */
 int silent_displayer_step(silent_displayer* d, const void* frame_host, const float** results, float* gpu_ms);
+/* The displayer's pinned input buffer: a capture loop that writes the camera frame THERE and passes this pointer to
+ * silent_displayer_step skips the staging copy (6 MB per 1080p frame). */
+int silent_displayer_input(silent_displayer* d, void** frame_buffer, size_t* bytes);
 int silent_displayer_get_state(silent_displayer* d, float* energy_host);       /* [L, ch, cw] */
 int silent_displayer_set_state(silent_displayer* d, const float* energy_host);
 

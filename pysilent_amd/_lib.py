@@ -31,7 +31,7 @@ MAX_LEVELS = 16
 TUNE_GRAY, TUNE_RGB, TUNE_PYRAMID = 0, 1, 2
 GRAY_PART_PYRAMID, GRAY_PART_FILTER = 1, 2
 DT_U8, DT_F32, DT_F64, DT_I32, DT_U16, DT_I16, DT_I64 = 0, 1, 2, 3, 4, 5, 6
-ABI_VERSION = 3
+ABI_VERSION = 4
 
 
 class Extent(C.Structure):
@@ -148,6 +148,7 @@ _SIGNATURES = {
     "silent_displayer_destroy": [_vp],
     "silent_displayer_shape": [_vp, C.POINTER(C.c_int32), C.POINTER(_sz)],
     "silent_displayer_step": [_vp, _vp, C.POINTER(_vp), C.POINTER(_f)],
+    "silent_displayer_input": [_vp, C.POINTER(_vp), C.POINTER(_sz)],
     "silent_displayer_get_state": [_vp, _fp],
     "silent_displayer_set_state": [_vp, _fp],
 }

@@ -637,13 +637,20 @@ class FrameDisplayer(object):
         self._res = (C.c_void_p * 6)()
         self._ms = C.c_float(0)
         self.gpu_ms = 0.0
+        ptr, nbytes = C.c_void_p(), C.c_size_t(0)
+        self.ctx.check(lib.silent_displayer_input(self.handle, C.byref(ptr), C.byref(nbytes)))
+        buf = (C.c_char * nbytes.value).from_address(ptr.value)
+        buf._owner = self
+        #: the displayer's pinned input buffer as an [H, W, 3] array: a capture loop that grabs INTO it (``cap.read(disp.frame_buffer)``,
+        #: ``np.copyto``) and passes it to ``step`` is uploaded without the staging copy
+        self.frame_buffer = np.frombuffer(buf, self.dtype).reshape(self.frame_shape)
 
     def step(self, frame):
         """frame: [H, W, 3] ndarray of the displayer's dtype.  Returns the six float32 arrays as VIEWS of the displayer's pinned
         result slot -- valid until the second next step (two slots alternate); copy what has to live longer."""
         if not isinstance(frame, np.ndarray) or frame.dtype != self.dtype or tuple(frame.shape) != self.frame_shape:
             raise ValueError("frame must be a %s ndarray of shape %s" % (self.dtype, self.frame_shape,))
-        f = np.ascontiguousarray(frame)
+        f = frame if frame.flags["C_CONTIGUOUS"] else np.ascontiguousarray(frame)
         self.ctx.check(self._lib.silent_displayer_step(self.handle, C.c_void_p(f.ctypes.data), self._res, C.byref(self._ms)))
         self.gpu_ms = float(self._ms.value)
         out = []

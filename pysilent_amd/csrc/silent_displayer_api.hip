@@ -24,13 +24,13 @@ struct silent_displayer {
     // device
     void* slab = nullptr;
     void* d_raw = nullptr;
-    float *d_frame = nullptr, *d_pyr = nullptr, *d_orient = nullptr, *d_line = nullptr, *d_value = nullptr, *d_g = nullptr, *d_dist1 = nullptr,
-          *d_tot1 = nullptr, *d_imp = nullptr, *d_im2 = nullptr, *d_im2n = nullptr, *d_dist2 = nullptr, *d_tot2 = nullptr, *d_fired = nullptr,
-          *d_update = nullptr, *d_energy = nullptr, *d_out1 = nullptr, *d_out2 = nullptr, *d_out3 = nullptr;
+    float *d_frame = nullptr, *d_pyr = nullptr, *d_orient = nullptr, *d_line = nullptr, *d_value = nullptr, *d_g = nullptr, *d_tot1 = nullptr,
+          *d_imp = nullptr, *d_im2n = nullptr, *d_update = nullptr, *d_energy = nullptr, *d_out1 = nullptr, *d_out2 = nullptr, *d_out3 = nullptr;
     // pinned host: the frame, and two result slots (the results of step n stay valid until step n + 2)
     void* h_in = nullptr;
     float* h_out[2] = {nullptr, nullptr};
-    size_t out_floats[6] = {0, 0, 0, 0, 0, 0}, out_total = 0;
+    size_t out_floats[6] = {0, 0, 0, 0, 0, 0}, out_off[6] = {0, 0, 0, 0, 0, 0}, out_total = 0;   // (offsets / total in floats, 64-byte steps)
+    float* d_results = nullptr;           // the six results back to back on the device, in the layout of a host slot: ONE download
     int slot = 0;
     long long steps = 0;
 };
@@ -68,8 +68,7 @@ static int displayer_enqueue(silent_displayer* d, int slot) {
     silent_ctx* c = d->ctx;
     silent_stream s = (silent_stream)d->stream;
     const int L = d->L;
-    const size_t px = (size_t)L * d->h * d->w, cells = (size_t)L * d->ch * d->cw, px2 = (size_t)L * d->hh * d->hw;
-    const silent_extent lev = {d->h, d->w}, half = {d->hh, d->hw}, cell = {d->ch, d->cw};
+    const silent_extent lev = {d->h, d->w};
     HIP_TRY(d->owner, hipMemcpyAsync(d->d_raw, d->h_in, d->in_bytes, hipMemcpyHostToDevice, d->stream));
     // np.asarray(frame, dtype=float32) (:141)
     if (d->prm.frame_dtype != SILENT_DT_F32)
@@ -80,28 +79,12 @@ static int displayer_enqueue(silent_displayer* d, int slot) {
     silent_rgb_chain_params cp = d->prm.chain;
     cp.rgc = d->kernels; cp.rgby = d->kernels + 81; cp.stripe = d->kernels + 162; cp.end = d->kernels + 243; cp.blur = d->kernels + 324;
     TRY(silent_rgb_line_end_dev(c, d->d_pyr, &lev, 1, L, &cp, d->d_orient, d->d_line, d->d_value, s));
-    // centroids of gray / 255 (:79-80), importances (:81); the same on the nearest-neighbour half-size map (:82-84)
-    const silent_affine_params by255 = {1.f, 255.f, 0.f, -INFINITY, INFINITY, 0.f};
-    TRY(silent_affine_clip_dev(c, d->d_value, px, &by255, d->d_g, s));
-    TRY(silent_centroids_dev(c, d->d_g, &lev, 1, L, d->prm.centroid_region_h, d->prm.centroid_region_w, d->d_dist1, d->d_tot1, s));
-    const silent_affine_params imp = {255.f / 4.0f, 1.f, 0.f, 1.f, 256.f, -1.f};
-    TRY(silent_affine_clip_dev(c, d->d_tot1, cells, &imp, d->d_imp, s));
-    TRY(silent_resize_nearest_dev(c, d->d_value, &lev, 1, L, 1, &half, d->d_im2, s));
-    TRY(silent_affine_clip_dev(c, d->d_im2, px2, &by255, d->d_im2n, s));
-    TRY(silent_centroids_dev(c, d->d_im2n, &half, 1, L, d->prm.centroid_region_h, d->prm.centroid_region_w, d->d_dist2, d->d_tot2, s));
-    // get_boosting (:86): advances energy_values
-    TRY(silent_boosting_step_dev(c, d->d_imp, &cell, 1, L, &d->prm.boosting, d->d_energy, d->d_fired, d->d_update, s));
-    // what the reference fetches (:99-100): orient, 255 - centroids * 255, 255 - centroids2 * 255, fired * 255, update, padded line_end
-    const silent_affine_params inv = {-255.f, 1.f, 255.f, -INFINITY, INFINITY, 0.f}, x255 = {255.f, 1.f, 0.f, -INFINITY, INFINITY, 0.f};
-    TRY(silent_affine_clip_dev(c, d->d_dist1, px, &inv, d->d_out1, s));
-    TRY(silent_affine_clip_dev(c, d->d_dist2, px2, &inv, d->d_out2, s));
-    TRY(silent_affine_clip_dev(c, d->d_fired, cells * (d->prm.boosting.visualize ? 3 : 1), &x255, d->d_out3, s));
-    const float* src[6] = {d->d_orient, d->d_out1, d->d_out2, d->d_out3, d->d_update, d->d_line};
-    float* dst = d->h_out[slot];
-    for (int i = 0; i < 6; ++i) {
-        HIP_TRY(d->owner, hipMemcpyAsync(dst, src[i], d->out_floats[i] * 4, hipMemcpyDeviceToHost, d->stream));
-        dst += d->out_floats[i];
-    }
+    // centroids of gray / 255 (:79-80), importances (:81); the same on the nearest-neighbour half-size map (:82-84); get_boosting
+    // (:86, advances energy_values); what the reference fetches (:99-100): 255 - centroids * 255 (both), fired * 255, update --
+    // fifteen launches of the per-op path (affine, centroid cells / dist, resize, boost power / update) as four (silent_peaks.h, DispTail)
+    TRY(displayer_tail(c, L, d->h, d->w, d->prm.centroid_region_h, d->prm.centroid_region_w, d->hh, d->hw, &d->prm.boosting, d->d_value,
+                       d->d_g, d->d_im2n, d->d_tot1, d->d_imp, d->d_energy, d->d_out1, d->d_out2, d->d_out3, d->d_update, d->stream));
+    HIP_TRY(d->owner, hipMemcpyAsync(d->h_out[slot], d->d_results, d->out_total * 4, hipMemcpyDeviceToHost, d->stream));
     return SILENT_OK;
 }
 
@@ -148,22 +131,30 @@ SILENT_EXPORT int silent_displayer_create(silent_ctx* ctx, const silent_displaye
     const size_t px = (size_t)d->L * d->h * d->w, cells = (size_t)d->L * d->ch * d->cw, px2 = (size_t)d->L * d->hh * d->hw;
     const int vis = p->boosting.visualize ? 3 : 1;
     d->in_bytes = (size_t)p->frame_h * p->frame_w * 3 * dt_size(p->frame_dtype);
-    const size_t want[] = {d->in_bytes, (size_t)p->frame_h * p->frame_w * 12, px * 12, px * 12, px * 12, px * 4, px * 4, px * 4, cells * 4, cells * 4,
-                           px2 * 4, px2 * 4, px2 * 4, cells * 4, cells * 4 * vis, cells * 4 * vis, cells * 4, px * 4, px2 * 4, cells * 4 * vis};
+    // the six results first, back to back in 64-byte steps: the device block and a host slot share one layout
+    const size_t outs[6] = {px * 3, px, px2, cells * vis, cells * vis, px * 3};
+    for (int i = 0; i < 6; ++i) {
+        d->out_floats[i] = outs[i];
+        d->out_off[i] = d->out_total;
+        d->out_total += (outs[i] + 15) / 16 * 16;
+    }
+    const size_t want[] = {d->out_total * 4, d->in_bytes, (size_t)p->frame_h * p->frame_w * 12, px * 12, px * 4, px * 4, cells * 4, cells * 4, px2 * 4,
+                           cells * 4};
     size_t total = 0;
     for (size_t b : want) total += align_up(b);
     HIP_TRY(ctx, hipMalloc(&d->slab, total));
     char* at = (char*)d->slab;
     auto take = [&](size_t b) { char* r = at; at += align_up(b); return r; };
-    d->d_raw = take(want[0]);
-    float** f[] = {&d->d_frame, &d->d_pyr, &d->d_orient, &d->d_line, &d->d_value, &d->d_g, &d->d_dist1, &d->d_tot1, &d->d_imp, &d->d_im2,
-                   &d->d_im2n, &d->d_dist2, &d->d_tot2, &d->d_fired, &d->d_update, &d->d_energy, &d->d_out1, &d->d_out2, &d->d_out3};
-    for (size_t i = 0; i < sizeof(f) / sizeof(f[0]); ++i) *f[i] = (float*)take(want[i + 1]);
-    const size_t outs[6] = {px * 3, px, px2, cells * vis, cells * vis, px * 3};
-    for (int i = 0; i < 6; ++i) {
-        d->out_floats[i] = outs[i];
-        d->out_total += outs[i];
-    }
+    d->d_results = (float*)take(want[0]);
+    d->d_orient = d->d_results + d->out_off[0];
+    d->d_out1 = d->d_results + d->out_off[1];
+    d->d_out2 = d->d_results + d->out_off[2];
+    d->d_out3 = d->d_results + d->out_off[3];
+    d->d_update = d->d_results + d->out_off[4];
+    d->d_line = d->d_results + d->out_off[5];
+    d->d_raw = take(want[1]);
+    float** f[] = {&d->d_frame, &d->d_pyr, &d->d_value, &d->d_g, &d->d_tot1, &d->d_imp, &d->d_im2n, &d->d_energy};
+    for (size_t i = 0; i < sizeof(f) / sizeof(f[0]); ++i) *f[i] = (float*)take(want[i + 2]);
     HIP_TRY(ctx, hipHostMalloc(&d->h_in, d->in_bytes, hipHostMallocDefault));
     for (float*& hp : d->h_out) HIP_TRY(ctx, hipHostMalloc((void**)&hp, d->out_total * 4, hipHostMallocDefault));
     HIP_TRY(ctx, hipStreamCreateWithFlags(&d->stream, hipStreamNonBlocking));
@@ -212,7 +203,7 @@ SILENT_EXPORT int silent_displayer_step(silent_displayer* d, const void* frame_h
     NEED_CTX(ctx);
     const char* who = "silent_displayer_step";
     if (!frame_host || !results) return fail(ctx, SILENT_E_INVALID, std::string(who) + ": NULL pointer");
-    std::memcpy(d->h_in, frame_host, d->in_bytes);
+    if (frame_host != d->h_in) std::memcpy(d->h_in, frame_host, d->in_bytes);   // (a capture loop may grab INTO silent_displayer_input)
     const int slot = d->slot;
     d->ctx->err.clear();
     HIP_TRY(ctx, hipEventRecord(d->ev[0], d->stream));
@@ -244,16 +235,23 @@ SILENT_EXPORT int silent_displayer_step(silent_displayer* d, const void* frame_h
     HIP_TRY(ctx, hipEventRecord(d->ev[1], d->stream));
     HIP_TRY(ctx, hipStreamSynchronize(d->stream));
     if (gpu_ms) HIP_TRY(ctx, hipEventElapsedTime(gpu_ms, d->ev[0], d->ev[1]));
-    const float* r = d->h_out[slot];
-    for (int i = 0; i < 6; ++i) {
-        results[i] = r;
-        r += d->out_floats[i];
-    }
+    for (int i = 0; i < 6; ++i) results[i] = d->h_out[slot] + d->out_off[i];
     d->slot ^= 1;
     ++d->steps;
     return SILENT_OK;
 } catch (...) {
     return on_exception(d ? d->owner : nullptr, "silent_displayer_step");
+}
+
+// The displayer's pinned input buffer (frame_h x frame_w x 3 of the frame dtype): a frame written there and passed to
+// silent_displayer_step as this very pointer is uploaded without the staging copy.
+SILENT_EXPORT int silent_displayer_input(silent_displayer* d, void** frame_buffer, size_t* bytes) try {
+    if (!d || !frame_buffer) return fail(d ? d->owner : nullptr, SILENT_E_INVALID, "silent_displayer_input: NULL pointer");
+    *frame_buffer = d->h_in;
+    if (bytes) *bytes = d->in_bytes;
+    return SILENT_OK;
+} catch (...) {
+    return on_exception(d ? d->owner : nullptr, "silent_displayer_input");
 }
 
 // The boosting state (energy_values, recognition_testing.py:56): [levels, ceil(h / region_h), ceil(w / region_w)] float32.

@@ -928,6 +928,25 @@ struct CellTab {
     float yscale[kMaxLevels], xscale[kMaxLevels];  // float32 cells / extent: nearest-neighbour resize back
 };
 
+// cell (j, i) of one H x W map v: total of the box, and its centroid (0 / 0 = NaN in an empty cell, like the reference)
+__device__ __forceinline__ void centroid_cell(const float* __restrict__ v, int H, int W, int y_first, int x_first, int rh, int rw, int j, int i,
+                                              float* tot_out, float* cx, float* cy) {
+    const int y0 = max(y_first + j * rh, 0), y1 = min(y_first + j * rh + rh, H);
+    const int x0 = max(x_first + i * rw, 0), x1 = min(x_first + i * rw + rw, W);
+    float tot = 0.0f, sx = 0.0f, sy = 0.0f;
+    for (int y = y0; y < y1; ++y)
+        for (int x = x0; x < x1; ++x) {
+            const float val = v[(long long)y * W + x];
+            sx = __fadd_rn(sx, __fmul_rn((float)x, val));   // ind_tens * value, then the box sum (float32)
+            sy = __fadd_rn(sy, __fmul_rn((float)y, val));
+            const float half = __fmul_rn(val, 0.5f);        // value tiled to 2 channels times the 1/2 tap
+            tot = __fadd_rn(__fadd_rn(tot, half), half);
+        }
+    *tot_out = tot;
+    *cx = sx / tot;
+    *cy = sy / tot;
+}
+
 __global__ __launch_bounds__(256) void centroid_cells_kernel(const float* __restrict__ value, const LevelTab tab,
                                                              const CellTab ct, int n_frames,
                                                              float* __restrict__ total_out, float* __restrict__ cxy) {
@@ -940,27 +959,21 @@ __global__ __launch_bounds__(256) void centroid_cells_kernel(const float* __rest
     for (int i = 1; i < kMaxLevels; ++i)
         if (i < tab.n_levels && rem >= ct.cell_off[i]) l = i;
     rem -= ct.cell_off[l];
-    const int H = tab.h[l], W = tab.w[l];
     const int j = (int)(rem / ct.ow[l]), i = (int)(rem - (long long)j * ct.ow[l]);
     const float* __restrict__ v = value + (long long)frame * tab.frame_px + tab.px_off[l];
-    const int y0 = max(ct.y_first[l] + j * ct.rh, 0), y1 = min(ct.y_first[l] + j * ct.rh + ct.rh, H);
-    const int x0 = max(ct.x_first[l] + i * ct.rw, 0), x1 = min(ct.x_first[l] + i * ct.rw + ct.rw, W);
-    float tot = 0.0f, sx = 0.0f, sy = 0.0f;
-    for (int y = y0; y < y1; ++y)
-        for (int x = x0; x < x1; ++x) {
-            const float val = v[(long long)y * W + x];
-            sx = __fadd_rn(sx, __fmul_rn((float)x, val));   // ind_tens * value, then the box sum (float32)
-            sy = __fadd_rn(sy, __fmul_rn((float)y, val));
-            const float half = __fmul_rn(val, 0.5f);        // value tiled to 2 channels times the 1/2 tap
-            tot = __fadd_rn(__fadd_rn(tot, half), half);
-        }
     const long long cell = (long long)frame * ct.frame_cells + ct.cell_off[l] + rem;
-    total_out[cell] = tot;
-    cxy[cell * 2 + 0] = sx / tot;
-    cxy[cell * 2 + 1] = sy / tot;
+    centroid_cell(v, tab.h[l], tab.w[l], ct.y_first[l], ct.x_first[l], ct.rh, ct.rw, j, i, &total_out[cell], &cxy[cell * 2], &cxy[cell * 2 + 1]);
 }
 
-// per pixel: |cx(cell) - x| + |cy(cell) - y| with the TF1 nearest-neighbour cell lookup
+// per pixel: |cx(cell) - x| + |cy(cell) - y| with the TF1 nearest-neighbour cell lookup (c: the map's [oh][ow][2] centroids)
+__device__ __forceinline__ float centroid_dist_px(const float* __restrict__ c, int y, int x, int oh, int ow, float yscale, float xscale) {
+    int sy = (int)floorf(__fmul_rn((float)y, yscale));
+    int sx = (int)floorf(__fmul_rn((float)x, xscale));
+    sy = min(sy, oh - 1);
+    sx = min(sx, ow - 1);
+    const float cx = c[((long long)sy * ow + sx) * 2], cy = c[((long long)sy * ow + sx) * 2 + 1];
+    return __fadd_rn(fabsf(cx - (float)x), fabsf(cy - (float)y));
+}
 __global__ __launch_bounds__(256) void centroid_dist_kernel(const LevelTab tab, const CellTab ct,
                                                             const float* __restrict__ cxy, float* __restrict__ out) {
     const TileCoord tc = locate_tile(tab, blockIdx.x);
@@ -972,12 +985,7 @@ __global__ __launch_bounds__(256) void centroid_dist_kernel(const LevelTab tab, 
         const int p = tc.tx * kChunk + k * 256 + threadIdx.x;
         if (p >= npx) break;
         const int y = p / W, x = p - y * W;
-        int sy = (int)floorf(__fmul_rn((float)y, ct.yscale[l]));
-        int sx = (int)floorf(__fmul_rn((float)x, ct.xscale[l]));
-        sy = min(sy, ct.oh[l] - 1);
-        sx = min(sx, ct.ow[l] - 1);
-        const float cx = c[((long long)sy * ct.ow[l] + sx) * 2], cy = c[((long long)sy * ct.ow[l] + sx) * 2 + 1];
-        out[base_px + p] = __fadd_rn(fabsf(cx - (float)x), fabsf(cy - (float)y));
+        out[base_px + p] = centroid_dist_px(c, y, x, ct.oh[l], ct.ow[l], ct.yscale[l], ct.xscale[l]);
     }
 }
 
@@ -1000,6 +1008,33 @@ struct BoostP {
 
 // step 2: has_fired = (m == maxpool3x3 SAME(m)); energy <- clip((energy*255 - fired*255 + recovery) / 255, lo, hi)
 // in place (a pixel's update reads only its own energy; the neighbours enter through m, which is a separate buffer).
+// One pixel p of an H x W map m: returns the new energy; *f_out / *e_out = what the fired / energy maps show.
+__device__ __forceinline__ float boost_update_px(const float* __restrict__ src, int H, int W, int p, float xin, float e, const BoostP& bp,
+                                                 float* f_out, float* e_out) {
+    const int y = p / W, xx0 = p - y * W;
+    float mx = kPoolLowest;
+    for (int dy = -1; dy <= 1; ++dy) {
+        const int yy = y + dy;
+        if (yy < 0 || yy >= H) continue;
+        for (int dx = -1; dx <= 1; ++dx) {
+            const int xx = xx0 + dx;
+            if (xx < 0 || xx >= W) continue;
+            mx = pool_max(mx, src[(long long)yy * W + xx]);
+        }
+    }
+    const float fired = src[p] == mx ? 1.0f : 0.0f;
+    const float strength = __fmul_rn(fired, xin);
+    const float r_in = __fmul_rn(strength, bp.recovery_percentage);
+    float rec = bp.recovery_amount;
+    if (bp.recovery_mode == 2) rec = r_in;
+    else if (bp.recovery_mode == 3) rec = r_in < bp.recovery_amount ? bp.recovery_amount : r_in;
+    float u = __fadd_rn(__fsub_rn(__fmul_rn(e, 255.0f), __fmul_rn(fired, 255.0f)), rec) / 255.0f;
+    u = u < bp.lo ? bp.lo : u;
+    u = u > bp.hi ? bp.hi : u;
+    *f_out = bp.visualize ? strength : fired;
+    *e_out = bp.visualize ? __fadd_rn(__fmul_rn(u, bp.normer), bp.centerer) : u;
+    return u;
+}
 __global__ __launch_bounds__(256) void boost_update_kernel(const float* __restrict__ x, const float* __restrict__ m,
                                                            float* __restrict__ energy, float* __restrict__ fired_out,
                                                            float* __restrict__ energy_out, const LevelTab tab,
@@ -1013,31 +1048,8 @@ __global__ __launch_bounds__(256) void boost_update_kernel(const float* __restri
     for (int k = 0; k < 4; ++k) {
         const int p = tc.tx * kChunk + k * 256 + threadIdx.x;
         if (p >= npx) break;
-        const int y = p / W, xx0 = p - y * W;
-        float mx = kPoolLowest;
-        for (int dy = -1; dy <= 1; ++dy) {
-            const int yy = y + dy;
-            if (yy < 0 || yy >= H) continue;
-            for (int dx = -1; dx <= 1; ++dx) {
-                const int xx = xx0 + dx;
-                if (xx < 0 || xx >= W) continue;
-                mx = pool_max(mx, src[(long long)yy * W + xx]);
-            }
-        }
-        const float fired = src[p] == mx ? 1.0f : 0.0f;
-        const float xin = x[base_px + p];
-        const float strength = __fmul_rn(fired, xin);
-        const float r_in = __fmul_rn(strength, bp.recovery_percentage);
-        float rec = bp.recovery_amount;
-        if (bp.recovery_mode == 2) rec = r_in;
-        else if (bp.recovery_mode == 3) rec = r_in < bp.recovery_amount ? bp.recovery_amount : r_in;
-        const float e = energy[base_px + p];
-        float u = __fadd_rn(__fsub_rn(__fmul_rn(e, 255.0f), __fmul_rn(fired, 255.0f)), rec) / 255.0f;
-        u = u < bp.lo ? bp.lo : u;
-        u = u > bp.hi ? bp.hi : u;
-        energy[base_px + p] = u;
-        const float f_out = bp.visualize ? strength : fired;
-        const float e_out = bp.visualize ? __fadd_rn(__fmul_rn(u, bp.normer), bp.centerer) : u;
+        float f_out, e_out;
+        energy[base_px + p] = boost_update_px(src, H, W, p, x[base_px + p], energy[base_px + p], bp, &f_out, &e_out);
         for (int c = 0; c < C; ++c) {
             fired_out[(base_px + p) * C + c] = f_out;
             if (energy_out) energy_out[(base_px + p) * C + c] = e_out;
@@ -1051,6 +1063,13 @@ struct AffineP {
     float mul, div, add, lo, hi, post_add;
 };
 
+__device__ __forceinline__ float affine_px(float v, const AffineP& ap) {
+    float y = __fadd_rn(__fdiv_rn(__fmul_rn(v, ap.mul), ap.div), ap.add);
+    y = y < ap.lo ? ap.lo : y;
+    y = y > ap.hi ? ap.hi : y;
+    return __fadd_rn(y, ap.post_add);
+}
+
 __global__ __launch_bounds__(256) void affine_clip_kernel(const float* __restrict__ in, float* __restrict__ out,
                                                           long long n, const AffineP ap) {
     // 8 elements per thread, 256 apart (coalesced), all requested before the first use
@@ -1061,10 +1080,7 @@ __global__ __launch_bounds__(256) void affine_clip_kernel(const float* __restric
 #pragma unroll
     for (int k = 0; k < 8; ++k) {
         const long long i = i0 + k * 256;
-        float y = __fadd_rn(__fdiv_rn(__fmul_rn(v[k], ap.mul), ap.div), ap.add);
-        y = y < ap.lo ? ap.lo : y;
-        y = y > ap.hi ? ap.hi : y;
-        if (i < n) out[i] = __fadd_rn(y, ap.post_add);
+        if (i < n) out[i] = affine_px(v[k], ap);
     }
 }
 
@@ -1107,6 +1123,98 @@ __global__ __launch_bounds__(256) void resize_nearest_kernel(const float* __rest
         const int sy = min((int)floorf(__fmul_rn((float)y, rt.yscale[l])), rt.ih[l] - 1);
         const int sx = min((int)floorf(__fmul_rn((float)x, rt.xscale[l])), rt.iw[l] - 1);
         for (int c = 0; c < C; ++c) dst[(long long)p * C + c] = src[((long long)sy * rt.iw[l] + sx) * C + c];
+    }
+}
+
+// ---- the tail of the reference's application graph for ONE frame (silent_displayer_step; recognition_testing.py:77-100) in five
+// launches instead of fifteen: every launch of the per-op sequence is at its 4.7 us floor on a 640 x 480 frame, so the graph's
+// device time was a third small-kernel floors.  Each kernel below is several of the per-op kernels side by side over ONE index
+// space -- the per-element arithmetic is the per-op kernels' own (affine_px, centroid_cell, centroid_dist_px, boost_update_px), so
+// the results are bit-identical (test_line_end_displayer_three_frames: native against per-op).
+// Geometry: L maps of h x w (the pyramid's levels are the batch), cells of rh x rw -> ch x cw; the nearest-neighbour resized maps
+// h2 x w2 -> ch2 x cw2 cells.
+struct DispTail {
+    int L, h, w, ch, cw, h2, w2, ch2, cw2, rh, rw;
+    int y_first, x_first, y_first2, x_first2;      // first input index of cell 0 (TF SAME padding), both maps
+    float yscale_c, xscale_c, yscale_c2, xscale_c2; // float32 cells / extent: nearest-neighbour cell lookup, both maps
+    float yscale_r, xscale_r;                      // float32 h / h2, w / w2: nearest-neighbour resize
+    AffineP by255, imp, inv, x255;
+    BoostP bp;
+    const float* value;                            // [L, h, w]
+    float *g, *im2n;                               // value / 255; resized value / 255
+    float *cxy, *cxy2, *tot1;                      // centroids of both maps [cells][2]; cell totals of the first
+    float *imp_out, *m;                            // importances; importances ** energy
+    float *energy;                                 // [L, ch, cw] state, advanced in place
+    float *out1, *out2, *out3, *update;            // 255 - dist * 255 (both maps), fired * 255, update_importances
+};
+
+// g = value / 255 on the full map; im2n = resize_nearest(value) / 255 on the half map
+__global__ __launch_bounds__(256) void disp_prep_kernel(const DispTail t) {
+    const long long px = (long long)t.L * t.h * t.w, px2 = (long long)t.L * t.h2 * t.w2;
+    const long long gid = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (gid < px) {
+        t.g[gid] = affine_px(t.value[gid], t.by255);
+    } else if (gid < px + px2) {
+        const long long q = gid - px;
+        const int f = (int)(q / ((long long)t.h2 * t.w2)), p = (int)(q - (long long)f * t.h2 * t.w2);
+        const int y = p / t.w2, x = p - y * t.w2;
+        const int sy = min((int)floorf(__fmul_rn((float)y, t.yscale_r)), t.h - 1);
+        const int sx = min((int)floorf(__fmul_rn((float)x, t.xscale_r)), t.w - 1);
+        t.im2n[q] = affine_px(t.value[((long long)f * t.h + sy) * t.w + sx], t.by255);
+    }
+}
+
+// the centroid cells of both maps
+__global__ __launch_bounds__(256) void disp_cells_kernel(const DispTail t) {
+    const long long c1 = (long long)t.L * t.ch * t.cw, c2 = (long long)t.L * t.ch2 * t.cw2;
+    const long long gid = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (gid < c1) {
+        const int f = (int)(gid / ((long long)t.ch * t.cw)), r = (int)(gid - (long long)f * t.ch * t.cw);
+        centroid_cell(t.g + (long long)f * t.h * t.w, t.h, t.w, t.y_first, t.x_first, t.rh, t.rw, r / t.cw, r % t.cw, &t.tot1[gid],
+                      &t.cxy[gid * 2], &t.cxy[gid * 2 + 1]);
+    } else if (gid < c1 + c2) {
+        const long long q = gid - c1;
+        const int f = (int)(q / ((long long)t.ch2 * t.cw2)), r = (int)(q - (long long)f * t.ch2 * t.cw2);
+        float tot;
+        centroid_cell(t.im2n + (long long)f * t.h2 * t.w2, t.h2, t.w2, t.y_first2, t.x_first2, t.rh, t.rw, r / t.cw2, r % t.cw2, &tot,
+                      &t.cxy2[q * 2], &t.cxy2[q * 2 + 1]);
+    }
+}
+
+// 255 - dist * 255 of both maps, the importances (total_pool * 255 / 4 clipped to [1, 256], - 1) and importances ** energy
+__global__ __launch_bounds__(256) void disp_dist_kernel(const DispTail t) {
+    const long long px = (long long)t.L * t.h * t.w, px2 = (long long)t.L * t.h2 * t.w2, c1 = (long long)t.L * t.ch * t.cw;
+    const long long gid = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (gid < px) {
+        const int f = (int)(gid / ((long long)t.h * t.w)), p = (int)(gid - (long long)f * t.h * t.w);
+        const float d = centroid_dist_px(t.cxy + (long long)f * t.ch * t.cw * 2, p / t.w, p % t.w, t.ch, t.cw, t.yscale_c, t.xscale_c);
+        t.out1[gid] = affine_px(d, t.inv);
+    } else if (gid < px + px2) {
+        const long long q = gid - px;
+        const int f = (int)(q / ((long long)t.h2 * t.w2)), p = (int)(q - (long long)f * t.h2 * t.w2);
+        const float d = centroid_dist_px(t.cxy2 + (long long)f * t.ch2 * t.cw2 * 2, p / t.w2, p % t.w2, t.ch2, t.cw2, t.yscale_c2, t.xscale_c2);
+        t.out2[q] = affine_px(d, t.inv);
+    } else if (gid < px + px2 + c1) {
+        const long long q = gid - px - px2;
+        const float v = affine_px(t.tot1[q], t.imp);
+        t.imp_out[q] = v;
+        t.m[q] = (float)pow((double)v, (double)t.energy[q]);          // boost_power_kernel
+    }
+}
+
+// boost_update_kernel + fired * 255 (C channels: 3 with bp.visualize)
+__global__ __launch_bounds__(256) void disp_boost_kernel(const DispTail t) {
+    const long long c1 = (long long)t.L * t.ch * t.cw;
+    const long long gid = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (gid >= c1) return;
+    const int f = (int)(gid / ((long long)t.ch * t.cw)), p = (int)(gid - (long long)f * t.ch * t.cw);
+    float f_out, e_out;
+    t.energy[gid] = boost_update_px(t.m + (long long)f * t.ch * t.cw, t.ch, t.cw, p, t.imp_out[gid], t.energy[gid], t.bp, &f_out, &e_out);
+    const int C = t.bp.visualize ? 3 : 1;
+    const float shown = affine_px(f_out, t.x255);
+    for (int c = 0; c < C; ++c) {
+        t.out3[gid * C + c] = shown;
+        t.update[gid * C + c] = e_out;
     }
 }
 

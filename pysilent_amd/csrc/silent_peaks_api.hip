@@ -637,6 +637,44 @@ SILENT_EXPORT int silent_resize_nearest_dev(silent_ctx* ctx, const float* in, co
     return on_exception(ctx, "silent_resize_nearest_dev");
 }
 
+// ------------------------------------------------------------------------------------------ the displayer's fused tail
+// (silent_displayer_api.hip) value [L, h, w] -> the four small results + the advanced state, in five launches (silent_peaks.h, DispTail)
+int displayer_tail(silent_ctx* ctx, int L, int h, int w, int rh, int rw, int h2, int w2, const silent_boosting_params* boost, const float* value,
+                   float* g, float* im2n, float* tot1, float* imp, float* energy, float* out1, float* out2, float* out3, float* update,
+                   hipStream_t s) {
+    const char* who = "silent_displayer_step";
+    DispTail t;
+    std::memset(&t, 0, sizeof(t));
+    TRY(check_boost_params(ctx, boost, &t.bp));
+    const silent_extent full = {h, w}, half = {h2, w2};
+    CellTab c1, c2;
+    TRY(build_cell_tab(ctx, who, &full, 1, rh, rw, &c1));
+    TRY(build_cell_tab(ctx, who, &half, 1, rh, rw, &c2));
+    t.L = L; t.h = h; t.w = w; t.h2 = h2; t.w2 = w2; t.rh = rh; t.rw = rw;
+    t.ch = c1.oh[0]; t.cw = c1.ow[0]; t.ch2 = c2.oh[0]; t.cw2 = c2.ow[0];
+    t.y_first = c1.y_first[0]; t.x_first = c1.x_first[0]; t.y_first2 = c2.y_first[0]; t.x_first2 = c2.x_first[0];
+    t.yscale_c = c1.yscale[0]; t.xscale_c = c1.xscale[0]; t.yscale_c2 = c2.yscale[0]; t.xscale_c2 = c2.xscale[0];
+    t.yscale_r = (float)h / (float)h2;      // (silent_resize_nearest_dev: float32 in / out)
+    t.xscale_r = (float)w / (float)w2;
+    t.by255 = AffineP{1.f, 255.f, 0.f, -INFINITY, INFINITY, 0.f};
+    t.imp = AffineP{255.f / 4.0f, 1.f, 0.f, 1.f, 256.f, -1.f};
+    t.inv = AffineP{-255.f, 1.f, 255.f, -INFINITY, INFINITY, 0.f};
+    t.x255 = AffineP{255.f, 1.f, 0.f, -INFINITY, INFINITY, 0.f};
+    const long long px = (long long)L * h * w, px2 = (long long)L * h2 * w2, cells = (long long)L * t.ch * t.cw, cells2 = (long long)L * t.ch2 * t.cw2;
+    TRY(workspace(ctx, s, (size_t)(cells * 2 + cells2 * 2 + cells) * sizeof(float)));
+    t.cxy = (float*)ctx->ws.p;
+    t.cxy2 = t.cxy + cells * 2;
+    t.m = t.cxy2 + cells2 * 2;
+    t.value = value; t.g = g; t.im2n = im2n; t.tot1 = tot1; t.imp_out = imp; t.energy = energy;
+    t.out1 = out1; t.out2 = out2; t.out3 = out3; t.update = update;
+    auto grid = [](long long n) { return dim3((unsigned)((n + 255) / 256)); };
+    hipLaunchKernelGGL(disp_prep_kernel, grid(px + px2), dim3(256), 0, s, t);
+    hipLaunchKernelGGL(disp_cells_kernel, grid(cells + cells2), dim3(256), 0, s, t);
+    hipLaunchKernelGGL(disp_dist_kernel, grid(px + px2 + cells), dim3(256), 0, s, t);
+    hipLaunchKernelGGL(disp_boost_kernel, grid(cells), dim3(256), 0, s, t);
+    return check_launch(ctx, who);
+}
+
 // ------------------------------------------------------------------------------------------ RGB chain + keypoints
 
 // Config 3 from the pyramid on in one call: silent_rgb_line_end + silent_select_keypoints on its line_end / value maps.
