@@ -22,7 +22,7 @@ struct silent_pyramid_plan {
     // other level on the same crop), a crop layout like the reference's one plan per level; row programs (completion records)
     // + column records per wave tile live in walk_tables
     bool walk_pyr_ok = false;
-    int walk_px = 36;                    // pixels per consumer wave: 36, or 32 for zoom steps below 1.875
+    int walk_px = 36;                    // pixels per consumer wave: 36; 32 / 28 / 24 for zoom steps below 1.875 / 1.6 / 1.4
     int walk_G = 4;                      // general levels the kernel is instantiated for (4 or 7)
     void* walk_tables = nullptr;
     silent::Walk3Args walk{};                    // everything but the per-launch decomposition (strips / segments / block0)

@@ -316,7 +316,10 @@ SILENT_EXPORT int silent_pyramid_plan_create(silent_ctx* ctx, int frame_h, int f
     // last output rows and columns go to pyramid_border_kernel -- or, where that is not eligible, one plan per level on its own crop.
     // Per plan: a row program (one record per source row of the crop: "an output row of level g completes here" + its 6 vertical
     // weights) and column records per PX-pixel wave tile.
-    if (channels == 3 && tab.W % 4 == 0 && n_levels <= 7 + kW3MaxPlans) {
+    // A classic pyramid of more than 7 general levels stays on the unit + region kernels: the levels beyond the seventh as walk plans
+    // of their own, or left to pyramid_region_kernel behind the walk, cost a second pass over the frame for a few small levels
+    // (32 x 1080p, sqrt 2, 12 levels: 1.38 / 1.35 ms against 1.27 ms; profiles/r05_experiments.txt).
+    if (channels == 3) {
         struct HostPlan {
             int unit;                 // level index of the plan's unit level, or -1
             int crop;                 // the level whose crop the plan walks
@@ -341,6 +344,10 @@ SILENT_EXPORT int silent_pyramid_plan_create(silent_ctx* ctx, int frame_h, int f
                 HostPlan h{unit, unit, {}};
                 for (int l = 0; l < n_levels; ++l)
                     if (tab.lv[l].kind == kPyrGeneral) h.gen.push_back(l);
+                // finest level first: the column records' capacity per wave tile shrinks with the position (w3_rec_cap)
+                std::stable_sort(h.gen.begin(), h.gen.end(), [&](int x, int y) {
+                    return (double)tab.lv[x].zoom_w / tab.lv[x].src_w > (double)tab.lv[y].zoom_w / tab.lv[y].src_w;
+                });
                 candidates.push_back({h});
             } else {
                 std::vector<HostPlan> units, singles;
@@ -388,7 +395,7 @@ SILENT_EXPORT int silent_pyramid_plan_create(silent_ctx* ctx, int frame_h, int f
             int maxg = 0;
             for (const HostPlan& h : hp) maxg = std::max(maxg, (int)h.gen.size());
             const int Gp = stream_pad_levels(std::max(maxg, 1)), PR = w3_prog_row(Gp);
-            for (int px : {36, 32}) {
+            for (int px : {36, 32, 28, 24}) {
                 if (!usable || plan->walk_pyr_ok) break;
                 const int rec_total = w3_rec_total(px, Gp);
                 std::vector<int> blob;                        // all tables of all plans, offsets in ints
@@ -418,7 +425,7 @@ SILENT_EXPORT int silent_pyramid_plan_create(silent_ctx* ctx, int frame_h, int f
                         // (rows / columns base - 2 .. base + 3) stay inside its own crop
                         const int dy = d.src_y0 - c.src_y0, dx = d.src_x0 - c.src_x0;
                         int oy_lo = 0, oy_hi = zr, ox_lo = 0, ox_hi = zc;
-                        if (h.unit < 0 && h.gen[g] != h.crop) {
+                        if (d.src_y0 != c.src_y0 || d.src_x0 != c.src_x0 || d.src_h != c.src_h || d.src_w != c.src_w) {
                             while (oy_lo < zr && yb[oy_lo] - 2 < 0) ++oy_lo;
                             while (oy_hi > oy_lo && yb[oy_hi - 1] + 3 > d.src_h - 1) --oy_hi;
                             while (ox_lo < zc && xb[ox_lo] - 2 < 0) ++ox_lo;
@@ -464,7 +471,7 @@ SILENT_EXPORT int silent_pyramid_plan_create(silent_ctx* ctx, int frame_h, int f
                     }
                     if (!ok) break;
                     wp3.src_y0 = c.src_y0; wp3.src_x0 = c.src_x0; wp3.src_h = c.src_h; wp3.src_w = c.src_w;
-                    wp3.shift = (c.src_x0 * 3) % 4;
+                    wp3.shift = tab.W % 4 ? 0 : (c.src_x0 * 3) % 4;   // (other widths: the loader fetches single floats, not 16-byte groups)
                     wp3.has_unit = h.unit >= 0 ? 1 : 0;
                     wp3.out_h = walk_h; wp3.out_w = walk_w;
                     wp3.eff_h = h.unit >= 0 ? std::min(c.zoom_h, c.out_h) : walk_h;
@@ -542,9 +549,10 @@ static bool walk3_plan(const silent_ctx* ctx, const silent_pyramid_plan* plan, i
     if (plan->tab.C != 3 || !plan->walk_pyr_ok) return false;
     *wa = plan->walk;
     const int px = plan->walk_px;
-    int per_cu;
-    if (px == 36) per_cu = plan->walk_G <= 4 ? walk3_blocks_per_cu<4, 36>() : walk3_blocks_per_cu<7, 36>();
-    else per_cu = plan->walk_G <= 4 ? walk3_blocks_per_cu<4, 32>() : walk3_blocks_per_cu<7, 32>();
+    int per_cu = 1;
+#define PER_CU(PX_) case PX_: per_cu = plan->walk_G <= 4 ? walk3_blocks_per_cu<4, PX_>() : walk3_blocks_per_cu<7, PX_>(); break
+    switch (px) { PER_CU(36); PER_CU(32); PER_CU(28); PER_CU(24); default: return false; }
+#undef PER_CU
     const long long resident = (long long)per_cu * ctx->n_cus;
     long long block0 = 0;
     for (int pi = 0; pi < wa->n_plans; ++pi) {
@@ -615,13 +623,9 @@ int launch_pyramid(silent_ctx* ctx, const char* who, const silent_pyramid_plan* 
         // single-read RGB pyramid (pyramid_walk3_kernel, silent_walk_rgb.h); PYRAMID knob bits 1 / 2: unit + region kernels
         const long long wblocks = (long long)n_frames * w3t.blocks_per_frame;
 #define WALK3(G_, PX_) hipLaunchKernelGGL((pyramid_walk3_kernel<G_, PX_>), dim3((unsigned)wblocks), dim3(kW3Threads), 0, s, frames, pyr, w3t)
-        if (plan->walk_px == 36) {
-            if (plan->walk_G <= 4) WALK3(4, 36);
-            else WALK3(7, 36);
-        } else {
-            if (plan->walk_G <= 4) WALK3(4, 32);
-            else WALK3(7, 32);
-        }
+#define WALK3_PX(PX_) case PX_: if (plan->walk_G <= 4) WALK3(4, PX_); else WALK3(7, PX_); break
+        switch (plan->walk_px) { WALK3_PX(36); WALK3_PX(32); WALK3_PX(28); WALK3_PX(24); default: break; }   // (walk3_plan refuses any other)
+#undef WALK3_PX
 #undef WALK3
         if (plan->walk_border.n > 0) {   // union plans: the inner levels' first / last output rows and columns
             const long long threads = (long long)plan->walk_border.per_frame * 3 * n_frames;

@@ -69,7 +69,8 @@ constexpr int kW3HaloL = 4, kW3HaloR = 3;       // ring halo in pixels
 constexpr int kW3MaxPlans = 8;                  // walk plans per launch
 constexpr int kW3TileL = 2;                     // a wave's line starts 2 pixels left of its first pixel ...
 constexpr int kW3TileF = 124;                   // ... and holds 124 floats (41 pixels + 1 float): taps -2 .. +3 of its anchors
-constexpr int kW3RowF = 456;                    // floats per ring row ((144 + 7) * 3 = 453 used, + up to 3 of alignment shift)
+// floats per ring row: the strip's 4 PX pixels + 7 of halo, + up to 3 floats of alignment shift, in whole 16-byte pieces (PX = 36: 456)
+__host__ __device__ constexpr int w3_row_f(int px) { return ((kW3NC * px + kW3HaloL + kW3HaloR) * 3 + 3 + 3) / 4 * 4; }
 constexpr int kW3RingTail = 16;                 // floats behind the ring's last row: a lane's six taps are tap 0 + 0, 3 .. 15 floats, and the
                                                 // idle tail lanes of a wave's line read up to 12 floats past their row (into the next one)
 constexpr int kW3Threads = (kW3NC + 1) * 64;
@@ -80,10 +81,13 @@ constexpr int kW3CH = SILENT_W3_CH;             // rows per chunk: a 12-row ring
                                                 // being the limit (all loads alone: 0.14 ms), the consumers are latency-bound and
                                                 // want waves: 31 KB of LDS per block = 4 blocks (16 consumer waves) per CU instead of 3
 // column records per wave tile and level: output PIXELS anchored in a wave's PX pixels (36: zoom steps >= 1.875 ^ (g + 1);
-// 32: >= 1.6 ^ (g + 1)); never more than 21 (the gather works on lane 3 j + c)
+// 32: >= 1.6 ^ (g + 1); 28: >= 1.4 ^ (g + 1), e.g. sqrt 2; 24: >= 1.2 ^ (g + 1), e.g. 2 ^ (1/3)); never more than 21 (the gather
+// works on lane 3 j + c).  The host tries 36, 32, 28, 24 in this order and takes the first whose capacities hold the plan.
 __host__ __device__ constexpr int w3_rec_cap(int px, int g) {
-    return px == 36 ? (g == 0 ? 21 : (g == 1 ? 11 : (g == 2 ? 6 : (g == 3 ? 4 : (g <= 5 ? 2 : 1)))))
-                    : (g == 0 ? 21 : (g == 1 ? 14 : (g == 2 ? 9 : (g == 3 ? 6 : (g == 4 ? 5 : 3)))));
+    return px == 36   ? (g == 0 ? 21 : (g == 1 ? 11 : (g == 2 ? 6 : (g == 3 ? 4 : (g <= 5 ? 2 : 1)))))
+           : px == 32 ? (g == 0 ? 21 : (g == 1 ? 14 : (g == 2 ? 9 : (g == 3 ? 6 : (g == 4 ? 5 : 3)))))
+           : px == 28 ? (g == 0 ? 21 : (g == 1 ? 15 : (g == 2 ? 11 : (g == 3 ? 8 : (g == 4 ? 6 : (g == 5 ? 4 : 3))))))
+                      : (g == 0 ? 21 : (g == 1 ? 17 : (g == 2 ? 14 : (g == 3 ? 12 : (g == 4 ? 10 : (g == 5 ? 9 : 7))))));
 }
 __host__ __device__ constexpr int w3_rec_base(int px, int g) {
     int n = 0;
@@ -118,8 +122,9 @@ template <int G, int PX>
 __global__ __launch_bounds__(kW3Threads) void pyramid_walk3_kernel(const float* __restrict__ frames, float* __restrict__ pyr,
                                                                     const Walk3Args args) {
     static_assert(G == stream_pad_levels(G), "row programs are padded to 4 or 7 levels");
-    static_assert(PX == 36 || PX == 32, "");
-    constexpr int kW3Px = PX, kW3StripPx = kW3NC * PX;
+    static_assert(PX == 36 || PX == 32 || PX == 28 || PX == 24, "");
+    constexpr int kW3Px = PX, kW3StripPx = kW3NC * PX, kW3RowF = w3_row_f(PX);
+    static_assert(kW3RowF > 256 && kW3RowF <= 512, "two DMA loads of 64 x 16 bytes per ring row");
     constexpr int PR = w3_prog_row(G);
     constexpr int kRecTotal = w3_rec_total(PX, G);
     __shared__ __attribute__((aligned(16))) float s_ring_f[kWalkSlots * kW3CH * kW3RowF + kW3RingTail];
@@ -151,68 +156,86 @@ __global__ __launch_bounds__(kW3Threads) void pyramid_walk3_kernel(const float* 
     if (wave == kW3NC) {
         // ------------------------------------------------------------------ loader: LDS-DMA only
         const float* __restrict__ src = frames + (long long)frame * args.H * args.W * 3;
-        const int rowf = args.W * 3;                           // floats of a FRAME row (multiple of 4: host-checked)
-        // ring float r <-> frame-row float A + r, A = the crop's pixel R0 minus the alignment shift: a multiple of 4, so every
-        // 4-float group is a 16-byte aligned piece of the frame row.  Groups that stick out of the row are clamped to a valid
+        const int rowf = args.W * 3;                           // floats of a FRAME row
+        // ring float r <-> frame-row float A + r, A = the crop's pixel R0 minus the alignment shift.  Frame widths that are a
+        // multiple of 4 (every row starts on 16 bytes): A is a multiple of 4 and a lane fetches a 16-byte aligned group of 4 floats,
+        // two DMA loads per ring row.  Other widths (round 5): no shift, a lane fetches ONE FLOAT, 5 - 8 loads per ring row -- the
+        // loader has the time (one row per ~2000 cycles of its consumers).  (The 12-byte DMA, one pixel per lane, is no way out: it
+        // writes lane l's 12 bytes at 16 l, scripts/ubench/lds_dma_b96.hip.)  Pieces that stick out of the row are clamped to a valid
         // address; whatever lies outside the CROP is never read (the consumers read mirrored pixels instead)
         const int A = (tab.src_x0 + R0) * 3 - tab.shift;
-        const int f0 = min(max(A + lane * 4, 0), rowf - 4);
-        const int f1 = min(max(A + 256 + lane * 4, 0), rowf - 4);
-        auto issue = [&](int c, int slot) {
+        auto loader = [&](auto dword_dma) {
+            constexpr bool DWORD_DMA = decltype(dword_dma)::value;
+            constexpr int kRowLoads = DWORD_DMA ? (kW3RowF + 63) / 64 : 2;   // DMA instructions per ring row
+            int f[kRowLoads];
 #pragma unroll
-            for (int r = 0; r < kW3CH; ++r) {
-                const int y = seg_y0 - 4 + c * kW3CH + r;
-                const float* rp = src + (long long)(mirror_near(y, tab.src_h) + tab.src_y0) * args.W * 3;
-                float* dst = &s_ring[slot * kW3CH + r][0];
-                __builtin_amdgcn_global_load_lds((walk_glb_ptr)(rp + f0), (walk_lds_ptr)dst, 16, 0, 0);
-                if (lane < (kW3RowF - 256) / 4)
-                    __builtin_amdgcn_global_load_lds((walk_glb_ptr)(rp + f1), (walk_lds_ptr)(dst + 256), 16, 0, 0);
-            }
-            const int* rp = wp.row_prog + ((long long)seg_y0 + (long long)c * kW3CH) * PR + lane * 4;
-            int* dst = s_prog + slot * (kW3CH * PR);
-            constexpr int NV = kW3CH * PR / 4;               // 16-byte pieces of a chunk's records
-            if (lane < NV) __builtin_amdgcn_global_load_lds((walk_glb_ptr)rp, (walk_lds_ptr)dst, 16, 0, 0);
-            if constexpr (NV > 64) {
-                if (lane < NV - 64) __builtin_amdgcn_global_load_lds((walk_glb_ptr)(rp + 256), (walk_lds_ptr)(dst + 256), 16, 0, 0);
-            }
-        };
-        // scipy mirrors every tap at the CROP's edge (d c b | a b c d | c b a).  The ring row of a strip at the crop's left / right
-        // edge holds whatever lies beside the crop in the frame (or a clamped address): the loader writes the mirrored pixels over
-        // those halo positions -- up to 4 pixels left (q = -4 .. -1 <- -q) and 3 right (q = n .. n + 2 <- 2 (n - 1) - q) -- once per
-        // chunk, so that the consumers read every tap at a fixed offset from tap 0 (no per-tap offsets, no mirror arithmetic)
-        int fix_dst = 0, fix_src = 0;
-        bool fix = false;
-        {
-            const int n = tab.src_w;
-            const int q = lane < 12 ? -4 + lane / 3 : n + (lane - 12) / 3;
-            const int ch = lane < 12 ? lane % 3 : (lane - 12) % 3;
-            const int qs = lane < 12 ? -q : 2 * (n - 1) - q;
-            fix = lane < 21 && q - R0 >= 0 && q - R0 < kW3StripPx + kW3HaloL + kW3HaloR && qs - R0 >= 0 && qs - R0 < kW3StripPx + kW3HaloL + kW3HaloR;
-            fix_dst = (q - R0) * 3 + ch + tab.shift;
-            fix_src = (qs - R0) * 3 + ch + tab.shift;
-        }
-        const bool any_fix = __any(fix);                        // wave-uniform: an edge strip
-        static_assert(kWalkSlots == 2 || kWalkSlots == 3, "");
-        issue(0, 0);
-        if (kWalkSlots == 3 && n_chunks > 1) issue(1, 1);
-        int slot2 = kWalkSlots - 1, slot0 = 0;
-        for (int c = 0; c < n_chunks; ++c) {
-            // chunk c has landed when at most the next chunk's loads (three slots: one chunk in flight behind it) are outstanding
-            if (kWalkSlots == 3 && c + 1 < n_chunks) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * kW3CH + (kW3CH * PR / 4 > 64 ? 2 : 1)) : "memory");
-            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            if (any_fix) {
+            for (int k = 0; k < kRowLoads; ++k)
+                f[k] = DWORD_DMA ? min(max(A + lane + 64 * k, 0), rowf - 1) : min(max(A + 256 * k + lane * 4, 0), rowf - 4);
+            auto issue = [&](int c, int slot) {
 #pragma unroll
                 for (int r = 0; r < kW3CH; ++r) {
-                    float* row = &s_ring[slot0 * kW3CH + r][0];
-                    if (fix) row[fix_dst] = row[fix_src];
+                    const int y = seg_y0 - 4 + c * kW3CH + r;
+                    const float* rp = src + (long long)(mirror_near(y, tab.src_h) + tab.src_y0) * args.W * 3;
+                    float* dst = &s_ring[slot * kW3CH + r][0];
+                    if constexpr (DWORD_DMA) {
+#pragma unroll
+                        for (int k = 0; k < kRowLoads; ++k)
+                            if (k + 1 < kRowLoads || lane < kW3RowF - 64 * k)
+                                __builtin_amdgcn_global_load_lds((walk_glb_ptr)(rp + f[k]), (walk_lds_ptr)(dst + 64 * k), 4, 0, 0);
+                    } else {
+                        __builtin_amdgcn_global_load_lds((walk_glb_ptr)(rp + f[0]), (walk_lds_ptr)dst, 16, 0, 0);
+                        if (lane < (kW3RowF - 256) / 4)
+                            __builtin_amdgcn_global_load_lds((walk_glb_ptr)(rp + f[1]), (walk_lds_ptr)(dst + 256), 16, 0, 0);
+                    }
                 }
-                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                const int* rp = wp.row_prog + ((long long)seg_y0 + (long long)c * kW3CH) * PR + lane * 4;
+                int* dst = s_prog + slot * (kW3CH * PR);
+                constexpr int NV = kW3CH * PR / 4;               // 16-byte pieces of a chunk's records
+                if (lane < NV) __builtin_amdgcn_global_load_lds((walk_glb_ptr)rp, (walk_lds_ptr)dst, 16, 0, 0);
+                if constexpr (NV > 64) {
+                    if (lane < NV - 64) __builtin_amdgcn_global_load_lds((walk_glb_ptr)(rp + 256), (walk_lds_ptr)(dst + 256), 16, 0, 0);
+                }
+            };
+            // scipy mirrors every tap at the CROP's edge (d c b | a b c d | c b a).  The ring row of a strip at the crop's left / right
+            // edge holds whatever lies beside the crop in the frame (or a clamped address): the loader writes the mirrored pixels over
+            // those halo positions -- up to 4 pixels left (q = -4 .. -1 <- -q) and 3 right (q = n .. n + 2 <- 2 (n - 1) - q) -- once per
+            // chunk, so that the consumers read every tap at a fixed offset from tap 0 (no per-tap offsets, no mirror arithmetic)
+            int fix_dst = 0, fix_src = 0;
+            bool fix = false;
+            {
+                const int n = tab.src_w;
+                const int q = lane < 12 ? -4 + lane / 3 : n + (lane - 12) / 3;
+                const int ch = lane < 12 ? lane % 3 : (lane - 12) % 3;
+                const int qs = lane < 12 ? -q : 2 * (n - 1) - q;
+                fix = lane < 21 && q - R0 >= 0 && q - R0 < kW3StripPx + kW3HaloL + kW3HaloR && qs - R0 >= 0 && qs - R0 < kW3StripPx + kW3HaloL + kW3HaloR;
+                fix_dst = (q - R0) * 3 + ch + tab.shift;
+                fix_src = (qs - R0) * 3 + ch + tab.shift;
             }
-            slot0 = slot0 == kWalkSlots - 1 ? 0 : slot0 + 1;
-            __builtin_amdgcn_s_barrier();
-            if (c + kWalkSlots - 1 < n_chunks) issue(c + kWalkSlots - 1, slot2);
-            slot2 = slot2 == kWalkSlots - 1 ? 0 : slot2 + 1;
-        }
+            const bool any_fix = __any(fix);                        // wave-uniform: an edge strip
+            static_assert(kWalkSlots == 2 || kWalkSlots == 3, "");
+            issue(0, 0);
+            if (kWalkSlots == 3 && n_chunks > 1) issue(1, 1);
+            int slot2 = kWalkSlots - 1, slot0 = 0;
+            for (int c = 0; c < n_chunks; ++c) {
+                // chunk c has landed when at most the next chunk's loads (three slots: one chunk in flight behind it) are outstanding
+                if (kWalkSlots == 3 && c + 1 < n_chunks) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(kRowLoads * kW3CH + (kW3CH * PR / 4 > 64 ? 2 : 1)) : "memory");
+                else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                if (any_fix) {
+#pragma unroll
+                    for (int r = 0; r < kW3CH; ++r) {
+                        float* row = &s_ring[slot0 * kW3CH + r][0];
+                        if (fix) row[fix_dst] = row[fix_src];
+                    }
+                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                }
+                slot0 = slot0 == kWalkSlots - 1 ? 0 : slot0 + 1;
+                __builtin_amdgcn_s_barrier();
+                if (c + kWalkSlots - 1 < n_chunks) issue(c + kWalkSlots - 1, slot2);
+                slot2 = slot2 == kWalkSlots - 1 ? 0 : slot2 + 1;
+            }
+        };
+        if (rowf & 3) loader(std::true_type{});                 // block-uniform
+        else loader(std::false_type{});
         return;
     }
 

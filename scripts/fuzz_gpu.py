@@ -351,11 +351,11 @@ def case_crop_walk(rng, k):
     """3-channel pyramids in the reference's crop layout (image_to_zoom_tensor: nested centre crops) and classic ones at small
     zoom steps: the strip-walk kernel's walk plans against the unit + region kernels (bit for bit) and the oracle."""
     from pysilent_amd.util.zoom.from_image import reference_levels
-    h, w = int(rng.integers(40, 400)), int(rng.integers(10, 160)) * 4
-    scale = float(rng.choice([1.6, math.e ** .5, 1.7, 2.0, 2.5]))
+    h, w = int(rng.integers(40, 400)), int(rng.integers(10, 160)) * 4 + (int(rng.integers(0, 4)) if rng.integers(0, 2) else 0)   # any width
+    scale = float(rng.choice([1.2, 2 ** (1 / 3), 1.3, 2 ** .5, 1.5, 1.6, math.e ** .5, 1.7, 2.0, 2.5]))
     B = int(rng.integers(1, 4))
     if rng.integers(0, 3) == 0:
-        n = int(rng.integers(2, 6))
+        n = int(rng.integers(2, 10))
         desc = "crop_walk classic h=%d w=%d scale=%.3f n=%d B=%d" % (h, w, scale, n, B)
         try:
             levels = classic_levels((h, w), scale, n)

@@ -1721,6 +1721,10 @@ def test_pipeline_flags_keypoint_overflow(rt, kernels):
                                              ((97, 1000, 3), 2.0, 4, 2),         # 7 strips, the last holds 136 pixels
                                              ((200, 148, 3), 2.5, 3, 2),         # second strip holds 4 pixels
                                              ((40, 8, 3), 2.0, 2, 1),            # narrower than a wave tile
+                                             ((135, 241, 3), 2.0, 4, 2),         # widths that are not a multiple of 4 (round 5): rows start on
+                                             ((64, 66, 3), 2.0, 3, 3),           # 4, 8 or 12 bytes -- the loader fetches 12-byte pixels
+                                             ((97, 999, 3), 2.0, 4, 2),
+                                             ((270, 1366, 3), math.e ** .5, 5, 1),
                                              ((1080, 1920, 3), 2.0, 6, 1)])      # config 3 geometry
 def test_rgb_pyramid_walk_is_bit_identical_to_unit_plus_region_kernels(rt, shape, scale, n, B):
     """pyramid_walk3_kernel (one read of the frame: loader wave + ring, two floats per lane, other levels gathered from a
@@ -1731,7 +1735,7 @@ def test_rgb_pyramid_walk_is_bit_identical_to_unit_plus_region_kernels(rt, shape
     frames[0, shape[0] // 2, shape[1] // 3, 1] = np.nan
     frames[B - 1, 0, 0, 2] = np.inf
     plan = rt.PyramidPlan(shape[0], shape[1], 3, classic_levels(shape[:2], scale, n))
-    assert plan.walk_plans == ((1, 36 if scale >= 1.875 else 32) if shape[1] % 4 == 0 and n > 1 else (0, 0))
+    assert plan.walk_plans == ((1, 36 if scale >= 1.875 else 32) if n > 1 else (0, 0))
     got = plan.run(frames)
     with rt.tuning(TUNE_PYRAMID, 2):
         two = plan.run(frames)
@@ -1748,6 +1752,8 @@ def test_rgb_pyramid_walk_is_bit_identical_to_unit_plus_region_kernels(rt, shape
                                                   ((480, 640, 3), (160, 120), math.e ** .5, 1),      # 3 levels
                                                   ((270, 480, 3), (61, 45), 2.0, 2),                 # odd extents and crop offsets (alignment shift 1..3)
                                                   ((300, 500, 3), (100, 37), 1.7, 2),                # one axis clips first
+                                                  ((270, 482, 3), (61, 45), 2.0, 2),                 # frame widths that are not a multiple of 4
+                                                  ((481, 641, 3), (288, 192), math.e ** .5, 1),
                                                   ((97, 132, 3), (32, 24), 1.7, 1)])
 def test_rgb_pyramid_walk_on_the_references_crop_layout(rt, shape, center, scale, B):
     """The reference's own pyramid layout (image_to_zoom_tensor, from_image.py:45-64: nested centre crops resampled to one
@@ -1805,6 +1811,31 @@ def test_rgb_pyramid_walk_takes_zoom_steps_down_to_1_6(rt, shape, scale, n):
     want = so.classic_pyramid(frames[1], scale, n)
     for l in range(n):
         assert_close(got.level(l)[1:2], want[l], RTOL, scale=255.0, what="walk px 32 level %d" % l, bound=eb.zoom(want[l]))
+
+
+@pytest.mark.parametrize("shape,scale,n,px", [((270, 480, 3), 2 ** .5, 6, 28),          # sqrt 2
+                                              ((270, 480, 3), 2 ** .5, 10, 0),          # 9 general levels: unit + region kernels
+                                              ((200, 300, 3), 2 ** (1 / 3), 5, 24),
+                                              ((240, 320, 3), 1.2, 8, 24),
+                                              ((1080, 1920, 3), 2 ** .5, 8, 28)])
+def test_rgb_pyramid_walk_takes_zoom_steps_down_to_1_2(rt, shape, scale, n, px):
+    """Round 5: zoom steps below 1.6 keep the single-read walk -- 28 pixels per consumer wave down to 1.4, 24
+    down to 1.2 (a ladder of more than 7 general levels stays on the unit + region kernels: measured faster there).  Bit-identical to the unit + region kernels, non-finite pixels included; within tolerance of the oracle."""
+    from pysilent_amd.util.zoom.from_image import classic_levels
+    frames = np.stack([noise_frame(120 + s_, *shape) for s_ in range(2)])
+    frames[0, shape[0] // 2, shape[1] // 3, 1] = np.nan
+    frames[0, 0, shape[1] - 1, 2] = np.inf
+    plan = rt.PyramidPlan(shape[0], shape[1], 3, classic_levels(shape[:2], scale, n))
+    assert plan.walk_plans == ((1, px) if px else (0, 0))
+    got = plan.run(frames)
+    with rt.tuning(TUNE_PYRAMID, 2):
+        two = plan.run(frames)
+    a, b = np.asarray(got.data), np.asarray(two.data)
+    assert np.array_equal(np.isnan(a), np.isnan(b))
+    np.testing.assert_array_equal(np.nan_to_num(a, nan=7.0), np.nan_to_num(b, nan=7.0))
+    want = so.classic_pyramid(frames[1], scale, n)
+    for l in range(n):
+        assert_close(got.level(l)[1:2], want[l], RTOL, scale=255.0, what="walk px %d level %d" % (px, l), bound=eb.zoom(want[l]))
 
 
 def test_workspace_follows_the_callers_stream(rt):
