@@ -278,6 +278,29 @@ __global__ __launch_bounds__(256) void nms3x3_stream_kernel(const float* __restr
     }
 }
 
+// Sparse tail: a kernel that usually finds nothing to do runs with a BOUNDED grid.  Block b owns the tiles b, b + G, b + 2 G ...
+// (at most 64 of them: host-checked, sparse_grid); lane i of every wave looks at tile b + i G -- one round trip -- and the block
+// then visits the live ones only.  select_peaks_kernel on config 3: 11 600 blocks that all return at once took 9.4 us, 2048 blocks
+// take 4.7.  (Measured and not kept: the same for region_count_kernel and region_write_kernel -- their time is the work of the
+// "zero map" levels, every pixel of a window without a peak is a keypoint -- and more summary entries per thread in
+// sparse_select_kernel: a wave handles the groups that reach the threshold one after the other, 16x the entries per wave made
+// the kernel 1.6 - 2.7x longer.  profiles/r05_experiments.txt)
+// `live` must give every wave of the block the same answer.
+template <class Live, class Body>
+__device__ __forceinline__ void for_live_tiles(unsigned n_tiles, Live live, Body body) {
+    if (gridDim.x >= n_tiles) {
+        body(blockIdx.x);
+        return;
+    }
+    const unsigned t = blockIdx.x + (threadIdx.x & 63u) * gridDim.x;
+    unsigned long long todo = __ballot(t < n_tiles && live(t));
+    while (todo) {   // block-uniform
+        const int i = __ffsll((long long)todo) - 1;
+        todo &= todo - 1;
+        body(blockIdx.x + (unsigned)i * gridDim.x);
+    }
+}
+
 // ---- a-10 -> a-9 -> a-8 in one streaming pass ("top 10 %, NMS" between the chain and the keypoints)
 //   top   = color * (value >= thr ? 1 : 0)                          top_value_points_kernel
 //   peaks = top * (top == maxpool3x3 SAME(top) ? top : 0)           nms3x3_kernel, SILENT_NMS_PRODUCT
@@ -292,16 +315,13 @@ constexpr int kSelCols = 60, kSelTW = 4 * kSelCols, kSelTH = 32;
 // pass -- the lane's column segment is fixed, the row segment is wave-uniform, so it is one running maximum per lane
 // and a segmented wave reduction + one atomic per (row segment, column segment) and tile.
 template <int C, bool CELLS>
-__global__ __launch_bounds__(256) void select_peaks_kernel(const float* __restrict__ color,
-                                                           const float* __restrict__ value,
-                                                           float* __restrict__ top_out, float* __restrict__ peaks_out,
-                                                           float* __restrict__ pv_out, const LevelTab tab,
-                                                           float one_minus_p, float p_f,
-                                                           const unsigned* __restrict__ mm, const RegionTab rt,
-                                                           unsigned* __restrict__ cells,
-                                                           const int* __restrict__ dense_flags) {
+__device__ __forceinline__ void select_peaks_tile(const float* __restrict__ color, const float* __restrict__ value,
+                                                  float* __restrict__ top_out, float* __restrict__ peaks_out,
+                                                  float* __restrict__ pv_out, const LevelTab& tab, float one_minus_p, float p_f,
+                                                  const unsigned* __restrict__ mm, const RegionTab& rt, unsigned* __restrict__ cells,
+                                                  const int* __restrict__ dense_flags, unsigned tile) {
     constexpr int R = kSelTH;
-    const TileCoord tc = locate_tile(tab, blockIdx.x);
+    const TileCoord tc = locate_tile(tab, tile);
     // sparse tail (sparse_modes_kernel): only the (frame, level)s in dense mode run this pass
     if (dense_flags && dense_flags[tc.frame * tab.n_levels + tc.level] != kTailDense) return;
     const int H = tab.h[tc.level], W = tab.w[tc.level];
@@ -427,6 +447,26 @@ __global__ __launch_bounds__(256) void select_peaks_kernel(const float* __restri
     if constexpr (CELLS) flush_cells();
 }
 
+// n_tiles: tiles of `tab` (the sparse tail launches fewer blocks than that: for_live_tiles)
+template <int C, bool CELLS>
+__global__ __launch_bounds__(256) void select_peaks_kernel(const float* __restrict__ color,
+                                                           const float* __restrict__ value,
+                                                           float* __restrict__ top_out, float* __restrict__ peaks_out,
+                                                           float* __restrict__ pv_out, const LevelTab tab,
+                                                           float one_minus_p, float p_f,
+                                                           const unsigned* __restrict__ mm, const RegionTab rt,
+                                                           unsigned* __restrict__ cells,
+                                                           const int* __restrict__ dense_flags, unsigned n_tiles) {
+    for_live_tiles(
+        n_tiles,
+        [&](unsigned t) {
+            const TileCoord tc = locate_tile(tab, t);
+            return dense_flags[tc.frame * tab.n_levels + tc.level] == kTailDense;
+        },
+        [&](unsigned t) { select_peaks_tile<C, CELLS>(color, value, top_out, peaks_out, pv_out, tab, one_minus_p, p_f, mm, rt, cells, dense_flags, t); });
+}
+
+
 
 // (y, x) of pixel p are carried by the caller: the kernels walk their pixels with a fixed stride, so one integer
 // division per thread replaces one per pixel
@@ -484,8 +524,9 @@ __global__ __launch_bounds__(256) void region_cell_max_kernel(const float* __res
 }
 
 // window maxima of one (frame, level) into LDS: pooled[j * kMaxWin + i]
-__device__ __forceinline__ void load_pooled(const unsigned* __restrict__ cells, const RegionLevel& rl,
-                                            float* s_pooled) {
+// `cells`: the level's kCells cell maxima -- in LDS (pooled_from_cells), or in memory: staged with ONE round trip first (a thread
+// that walks its window's cells in memory pays a dependent load per cell: 9 in a row for a window of 3 x 3 segments)
+__device__ __forceinline__ void pooled_from_cells(const unsigned* cells, const RegionLevel& rl, float* s_pooled) {
     for (int wi = threadIdx.x; wi < rl.oh * rl.ow; wi += 256) {
         const int j = wi / rl.ow, i = wi - j * rl.ow;
         unsigned m = pool_lowest_ord();
@@ -497,6 +538,12 @@ __device__ __forceinline__ void load_pooled(const unsigned* __restrict__ cells, 
         s_pooled[j * kMaxWin + i] = ord2f(m);
     }
 }
+__device__ __forceinline__ void load_pooled(const unsigned* __restrict__ cells, const RegionLevel& rl, float* s_pooled, unsigned* s_cells) {
+    if (threadIdx.x < kCells) s_cells[threadIdx.x] = cells[threadIdx.x];
+    __syncthreads();
+    pooled_from_cells(s_cells, rl, s_pooled);
+}
+
 
 // threshold of pixel (y, x): the window maximum its cell maps back to.  `pooled` is the LDS copy of the (<= 4 x 4)
 // window maxima with row stride kMaxWin, or (GEN) the level's [oh][ow] table in the workspace.
@@ -628,6 +675,7 @@ __global__ __launch_bounds__(256) void region_count_kernel(const float* __restri
                                                            unsigned long long* __restrict__ hit_masks,
                                                            const int* __restrict__ dense_flags) {
     __shared__ float s_pooled[kMaxWin * kMaxWin];
+    __shared__ unsigned s_cells[kCells];
     __shared__ int s_cnt[4];
     const TileCoord tc = locate_tile(tab, blockIdx.x);
     // sparse tail: kTailSparse levels are settled by the candidates alone; kTailZero levels hold no NaN and every pixel that is
@@ -653,7 +701,7 @@ __global__ __launch_bounds__(256) void region_count_kernel(const float* __restri
     if constexpr (GEN) {
         pooled = pooled_g + (long long)tc.frame * rt.pooled_per_frame + rl.pooled_off;
     } else {
-        load_pooled(cells + ((long long)tc.frame * tab.n_levels + tc.level) * kCells, rl, s_pooled);
+        load_pooled(cells + ((long long)tc.frame * tab.n_levels + tc.level) * kCells, rl, s_pooled, s_cells);
         __syncthreads();
     }
     int n = 0;
@@ -773,14 +821,21 @@ __global__ __launch_bounds__(256) void sparse_select_kernel(const float* __restr
     }
 }
 
-// one block per frame: the mode of every level (dense_flags[frame][level]), before the dense kernels
-__global__ __launch_bounds__(64) void sparse_modes_kernel(const LevelTab tab, const RegionTab rt, const unsigned* __restrict__ cells,
-                                                          const int* __restrict__ cand_n, const int* __restrict__ nan_flags,
-                                                          int* __restrict__ dense_flags, int map_wanted) {
+// one block per frame: the mode of every level (dense_flags[frame][level]), before the dense kernels.  The frame's cell maxima come
+// in with one round trip (a thread that walks its windows' cells in memory pays a dependent load per cell)
+__global__ __launch_bounds__(256) void sparse_modes_kernel(const LevelTab tab, const RegionTab rt, const unsigned* __restrict__ cells,
+                                                           const int* __restrict__ cand_n, const int* __restrict__ nan_flags,
+                                                           int* __restrict__ dense_flags, int map_wanted) {
+    __shared__ unsigned s_cells[kMaxLevels * kCells];
     const int f = blockIdx.x, l = threadIdx.x;
+    const unsigned* fc = cells + (long long)f * tab.n_levels * kCells;
+    for (int i = threadIdx.x; i < tab.n_levels * kCells; i += 256) s_cells[i] = fc[i];
+    const bool overflow = cand_n[f] > kCandCap;
+    const bool has_nan = l < tab.n_levels && nan_flags[f * tab.n_levels + l] != 0;
+    __syncthreads();
     if (l >= tab.n_levels) return;
     const RegionLevel& rl = rt.lv[l];
-    const unsigned* c = cells + ((long long)f * tab.n_levels + l) * kCells;
+    const unsigned* c = s_cells + l * kCells;
     bool all_pos = true;
     for (int j = 0; j < rl.oh; ++j)
         for (int i = 0; i < rl.ow; ++i) {
@@ -789,11 +844,9 @@ __global__ __launch_bounds__(64) void sparse_modes_kernel(const LevelTab tab, co
                 for (int cs = rl.wx_lo[i]; cs < rl.wx_hi[i]; ++cs) m = max(m, c[rs * kMaxSeg + cs]);
             all_pos = all_pos && ord2f(m) > 0.0f;
         }
-    const bool overflow = cand_n[f] > kCandCap;
     int mode = kTailDense;
     // map_wanted: the caller takes the peak-value MAP too.  Without NaNs in the level it is zeros + the candidates' values
     // (sparse_fill_map_kernel, sparse_finish_kernel); a NaN pixel's peak value is a NaN, which only the dense pass can place
-    const bool has_nan = nan_flags[f * tab.n_levels + l] != 0;
     if (!overflow) mode = (map_wanted && has_nan) ? kTailDense : (all_pos ? kTailSparse : (has_nan ? kTailDense : kTailZero));
     dense_flags[f * tab.n_levels + l] = mode;
 }
@@ -812,46 +865,22 @@ __global__ __launch_bounds__(256) void sparse_fill_map_kernel(const LevelTab tab
     }
 }
 
-// one block per frame, AFTER the count pass; `tab` is the count / write pass's chunk table (kKpChunk pixels per block): the
-// candidates that reach a POSITIVE window maximum become hit bits + chunk counts (in a window without a positive peak the
-// count pass has already set every pixel of a kTailZero level)
-__global__ __launch_bounds__(256) void sparse_finish_kernel(const LevelTab tab, const RegionTab rt, const unsigned* __restrict__ cells,
-                                                            const Candidate* __restrict__ cand, const int* __restrict__ cand_n,
-                                                            const int* __restrict__ dense_flags, unsigned long long* __restrict__ hit_masks,
-                                                            int* __restrict__ chunk_counts, float* __restrict__ pv_map) {
-    __shared__ float s_pooled[kMaxLevels][kMaxWin * kMaxWin];
-    const int f = blockIdx.x;
-    const int n = cand_n[f];
-    if (n > kCandCap) return;     // block-uniform: every level of this frame ran the dense kernels
-    for (int l = 0; l < tab.n_levels; ++l)
-        load_pooled(cells + ((long long)f * tab.n_levels + l) * kCells, rt.lv[l], s_pooled[l]);
-    __syncthreads();
-    for (int i = threadIdx.x; i < n; i += 256) {
-        const Candidate c = cand[(long long)f * kCandCap + i];
-        if (dense_flags[f * tab.n_levels + c.level] == kTailDense) continue;
-        if (pv_map)      // the caller's peak-value map: zero-filled for this level (sparse_fill_map_kernel), the passers' values go in
-            pv_map[(long long)f * tab.frame_px + tab.px_off[c.level] + (long long)c.y * tab.w[c.level] + c.x] = c.pv;
-        const float thr = region_thr<false>(c.y, c.x, rt.lv[c.level], s_pooled[c.level]);
-        if (!(thr > 0.0f && c.pv >= thr)) continue;
-        const int p = c.y * tab.w[c.level] + c.x;
-        const long long blk = (long long)f * tab.tiles_per_frame + tab.tile_start[c.level] + (p / kKpChunk);
-        atomicOr(hit_masks + blk * (kKpChunk / 64) + ((p % kKpChunk) >> 6), 1ull << (p & 63));
-        atomicAdd(chunk_counts + blk, 1);
-    }
-}
+// a load that sees what other workgroups' atomics have left (it bypasses this CU's L1)
+__device__ __forceinline__ int coherent_load(const int* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 
-// pass 2: exclusive scan of the chunk counts of one frame (one block per frame)
-__global__ __launch_bounds__(256) void region_scan_kernel(const int* __restrict__ chunk_counts,
-                                                          long long* __restrict__ chunk_offsets,
-                                                          int chunks_per_frame, int64_t* __restrict__ counts) {
+// exclusive scan of the chunk counts of frame f by one block.  COHERENT: the counts hold this block's own atomics (and a cache line
+// may be shared with the neighbouring frame's counts, which another block on this CU may have read before): read around the L1
+template <bool COHERENT>
+__device__ __forceinline__ void scan_frame_chunks(const int* __restrict__ chunk_counts, long long* __restrict__ chunk_offsets,
+                                                  int chunks_per_frame, int64_t* __restrict__ counts, int f) {
     __shared__ long long s_part[256];
-    const int f = blockIdx.x;
     const int* cc = chunk_counts + (long long)f * chunks_per_frame;
     long long* off = chunk_offsets + (long long)f * chunks_per_frame;
     const int per = (chunks_per_frame + 255) / 256;
     const int lo = min((int)threadIdx.x * per, chunks_per_frame), hi = min(lo + per, chunks_per_frame);
+    auto at = [&](int i) { return COHERENT ? coherent_load(cc + i) : cc[i]; };
     long long s = 0;
-    for (int i = lo; i < hi; ++i) s += cc[i];
+    for (int i = lo; i < hi; ++i) s += at(i);
     s_part[threadIdx.x] = s;
     __syncthreads();
     if (threadIdx.x == 0) {
@@ -867,8 +896,55 @@ __global__ __launch_bounds__(256) void region_scan_kernel(const int* __restrict_
     long long run = s_part[threadIdx.x];
     for (int i = lo; i < hi; ++i) {
         off[i] = run;
-        run += cc[i];
+        run += at(i);
     }
+}
+
+// one block per frame, AFTER the count pass; `tab` is the count / write pass's chunk table (kKpChunk pixels per block): the
+// candidates that reach a POSITIVE window maximum become hit bits + chunk counts (in a window without a positive peak the
+// count pass has already set every pixel of a kTailZero level); then the scan of the frame's chunk counts (pass 2: the same
+// grid, round 4 spent a launch on it)
+__global__ __launch_bounds__(256) void sparse_finish_kernel(const LevelTab tab, const RegionTab rt, const unsigned* __restrict__ cells,
+                                                            const Candidate* __restrict__ cand, const int* __restrict__ cand_n,
+                                                            const int* __restrict__ dense_flags, unsigned long long* __restrict__ hit_masks,
+                                                            int* __restrict__ chunk_counts, float* __restrict__ pv_map,
+                                                            long long* __restrict__ chunk_offsets, int64_t* __restrict__ counts) {
+    __shared__ float s_pooled[kMaxLevels][kMaxWin * kMaxWin];
+    __shared__ unsigned s_cells[kMaxLevels * kCells];
+    const int f = blockIdx.x;
+    const int n = cand_n[f];
+    if (n <= kCandCap) {     // block-uniform (more: every level of this frame ran the dense kernels)
+        const unsigned* fc = cells + (long long)f * tab.n_levels * kCells;
+        for (int i = threadIdx.x; i < tab.n_levels * kCells; i += 256) s_cells[i] = fc[i];   // one round trip for every level
+        __syncthreads();
+        for (int l = 0; l < tab.n_levels; ++l) pooled_from_cells(s_cells + l * kCells, rt.lv[l], s_pooled[l]);
+        __syncthreads();
+        for (int i = threadIdx.x; i < n; i += 256) {
+            const Candidate c = cand[(long long)f * kCandCap + i];
+            if (dense_flags[f * tab.n_levels + c.level] == kTailDense) continue;
+            if (pv_map)      // the caller's peak-value map: zero-filled for this level (sparse_fill_map_kernel), the passers' values go in
+                pv_map[(long long)f * tab.frame_px + tab.px_off[c.level] + (long long)c.y * tab.w[c.level] + c.x] = c.pv;
+            const float thr = region_thr<false>(c.y, c.x, rt.lv[c.level], s_pooled[c.level]);
+            if (!(thr > 0.0f && c.pv >= thr)) continue;
+            const int p = c.y * tab.w[c.level] + c.x;
+            const long long blk = (long long)f * tab.tiles_per_frame + tab.tile_start[c.level] + (p / kKpChunk);
+            atomicOr(hit_masks + blk * (kKpChunk / 64) + ((p % kKpChunk) >> 6), 1ull << (p & 63));
+            atomicAdd(chunk_counts + blk, 1);
+        }
+    }
+    // This block's atomics have been performed (device-scope atomics act at the memory side and are acknowledged from there) once the
+    // counter is at zero; the scan reads the counts with loads that go to the same place.  (No __threadfence(): its release half
+    // writes the L2 back, per wave -- in a kernel that every block ends with one it cost 10x the kernel's time.)
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    __syncthreads();
+    scan_frame_chunks<true>(chunk_counts, chunk_offsets, tab.tiles_per_frame, counts, f);
+}
+
+// pass 2: exclusive scan of the chunk counts of one frame (one block per frame)
+__global__ __launch_bounds__(256) void region_scan_kernel(const int* __restrict__ chunk_counts,
+                                                          long long* __restrict__ chunk_offsets,
+                                                          int chunks_per_frame, int64_t* __restrict__ counts) {
+    scan_frame_chunks<false>(chunk_counts, chunk_offsets, chunks_per_frame, counts, blockIdx.x);
 }
 
 // pass 3: ordered write of (level, y, x, 0) rows: rank = chunk offset + hits of the lower waves + hits of this wave's

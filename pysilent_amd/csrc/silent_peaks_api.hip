@@ -145,10 +145,10 @@ SILENT_EXPORT int silent_select_peaks_dev(silent_ctx* ctx, const float* color, c
     std::memset(&no_regions, 0, sizeof(no_regions));
     if (channels == 3)
         hipLaunchKernelGGL((select_peaks_kernel<3, false>), dim3((unsigned)blocks), dim3(256), 0, s, color, value, top_out,
-                           peaks_out, peak_value_out, tab, a, b, mm, no_regions, nullptr, nullptr);
+                           peaks_out, peak_value_out, tab, a, b, mm, no_regions, nullptr, nullptr, (unsigned)blocks);
     else
         hipLaunchKernelGGL((select_peaks_kernel<1, false>), dim3((unsigned)blocks), dim3(256), 0, s, color, value, top_out,
-                           peaks_out, peak_value_out, tab, a, b, mm, no_regions, nullptr, nullptr);
+                           peaks_out, peak_value_out, tab, a, b, mm, no_regions, nullptr, nullptr, (unsigned)blocks);
     return check_launch(ctx, who);
 } catch (...) {
     return on_exception(ctx, "silent_select_peaks_dev");
@@ -293,6 +293,10 @@ static int region_window_maxima(silent_ctx* ctx, const char* who, const float* v
     return check_launch(ctx, who);
 }
 
+// Blocks of a sparse-tail launch over n tiles whose blocks mostly find nothing to do (for_live_tiles, silent_peaks.h): a block
+// looks at up to 64 tiles; 2048 blocks keep the chip busy where a frame does run the dense kernels.
+static unsigned sparse_grid(long long n) { return (unsigned)std::min<long long>(n, std::max<long long>((n + 63) / 64, 2048)); }
+
 // count -> scan -> ordered write, given the cell maxima
 static void keypoint_passes(const float* value, const LevelTab& tab, long long blocks, const RegionTab& rt, const KeypointWs& w,
                             bool general, int n_frames, int64_t* idx, size_t cap_per_frame, int64_t* counts, hipStream_t s,
@@ -301,11 +305,12 @@ static void keypoint_passes(const float* value, const LevelTab& tab, long long b
         hipLaunchKernelGGL(region_count_kernel<true>, dim3((unsigned)blocks), dim3(256), 0, s, value, tab, rt, w.cells, w.pooled, w.chunk_counts, w.hit_masks, dense_flags);
     else
         hipLaunchKernelGGL(region_count_kernel<false>, dim3((unsigned)blocks), dim3(256), 0, s, value, tab, rt, w.cells, w.pooled, w.chunk_counts, w.hit_masks, dense_flags);
-    if (dense_flags)   // sparse tail: the candidates' hits join what the count pass left
+    if (dense_flags)   // sparse tail: the candidates' hits join what the count pass left, then the scan (one block per frame both)
         hipLaunchKernelGGL(sparse_finish_kernel, dim3((unsigned)n_frames), dim3(256), 0, s, tab, rt, w.cells, w.cand, w.cand_n, dense_flags,
-                           w.hit_masks, w.chunk_counts, caller_map);
-    hipLaunchKernelGGL(region_scan_kernel, dim3((unsigned)n_frames), dim3(256), 0, s, w.chunk_counts, w.chunk_offsets,
-                       tab.tiles_per_frame, counts);
+                           w.hit_masks, w.chunk_counts, caller_map, w.chunk_offsets, counts);
+    else
+        hipLaunchKernelGGL(region_scan_kernel, dim3((unsigned)n_frames), dim3(256), 0, s, w.chunk_counts, w.chunk_offsets,
+                           tab.tiles_per_frame, counts);
     if (!cap_per_frame) return;
     hipLaunchKernelGGL(region_write_kernel, dim3((unsigned)blocks), dim3(256), 0, s, tab, w.hit_masks, w.chunk_offsets, idx,
                        (long long)cap_per_frame, w.chunk_counts);
@@ -414,7 +419,7 @@ static int select_run(silent_ctx* ctx, const char* who, const float* color, cons
         // (sparse implies: 3 channels, cell tables, extrema present, no caller-side peak-value map; select_prepare zeroed the counters)
         hipLaunchKernelGGL(sparse_select_kernel, dim3((unsigned)((sp.st.frame_entries + 255) / 256), (unsigned)n_frames), dim3(256), 0, s, color, sp.tab, sp.st, w.sum,
                            n_frames, a, b, mm, rt, w.cells, w.cand, w.cand_n);
-        hipLaunchKernelGGL(sparse_modes_kernel, dim3((unsigned)n_frames), dim3(64), 0, s, sp.tab, rt, w.cells, w.cand_n, w.nan_flags,
+        hipLaunchKernelGGL(sparse_modes_kernel, dim3((unsigned)n_frames), dim3(256), 0, s, sp.tab, rt, w.cells, w.cand_n, w.nan_flags,
                            w.dense_flags, peak_value_out ? 1 : 0);
         if (peak_value_out)   // the map the caller takes: zeros wherever the dense pass will not write
             hipLaunchKernelGGL(sparse_fill_map_kernel, dim3((unsigned)sp.blocks), dim3(256), 0, s, sp.tab, w.dense_flags, peak_value_out);
@@ -425,17 +430,18 @@ static int select_run(silent_ctx* ctx, const char* who, const float* color, cons
         // many windows: the selection pass without the folded cell maxima, then the separable window maxima
         if (channels == 3)
             hipLaunchKernelGGL((select_peaks_kernel<3, false>), dim3((unsigned)sp.sblocks), dim3(256), 0, s, color, value, nullptr, nullptr,
-                               peak_value_out, sp.stab, a, b, mm, rt, nullptr, nullptr);
+                               peak_value_out, sp.stab, a, b, mm, rt, nullptr, nullptr, (unsigned)sp.sblocks);
         else
             hipLaunchKernelGGL((select_peaks_kernel<1, false>), dim3((unsigned)sp.sblocks), dim3(256), 0, s, color, value, nullptr, nullptr,
-                               peak_value_out, sp.stab, a, b, mm, rt, nullptr, nullptr);
+                               peak_value_out, sp.stab, a, b, mm, rt, nullptr, nullptr, (unsigned)sp.sblocks);
         TRY(region_window_maxima(ctx, who, peak_value_out, levels, n_levels, n_frames, rt, w, s));
     } else if (channels == 3) {
-        hipLaunchKernelGGL((select_peaks_kernel<3, true>), dim3((unsigned)sp.sblocks), dim3(256), 0, s, color, value, nullptr, nullptr,
-                           peak_value_out, sp.stab, a, b, mm, rt, w.cells, dense_flags);
+        // (sparse tail: a bounded grid -- usually no (frame, level) runs this pass)
+        hipLaunchKernelGGL((select_peaks_kernel<3, true>), dim3(dense_flags ? sparse_grid(sp.sblocks) : (unsigned)sp.sblocks), dim3(256), 0, s, color, value, nullptr, nullptr,
+                           peak_value_out, sp.stab, a, b, mm, rt, w.cells, dense_flags, (unsigned)sp.sblocks);
     } else {
         hipLaunchKernelGGL((select_peaks_kernel<1, true>), dim3((unsigned)sp.sblocks), dim3(256), 0, s, color, value, nullptr, nullptr,
-                           peak_value_out, sp.stab, a, b, mm, rt, w.cells, dense_flags);
+                           peak_value_out, sp.stab, a, b, mm, rt, w.cells, dense_flags, (unsigned)sp.sblocks);
     }
     keypoint_passes(peak_value_out, sp.tab, sp.blocks, rt, w, sp.general, n_frames, idx, cap_per_frame, counts, s, dense_flags,
                     dense_flags ? caller_map : nullptr);
