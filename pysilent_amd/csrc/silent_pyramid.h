@@ -329,10 +329,11 @@ struct BorderTab {
     BorderLevel lv[kMaxLevels];
 };
 
-template <int C>
-__global__ __launch_bounds__(256) void pyramid_border_kernel(const float* __restrict__ frames, float* __restrict__ pyr, const PyrTab tab,
-                                                             const BorderTab bt, int n_frames) {
-    const long long gid = (long long)blockIdx.x * 256 + threadIdx.x;
+// border pixel x channel number gid of the launch (frames x bt.per_frame x C of them).  LEAN: one tap column at a time (6 loads in
+// flight instead of 36) -- inside the walk kernel, whose 7 waves per SIMD must not pay for this path's registers
+template <int C, bool LEAN = false>
+__device__ __forceinline__ void pyramid_border_px(const float* __restrict__ frames, float* __restrict__ pyr, const PyrTab& tab,
+                                                  const BorderTab& bt, long long gid, int n_frames) {
     const long long per_frame = (long long)bt.per_frame * C;
     if (gid >= per_frame * n_frames) return;
     const int frame = (int)(gid / per_frame);
@@ -368,19 +369,34 @@ __global__ __launch_bounds__(256) void pyramid_border_kernel(const float* __rest
     const int* __restrict__ xi = tab.xidx + (long long)(lv.xtab_off + ox) * 6;
     const float* __restrict__ wy = tab.yw + (long long)(lv.ytab_off + oy) * 6;
     const float* __restrict__ wx = tab.xw + (long long)(lv.xtab_off + ox) * 6;
-    float v[6];
-#pragma unroll
-    for (int j = 0; j < 6; ++j) {
+    auto column = [&](int j) {
         const long long col = (long long)(xi[j] + lv.src_x0) * C + ch;
         float a = __builtin_fmaf(wy[0], src[(long long)(yi[0] + lv.src_y0) * tab.W * C + col], 0.0f);
 #pragma unroll
         for (int i = 1; i < 6; ++i) a = __builtin_fmaf(wy[i], src[(long long)(yi[i] + lv.src_y0) * tab.W * C + col], a);
-        v[j] = a;
-    }
-    float acc = wx[0] * v[0];
+        return a;
+    };
+    float acc;
+    if constexpr (LEAN) {
+        acc = wx[0] * column(0);
+#pragma unroll 1
+        for (int j = 1; j < 6; ++j) acc = __builtin_fmaf(wx[j], column(j), acc);
+    } else {
+        float v[6];
 #pragma unroll
-    for (int j = 1; j < 6; ++j) acc = __builtin_fmaf(wx[j], v[j], acc);
+        for (int j = 0; j < 6; ++j) v[j] = column(j);
+        acc = wx[0] * v[0];
+#pragma unroll
+        for (int j = 1; j < 6; ++j) acc = __builtin_fmaf(wx[j], v[j], acc);
+    }
     pyr[((long long)frame * tab.frame_px_out + tab.px_off[b.level] + (long long)oy * lv.out_w + ox) * C + ch] = acc;
+}
+
+// (on its own: PYRAMID knob 8; by default these pixels are the first blocks of the walk's launch, silent_walk_rgb.h)
+template <int C>
+__global__ __launch_bounds__(256) void pyramid_border_kernel(const float* __restrict__ frames, float* __restrict__ pyr, const PyrTab tab,
+                                                             const BorderTab bt, int n_frames) {
+    pyramid_border_px<C>(frames, pyr, tab, bt, (long long)blockIdx.x * 256 + threadIdx.x, n_frames);
 }
 
 // ------------------------------------------------------------------------------------------ ZERO FILL

@@ -621,17 +621,29 @@ int launch_pyramid(silent_ctx* ctx, const char* who, const silent_pyramid_plan* 
 #undef PYR_STREAM
     } else if (tab.C == 3 && plan->walk_pyr_ok && with_unit && with_region && !(kopts & 3u) && walk3_plan(ctx, plan, n_frames, &w3t)) {
         // single-read RGB pyramid (pyramid_walk3_kernel, silent_walk_rgb.h); PYRAMID knob bits 1 / 2: unit + region kernels
-        const long long wblocks = (long long)n_frames * w3t.blocks_per_frame;
-#define WALK3(G_, PX_) hipLaunchKernelGGL((pyramid_walk3_kernel<G_, PX_>), dim3((unsigned)wblocks), dim3(kW3Threads), 0, s, frames, pyr, w3t)
+        // union plans: the inner levels' first / last output rows and columns -- the last blocks of the same launch (PYRAMID knob 8:
+        // a launch of their own behind the walk)
+        const long long bthreads = (long long)plan->walk_border.per_frame * 3 * n_frames;
+        const long long bblocks = (bthreads + 255) / 256;
+        const bool border_inside = bblocks > 0 && !(kopts & 8u);
+        const long long wblocks = (long long)n_frames * w3t.blocks_per_frame + (border_inside ? bblocks : 0);
+        if (wblocks > 0x7fffffffll || bblocks > 0x7fffffffll) return fail(ctx, SILENT_E_INVALID, std::string(who) + ": too many blocks for one launch");
+        WalkBorderArgs wb;
+        std::memset(&wb, 0, sizeof(wb));
+        wb.first = 0x7fffffff;
+        if (border_inside) {
+            wb.first = (int)((long long)n_frames * w3t.blocks_per_frame);
+            wb.n_frames = n_frames;
+            wb.tab = tab;
+            wb.bt = plan->walk_border;
+        }
+#define WALK3(G_, PX_) hipLaunchKernelGGL((pyramid_walk3_kernel<G_, PX_>), dim3((unsigned)wblocks), dim3(kW3Threads), 0, s, frames, pyr, w3t, wb)
 #define WALK3_PX(PX_) case PX_: if (plan->walk_G <= 4) WALK3(4, PX_); else WALK3(7, PX_); break
         switch (plan->walk_px) { WALK3_PX(36); WALK3_PX(32); WALK3_PX(28); WALK3_PX(24); default: break; }   // (walk3_plan refuses any other)
 #undef WALK3_PX
 #undef WALK3
-        if (plan->walk_border.n > 0) {   // union plans: the inner levels' first / last output rows and columns
-            const long long threads = (long long)plan->walk_border.per_frame * 3 * n_frames;
-            if ((threads + 255) / 256 > 0x7fffffffll) return fail(ctx, SILENT_E_INVALID, std::string(who) + ": too many border pixels for one launch");
-            hipLaunchKernelGGL(pyramid_border_kernel<3>, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, s, frames, pyr, tab, plan->walk_border, n_frames);
-        }
+        if (bblocks > 0 && !border_inside)
+            hipLaunchKernelGGL(pyramid_border_kernel<3>, dim3((unsigned)bblocks), dim3(256), 0, s, frames, pyr, tab, plan->walk_border, n_frames);
     } else if (tab.C == 1) {
         if (b_unit) hipLaunchKernelGGL(pyramid_unit_kernel<1>, dim3((unsigned)b_unit), dim3(256), 0, s, frames, pyr, tab);
         if (b_region) hipLaunchKernelGGL(pyramid_region_kernel<1>, dim3((unsigned)b_region), dim3(256), 0, s, frames, pyr, tab);

@@ -32,6 +32,7 @@
 
 #include "silent_common.h"
 #include "silent_gray.h"
+#include "silent_pyramid.h"
 
 namespace silent {
 
@@ -114,13 +115,21 @@ struct Walk3Args {
     float wx[6];                         // [1, 26, 66, 26, 1] / 120 and scipy's sixth tap, 2^-53, as float32 (both axes)
     Walk3Plan plan[kW3MaxPlans];
 };
+// Union plans: the inner levels' first / last output rows and columns (pyramid_border_px, silent_pyramid.h: one thread per pixel and
+// channel, taps straight from the frame) are the LAST blocks of the walk's launch, from block `first` on -- they fill the slots the
+// walk's last round of blocks leaves idle instead of running behind it in a launch of their own.
+struct WalkBorderArgs {
+    int first, n_frames;                 // first = INT_MAX: none
+    PyrTab tab;
+    BorderTab bt;
+};
 // row record of the walk: [meta(0) .. meta(Gp-1)] [6 weights of level 0] ... [6 weights of level Gp-1], padded to a multiple
 // of 4 dwords.  meta: bit 0 "an output row of this level completes with this source row", bits 8.. that output row.
 __host__ __device__ constexpr int w3_prog_row(int gp) { return (gp * 7 + 3) / 4 * 4; }
 
 template <int G, int PX>
 __global__ __launch_bounds__(kW3Threads) void pyramid_walk3_kernel(const float* __restrict__ frames, float* __restrict__ pyr,
-                                                                    const Walk3Args args) {
+                                                                    const Walk3Args args, const WalkBorderArgs border) {
     static_assert(G == stream_pad_levels(G), "row programs are padded to 4 or 7 levels");
     static_assert(PX == 36 || PX == 32 || PX == 28 || PX == 24, "");
     constexpr int kW3Px = PX, kW3StripPx = kW3NC * PX, kW3RowF = w3_row_f(PX);
@@ -133,8 +142,14 @@ __global__ __launch_bounds__(kW3Threads) void pyramid_walk3_kernel(const float* 
     __shared__ __attribute__((aligned(16))) float s_line[kW3NC * 128];                            // a completed row, per wave
     __shared__ __attribute__((aligned(16))) int s_rec[kW3NC * kRecTotal * 8];                     // column records, per wave
 
-    const int frame = (int)(blockIdx.x / (unsigned)args.blocks_per_frame);
-    int rest = (int)(blockIdx.x - (unsigned)frame * (unsigned)args.blocks_per_frame);
+    if (blockIdx.x >= (unsigned)border.first) {   // block-uniform
+        if (threadIdx.x < 256)
+            pyramid_border_px<3, true>(frames, pyr, border.tab, border.bt, (long long)(blockIdx.x - (unsigned)border.first) * 256 + threadIdx.x, border.n_frames);
+        return;
+    }
+    const unsigned bid = blockIdx.x;
+    const int frame = (int)(bid / (unsigned)args.blocks_per_frame);
+    int rest = (int)(bid - (unsigned)frame * (unsigned)args.blocks_per_frame);
     int pi = 0;
 #pragma unroll
     for (int i = 1; i < kW3MaxPlans; ++i)

@@ -1782,10 +1782,13 @@ def test_rgb_pyramid_walk_on_the_references_crop_layout(rt, shape, center, scale
     got = plan.run(frames)
     with rt.tuning(TUNE_PYRAMID, 2):
         two = plan.run(frames)
-    a, b, c = np.asarray(got.data), np.asarray(two.data), np.asarray(per_level.run(frames).data)
-    assert np.array_equal(np.isnan(a), np.isnan(b)) and np.array_equal(np.isnan(a), np.isnan(c))
+    with rt.tuning(TUNE_PYRAMID, 8):          # the border pixels as a launch of their own instead of the walk launch's first blocks
+        own = plan.run(frames)
+    a, b, c, d = np.asarray(got.data), np.asarray(two.data), np.asarray(per_level.run(frames).data), np.asarray(own.data)
+    assert np.array_equal(np.isnan(a), np.isnan(b)) and np.array_equal(np.isnan(a), np.isnan(c)) and np.array_equal(np.isnan(a), np.isnan(d))
     np.testing.assert_array_equal(np.nan_to_num(a, nan=7.0), np.nan_to_num(b, nan=7.0))
     np.testing.assert_array_equal(np.nan_to_num(a, nan=7.0), np.nan_to_num(c, nan=7.0))
+    np.testing.assert_array_equal(np.nan_to_num(a, nan=7.0), np.nan_to_num(d, nan=7.0))
     with np.errstate(invalid="ignore", over="ignore"):
         bad_want = so.zoom_from_image(frames[0], 3, center, scale)
         assert_close(a.reshape((B,) + bad_want.shape)[0], bad_want, RTOL, scale=255.0, what="reference layout, non-finite pixels on the crop corners",
