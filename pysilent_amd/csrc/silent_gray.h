@@ -346,7 +346,7 @@ __global__ __launch_bounds__(64 * kFusedWaves) void gray_unit_fused_kernel(const
 // same single stream of frame rows (the frame is read once for the whole pyramid).
 //
 // Eligible plans (host-checked): one unit level, and every other level resamples the SAME crop with a
-// step > 1.25 source pixels per output pixel (classic whole-frame pyramids; the reference layout, whose
+// step of at least 1.4 source pixels per output pixel (classic whole-frame pyramids; the reference layout, whose
 // levels are different crops, keeps the region kernel).
 //
 // Pass 1 (registers, fully unrolled) is exactly gray_unit_fused_kernel; on the way the wave also drops its
@@ -358,22 +358,27 @@ __global__ __launch_bounds__(64 * kFusedWaves) void gray_unit_fused_kernel(const
 // Horizontal pass of a completed row: the outputs anchored in the wave's 56 columns gather their 6 taps from
 // the other lanes with ds_bpermute (lane = tap position - first column of the wave) and store one coalesced
 // run.  Arithmetic order = region kernel's (vertical then horizontal, taps ascending): bit-identical output.
-constexpr int kStreamSlots = 4;
-// output rows of general level number g that can be in flight at once (their vertical taps overlap): 4, 3, 2, 2,
-// then 1 -- enough for zoom ladders of ratio >= e^0.5 (the reference's default) and 2; host-checked per plan
-__host__ __device__ constexpr int stream_slots(int g) { return g == 0 ? 4 : (g == 1 ? 3 : (g <= 3 ? 2 : 1)); }
+constexpr int kStreamSlots = 5;   // (the most of any layout)
+// Output rows of general level number g that can be in flight at once (their vertical taps overlap), host-checked per plan.
+// Layout 0: 4, 3, 2, 2, then 1 -- enough for zoom ladders of ratio >= e^0.5 (the reference's default) and 2.  Layout 1 (round 5,
+// "dense" ladders down to a ratio of 1.4, e.g. sqrt 2): 5, 4, 3, 2, 2, 1, 1, always instantiated for 7 levels.  The host tries 0 first.
+__host__ __device__ constexpr int stream_slots(int layout, int g) {
+    return layout == 0 ? (g == 0 ? 4 : (g == 1 ? 3 : (g <= 3 ? 2 : 1))) : (g == 0 ? 5 : (g == 1 ? 4 : (g == 2 ? 3 : (g <= 4 ? 2 : 1))));
+}
 constexpr int kStreamRows = kFusedTH + 8;
 // Row program, one record per stream row of a tile row, padded to the kernel's template G (4 or 7 levels):
-//   [meta(0) .. meta(Gp-1)] [weights of level 0 (4)] [level 1 (3)] [level 2 (2)] ... ; kStreamProgRow(Gp) dwords.
+//   [meta(0) .. meta(Gp-1)] [weights of level 0 (4)] [level 1 (3)] [level 2 (2)] ... ; kStreamProgRow(layout, Gp) dwords.
 // It is wave-uniform data: the kernel reads it with scalar loads, one record ahead of the row it is working on.
 __host__ __device__ constexpr int stream_pad_levels(int g) { return g <= 4 ? 4 : 7; }
-__host__ __device__ constexpr int stream_w_off(int gp, int g) {
+__host__ __device__ constexpr int stream_w_off(int layout, int gp, int g) {
     int o = gp;
-    for (int h = 0; h < g; ++h) o += (h == 0 ? 4 : (h == 1 ? 3 : (h <= 3 ? 2 : 1)));
+    for (int h = 0; h < g; ++h) o += stream_slots(layout, h);
     return o;
 }
-__host__ __device__ constexpr int kStreamProgRow(int gp) { return gp <= 4 ? 16 : 24; }  // >= stream_w_off(gp, gp)
-// meta: bits 0-3 "slot restarts", bits 4-6 completing slot (7 = none), bit 7 "row feeds this level", bits 8.. output row
+__host__ __device__ constexpr int kStreamProgRow(int layout, int gp) { return (stream_w_off(layout, gp, gp) + 3) / 4 * 4; }   // layout 0: 16 / 24
+// meta: bits 0.. "slot restarts", 3 bits completing slot (7 = none), bit 7 "row feeds this level", then the output row
+__host__ __device__ constexpr int stream_done_shift(int layout) { return layout == 0 ? 4 : 8; }
+__host__ __device__ constexpr int stream_row_shift(int layout) { return layout == 0 ? 8 : 12; }
 
 struct StreamTab {
     int G;                        // general levels handled here (<= template G; extra ones are inert)
@@ -417,7 +422,7 @@ __device__ __forceinline__ StreamCol stream_col(const StreamTab& st, int g, int 
 #endif
 constexpr int kStreamRegLevels = SILENT_STREAM_REG_LEVELS;
 
-template <int K, int G>
+template <int K, int G, int L = 0>
 __global__ __launch_bounds__(64 * kFusedWaves) void gray_stream_kernel(const float* __restrict__ frames, float* __restrict__ pyr,
                                                           float* __restrict__ cs_out, float* __restrict__ end_out,
                                                           const FusedTab tab, const StreamTab st, const GrayW wts,
@@ -487,7 +492,7 @@ __global__ __launch_bounds__(64 * kFusedWaves) void gray_stream_kernel(const flo
 #pragma unroll
         for (int k = 0; k < kStreamSlots; ++k) vacc[g][k] = 0.0f;
     static_assert(G == stream_pad_levels(G), "row programs are padded to 4 or 7 levels");
-    constexpr int PR = kStreamProgRow(G);
+    constexpr int PR = kStreamProgRow(L, G);
     // constant address space: with a wave-uniform address these are s_load_dwordx16 (no VGPR, no readfirstlane)
     typedef const __attribute__((address_space(4))) int* const_int_ptr;
     const_int_ptr prog = (const_int_ptr)(st.row_prog + (long long)ty * (NR * PR));
@@ -508,17 +513,17 @@ __global__ __launch_bounds__(64 * kFusedWaves) void gray_stream_kernel(const flo
             const int meta = cur[g];
             if (!(meta & 128)) continue;  // wave-uniform: this stream row carries no tap of level g
 #pragma unroll
-            for (int k = 0; k < stream_slots(g); ++k) {
-                const float w = __int_as_float(cur[stream_w_off(G, g) + k]);
+            for (int k = 0; k < stream_slots(L, g); ++k) {
+                const float w = __int_as_float(cur[stream_w_off(L, G, g) + k]);
                 const float prev = (meta >> k) & 1 ? 0.0f : vacc[g][k];
                 vacc[g][k] = __builtin_fmaf(w, c0, prev);
             }
-            const int done = (meta >> 4) & 7;
-            if (done < kStreamSlots) {  // wave-uniform: slot `done` holds a finished output row of level g
-                const int oy = meta >> 8;
+            const int done = (meta >> stream_done_shift(L)) & 7;
+            if (done != 7) {  // wave-uniform: slot `done` holds a finished output row of level g
+                const int oy = meta >> stream_row_shift(L);
                 float v = vacc[g][0];
 #pragma unroll
-                for (int k = 1; k < stream_slots(g); ++k) v = done == k ? vacc[g][k] : v;
+                for (int k = 1; k < stream_slots(L, g); ++k) v = done == k ? vacc[g][k] : v;
                 const int vbits = __float_as_int(v);
                 const StreamCol cr = g < GR ? col[g < GR ? g : 0] : stream_col(st, g, wx_tile, lane);   // (g is a constant here)
                 float acc = cr.w[0] * __int_as_float(__builtin_amdgcn_ds_bpermute(cr.lane4, vbits));
@@ -677,7 +682,7 @@ __global__ __launch_bounds__(64 * kFusedWaves) void gray_stream_kernel(const flo
 // read and written at a stride of C floats.  Used for C = 1 only: two-step gray pyramids 0.58 -> 0.51 ms per 64 1080p
 // frames; with C = 3 the stride-3 loads and partial-line stores made it 1.5 ms against 1.0 ms for unit + region
 // kernels on 32 RGB frames (measured, bit-identical either way), so RGB plans are not marked streamable.
-template <int C, int G>
+template <int C, int G, int L = 0>
 __global__ __launch_bounds__(64 * kFusedWaves) void pyramid_stream_kernel(const float* __restrict__ frames, float* __restrict__ pyr,
                                                              const FusedTab tab, const StreamTab st) {
     constexpr int R = kFusedTH, NR = kStreamRows;
@@ -708,7 +713,7 @@ __global__ __launch_bounds__(64 * kFusedWaves) void pyramid_stream_kernel(const 
     const bool col_eff = ox >= 0 && ox < eff_w;
     const bool out_lane = lane >= 4 && lane < 4 + kFusedCols && ox < lv.out_w;
     static_assert(G == stream_pad_levels(G), "row programs are padded to 4 or 7 levels");
-    constexpr int PR = kStreamProgRow(G);
+    constexpr int PR = kStreamProgRow(L, G);
     typedef const __attribute__((address_space(4))) int* const_int_ptr;
     const_int_ptr prog = (const_int_ptr)(st.row_prog + (long long)ty * (NR * PR));
 
@@ -745,17 +750,17 @@ __global__ __launch_bounds__(64 * kFusedWaves) void pyramid_stream_kernel(const 
                     const int meta = cur[g];
                     if (!(meta & 128)) continue;
 #pragma unroll
-                    for (int k = 0; k < stream_slots(g); ++k) {
-                        const float w = __int_as_float(cur[stream_w_off(G, g) + k]);
+                    for (int k = 0; k < stream_slots(L, g); ++k) {
+                        const float w = __int_as_float(cur[stream_w_off(L, G, g) + k]);
                         const float prev = (meta >> k) & 1 ? 0.0f : vacc[g][k];
                         vacc[g][k] = __builtin_fmaf(w, c0, prev);
                     }
-                    const int done = (meta >> 4) & 7;
-                    if (done < kStreamSlots) {
-                        const int oy = meta >> 8;
+                    const int done = (meta >> stream_done_shift(L)) & 7;
+                    if (done != 7) {
+                        const int oy = meta >> stream_row_shift(L);
                         float v = vacc[g][0];
 #pragma unroll
-                        for (int k = 1; k < stream_slots(g); ++k) v = done == k ? vacc[g][k] : v;
+                        for (int k = 1; k < stream_slots(L, g); ++k) v = done == k ? vacc[g][k] : v;
                         const int vbits = __float_as_int(v);
                         const StreamCol cr = g < GR ? col[g < GR ? g : 0] : stream_col(st, g, wx_tile, lane);   // (g is a constant here)
                         float acc = cr.w[0] * __int_as_float(__builtin_amdgcn_ds_bpermute(cr.lane4, vbits));

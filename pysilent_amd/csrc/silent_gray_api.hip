@@ -114,16 +114,20 @@ static int gray_pass_parts(silent_ctx* ctx, const silent_pyramid_plan* plan, con
         if (ctx->prof_sample) HIP_TRY(ctx, hipEventRecord(ctx->prof_ev[prof_slot][0], s));
         if (stream_path) {
             const StreamTab& st = plan->stream;
-#define STREAM_LAUNCH(K_, G_) \
-    hipLaunchKernelGGL((gray_stream_kernel<K_, G_>), dim3((unsigned)blocks), dim3(64 * kFusedWaves), 0, s, frames, pyr, cs_out, end_out, ft, st, w, clip_hi, (unsigned)((kopts >> 5) & 1))
-            if (st.G <= 4) {
-                if (n_orient == 3) STREAM_LAUNCH(3, 4);
-                else if (n_orient == 4) STREAM_LAUNCH(4, 4);
-                else STREAM_LAUNCH(8, 4);
+#define STREAM_LAUNCH(K_, G_, L_) \
+    hipLaunchKernelGGL((gray_stream_kernel<K_, G_, L_>), dim3((unsigned)blocks), dim3(64 * kFusedWaves), 0, s, frames, pyr, cs_out, end_out, ft, st, w, clip_hi, (unsigned)((kopts >> 5) & 1))
+            if (plan->stream_layout == 1) {          // zoom ladders of ratio 1.4 .. e^.5: five rows of the first level in flight
+                if (n_orient == 3) STREAM_LAUNCH(3, 7, 1);
+                else if (n_orient == 4) STREAM_LAUNCH(4, 7, 1);
+                else STREAM_LAUNCH(8, 7, 1);
+            } else if (st.G <= 4) {
+                if (n_orient == 3) STREAM_LAUNCH(3, 4, 0);
+                else if (n_orient == 4) STREAM_LAUNCH(4, 4, 0);
+                else STREAM_LAUNCH(8, 4, 0);
             } else {
-                if (n_orient == 3) STREAM_LAUNCH(3, 7);
-                else if (n_orient == 4) STREAM_LAUNCH(4, 7);
-                else STREAM_LAUNCH(8, 7);
+                if (n_orient == 3) STREAM_LAUNCH(3, 7, 0);
+                else if (n_orient == 4) STREAM_LAUNCH(4, 7, 0);
+                else STREAM_LAUNCH(8, 7, 0);
             }
 #undef STREAM_LAUNCH
         } else {

@@ -18,6 +18,7 @@ struct silent_pyramid_plan {
     void* stream_tables = nullptr;
     silent::StreamTab stream{};
     int stream_unit_level = -1;
+    int stream_layout = 0;               // slot layout of the row programs (stream_slots, silent_gray.h): 1 = dense ladders, 7-level kernels
     // walk plans of pyramid_walk3_kernel (silent_walk_rgb.h; 3 channels): a classic pyramid is ONE plan (unit level + every
     // other level on the same crop), a crop layout like the reference's one plan per level; row programs (completion records)
     // + column records per wave tile live in walk_tables

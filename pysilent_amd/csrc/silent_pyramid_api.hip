@@ -225,16 +225,19 @@ SILENT_EXPORT int silent_pyramid_plan_create(silent_ctx* ctx, int frame_h, int f
                 ok = d.src_y0 == u.src_y0 && d.src_x0 == u.src_x0 && d.src_h == u.src_h && d.src_w == u.src_w;
             }
         }
-        if (ok) {
+        const bool eligible = ok;
+        // slot layouts (silent_gray.h, stream_slots): 0 for ladders of ratio >= e^.5, 1 ("dense", kernels for 7 levels only) down to 1.4
+        for (int layout = 0; layout < 2 && eligible && !plan->stream_ok; ++layout) {
+            ok = true;
             const PyrLevelDev& u = tab.lv[unit];
             const int G = tab.n_general;
             const int tiles_y = (u.out_h + kFusedTH - 1) / kFusedTH;
             const int waves_x = ((u.out_w + kFusedTW - 1) / kFusedTW) * kFusedWaves;
-            const int Gp = stream_pad_levels(G), PR = kStreamProgRow(Gp);
+            const int Gp = layout ? 7 : stream_pad_levels(G), PR = kStreamProgRow(layout, Gp);
             const size_t n_rec = (size_t)tiles_y * kStreamRows;
             std::vector<int> prog(n_rec * PR, 0), hdr((size_t)G * waves_x * 2, 0), rec((size_t)G * waves_x * 64 * 8, 0);
             for (size_t r = 0; r < n_rec; ++r)
-                for (int gg = 0; gg < Gp; ++gg) prog[r * PR + gg] = 7 << 4;  // inert: feeds nothing, no slot completes
+                for (int gg = 0; gg < Gp; ++gg) prog[r * PR + gg] = 7 << stream_done_shift(layout);  // inert: feeds nothing, no slot completes
             std::vector<char> used(n_rec * G * kStreamSlots, 0);
             int g = 0;
             for (int l = 0; l < n_levels && ok; ++l) {
@@ -246,7 +249,7 @@ SILENT_EXPORT int silent_pyramid_plan_create(silent_ctx* ctx, int frame_h, int f
                 for (int oy = 0; oy < zr && ok; ++oy) {
                     const int t = yb[oy] / kFusedTH;
                     if (yb[oy] < 0 || t >= tiles_y) { ok = false; break; }
-                    const int slot = oy % stream_slots(g);
+                    const int slot = oy % stream_slots(layout, g);
                     for (int j = 0; j < 6; ++j) {
                         const int i = yb[oy] - t * kFusedTH + 2 + j;  // stream row of tap j (a tile streams rows y0-4 ..)
                         if (i < 0 || i >= kStreamRows) { ok = false; break; }
@@ -256,12 +259,13 @@ SILENT_EXPORT int silent_pyramid_plan_create(silent_ctx* ctx, int frame_h, int f
                         used[e * kStreamSlots + slot] = 1;
                         int* pr = prog.data() + r * PR;
                         int& meta = pr[g];
-                        std::memcpy(pr + stream_w_off(Gp, g) + slot, &yw[(size_t)(d.ytab_off + oy) * 6 + j], 4);
+                        std::memcpy(pr + stream_w_off(layout, Gp, g) + slot, &yw[(size_t)(d.ytab_off + oy) * 6 + j], 4);
                         meta |= 128;  // this stream row feeds level g
                         if (j == 0) meta |= 1 << slot;
                         if (j == 5) {
-                            if (((meta >> 4) & 7) != 7) { ok = false; break; }  // two rows completing together
-                            meta = (meta & 0x8f) | (slot << 4) | (oy << 8);
+                            const int ds = stream_done_shift(layout);
+                            if (((meta >> ds) & 7) != 7) { ok = false; break; }  // two rows completing together
+                            meta = (meta & ~(7 << ds)) | (slot << ds) | (oy << stream_row_shift(layout));
                         }
                     }
                 }
@@ -304,6 +308,7 @@ SILENT_EXPORT int silent_pyramid_plan_create(silent_ctx* ctx, int frame_h, int f
                     plan->stream.col_hdr = (const int*)((char*)plan->stream_tables + b0);
                     plan->stream.col_rec = (const int*)((char*)plan->stream_tables + b0 + b1);
                     plan->stream_unit_level = unit;
+                    plan->stream_layout = layout;
                     plan->stream_ok = true;
                 }
             }
@@ -614,10 +619,11 @@ int launch_pyramid(silent_ctx* ctx, const char* who, const silent_pyramid_plan* 
         ft.frame_px = tab.frame_px_out;
         const long long blocks = (long long)ft.tiles_per_frame * n_frames;
         if (blocks > 0x7fffffffll) return fail(ctx, SILENT_E_INVALID, std::string(who) + ": too many tiles for one launch");
-#define PYR_STREAM(G_) \
-    hipLaunchKernelGGL((pyramid_stream_kernel<1, G_>), dim3((unsigned)blocks), dim3(64 * kFusedWaves), 0, s, frames, pyr, ft, plan->stream)
-        if (plan->stream.G <= 4) PYR_STREAM(4);
-        else PYR_STREAM(7);
+#define PYR_STREAM(G_, L_) \
+    hipLaunchKernelGGL((pyramid_stream_kernel<1, G_, L_>), dim3((unsigned)blocks), dim3(64 * kFusedWaves), 0, s, frames, pyr, ft, plan->stream)
+        if (plan->stream_layout == 1) PYR_STREAM(7, 1);
+        else if (plan->stream.G <= 4) PYR_STREAM(4, 0);
+        else PYR_STREAM(7, 0);
 #undef PYR_STREAM
     } else if (tab.C == 3 && plan->walk_pyr_ok && with_unit && with_region && !(kopts & 3u) && walk3_plan(ctx, plan, n_frames, &w3t)) {
         // single-read RGB pyramid (pyramid_walk3_kernel, silent_walk_rgb.h); PYRAMID knob bits 1 / 2: unit + region kernels

@@ -46,7 +46,7 @@ def case_gray_pass(rng, k):
         w = int(rng.integers(420, 1400))          # several 224-column blocks per row
     if rng.integers(0, 2) == 0:
         w = max(4, w // 4 * 4)                    # 16-byte aligned rows
-    scale = float(rng.choice([1.3, 1.5, 1.7, 2.0, 2.5, math.e ** .5]))
+    scale = float(rng.choice([1.3, 1.4, 2 ** .5, 1.5, 1.7, 2.0, 2.5, math.e ** .5]))
     n = int(rng.integers(1, 7))
     K = int(rng.choice([3, 4, 8]))
     B = int(rng.integers(1, 4))

@@ -338,14 +338,17 @@ def test_classic_pyramid(rt, shape, scale, n):
 
 @pytest.mark.parametrize("shape,scale,n", [((135, 240, 3), 2.0, 4), ((97, 131, 1), 1.7, 4), ((64, 64, 3), 2.0, 3), ((65, 129, 3), 2.0, 2),
                                            ((270, 480, 3), 2.0, 8), ((270, 480, 1), math.e ** .5, 6), ((33, 17, 3), 2.0, 2),
-                                           ((100, 260, 3), 1.2, 3)])
+                                           ((100, 260, 3), 1.2, 3),
+                                           ((270, 480, 1), 2 ** .5, 8), ((135, 240, 1), 1.5, 4), ((200, 300, 1), 1.4, 3),   # the dense slot layout
+                                           ((200, 300, 1), 1.3, 3), ((200, 300, 1), 1.15, 3)])                              # 1.15: too dense for it
 def test_pyramid_single_read_kernel_equals_unit_plus_region(rt, shape, scale, n):
     """silent_pyramid on classic pyramids: the single-read kernel (pyramid_stream_kernel, 1 and 3 channels) is
     bit-identical to the unit + region kernels (tuning knob PYRAMID = 1 selects those) and matches the oracle."""
     from pysilent_amd.util.zoom.from_image import classic_levels
     frames = np.stack([noise_frame(60 + s_, *shape) for s_ in range(3)])
     plan = rt.PyramidPlan(shape[0], shape[1], shape[2], classic_levels(shape[:2], scale, n))
-    assert plan.streamable == (scale > 1.25 and shape[2] == 1)       # RGB plans keep unit + region kernels
+    # (the host checks the row programs themselves: five rows of the first level in flight hold ratios down to about 1.3)
+    assert plan.streamable == (scale >= 1.3 and shape[2] == 1)       # RGB plans keep unit + region kernels
     got = plan.run(frames)
     with rt.tuning(TUNE_PYRAMID, 1):
         two = plan.run(frames)
@@ -1121,14 +1124,17 @@ def test_torch_device_path_is_bit_identical(rt, kernels):
                                              ((33, 57, 1), 2.0, 1, 4),
                                              ((270, 480, 1), 2.0, 8, 4),            # 7 general levels: stream kernel <K, 7>
                                              ((270, 480, 1), math.e ** .5, 6, 8),   # the reference's zoom ratio
-                                             ((100, 260, 1), 1.2, 3, 4)])           # step 1.2: not stream-eligible -> region path
+                                             ((100, 260, 1), 1.2, 3, 4),            # step 1.2: not stream-eligible -> region path
+                                             ((270, 480, 1), 2 ** .5, 8, 4),        # round 5: the dense slot layout (stream kernel <K, 7, 1>):
+                                             ((135, 240, 1), 1.5, 4, 8),            #   five rows of the first level in flight, ratios down to 1.4
+                                             ((216, 384, 1), 2 ** .5, 6, 3)])
 def test_gray_pass_equals_pyramid_then_filters(rt, kernels, shape, scale, n, K):
     """silent_gray_pass (level 0 smoothed + filtered in one kernel) is bit-identical to the two-step path,
     and both match the oracle."""
     from pysilent_amd.util.zoom.from_image import classic_levels
     frames = np.stack([noise_frame(s, *shape) for s in range(2)])
     plan = rt.PyramidPlan(shape[0], shape[1], 1, classic_levels(shape[:2], scale, n))
-    assert plan.streamable == (n > 1 and scale > 1.25)      # which path silent_gray_pass takes for this plan
+    assert plan.streamable == (n > 1 and scale >= 1.4)      # which path silent_gray_pass takes for this plan
     bank = kernels["end%d" % K]
     pyr, cs, end = plan.gray_pass(frames, kernels["cs_gray"], bank)
     pyr2 = plan.run(frames)
@@ -1208,6 +1214,7 @@ def _nonfinite_frame(seed, h, w, c):
 
 @pytest.mark.parametrize("shape,scale,n,K", [((96, 160, 1), 2.0, 3, 4), ((135, 300, 1), 2.0, 8, 8), ((135, 300, 1), math.e ** .5, 5, 3),
                                              ((100, 260, 1), 1.2, 3, 8),
+                                             ((135, 300, 1), 2 ** .5, 6, 4),   # the dense slot layout <K, 7, 1>
                                              ((109, 216, 1), 2.0, 4, 4)])   # levels whose last row / column is scipy's mode-'constant' artefact
 def test_gray_pass_nonfinite_pixels_reach_scipys_six_taps(rt, kernels, shape, scale, n, K):
     """A NaN / inf FRAME pixel poisons what it poisons in the reference: at zoom 1 scipy.ndimage.zoom(order=5) multiplies SIX taps per
