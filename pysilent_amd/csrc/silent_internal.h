@@ -153,7 +153,7 @@ int check_levels(silent_ctx* ctx, const char* who, const silent_extent* levels, 
 int launch_regulate_sum(silent_ctx* ctx, const float* in, const silent_extent* levels, int n_levels, int n_frames, const float* blur_hwio,
                         float regulation_value, float regulation_root, int flat_policy, float* out, hipStream_t s);
 // (silent_rgb_api.hip) which fused kernel a chain launch over these levels uses and its tile height (output rows per tile)
-int rgb_chain_tile_height(const silent_ctx* ctx, const silent_extent* levels, int n_levels, int n_frames, bool* pair);
+int rgb_chain_tile_height(const silent_ctx* ctx, const silent_extent* levels, int n_levels, int n_frames, bool* pair, bool with_extrema);
 // (silent_rgb_api.hip) mm: optional per-level extrema slots (already initialised); *mm_done tells whether the launch filled them
 // (only the pair kernel's two-group instantiation does -- everything else leaves them to level_maxmin_kernel); st / sum /
 // nan_flags: the value summary of the sparse keypoint tail (silent_peaks_api.hip)

@@ -716,7 +716,7 @@ SILENT_EXPORT int silent_rgb_keypoints_dev(silent_ctx* ctx, const float* pyr, co
     // a per-group maximum of the value map, and selection / NMS / keypoint search look only at the groups that reach their
     // level's threshold; whatever that cannot settle exactly runs the dense kernels on a map in the workspace.
     bool pair_kernel = false;
-    const int th = rgb_chain_tile_height(ctx, levels, n_levels, n_frames, &pair_kernel);
+    const int th = rgb_chain_tile_height(ctx, levels, n_levels, n_frames, &pair_kernel, true);
     const bool want_sparse = pair_kernel && !(ctx->tune[SILENT_TUNE_RGB] & 32u);
     SelectPlan sp;
     TRY(select_prepare(ctx, who, levels, n_levels, n_frames, regions, s, &sp, want_sparse ? th : 0, !peak_value_out));

@@ -230,7 +230,7 @@ SILENT_EXPORT int silent_rgb_chain_structure(const silent_rgb_chain_params* para
 
 
 // Which fused kernel a chain launch over these levels uses and its tile height (output rows per tile).
-int rgb_chain_tile_height(const silent_ctx* ctx, const silent_extent* levels, int n_levels, int n_frames, bool* pair) {
+int rgb_chain_tile_height(const silent_ctx* ctx, const silent_extent* levels, int n_levels, int n_frames, bool* pair, bool with_extrema) {
     const unsigned kopts = ctx->tune[SILENT_TUNE_RGB];  // 1: dense, 2: no two-group, 8: 90-row tiles, bits 8-15: tile height / 2
     // two pixels per lane on packed f32 (silent_rgb2.h; its buffer addressing wants levels below 2^30 bytes per map); 16: one pixel per lane
     bool pair_kernel = !(kopts & 16u);
@@ -244,7 +244,10 @@ int rgb_chain_tile_height(const silent_ctx* ctx, const silent_extent* levels, in
     if ((kopts >> 8) & 0xffu) {
         th = std::min(std::max((int)((kopts >> 8) & 0xffu) * 2, 2), 400);
     } else if (!(kopts & 8u)) {
-        const long long resident = (pair_kernel ? 16ll / kRgb2Waves : 5ll) * ctx->n_cus;   // 128 / 94 VGPRs, 256 threads: 4 / 5 tiles per CU
+        // resident tiles: the pair kernel runs 4 waves per SIMD, 3 where it also leaves the extrema and the value summary of the
+        // keypoint tail (149 VGPRs; round 5: the model counted 4 there as well and picked 24-row tiles for the reference layout --
+        // 2048 tiles on a chip that holds 1536; with 32 rows it is one round: step 0.357 -> 0.349 ms); the one-pixel kernel 5 tiles
+        const long long resident = (pair_kernel ? (with_extrema ? 12ll : 16ll) / kRgb2Waves : 5ll) * ctx->n_cus;
         const int tw = pair_kernel ? kRgb2TW : kRgbTW;
         long long best = -1;
         // Launches that fill the chip several times over keep round 1's 90 rows: a sweep on config 3 (scripts/sweep_rgb_th.py:
@@ -299,7 +302,7 @@ int rgb_chain_launch(silent_ctx* ctx, const char* who, const float* pyr, const s
         long long blocks;
         const unsigned kopts = ctx->tune[SILENT_TUNE_RGB];  // 1: dense, 2: no two-group, 8: 90-row tiles, bits 8-15: tile height / 2
         bool pair_kernel;
-        const int th = rgb_chain_tile_height(ctx, levels, n_levels, n_frames, &pair_kernel);
+        const int th = rgb_chain_tile_height(ctx, levels, n_levels, n_frames, &pair_kernel, mm != nullptr);
         TRY(build_level_tab(ctx, who, levels, n_levels, n_frames, pair_kernel ? kRgb2TW : kRgbTW, th, &tab, &blocks));
         if (p->flat_policy != SILENT_FLAT_IEEE && p->flat_policy != SILENT_FLAT_ZERO)
             return fail(ctx, SILENT_E_INVALID, std::string(who) + ": flat_policy must be SILENT_FLAT_IEEE or SILENT_FLAT_ZERO");
