@@ -51,7 +51,9 @@ def packed(ext, c, n_frames):
 def one_plan():
     h, w, c = int(rng.integers(8, 160)), int(rng.integers(8, 200)), int(rng.choice([1, 3]))
     if rng.random() < 0.5:
-        levels = classic_levels((h, w), float(rng.choice([2.0, 1.6, math.e ** .5, 1.3, 3.0])), int(rng.integers(1, 8)))
+        # (ratios below e ** .5: the stream kernels' dense slot layout, the walk's 28 / 24-pixel tiles; up to 10 levels: ladders the
+        # single-read paths refuse)
+        levels = classic_levels((h, w), float(rng.choice([2.0, 1.6, math.e ** .5, 2 ** .5, 1.3, 1.2, 3.0])), int(rng.integers(1, 11)))
     else:
         cw, ch = int(rng.integers(4, max(5, w // 2 + 1))), int(rng.integers(4, max(5, h // 2 + 1)))
         levels = reference_levels((h, w), (cw, ch), float(rng.choice([2.0, math.e ** .5, 1.5])))
