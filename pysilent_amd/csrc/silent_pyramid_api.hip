@@ -414,8 +414,16 @@ SILENT_EXPORT int silent_pyramid_plan_create(silent_ctx* ctx, int frame_h, int f
                 for (size_t pi = 0; pi < hp.size() && ok; ++pi) {
                     const HostPlan& h = hp[pi];
                     const PyrLevelDev& c = tab.lv[h.crop];
-                    const int walk_h = h.unit >= 0 ? c.out_h : c.src_h, walk_w = h.unit >= 0 ? c.out_w : c.src_w;
+                    const int walk_h = h.unit >= 0 ? c.out_h : c.src_h;
+                    int walk_w = h.unit >= 0 ? c.out_w : c.src_w;
                     const int G = (int)h.gen.size();
+                    // A last strip that holds a sliver of the crop costs a whole strip of row steps (the reference layout on 1080p: 10
+                    // of 128 pixels, one block in eleven).  Plans of general levels only give it up: the few output columns anchored in
+                    // it join the border pixels (pyramid_border_px: taps straight from the frame), the walk ends at the strip boundary --
+                    // the pixels behind it are still in the frame for the last strip's halo.
+                    const int strip_px = kW3NC * px;
+                    if (h.unit < 0 && G >= 2 && walk_w > strip_px && walk_w % strip_px != 0 && walk_w % strip_px <= px / 2)
+                        walk_w -= walk_w % strip_px;
                     const int waves_x = ((walk_w + kW3NC * px - 1) / (kW3NC * px)) * kW3NC;
                     const size_t n_rec = (size_t)walk_h + 8;                 // stream rows y = -4 .. walk_h + 3 at index y + 4
                     const size_t n_rec_pad = n_rec + 2 * kWalkCH;            // the loader fetches whole chunks of records
@@ -435,6 +443,9 @@ SILENT_EXPORT int silent_pyramid_plan_create(silent_ctx* ctx, int frame_h, int f
                             while (oy_hi > oy_lo && yb[oy_hi - 1] + 3 > d.src_h - 1) --oy_hi;
                             while (ox_lo < zc && xb[ox_lo] - 2 < 0) ++ox_lo;
                             while (ox_hi > ox_lo && xb[ox_hi - 1] + 3 > d.src_w - 1) --ox_hi;
+                        }
+                        while (ox_hi > ox_lo && xb[ox_hi - 1] + dx >= walk_w) --ox_hi;   // anchored behind a trimmed walk
+                        if (oy_lo > 0 || oy_hi < zr || ox_lo > 0 || ox_hi < zc) {
                             if (oy_hi <= oy_lo || ox_hi <= ox_lo || bt.n >= kMaxLevels) { ok = false; break; }
                             BorderLevel& bl = bt.lv[bt.n++];
                             bl.level = h.gen[g];
@@ -547,9 +558,12 @@ static int walk3_blocks_per_cu() {
     return std::max(per_cu, 1);
 }
 
-// Per-launch decomposition of the plan's walks (any batch size): strips of 4 x PX pixels, and per walk the segment height
-// that minimises ceil(blocks / resident blocks) x (segment rows + 8 halo rows) row steps (896 blocks on a chip that holds 768
-// run TWO rounds: measured 1.07 ms against 0.66 ms for 5 segments per frame).
+// Per-launch decomposition of the plan's walks (any batch size): strips of 4 x PX pixels, cut into segments of ONE height for
+// every plan of the launch -- the height that makes about 3.5 blocks per block the chip holds (but not below 32 rows: every
+// segment walks 8 rows of halo).  Rounds 2 - 4 minimised ceil(blocks / resident blocks) x (segment rows + 8) per plan; that
+// model is right for one plan of equal blocks that fills the chip a few times (config 3: 4 ... 20 segments per frame measured
+// flat within 3 %, both rules land there) and wrong for the reference layout, where it gave the union plan exactly one round of
+// 224-row blocks beside the unit plan's short ones: 0.199 ms, against 0.165 ms with 12 - 20 segments (profiles/r05_experiments.txt 7).
 static bool walk3_plan(const silent_ctx* ctx, const silent_pyramid_plan* plan, int n_frames, Walk3Args* wa) {
     if (plan->tab.C != 3 || !plan->walk_pyr_ok) return false;
     *wa = plan->walk;
@@ -559,24 +573,19 @@ static bool walk3_plan(const silent_ctx* ctx, const silent_pyramid_plan* plan, i
     switch (px) { PER_CU(36); PER_CU(32); PER_CU(28); PER_CU(24); default: return false; }
 #undef PER_CU
     const long long resident = (long long)per_cu * ctx->n_cus;
-    long long block0 = 0;
+    long long strip_rows = 0;                                   // rows x strips of every plan, one frame
     for (int pi = 0; pi < wa->n_plans; ++pi) {
         Walk3Plan& w = wa->plan[pi];
         w.strips_x = (w.out_w + kW3NC * px - 1) / (kW3NC * px);
-        const long long per_seg = (long long)n_frames * w.strips_x;
-        const int max_segs = std::max(1, w.out_h / 32);
-        long long best_cost = -1;
-        int seg_rows = w.out_h;
-        for (int segs = 1; segs <= max_segs; ++segs) {
-            int rows = (w.out_h + segs - 1) / segs;
-            rows = (rows + kWalkCH - 1) / kWalkCH * kWalkCH;
-            const long long n_seg = (w.out_h + rows - 1) / rows;
-            const long long cost = ((per_seg * n_seg + resident - 1) / resident) * (rows + 8);
-            if (best_cost < 0 || cost < best_cost) {
-                best_cost = cost;
-                seg_rows = rows;
-            }
-        }
+        strip_rows += (long long)w.strips_x * w.out_h;
+    }
+    const long long target = std::max<long long>(32, (2 * strip_rows * n_frames + 7 * resident - 1) / (7 * resident));   // rows per segment
+    long long block0 = 0;
+    for (int pi = 0; pi < wa->n_plans; ++pi) {
+        Walk3Plan& w = wa->plan[pi];
+        const int segs = (int)std::max<long long>(1, (w.out_h + target / 2) / target);
+        int seg_rows = (w.out_h + segs - 1) / segs;
+        seg_rows = (seg_rows + kWalkCH - 1) / kWalkCH * kWalkCH;
         w.seg_rows = seg_rows;
         w.segs_y = (w.out_h + seg_rows - 1) / seg_rows;
         w.block0 = (int)block0;
