@@ -315,9 +315,33 @@ def run_plan(c):
     plan.close()
 
 
+def plan_eligibility():
+    """Which plans get the single-read kernels is decided by host code alone (silent_pyramid_plan_create): the table of
+    INTEGRATION.md section 4, checked here without a GPU (and under the sanitizers)."""
+    def plan(shape, scale, n, c):
+        p = rt.PyramidPlan(shape[0], shape[1], c, classic_levels(shape, scale, n), 0)
+        r = (p.streamable, p.walk_plans)
+        p.close()
+        return r
+    assert plan((270, 480), 2.0, 6, 3) == (False, (1, 36))
+    assert plan((270, 480), math.e ** .5, 5, 3) == (False, (1, 32))
+    assert plan((270, 480), 2 ** .5, 6, 3) == (False, (1, 28))                 # round 5: zoom steps below 1.6
+    assert plan((200, 300), 2 ** (1 / 3), 5, 3) == (False, (1, 24))
+    assert plan((270, 482), 2.0, 4, 3) == (False, (1, 36))                      # round 5: widths that are not a multiple of 4
+    assert plan((270, 480), 2 ** .5, 10, 3) == (False, (0, 0))                  # more than 7 general levels: unit + region kernels
+    assert plan((270, 480), 2.0, 5, 1) == (True, (0, 0))
+    assert plan((270, 480), 2 ** .5, 8, 1) == (True, (0, 0))                    # round 5: the dense slot layout of the stream kernels
+    assert plan((100, 260), 1.15, 3, 1) == (False, (0, 0))
+    ref = rt.PyramidPlan(1080, 1920, 3, reference_levels((1080, 1920), (288, 192), math.e ** .5), 0)
+    assert ref.walk_plans == (2, 32)                                            # a plan for the unit level + one union plan
+    ref.close()
+    stats["plans"] += 10
+
+
 t0 = time.time()
 bad_arguments()
 exception_barrier()
+plan_eligibility()
 while time.time() - t0 < budget:
     try:
         r = rng.random()
