@@ -195,6 +195,22 @@ __global__ __launch_bounds__(256) void pyramid_region_kernel(const float* __rest
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const float* __restrict__ src = frames + (long long)frame * H * W * C;
 
+    // A region no level has an output in is not staged at all (crop layouts: the reference's nested centre crops leave about half
+    // of a 1080p frame's regions outside the outermost crop -- round 5: those blocks used to load their region and find nothing
+    // to do with it; reference_layout_gray pyramid 0.187 -> see profiles/r05_experiments.txt 9).  Block-uniform.
+    {
+        typedef const __attribute__((address_space(4))) int* const_int_ptr;
+        const_int_ptr xreg = (const_int_ptr)tab.xreg;
+        const_int_ptr yreg = (const_int_ptr)tab.yreg;
+        bool any = false;
+        for (int l = 0; l < tab.n_levels; ++l) {
+            const PyrLevelDev& lv = tab.lv[l];
+            if (lv.kind != kPyrGeneral) continue;
+            any = any || (xreg[lv.xreg_off + rx] < xreg[lv.xreg_off + rx + 1] && yreg[lv.yreg_off + ry] < yreg[lv.yreg_off + ry + 1]);
+        }
+        if (!any) return;
+    }
+
     // stage rows [Y0-3, Y0+RH+3) x columns [X0-4, X0+RW+4).  Taps are mirrored INTO the crop, so positions
     // outside the frame are never referenced: rows are clamped, out-of-frame column groups are skipped.
     if (((W * C) & 3) == 0) {

@@ -20,7 +20,7 @@ wl = bench.WORKLOADS[name]
 B = wl["frames"]
 pipe = bench.make_pipeline(wl, B, 0, None)
 ch = 1 if wl["mode"] == "gray" else 3
-frames = torch.randint(0, 256, (B,) + wl["hw"] + ((ch,) if ch == 3 else ()), device="cuda").float()
+frames = torch.randint(0, 256, (B,) + wl["hw"] + (ch,), device="cuda").float()
 
 
 def timed(n):
