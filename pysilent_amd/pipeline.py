@@ -242,7 +242,7 @@ class LineEndPipeline(object):
             best = t if best is None else min(best, t)
         return best
 
-    def tune_placement(self, frames=None, tries=10, steps=10, budget_s=4.0, spacer_gib=8.0, far_spacer_gib=40.0):
+    def tune_placement(self, frames=None, tries=10, steps=10, budget_s=4.0, spacer_gib=8.0, far_spacer_gib=24.0):
         """Pick the physical placement of the maps by measurement.  The same kernel on the same buffers AT THE SAME VIRTUAL
         ADDRESSES takes 1.23 ... 1.49 ms (config 5) from one allocation to the next: which physical pages the driver hands out
         decides how the dozen concurrent write streams of a step fall onto the HBM channels, and nothing an unprivileged process
@@ -252,9 +252,10 @@ class LineEndPipeline(object):
         of what is measured); default: synthetic noise.  Bounded by ``tries`` and by ``budget_s`` seconds.  Results never depend
         on the choice.  The decision is in ``placement_tuning``.  ``spacer_gib``: device memory allocated (and held until the end)
         between two draws, so that they sample different stretches of the physical memory.  ``far_spacer_gib``: the spacer taken
-        instead once three draws in a row have shown no contrast (within 2 % of each other): they all sit in one stretch -- fast or
-        slow, a draw cannot tell -- and the next one should land far from it (one bench line in seven of round 5 had six draws of
-        1.067 ... 1.078 ms for a step that takes 0.97 ms elsewhere in the same memory)."""
+        instead, once, when the first three draws have shown no contrast (within 2 % of each other): they all sit in one stretch --
+        fast or slow, a draw cannot tell -- and the next one should land far from it (one bench line in seven of round 5 had six
+        draws of 1.067 ... 1.078 ms for a step that takes 0.97 ms elsewhere in the same memory); still no contrast there: the
+        tuner stops."""
         import time
         torch = self.torch
         if frames is None:
@@ -269,6 +270,7 @@ class LineEndPipeline(object):
         best = (self._time_step(frames, steps), cur)
         tried = [round(best[0], 4)]
         jumps = []                                 # GiB held in front of draws 2, 3, ...
+        far_done = False
         held = []                                  # the losers stay allocated while there is room: a freed block comes straight back
         for _ in range(tries - 1):                 # from the caching allocator -- the same pages, the same time
             if time.perf_counter() - t_start > budget_s:
@@ -283,6 +285,9 @@ class LineEndPipeline(object):
             # consecutive draws land in the same one.  A spacer between the draws -- held like the losers, freed at the end -- moves
             # the next draw on by ``spacer_gib`` (while a third of the device stays free)
             flat = len(tried) >= 3 and max(tried) < 1.02 * min(tried)
+            if flat and far_done:
+                break                              # no contrast even far away: this workload does not care where its maps lie
+            far_done = far_done or flat
             spacer = int((far_spacer_gib if flat else spacer_gib) * (1 << 30))
             if spacer and free - spacer <= total // 3:
                 spacer = int(spacer_gib * (1 << 30))

@@ -124,7 +124,7 @@ def test_placement_tuning_keeps_the_results(mode):
     a = LineEndPipeline((h, w), mode=mode, n_levels=4, batch=B, placement="auto", overlap="auto", **kw)
     b = LineEndPipeline((h, w), mode=mode, n_levels=4, batch=B, **kw)
     t = a.placement_tuning
-    assert t and 1 <= len(t["tries_ms"]) <= 6 and t["chosen_ms"] == min(t["tries_ms"]) and b.placement_tuning is None
+    assert t and 1 <= len(t["tries_ms"]) <= 10 and t["chosen_ms"] == min(t["tries_ms"]) and b.placement_tuning is None
     assert a.tune_placement(tries=3, budget_s=0.0)["tries_ms"].__len__() == 1        # budget spent: the current set stays
     rng = np.random.default_rng(9)
     c = 1 if mode == "gray" else 3
