@@ -191,8 +191,14 @@ def pmc_traffic_per_launch(kernel_substr, frames_in_launch):
         for name, c in prof.items():
             if isinstance(c, dict) and kernel_substr in name and "FETCH_SIZE" in c and "WRITE_SIZE" in c:
                 per = (2.0 * c["FETCH_SIZE"]["mean_KiB_per_dispatch"] + c["WRITE_SIZE"]["mean_KiB_per_dispatch"]) * 1024.0
+                pmc_traffic_per_launch.source = "%s@%s (stored rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this bench at this csrc revision; not re-measured in this run)" % (
+                    os.path.relpath(path, ROOT), rev)
                 return int(per * frames_in_launch / c.get("frames_per_dispatch", 64))
+    pmc_traffic_per_launch.source = None
     return None
+
+
+pmc_traffic_per_launch.source = None
 
 
 # ------------------------------------------------------------------------------------------ CPU baselines
@@ -291,7 +297,7 @@ def overlap_policy(world):
 
 
 def placement_policy():
-    """SILENT_PLACEMENT=off: keep the first allocation of the maps; default: LineEndPipeline.tune_placement draws a few."""
+    """SILENT_PLACEMENT=off: keep the first allocation of the maps; default: the product default, LineEndPipeline.tune_placement."""
     return os.environ.get("SILENT_PLACEMENT", "").strip().lower() not in ("off", "0", "false", "no")
 
 
@@ -308,6 +314,7 @@ def make_pipeline(wl, B, local, consts, **over):
         kw = {"selection": True, "value_map": False, "peak_value_map": False}
     if "center" in wl:
         kw.update(center_dimensions=wl["center"], scale=wl["scale"])
+    kw.setdefault("placement", None)      # (UNTUNED: tune_pipeline() runs the product's placement="auto" tuner explicitly, outside the timed region)
     kw.update(over)
     # keypoint capacity = every pyramid pixel of a frame (the LineEndPipeline default): a window without a positive peak makes
     # every pixel mapped to it a keypoint (top_value_points.py:32-45), noise frames produce ~10^5 .. 10^6 rows, and a smaller
@@ -317,9 +324,10 @@ def make_pipeline(wl, B, local, consts, **over):
 
 
 def tune_pipeline(pipe, frames, overlap, placement=True):
-    """Outside every timed region, once per pipeline: (1) placement -- the maps are allocated a few times and the fastest set is
-    kept (the physical pages an allocation lands on move the same kernel by up to 20 %: LineEndPipeline.tune_placement,
-    profiles/r05/placement.md); (2) overlap="auto" -- candidate stream pairs against the one-stream step, consecutive batches
+    """Outside every timed region, once per pipeline: (1) placement -- what LineEndPipeline(placement="auto"), the product default,
+    does on its first batch: the big map stays, the small maps are drawn again a few times behind spacers and the fastest
+    relation is kept (the step's time depends on where the maps lie RELATIVE to each other in physical memory, by up to 25 %:
+    LineEndPipeline.tune_placement, profiles/r06/placement.md; <= 1 s, the first draw's time is reported beside the chosen one); (2) overlap="auto" -- candidate stream pairs against the one-stream step, consecutive batches
     overlap on two streams only where that measurably pays (gray: the stream kernel of batch n + 1 beside the filter kernel of
     batch n; rgb: the pyramid beside chain + tail).  Both leave their record on the pipeline; results never depend on either."""
     if placement:
@@ -498,6 +506,7 @@ def roofline_of(dom, B):
     gbs = dom["bytes"] / (dom["ms"] * 1e-3) / 1e9
     roof = {"bound": "hbm", "kernel": dom["kernel"], "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
             "frac": round(gbs / HBM_PEAK_GBS, 4), "traffic": pmc_traffic_per_launch(dom["pmc_name"], B),
+            "traffic_source": pmc_traffic_per_launch.source,
             "algorithmic_bytes_per_launch": dom["bytes"], "avg_launch_ms": round(dom["ms"], 4),
             "timing": "HIP events around the kernel's launches in a separate loop after the timed region"}
     if "unit_level_pixels_per_launch" in dom:
@@ -580,6 +589,46 @@ def config3_variants(torch, D, local, dev, rank, world, cpu=True):
     finally:
         ctx.set_tuning(_lib.TUNE_RGB, old)
     return out
+
+
+SIDE_KEYS = ("config3", "config3_one_stream", "config3_line_end_only", "config3_peak_value_map", "config5", "reference_layout",
+             "reference_layout_one_stream", "reference_layout_gray")
+
+
+def record_side(out):
+    """Every BASELINE config of the run where a reader who keeps only the headline keys (or only the tail of the line) still finds
+    it: flat scalars in ``config`` -- side_<workload>_ms / _frac (whole pass, fraction of the 8 TB/s peak) / _first_draw_ms (the
+    step on the FIRST allocation of the maps, before LineEndPipeline.tune_placement drew again) -- the same as ``config.side``
+    {name: [ms, frac, first_draw_ms]}, and one compact string as the LAST key of the line (``summary``)."""
+    cfg = out["config"]
+    pt = cfg.get("placement_tuning") or {}
+    cfg["first_draw_ms"] = (pt.get("tries_ms") or [None])[0]
+    cfg["chosen_ms"] = pt.get("chosen_ms")
+    side = {}
+    for k in SIDE_KEYS:
+        w = (out.get("other_workloads") or {}).get(k)
+        if not w:
+            continue
+        first = ((w.get("placement_tuning") or {}).get("tries_ms") or [None])[0]
+        side[k] = [w["ms_per_step"], w["whole_pass_frac_of_hbm_peak"], first]
+        cfg["side_%s_ms" % k] = w["ms_per_step"]
+        cfg["side_%s_frac" % k] = w["whole_pass_frac_of_hbm_peak"]
+        cfg["side_%s_first_draw_ms" % k] = first
+        cfg["side_%s_kernel_frac" % k] = w["dominant_kernel_frac_of_hbm_peak"]
+    lat = ((out.get("latency") or {}).get("640x480") or {})
+    if lat:
+        cfg["latency_480p_ms"] = lat.get("native_ms_p50")
+        cfg["latency_480p_gpu_busy_ms"] = lat.get("gpu_busy_ms")
+    cfg["side"] = side
+    parts = ["%s %.4f ms %.1f%% (first draw %s)" % (out["config"]["workload"].split(",")[0], out["ms_per_step"],
+                                                     100 * cfg["whole_pass_frac_of_hbm_peak"], cfg["first_draw_ms"])]
+    parts += ["%s %.4f ms %.1f%% (first draw %s)" % (k, v[0], 100 * v[1], v[2]) for k, v in side.items()]
+    if lat:
+        parts.append("latency 640x480 %.4f ms p50, GPU busy %.4f" % (lat.get("native_ms_p50", 0), lat.get("gpu_busy_ms", 0)))
+    r = out["roofline"]
+    parts.append("roofline %s %.4f ms frac %.4f traffic %s" % (r["kernel"], r["avg_launch_ms"], r["frac"], r["traffic"]))
+    text = "SUMMARY whole pass ms/step, %% of 8 TB/s: " + "; ".join(parts)
+    out["summary"] = text[:1500]
 
 
 _REAL_STDOUT = None
@@ -795,7 +844,10 @@ def run_rank(args):
         out["cpu_baseline"] = cpu_baseline(wl, consts)
     else:
         out["cpu_baseline"] = None
+    record_side(out)
     emit_line(json.dumps(out))
+    # the same summary once more as the LAST thing on stderr: a reader who keeps only the tail of the output still sees every config
+    print(out["summary"], file=sys.stderr, flush=True)
     D.finalize()
 
 

@@ -482,6 +482,10 @@ typedef struct silent_displayer_params {
 } silent_displayer_params;
 int silent_displayer_create(silent_ctx* ctx, const silent_displayer_params* params, const silent_pyr_level* levels, int n_levels,
                             silent_displayer** out);
+/* Lifetime: `ctx` (errors of the displayer's calls are reported there) must outlive every silent_displayer_step / _input /
+ * _get_state / _set_state call; silent_displayer_destroy itself does not touch it (it may run after silent_destroy(ctx), e.g. at
+ * interpreter shutdown).  destroy frees the pinned input buffer and both result slots: pointers handed out by _step / _input die
+ * with it. */
 void silent_displayer_destroy(silent_displayer* d);
 /* shape7 = {L, h, w, ch, cw, h2, w2}; out_floats6 (may be NULL): floats of each of the six results */
 int silent_displayer_shape(const silent_displayer* d, int32_t* shape7, size_t* out_floats6);
@@ -489,7 +493,8 @@ int silent_displayer_shape(const silent_displayer* d, int32_t* shape7, size_t* o
  * alternate).  gpu_ms (may be NULL): device time of the frame, upload to download. */
 int silent_displayer_step(silent_displayer* d, const void* frame_host, const float** results, float* gpu_ms);
 /* The displayer's pinned input buffer: a capture loop that writes the camera frame THERE and passes this pointer to
- * silent_displayer_step skips the staging copy (6 MB per 1080p frame). */
+ * silent_displayer_step skips the staging copy (6 MB per 1080p frame).  A frame_host that overlaps the buffer at another
+ * offset is moved into place (memmove). */
 int silent_displayer_input(silent_displayer* d, void** frame_buffer, size_t* bytes);
 int silent_displayer_get_state(silent_displayer* d, float* energy_host);       /* [L, ch, cw] */
 int silent_displayer_set_state(silent_displayer* d, const float* energy_host);

@@ -10,6 +10,8 @@ Anything else raises the reference's TypeError.
 import ctypes as C
 import os
 
+import weakref
+
 import numpy as np
 
 from . import _lib
@@ -637,17 +639,23 @@ class FrameDisplayer(object):
         self._res = (C.c_void_p * 6)()
         self._ms = C.c_float(0)
         self.gpu_ms = 0.0
+        self._exports = []                  # weak references to the ctypes buffers handed out as views (frame_buffer, step results)
         ptr, nbytes = C.c_void_p(), C.c_size_t(0)
         self.ctx.check(lib.silent_displayer_input(self.handle, C.byref(ptr), C.byref(nbytes)))
         buf = (C.c_char * nbytes.value).from_address(ptr.value)
         buf._owner = self
+        self._exports.append(weakref.ref(buf))
         #: the displayer's pinned input buffer as an [H, W, 3] array: a capture loop that grabs INTO it (``cap.read(disp.frame_buffer)``,
         #: ``np.copyto``) and passes it to ``step`` is uploaded without the staging copy
         self.frame_buffer = np.frombuffer(buf, self.dtype).reshape(self.frame_shape)
 
-    def step(self, frame):
-        """frame: [H, W, 3] ndarray of the displayer's dtype.  Returns the six float32 arrays as VIEWS of the displayer's pinned
-        result slot -- valid until the second next step (two slots alternate); copy what has to live longer."""
+    def step(self, frame, copy=False):
+        """frame: [H, W, 3] ndarray of the displayer's dtype.  Returns the six float32 arrays -- ``copy=False`` (the zero-copy form):
+        VIEWS of the displayer's pinned result slot, valid until the second next step (two slots alternate) and, like
+        ``frame_buffer``, only while the displayer is open (``close`` defers the free while such views are alive);
+        ``copy=True``: fresh arrays, like the reference's session.run (recognition_testing.py:132)."""
+        if not getattr(self, "handle", None):
+            raise RuntimeError("the displayer is closed")
         if not isinstance(frame, np.ndarray) or frame.dtype != self.dtype or tuple(frame.shape) != self.frame_shape:
             raise ValueError("frame must be a %s ndarray of shape %s" % (self.dtype, self.frame_shape,))
         f = frame if frame.flags["C_CONTIGUOUS"] else np.ascontiguousarray(frame)
@@ -656,8 +664,14 @@ class FrameDisplayer(object):
         out = []
         for ptr, sh in zip(self._res, self.shapes):
             buf = (C.c_float * int(np.prod(sh))).from_address(ptr)
+            if copy:
+                out.append(np.array(np.frombuffer(buf, np.float32).reshape(sh)))
+                continue
             buf._owner = self               # the views keep the displayer (and with it the pinned slot) alive
+            self._exports.append(weakref.ref(buf))
             out.append(np.frombuffer(buf, np.float32).reshape(sh))
+        if len(self._exports) > 64:
+            self._exports = [r for r in self._exports if r() is not None]
         return out
 
     def get_state(self):
@@ -672,13 +686,26 @@ class FrameDisplayer(object):
         self.ctx.check(self._lib.silent_displayer_set_state(self.handle, C.c_void_p(st.ctypes.data)))
 
     def close(self):
-        if getattr(self, "handle", None):
-            self._lib.silent_displayer_destroy(self.handle)
-            self.handle = C.c_void_p()
+        """Free the displayer (graphs, device buffers, the pinned frame buffer and result slots).  While views handed out by
+        ``step(copy=False)`` or ``frame_buffer`` are still referenced the free is DEFERRED: every view keeps the displayer alive
+        (``_owner``), and it is destroyed when the last of them goes -- never under an array somebody still holds.  Further
+        ``step`` calls raise either way."""
+        if not getattr(self, "handle", None):
+            return
+        fb = self.__dict__.pop("frame_buffer", None)      # our own reference to the input view does not count
+        del fb
+        if any(r() is not None for r in getattr(self, "_exports", ())):
+            self._deferred, self.handle = self.handle, C.c_void_p()
+            return
+        self._lib.silent_displayer_destroy(self.handle)
+        self.handle = C.c_void_p()
 
     def __del__(self):
         try:
-            self.close()
+            h = getattr(self, "_deferred", None) or getattr(self, "handle", None)
+            if h:                           # nobody references the displayer any more, hence no view either
+                self._lib.silent_displayer_destroy(h)
+                self.handle = self._deferred = C.c_void_p()
         except Exception:
             pass
 

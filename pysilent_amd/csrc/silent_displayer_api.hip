@@ -10,7 +10,9 @@
 using namespace silent;
 
 struct silent_displayer {
-    silent_ctx* owner = nullptr;          // the caller's context (errors are reported there)
+    silent_ctx* owner = nullptr;          // the caller's context (errors are reported there; it must outlive the displayer's CALLS,
+                                          // not its destruction: silent_displayer_destroy only uses `device`)
+    int device = 0;                       // the owner's device, kept here so that destroy never reads the owner
     silent_ctx* ctx = nullptr;            // private context: workspace of the graph's nodes
     silent_pyramid_plan* plan = nullptr;
     hipStream_t stream = nullptr;
@@ -108,6 +110,7 @@ SILENT_EXPORT int silent_displayer_create(silent_ctx* ctx, const silent_displaye
     } g{new silent_displayer()};
     silent_displayer* d = g.d;
     d->owner = ctx;
+    d->device = ctx->device;
     d->prm = *p;
     std::memcpy(d->kernels, p->chain.rgc, 81 * 4);
     std::memcpy(d->kernels + 81, p->chain.rgby, 81 * 4);
@@ -171,7 +174,7 @@ SILENT_EXPORT int silent_displayer_create(silent_ctx* ctx, const silent_displaye
 
 SILENT_EXPORT void silent_displayer_destroy(silent_displayer* d) try {
     if (!d) return;
-    DeviceGuard guard(d->owner ? d->owner->device : 0);
+    DeviceGuard guard(d->device);
     if (d->stream) (void)hipStreamSynchronize(d->stream);
     displayer_free(d);
 } catch (...) {
@@ -203,7 +206,8 @@ SILENT_EXPORT int silent_displayer_step(silent_displayer* d, const void* frame_h
     NEED_CTX(ctx);
     const char* who = "silent_displayer_step";
     if (!frame_host || !results) return fail(ctx, SILENT_E_INVALID, std::string(who) + ": NULL pointer");
-    if (frame_host != d->h_in) std::memcpy(d->h_in, frame_host, d->in_bytes);   // (a capture loop may grab INTO silent_displayer_input)
+    // (a capture loop may grab INTO silent_displayer_input; a frame that is a view at an offset into that buffer overlaps it: memmove)
+    if (frame_host != d->h_in) std::memmove(d->h_in, frame_host, d->in_bytes);
     const int slot = d->slot;
     d->ctx->err.clear();
     HIP_TRY(ctx, hipEventRecord(d->ev[0], d->stream));

@@ -108,11 +108,29 @@ def _staging_copy(dst, src, min_bytes=8 << 20, workers=16):
     list(_staging_pool.map(lambda i: np.copyto(d[i:i + step], s_[i:i + step]), range(0, int(src.shape[0]), step)))
 
 
+class _RawBlock(object):
+    """A device allocation of the library's own (silent_malloc / silent_free): the placement tuner's spacers and draws."""
+
+    def __init__(self, ctx, nbytes):
+        self.ctx, self.nbytes = ctx, int(nbytes)
+        p = C.c_void_p()
+        ctx.check(_lib.load().silent_malloc(ctx.handle, C.c_size_t(self.nbytes), C.byref(p)))
+        self.ptr = int(p.value)
+
+    def __del__(self):
+        try:
+            if getattr(self, "ptr", 0):
+                _lib.load().silent_free(self.ctx.handle, C.c_void_p(self.ptr))
+                self.ptr = 0
+        except Exception:
+            pass
+
+
 class LineEndPipeline(object):
     def __init__(self, frame_hw, mode="gray", n_levels=5, scale=2.0, n_orient=4, batch=1, device=None,
                  constants=None, center_dimensions=None, clip_hi=255.0, flat_policy="ieee", pad=2,
                  max_keypoints_per_frame=None, selection=False, top_percent=0.1, keep_selection_maps=False, value_map=True,
-                 peak_value_map=True, orient_map=True, overlap=False, overlap_priorities=True, placement=None):
+                 peak_value_map=True, orient_map=True, overlap=False, overlap_priorities=True, placement="auto"):
         import torch
         self.torch = torch
         self.mode = mode
@@ -191,10 +209,12 @@ class LineEndPipeline(object):
                 *[self.consts[k].ctypes.data_as(fp) for k in ("rgc", "rgby", "stripe", "blur", "end")],
                 1.0, 0.1, {"ieee": _lib.FLAT_IEEE, "zero": _lib.FLAT_ZERO}[flat_policy], self.clip_hi, self.pad)
         self._lib = _lib.load()
+        # placement="auto" (default): the first batch ``step`` sees tunes the placement of the small maps against the big one AND
+        # against that batch's own buffer (tune_placement: <= 1 s, bounded memory, results unaffected); None / False: the maps
+        # stay where the constructor's allocations landed -- side by side, which is the slow relation more often than not
         if placement not in (None, False, "auto"):
             raise ValueError("placement must be None or 'auto'")
-        if placement == "auto":
-            self.tune_placement()
+        self._placement_pending = placement == "auto"
         if overlap == "force":
             self._pyrs.append(torch.empty_like(self._pyrs[0]))
             # the chain + tail of batch n are the critical path, the pyramid of batch n + 1 only has to be ready in time: the chain's
@@ -222,10 +242,12 @@ class LineEndPipeline(object):
         return m
 
     def _adopt_maps(self, m):
-        self._pyrs = [m["pyr"]] + list(getattr(self, "_pyrs", [])[1:])
+        """Make ``m``'s tensors the pipeline's maps ("pyr1": the second pyramid buffer of an overlapped pipeline).  Views an earlier
+        ``outputs()`` handed out keep the OLD tensors (alive, no longer written): call ``outputs()`` again after a tuner ran."""
+        self._pyrs = [m["pyr"]] + ([m["pyr1"]] if "pyr1" in m else list(getattr(self, "_pyrs", [])[1:]))
         self.pyr = self._pyrs[0]
         for k, v in m.items():
-            if k != "pyr":
+            if k not in ("pyr", "pyr1"):
                 setattr(self, k, v)
 
     def _time_step(self, frames, steps, windows=2):
@@ -242,63 +264,84 @@ class LineEndPipeline(object):
             best = t if best is None else min(best, t)
         return best
 
-    def tune_placement(self, frames=None, tries=10, steps=10, budget_s=4.0, spacer_gib=8.0, far_spacer_gib=24.0):
-        """Pick the physical placement of the maps by measurement.  The same kernel on the same buffers AT THE SAME VIRTUAL
-        ADDRESSES takes 1.23 ... 1.49 ms (config 5) from one allocation to the next: which physical pages the driver hands out
-        decides how the dozen concurrent write streams of a step fall onto the HBM channels, and nothing an unprivileged process
-        can see predicts it -- not the addresses, not the copy rate of any single buffer, not the TLB counters
-        (profiles/r05/placement.md).  So it is drawn a few times: allocate the maps, time ``steps`` steps (after a warm-up), keep
-        the fastest set, return the others to the allocator.  ``frames``: the caller's resident batch (its placement is part
-        of what is measured); default: synthetic noise.  Bounded by ``tries`` and by ``budget_s`` seconds.  Results never depend
-        on the choice.  The decision is in ``placement_tuning``.  ``spacer_gib``: device memory allocated (and held until the end)
-        between two draws, so that they sample different stretches of the physical memory.  ``far_spacer_gib``: the spacer taken
-        instead, once, when the first three draws have shown no contrast (within 2 % of each other): they all sit in one stretch --
-        fast or slow, a draw cannot tell -- and the next one should land far from it (one bench line in seven of round 5 had six
-        draws of 1.067 ... 1.078 ms for a step that takes 0.97 ms elsewhere in the same memory); still no contrast there: the
-        tuner stops."""
+    def _raw_tensor(self, like):
+        """A device buffer of ``like``'s shape and dtype from the library's allocator (silent_malloc: a plain hipMalloc, given back
+        to the driver by silent_free the moment the last reference goes), wrapped as a torch tensor.  The tuner's draws and
+        spacers come from here, not from torch's caching allocator: nothing a draw leaves behind stays cached in the process."""
+        nbytes = like.numel() * like.element_size()
+        owner = _RawBlock(self.ctx, nbytes)
+        typestr = {4: "<f4", 1: "|u1", 8: "<i8"}[like.element_size()]
+        owner.__cuda_array_interface__ = {"shape": tuple(like.shape), "typestr": typestr, "data": (owner.ptr, False), "version": 2}
+        t = self.torch.as_tensor(owner, device=self.tdev)      # (holds a reference to ``owner`` for as long as the tensor lives)
+        assert t.data_ptr() == owner.ptr
+        return t
+
+    def tune_placement(self, frames=None, tries=8, steps=8, budget_s=1.0, spacer_gib=None, max_held_gib=None):
+        """Pick the physical placement of the SMALL maps by measurement; the largest map stays where it is.
+
+        What is measured (profiles/r06/placement.md): the step's time depends on where the maps lie RELATIVE to each other in the
+        device's physical memory -- not on where any one of them lies.  The same K-orientation map is fast with one allocation of
+        the CS map + pyramid and 25 % slower with another (1.18 vs 1.52 ms for config 5's dominant kernel), and the other way
+        round for another K map; a synthetic kernel that only issues the three store streams shows the same times draw by draw;
+        maps whose physical chunks are co-located on purpose are reliably SLOW.  The discriminating counter is
+        TCC_EA0_WRREQ_STALL (x 4.7 on a slow pair, concentrated in a few L2 channels) at identical request counts: the streams
+        collide behind the L2, in the memory's own address mapping, which an unprivileged process can neither see nor choose.
+        It can choose AGAIN, cheaply: the big map (most of the bytes) is kept, every other map is allocated anew ``tries - 1``
+        times -- behind a spacer, because the classes change every few tens of GiB -- ``steps`` steps are timed on each, the
+        fastest set is kept.  ``frames``: the caller's resident batch (its placement is part of the relation; ``placement="auto"``
+        tunes on the first batch ``step`` sees); default: synthetic noise.
+
+        Bounds: ``budget_s`` seconds; ``spacer_gib`` per spacer, default AND upper limit = the size of the pipeline's maps;
+        ``max_held_gib`` for everything the tuner holds at once (spacers + losing draws), default 8 x the maps, and never more
+        than leaves a quarter of the device free.  Spacers and draws come from silent_malloc and go back to the driver at the end:
+        torch's caching allocator is not involved and ``torch.cuda.empty_cache()`` is not called.  Results never depend on the choice.
+        The pipeline's map tensors are REPLACED: ``PackedPyramid`` views an earlier ``outputs()`` handed out keep pointing at the old
+        buffers (alive, but no longer written) -- call ``outputs()`` again.  The decision is in ``placement_tuning``."""
         import time
         torch = self.torch
         if frames is None:
             frames = torch.randint(0, 256, (self.batch,) + self.frame_shape, device=self.tdev).to(torch.float32)
+        self._placement_pending = False
+        self.wait()                                # nothing of an overlapped step in flight on the side streams
+        torch.cuda.synchronize(self.tdev)
         was = self.overlap
         self.overlap = False
         t_start = time.perf_counter()
-        for _ in range(30):                        # past the idle -> load transient of the chip
+        for _ in range(20):                        # past the idle -> load transient of the chip
             self.step(frames)
-        cur = {"pyr": self._pyrs[0]}
-        cur.update({k: getattr(self, k) for k in (("cs", "end") if self.mode == "gray" else ("orient", "line_end", "value"))})
-        best = (self._time_step(frames, steps), cur)
+        names = ("pyr", "cs", "end") if self.mode == "gray" else ("pyr", "orient", "line_end", "value")
+        cur = {k: (self._pyrs[0] if k == "pyr" else getattr(self, k)) for k in names}
+        if len(self._pyrs) > 1:                    # an overlapped pipeline alternates between two pyramid buffers: both are drawn
+            cur["pyr1"] = self._pyrs[1]
+        cur = {k: v for k, v in cur.items() if v is not None}
+        nbytes = {k: v.numel() * v.element_size() for k, v in cur.items()}
+        big = max(reversed(list(cur)), key=lambda k: nbytes[k])           # ties: the last map (end / line_end)
+        small = [k for k in cur if k != big]
+        total_maps = sum(nbytes.values())
+        spacer = total_maps if spacer_gib is None else min(int(spacer_gib * (1 << 30)), total_maps)
+        cap = 8 * total_maps if max_held_gib is None else int(max_held_gib * (1 << 30))
+        best = (self._time_step(frames, steps), {k: cur[k] for k in small})
         tried = [round(best[0], 4)]
-        jumps = []                                 # GiB held in front of draws 2, 3, ...
-        far_done = False
-        held = []                                  # the losers stay allocated while there is room: a freed block comes straight back
-        for _ in range(tries - 1):                 # from the caching allocator -- the same pages, the same time
+        held, held_bytes, stop = [], 0, "tries"
+        for _ in range(tries - 1):
             if time.perf_counter() - t_start > budget_s:
+                stop = "budget_s"
                 break
+            need = spacer + sum(nbytes[k] for k in small)
             free, total = torch.cuda.mem_get_info(self.tdev)
-            if free < total // 4:
-                held.clear()
-                torch.cuda.synchronize(self.tdev)
-                torch.cuda.empty_cache()
-                free, total = torch.cuda.mem_get_info(self.tdev)
-            # the fast and the slow stretches of physical memory are tens of GiB long (profiles/r05/placement.md, experiment 8):
-            # consecutive draws land in the same one.  A spacer between the draws -- held like the losers, freed at the end -- moves
-            # the next draw on by ``spacer_gib`` (while a third of the device stays free)
-            flat = len(tried) >= 3 and max(tried) < 1.02 * min(tried)
-            if flat and far_done:
-                break                              # no contrast even far away: this workload does not care where its maps lie
-            far_done = far_done or flat
-            spacer = int((far_spacer_gib if flat else spacer_gib) * (1 << 30))
-            if spacer and free - spacer <= total // 3:
-                spacer = int(spacer_gib * (1 << 30))
-            if spacer and free - spacer > total // 3:
-                held.append(torch.empty(spacer, dtype=torch.uint8, device=self.tdev))
-                jumps.append(round(spacer / (1 << 30)))
-            else:
-                jumps.append(0)
-            cand = self._alloc_maps()
+            if held_bytes + need > cap or free - need < total // 4:
+                stop = "memory cap"
+                break
+            try:
+                if spacer:
+                    held.append(_RawBlock(self.ctx, spacer))
+                cand = {k: self._raw_tensor(cur[k]) for k in small}
+            except RuntimeError:
+                stop = "allocation failed"
+                break
+            held_bytes += need
             self._adopt_maps(cand)
-            for _ in range(5):
+            for _ in range(3):
                 self.step(frames)
             t = self._time_step(frames, steps)
             tried.append(round(t, 4))
@@ -307,16 +350,15 @@ class LineEndPipeline(object):
                 best = (t, cand)
             else:
                 held.append(cand)
-            torch.cuda.synchronize(self.tdev)
             del cand
         self._adopt_maps(best[1])
-        held.clear()
+        torch.cuda.synchronize(self.tdev)
+        held.clear()                               # spacers and losing draws: back to the driver (silent_free), not to a cache
         del cur
         self.overlap = was
-        torch.cuda.synchronize(self.tdev)
-        torch.cuda.empty_cache()                   # the losing sets go back to the driver
-        self.placement_tuning = {"tries_ms": tried, "spacers_gib": jumps, "chosen_ms": round(best[0], 4),
-                                 "seconds": round(time.perf_counter() - t_start, 2)}
+        self.placement_tuning = {"tries_ms": tried, "first_draw_ms": tried[0], "chosen_ms": round(best[0], 4), "kept": big,
+                                 "redrawn": small, "spacer_gib": round(spacer / (1 << 30), 2), "stopped_by": stop,
+                                 "peak_held_gib": round(held_bytes / (1 << 30), 2), "seconds": round(time.perf_counter() - t_start, 2)}
         return self.placement_tuning
 
     def close(self):
@@ -363,6 +405,11 @@ class LineEndPipeline(object):
         paths)."""
         import time
         torch = self.torch
+        pending = self._placement_pending
+        if pending and frames is not None:
+            self.tune_placement(frames)            # first things first: which pair of streams pays depends on where the maps lie
+            pending = False
+        self._placement_pending = False            # (frames=None, the constructor's call: the placement waits for the caller's first batch)
         if frames is None:
             frames = torch.randint(0, 256, (self.batch,) + self.frame_shape, device=self.tdev).to(torch.float32)
         t_start = time.perf_counter()
@@ -417,6 +464,7 @@ class LineEndPipeline(object):
                                "chosen_ms": round(min(again_two), 4) if self.overlap else round(serial, 4),
                                "stream_pair_verified_concurrent": self.overlap_verified if self.overlap else None,
                                "seconds": round(time.perf_counter() - t_start, 2)}
+        self._placement_pending = pending
         return self.overlap_tuning
 
     # -- byte accounting -------------------------------------------------------
@@ -653,6 +701,8 @@ class LineEndPipeline(object):
 
     def step(self, frames):
         """One pass of the hot path over one batch of frames (asynchronous)."""
+        if self._placement_pending:
+            self.tune_placement(frames)            # once, on the first batch (placement="auto")
         if self.overlap:
             return self._step_overlapped(frames)
         s = self._stream()

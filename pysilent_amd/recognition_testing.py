@@ -27,8 +27,9 @@ class LineEndDisplayer(PyramidDisplayer):
     def __init__(self, n_dimensions=2, use_graph=False, native=True, **argv):
         """``native`` (default): ``callback`` hands the camera frame to ONE library call (silent_displayer_step: upload, cast,
         pyramid, the whole graph, download -- a HIP graph replayed per frame, buffers and boosting state owned by the library;
-        _runtime.FrameDisplayer).  The arrays it returns are views of a pinned result slot that stay valid until the second
-        next frame -- the reference returns fresh arrays from session.run; copy what has to live longer.  ``native=False``: the
+        _runtime.FrameDisplayer).  Like the reference's session.run (recognition_testing.py:132) ``callback`` returns FRESH
+        arrays; ``callback(frame, copy=False)`` returns views of a pinned result slot instead, valid until the second next
+        frame (0.03 ms less per 640 x 480 frame).  ``native=False``: the
         per-op path below (``run`` / ``run_device`` always take it: they start from a pyramid, not from a frame).
         ``use_graph`` (per-op path): capture the ~20 launches of one frame into a HIP graph the first time a pyramid shape is
         seen and replay it per frame (torch.cuda.CUDAGraph is only the capture / replay plumbing; every node is one
@@ -151,18 +152,18 @@ class LineEndDisplayer(PyramidDisplayer):
         key = (tuple(frame.shape), frame.dtype.str)
         if self._native is None or self._native[0] != key:
             # (like the reference, recognition_testing.py:108-117: a new frame shape compiles anew and re-initialises the state)
-            if self._native is not None:
-                self._native[1].close()
+            # (the old displayer is DROPPED, not closed: arrays a consumer still holds from callback(copy=False) / frame_buffer keep
+            # it -- and the pinned memory under them -- alive; it is destroyed with the last of them)
             self._native = (key, _runtime.FrameDisplayer(
                 frame.shape, frame.dtype, self.output_size, self.zoom_ratio, self.kernels, self.centroid_region_shape[1:],
                 recovery_mode(self.input_based_recovery, self.constant_recovery), device=self.device_index))
         return self._native[1]
 
-    def callback(self, frame, cam_id=None, depth=2):
+    def callback(self, frame, cam_id=None, depth=2, copy=True):
         import torch
         if self.native and isinstance(frame, np.ndarray) and frame.ndim == 3 and frame.shape[2] == 3 and self.output_colors == 3 \
                 and frame.dtype.name in _runtime.FrameDisplayer._DT:
-            tensors = self._native_for(frame).step(frame)
+            tensors = self._native_for(frame).step(frame, copy=copy)
             return [frame] + [[tensors[x][y] for y in range(len(tensors[x]))] for x in range(6)]
         # frame -> GPU once; the zoom pyramid stays on the device between from_image and the graph
         dev = torch.device("cuda", self.device_index)

@@ -229,6 +229,22 @@ def pytest_terminal_summary(terminalreporter):
         terminalreporter.write_line("all maps together: %d of %d elements >= 1e-3 range (%.2e) are off by more than 1e-5 of THEMSELVES; every "
                                     "one of them is inside its rounding bound (next line) and inside 1e-5 of (|value| + range)"
                                     % (tot_over, tot_sig, tot_over / max(tot_sig, 1)))
+    # the gray maps of BASELINE configs 1, 2, 4, 5 (the headline path) on a line of their own, whatever their rank among the RGB
+    # maps: per config and map kind over all levels -- worst relative error at the 0.1 and 1e-3 floors, share of the elements
+    # >= 1e-3 range beyond 1e-5 of themselves, worst |err| / rounding bound
+    gray = {}
+    for what, v in WORST_REL.items():
+        parts = what.split()
+        if len(parts) == 3 and parts[0] in ("pyramid", "cs", "end") and parts[1].startswith("config"):
+            g = gray.setdefault((parts[1], parts[0]), [0.0, 0.0, 0, 0, 0.0])
+            g[0], g[1], g[2], g[3] = max(g[0], v[0]), max(g[1], v[1]), g[2] + v[2], g[3] + v[3]
+            g[4] = max(g[4], WORST_BOUND.get(what, (0.0, 0.0))[0])
+    if gray:
+        terminalreporter.write_line("gray maps of the headline path (BASELINE configs 1 / 2 / 4 / 5, all levels): worst relative error at "
+                                    "|want| >= 0.1 range / >= 1e-3 range / share of elements >= 1e-3 range beyond 1e-5 of themselves / "
+                                    "worst |err| / rounding bound: " +
+                                    ", ".join("%s %s %.1e/%.1e/%.2e (%d of %d)/%.2f" % (c, m, g[0], g[1], g[2] / max(g[3], 1), g[2], g[3], g[4])
+                                              for (c, m), g in sorted(gray.items())))
     if WORST_BOUND:
         worst = sorted(WORST_BOUND.items(), key=lambda kv: -kv[1][0])[:12]
         terminalreporter.write_line("worst |gpu - oracle| / rounding bound per map (asserted <= 1; bound = (taps + 4) * 2^-24 * "

@@ -239,9 +239,9 @@ def test_config1_640x480_three_levels_center_surround(rt, kernels):
     want_pyr = so.classic_pyramid(frame, 2.0, 3)
     cs, _ = rt.gray_line_end(pyr, kernels["cs_gray"], kernels["end4"], want_end=False)
     for l in range(3):
-        assert_close(pyr.level(l), want_pyr[l], RTOL, what="pyramid level %d" % l, bound=eb.zoom(want_pyr[l]))
+        assert_close(pyr.level(l), want_pyr[l], RTOL, what="pyramid config1 %d" % l, bound=eb.zoom(want_pyr[l]))
         assert_close(cs.level(l), so.conv2d_same(want_pyr[l], kernels["cs_gray"], relu=True), RTOL, scale=255.0,
-                     what="cs level %d" % l, bound=eb.conv(want_pyr[l], kernels["cs_gray"], eb.zoom(want_pyr[l])))
+                     what="cs config1 %d" % l, bound=eb.conv(want_pyr[l], kernels["cs_gray"], eb.zoom(want_pyr[l])))
     # the 3-channel kernel of the reference's own test on the frame replicated to 3 channels
     from pysilent_amd.constant_convolutions import center_surround_tensor
     k3 = center_surround_tensor(2, [0, 1, 0], [1, 0, 0], [0, 0, 1], [1, 0, 0])
@@ -599,12 +599,12 @@ def test_line_end_displayer_three_frames(rt, kernels):
     held = []
     for step in range(6):
         frame = structured_frame(60 + step, 150, 230, 3)
-        a, b = native.callback(frame), per_op.callback(frame)
+        a, b = native.callback(frame, copy=False), per_op.callback(frame)
         for i in range(1, 7):
             np.testing.assert_array_equal(np.stack(a[i]), np.stack(b[i]), err_msg="native vs per-op, frame %d, output %d" % (step, i))
         np.testing.assert_array_equal(native.get_state(), per_op.get_state())
         held.append((np.stack(a[1]).copy(), a[1]))
-        if step >= 1:       # the previous frame's views are still intact (two result slots alternate)
+        if step >= 1:       # the previous frame's zero-copy views are still intact (two result slots alternate)
             np.testing.assert_array_equal(held[step - 1][0], np.stack(held[step - 1][1]))
     st = native.get_state()
     native.set_state(st * 0 + 3.0)
@@ -636,6 +636,51 @@ def test_line_end_displayer_three_frames(rt, kernels):
     assert len(shown) == 7 and float(np.nanmax(shown[6])) <= 1.0
     with pytest.raises(NotImplementedError):
         disp.run_camera()
+
+
+def test_line_end_displayer_results_outlive_frames_shape_changes_and_close(rt):
+    """like the reference's session.run (recognition_testing.py:132-144) ``callback`` returns FRESH arrays -- a consumer
+    (the reference's asynchronous display loop) may keep them over any number of frames; the zero-copy views (``copy=False``,
+    ``FrameDisplayer.step``, ``frame_buffer``) stay readable over a frame-shape change (the old displayer is dropped, not
+    destroyed) and over an explicit ``close()`` (deferred while such views are alive)."""
+    import gc
+    from pysilent_amd.recognition_testing import LineEndDisplayer
+    disp = LineEndDisplayer(output_size=(96, 64))
+    f0 = structured_frame(80, 150, 230, 3)
+    kept = disp.callback(f0)                                   # fresh arrays
+    assert all(lev.flags["OWNDATA"] or lev.base is not None and lev.base.flags["OWNDATA"] for lev in kept[1])
+    want = [np.stack(kept[i]).copy() for i in range(1, 7)]
+    views = disp.callback(f0 * 0 + 7.0, copy=False)            # views of a pinned slot (another state step: other values)
+    want_views = [np.stack(views[i]).copy() for i in range(1, 7)]
+    old = disp._native[1]
+    fb = old.frame_buffer
+    fb[...] = 5.0
+    for step in range(5):                                      # five more frames: both slots overwritten
+        disp.callback(structured_frame(81 + step, 150, 230, 3))
+    for i in range(6):
+        np.testing.assert_array_equal(np.stack(kept[1 + i]), want[i])
+    # a new frame shape: a new displayer; the old one's pinned memory stays under the views we hold
+    views = disp.callback(f0 * 0 + 7.0, copy=False)
+    want_views = [np.stack(views[i]).copy() for i in range(1, 7)]
+    disp.callback(structured_frame(90, 170, 250, 3))
+    assert disp._native[1] is not old
+    gc.collect()
+    for i in range(6):
+        np.testing.assert_array_equal(np.stack(views[1 + i]), want_views[i])
+    assert float(fb[0, 0, 0]) == 5.0
+    # an explicit close with views outstanding is deferred; stepping a closed displayer raises
+    old.close()
+    with pytest.raises(RuntimeError):
+        old.step(f0)
+    for i in range(6):
+        np.testing.assert_array_equal(np.stack(views[1 + i]), want_views[i])
+    assert float(fb[0, 0, 0]) == 5.0
+    del views, fb, old
+    gc.collect()                                               # now it is destroyed (nothing to assert but "no crash")
+    fresh = LineEndDisplayer(output_size=(96, 64))
+    again = fresh.callback(f0)
+    for i in range(6):
+        np.testing.assert_array_equal(np.stack(again[1 + i]), want[i])
 
 
 # ----------------------------------------------------------------------------- RGB chain
@@ -1310,7 +1355,7 @@ def test_config5_4k_8_levels_8_orientations_against_c_oracle(rt, kernels):
     want_pyr = co.classic_pyramid(frame, plan.extents)
     for l in range(8):
         wcs, wend = co.gray_line_end_level(want_pyr[l], kernels["cs_gray"], kernels["end8"])
-        assert_gray_level_close(pyr.level(l), cs.level(l), end.level(l), want_pyr[l], wcs, wend, kernels["cs_gray"], kernels["end8"], "%d" % l)
+        assert_gray_level_close(pyr.level(l), cs.level(l), end.level(l), want_pyr[l], wcs, wend, kernels["cs_gray"], kernels["end8"], "config5 %d" % l)
 
 
 def test_config3_1080p_rgb_full_size_against_c_oracle(rt, kernels):
@@ -1371,7 +1416,7 @@ def test_config2_1080p_full_size_against_c_oracle(rt, kernels):
     want_pyr = co.classic_pyramid(frame, pyr.extents)
     for l in range(5):
         wcs, wend = co.gray_line_end_level(want_pyr[l], kernels["cs_gray"], kernels["end4"])
-        assert_gray_level_close(pyr.level(l), cs.level(l), end.level(l), want_pyr[l], wcs, wend, kernels["cs_gray"], kernels["end4"], "%d" % l)
+        assert_gray_level_close(pyr.level(l), cs.level(l), end.level(l), want_pyr[l], wcs, wend, kernels["cs_gray"], kernels["end4"], "config2 %d" % l)
     # size-independent properties: linearity of the pyramid, and ReLU/clip range of the responses
     pyr2 = classic_pyramid(frame * np.float32(0.5), 2.0, 5)
     np.testing.assert_allclose(pyr2.data, pyr.data * np.float32(0.5), rtol=1e-6, atol=1e-4)
@@ -1408,7 +1453,7 @@ def test_config4_per_rank_share_64_frames_against_c_oracle(rt, kernels):
             wcs, wend = co.gray_line_end_level(want_pyr[l], kernels["cs_gray"], kernels["end4"])
             host = lambda name: out[name].level(l)[j:j + 1].cpu().numpy()
             assert_gray_level_close(host("pyramid"), host("cs"), host("end"), want_pyr[l], wcs, wend, kernels["cs_gray"],
-                                    kernels["end4"], "f%d l%d" % (j, l))
+                                    kernels["end4"], "config4 %d" % l)
     # every frame of the batch equals that frame run alone (batch position must not matter): compare per-frame sums
     solo = LineEndPipeline((1080, 1920), mode="gray", n_levels=5, n_orient=4, batch=1)
     for j in (1, 2, 30, 62):
