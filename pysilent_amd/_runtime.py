@@ -662,11 +662,17 @@ class FrameDisplayer(object):
         self.ctx.check(self._lib.silent_displayer_step(self.handle, C.c_void_p(f.ctypes.data), self._res, C.byref(self._ms)))
         self.gpu_ms = float(self._ms.value)
         out = []
+        if copy:
+            # ONE copy of the whole slot (the six results lie back to back, 64-byte steps), then views of the copy
+            ptrs = [int(p) for p in self._res]
+            total = (max(ptrs) - min(ptrs)) // 4 + int(np.prod(self.shapes[ptrs.index(max(ptrs))]))
+            whole = np.frombuffer((C.c_float * total).from_address(min(ptrs)), np.float32).copy()
+            for ptr, sh in zip(ptrs, self.shapes):
+                o = (ptr - min(ptrs)) // 4
+                out.append(whole[o:o + int(np.prod(sh))].reshape(sh))
+            return out
         for ptr, sh in zip(self._res, self.shapes):
             buf = (C.c_float * int(np.prod(sh))).from_address(ptr)
-            if copy:
-                out.append(np.array(np.frombuffer(buf, np.float32).reshape(sh)))
-                continue
             buf._owner = self               # the views keep the displayer (and with it the pinned slot) alive
             self._exports.append(weakref.ref(buf))
             out.append(np.frombuffer(buf, np.float32).reshape(sh))

@@ -276,27 +276,29 @@ class LineEndPipeline(object):
         assert t.data_ptr() == owner.ptr
         return t
 
-    def tune_placement(self, frames=None, tries=8, steps=8, budget_s=1.0, spacer_gib=None, max_held_gib=None):
-        """Pick the physical placement of the SMALL maps by measurement; the largest map stays where it is.
+    def tune_placement(self, frames=None, tries=10, steps=8, budget_s=1.0, spacer_gib=None, max_held_gib=None):
+        """Pick the physical placement of the maps RELATIVE to each other by measurement; the largest map is moved last.
 
-        What is measured (profiles/r06/placement.md): the step's time depends on where the maps lie RELATIVE to each other in the
+        What is measured (profiles/r06/placement.md): the step's time depends on where the maps lie relative to each other in the
         device's physical memory -- not on where any one of them lies.  The same K-orientation map is fast with one allocation of
         the CS map + pyramid and 25 % slower with another (1.18 vs 1.52 ms for config 5's dominant kernel), and the other way
         round for another K map; a synthetic kernel that only issues the three store streams shows the same times draw by draw;
         maps whose physical chunks are co-located on purpose are reliably SLOW.  The discriminating counter is
         TCC_EA0_WRREQ_STALL (x 4.7 on a slow pair, concentrated in a few L2 channels) at identical request counts: the streams
         collide behind the L2, in the memory's own address mapping, which an unprivileged process can neither see nor choose.
-        It can choose AGAIN, cheaply: the big map (most of the bytes) is kept, every other map is allocated anew ``tries - 1``
-        times -- behind a spacer, because the classes change every few tens of GiB -- ``steps`` steps are timed on each, the
-        fastest set is kept.  ``frames``: the caller's resident batch (its placement is part of the relation; ``placement="auto"``
-        tunes on the first batch ``step`` sees); default: synthetic noise.
+        It can choose AGAIN, cheaply: the big map (most of the bytes) is kept, every other map is allocated anew -- behind a
+        spacer, because the classes change every few tens of GiB -- ``steps`` steps are timed on each, the fastest set is kept.
+        When three draws in a row have shown no contrast (within 2 %) the big map is drawn again as well, once per three draws.
+        ``frames``: the caller's resident batch (its placement is part of the relation; ``placement="auto"`` tunes on the first batch
+        ``step`` sees); default: synthetic noise.
 
-        Bounds: ``budget_s`` seconds; ``spacer_gib`` per spacer, default AND upper limit = the size of the pipeline's maps;
-        ``max_held_gib`` for everything the tuner holds at once (spacers + losing draws), default 8 x the maps, and never more
-        than leaves a quarter of the device free.  Spacers and draws come from silent_malloc and go back to the driver at the end:
-        torch's caching allocator is not involved and ``torch.cuda.empty_cache()`` is not called.  Results never depend on the choice.
-        The pipeline's map tensors are REPLACED: ``PackedPyramid`` views an earlier ``outputs()`` handed out keep pointing at the old
-        buffers (alive, but no longer written) -- call ``outputs()`` again.  The decision is in ``placement_tuning``."""
+        Bounds: ``tries`` draws incl. the first; ``budget_s`` seconds; ``spacer_gib`` per spacer, default AND upper limit = the size
+        of the pipeline's maps; ``max_held_gib`` for everything the tuner holds at once (spacers + losing draws), default 16 x the
+        maps, and never more than a quarter of the device or than leaves a quarter of it free.  Spacers and draws come from
+        silent_malloc and go back to the driver at the end: torch's caching allocator is not involved and
+        ``torch.cuda.empty_cache()`` is not called.  Results never depend on the choice.  The pipeline's map tensors are REPLACED:
+        ``PackedPyramid`` views an earlier ``outputs()`` handed out keep pointing at the old buffers (alive, but no longer written)
+        -- call ``outputs()`` again.  The decision is in ``placement_tuning``."""
         import time
         torch = self.torch
         if frames is None:
@@ -315,19 +317,25 @@ class LineEndPipeline(object):
             cur["pyr1"] = self._pyrs[1]
         cur = {k: v for k, v in cur.items() if v is not None}
         nbytes = {k: v.numel() * v.element_size() for k, v in cur.items()}
-        big = max(reversed(list(cur)), key=lambda k: nbytes[k])           # ties: the last map (end / line_end)
+        big = max(reversed([k for k in names if k in cur]), key=lambda k: nbytes[k])    # ties: the last written map (end / line_end)
         small = [k for k in cur if k != big]
         total_maps = sum(nbytes.values())
         spacer = total_maps if spacer_gib is None else min(int(spacer_gib * (1 << 30)), total_maps)
-        cap = 8 * total_maps if max_held_gib is None else int(max_held_gib * (1 << 30))
-        best = (self._time_step(frames, steps), {k: cur[k] for k in small})
-        tried = [round(best[0], 4)]
-        held, held_bytes, stop = [], 0, "tries"
-        for _ in range(tries - 1):
+        free, total = torch.cuda.mem_get_info(self.tdev)
+        cap = min(16 * total_maps, total // 4) if max_held_gib is None else int(max_held_gib * (1 << 30))
+        best = (self._time_step(frames, steps), dict(cur))
+        tried, drawn = [round(best[0], 4)], ["first"]
+        held, held_bytes, stop, flat = [], 0, "tries", 0
+        for i in range(tries - 1):
             if time.perf_counter() - t_start > budget_s:
                 stop = "budget_s"
                 break
-            need = spacer + sum(nbytes[k] for k in small)
+            # no contrast in the last three draws: the small maps have not left their class -- move the big map too
+            flat = flat + 1 if max(tried[-3:]) < 1.02 * min(tried[-3:]) else 0
+            redraw = list(cur) if (flat >= 3 and len(tried) >= 3) else small
+            if redraw is not small:
+                flat = 0
+            need = spacer + sum(nbytes[k] for k in redraw)
             free, total = torch.cuda.mem_get_info(self.tdev)
             if held_bytes + need > cap or free - need < total // 4:
                 stop = "memory cap"
@@ -335,7 +343,8 @@ class LineEndPipeline(object):
             try:
                 if spacer:
                     held.append(_RawBlock(self.ctx, spacer))
-                cand = {k: self._raw_tensor(cur[k]) for k in small}
+                cand = dict(best[1])
+                cand.update({k: self._raw_tensor(cur[k]) for k in redraw})
             except RuntimeError:
                 stop = "allocation failed"
                 break
@@ -345,8 +354,9 @@ class LineEndPipeline(object):
                 self.step(frames)
             t = self._time_step(frames, steps)
             tried.append(round(t, 4))
+            drawn.append("all" if redraw is not small else "small")
             if t < best[0]:
-                held.append(best[1])
+                held.append(best[1])               # (tensors shared with ``cand`` stay alive through it)
                 best = (t, cand)
             else:
                 held.append(cand)
@@ -356,8 +366,8 @@ class LineEndPipeline(object):
         held.clear()                               # spacers and losing draws: back to the driver (silent_free), not to a cache
         del cur
         self.overlap = was
-        self.placement_tuning = {"tries_ms": tried, "first_draw_ms": tried[0], "chosen_ms": round(best[0], 4), "kept": big,
-                                 "redrawn": small, "spacer_gib": round(spacer / (1 << 30), 2), "stopped_by": stop,
+        self.placement_tuning = {"tries_ms": tried, "drawn": drawn, "first_draw_ms": tried[0], "chosen_ms": round(best[0], 4),
+                                 "big_map": big, "small_maps": small, "spacer_gib": round(spacer / (1 << 30), 2), "stopped_by": stop,
                                  "peak_held_gib": round(held_bytes / (1 << 30), 2), "seconds": round(time.perf_counter() - t_start, 2)}
         return self.placement_tuning
 

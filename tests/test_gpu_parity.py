@@ -654,7 +654,6 @@ def test_line_end_displayer_results_outlive_frames_shape_changes_and_close(rt):
     want_views = [np.stack(views[i]).copy() for i in range(1, 7)]
     old = disp._native[1]
     fb = old.frame_buffer
-    fb[...] = 5.0
     for step in range(5):                                      # five more frames: both slots overwritten
         disp.callback(structured_frame(81 + step, 150, 230, 3))
     for i in range(6):
@@ -662,6 +661,7 @@ def test_line_end_displayer_results_outlive_frames_shape_changes_and_close(rt):
     # a new frame shape: a new displayer; the old one's pinned memory stays under the views we hold
     views = disp.callback(f0 * 0 + 7.0, copy=False)
     want_views = [np.stack(views[i]).copy() for i in range(1, 7)]
+    fb[...] = 5.0                                              # (the old displayer's pinned input buffer: nobody writes it from here on)
     disp.callback(structured_frame(90, 170, 250, 3))
     assert disp._native[1] is not old
     gc.collect()
