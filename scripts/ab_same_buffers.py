@@ -66,6 +66,23 @@ for al in range(allocs):
             torch.cuda.synchronize()
             res[i]["kernel"].append(p.profiled_kernel()[0])
             p.set_profiling(0)
+    if os.environ.get("CHECK") == "1":     # the builds must write the same bits into the same maps
+        names = [k for k in maps if maps[k] is not None]
+        ref = None
+        for i, p in enumerate(pipes):
+            for k in names:
+                maps[k].fill_(-7.0)
+            p.step(frames)
+            torch.cuda.synchronize()
+            got = [maps[k].clone() for k in names]
+            if ref is None:
+                ref = got
+            else:
+                same = [bool(torch.equal(a.view(torch.int32), b.view(torch.int32))) for a, b in zip(ref, got)]
+                print("alloc %d  %s writes the same bits as %s: %s" % (al, os.path.basename(libs[i]), os.path.basename(libs[0]),
+                                                                         dict(zip(names, same))), flush=True)
+            del got
+        del ref
     for i, path in enumerate(libs):
         print("alloc %d  %-28s step %.4f (min %.4f)   dominant kernel %.4f (min %.4f) ms" % (
             al, os.path.basename(path), np.median(res[i]["step"]), np.min(res[i]["step"]), np.median(res[i]["kernel"]), np.min(res[i]["kernel"])), flush=True)
