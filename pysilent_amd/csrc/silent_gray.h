@@ -422,46 +422,6 @@ __device__ __forceinline__ StreamCol stream_col(const StreamTab& st, int g, int 
 #endif
 constexpr int kStreamRegLevels = SILENT_STREAM_REG_LEVELS;
 
-// Block-wide rows for the two 1-channel maps of the unit level (round 6, profiles/r06/placement.md experiment 6): a wave's own piece
-// of a map row is 56 floats = 224 B = 1.75 cache lines, so four waves used to write four short, line-sharing runs per row.  Now every
-// wave parks its pieces of four rows in LDS rows pass 1 has already consumed, and after ONE barrier per four rows wave w writes the
-// whole 224-pixel tile row 4 g + w of both maps (896 B = 7 whole lines when the row starts on a line) with one 16-byte store per lane.
-// The memory sees a quarter of the runs, four times as long: - 6 ... 8 % on the synthetic three-stream kernel in every placement class.
-#ifndef SILENT_STREAM_BLOCK_ROWS
-#define SILENT_STREAM_BLOCK_ROWS 0
-#endif
-constexpr bool kStreamBlockRows = SILENT_STREAM_BLOCK_ROWS != 0 && kFusedWaves == 4 && kFusedCols % 4 == 0 && kFusedTH % 4 == 0;
-
-typedef float sf4 __attribute__((ext_vector_type(4)));
-typedef sf4 sf4_u __attribute__((aligned(4)));   // a 16-byte store at a 4-byte aligned address (global memory takes it)
-
-// Rows 4 g + wave of the tile, both maps: lane l < 56 gathers pixels 4 l ... 4 l + 3 of the tile row from the four waves' parked pieces
-// (s_rows[w][slot][4 + column of the wave]) and writes them with one non-temporal 16-byte store.  parity = g & 1 (double-buffered slots).
-template <int NR>
-__device__ __forceinline__ void stream_flush_rows(float (&s_rows)[kFusedWaves][NR][64], int g, int wave, int lane, int y0, int tile_x0,
-                                                  int out_h, int out_w, float* __restrict__ pyr_lv, float* __restrict__ cs_lv /* level bases or NULL */) {
-    const int y = y0 + 4 * g + wave;
-    const int x = tile_x0 + 4 * lane;
-    if (y >= out_h || lane >= kFusedTW / 4 || x >= out_w) return;
-    const int src = (4 * lane) / kFusedCols, off = 4 + 4 * lane - src * kFusedCols;
-    const int slot = (g & 1) * 8 + wave;
-    const long long px = (long long)y * out_w + x;
-    const int nv = out_w - x;   // >= 1
-#pragma unroll
-    for (int m = 0; m < 2; ++m) {
-        float* __restrict__ dst = m == 0 ? pyr_lv : cs_lv;
-        if (!dst) continue;
-        const sf4 v = *reinterpret_cast<const sf4*>(&s_rows[src][slot + 4 * m][off]);
-        if (nv >= 4) {
-            __builtin_nontemporal_store(v, reinterpret_cast<sf4_u*>(dst + px));
-        } else {
-            __builtin_nontemporal_store(v.x, dst + px);
-            if (nv > 1) __builtin_nontemporal_store(v.y, dst + px + 1);
-            if (nv > 2) __builtin_nontemporal_store(v.z, dst + px + 2);
-        }
-    }
-}
-
 template <int K, int G, int L = 0>
 __global__ __launch_bounds__(64 * kFusedWaves) void gray_stream_kernel(const float* __restrict__ frames, float* __restrict__ pyr,
                                                           float* __restrict__ cs_out, float* __restrict__ end_out,
@@ -511,18 +471,7 @@ __global__ __launch_bounds__(64 * kFusedWaves) void gray_stream_kernel(const flo
 #pragma unroll
         for (int g = 0; g < GR; ++g) col[g] = stream_col(st, g, wx_tile, lane);
     }
-    if (!live) {
-        if constexpr (kStreamBlockRows) {
-            // a wave without columns of the level still writes ITS rows of the tile (the pieces the live waves park) -- one barrier
-            // per four rows, as in pass 1 below
-#pragma unroll
-            for (int g = 0; g < R / 4; ++g) {
-                __syncthreads();
-                stream_flush_rows<NR>(s_rows, g, wave, lane, y0, tx * kFusedTW, lv.out_h, lv.out_w, pyr + base_px, cs_out ? cs_out + base_px : nullptr);
-            }
-        }
-        return;
-    }
+    if (!live) return;
 #pragma unroll
     for (int i = 0; i < R + 8; ++i) asm volatile("" ::"v"(in[i]));  // retire loads before the first store
     asm volatile("" : "+v"(in_last), "+v"(xcol));
@@ -626,7 +575,12 @@ __global__ __launch_bounds__(64 * kFusedWaves) void gray_stream_kernel(const flo
     // costs 2.5 % by itself, hence no knob.
     // (Tried and dropped: a 3-instruction relu+clip (v_med3 + NaN select) instead of 4: no measurable change, the kernel
     // is not VALU-bound any more.  Parking 4 finished rows of the 1-channel maps in consumed LDS rows and writing them with one
-    // global_store_dwordx4 per 4 rows -- 24 instead of 48 stores per tile -- was 3.5 % slower in an alternating A/B.)
+    // global_store_dwordx4 per 4 rows -- 24 instead of 48 stores per tile -- was 3.5 % slower in an alternating A/B.
+    // Round 6, block-wide rows: every wave parks its 56-float pieces of four rows of both maps in consumed LDS rows and, after one
+    // barrier per four rows, wave w writes the whole 224-pixel tile row 4 g + w (896 B, 7 whole lines, one 16-byte store per lane).
+    // Bit-identical; on the SAME buffers (profiles/r06/evidence/ab_block_rows_same_buffers.txt): config 5 - 8 ... - 13 % on slow
+    // placements and + 0.5 ... 1.3 % on fast ones, config 2 + 10 ... 14 % on every placement (the barrier ties four waves that
+    // otherwise drift freely).  With the placement tuner choosing the fast relation it only costs: dropped (commit 02244a6 has it).)
     {
         float hw[6] = {0, 0, 0, 0, 0, 0};
         float iw[3][3], cw[3][3];
@@ -649,11 +603,9 @@ __global__ __launch_bounds__(64 * kFusedWaves) void gray_stream_kernel(const flo
 #pragma unroll
                 for (int j = 1; j < 6; ++j) v = __builtin_fmaf(wv[j], hw[j], v);
                 v = (p >= 0 && p < eff_h && col_eff) ? v : 0.0f;
-                if constexpr (!kStreamBlockRows) {
-                    if (p >= y0 && p < y0 + R && p < lv.out_h) {  // wave-uniform
-                        float* __restrict__ prow = pyr + (wave_px + (long long)p * lv.out_w);
-                        if (out_lane) __builtin_nontemporal_store(v, prow + lane);
-                    }
+                if (p >= y0 && p < y0 + R && p < lv.out_h) {  // wave-uniform
+                    float* __restrict__ prow = pyr + (wave_px + (long long)p * lv.out_w);
+                    if (out_lane) __builtin_nontemporal_store(v, prow + lane);
                 }
 #pragma unroll
                 for (int b = 0; b < 3; ++b) {
@@ -684,20 +636,11 @@ __global__ __launch_bounds__(64 * kFusedWaves) void gray_stream_kernel(const flo
             }
             if (i >= 9) {
                 const int y = y0 + i - 9;
-                if constexpr (kStreamBlockRows) {
-                    // park this wave's pieces of row i - 9 of both maps in consumed stream rows (iw[0][1] is the pyramid's row y: the value
-                    // the i - 2 step produced); slots: parity of the 4-row group x {pyramid 0..3, CS 4..7}
-                    const int r = i - 9, slot = ((r >> 2) & 1) * 8 + (r & 3);   // (slot + 4 < i: a stream row pass 1 has consumed)
-                    s_rows[wave][slot][lane] = iw[0][1];
-                    s_rows[wave][slot + 4][lane] = cw[1][1];
-                }
                 if (y < lv.out_h) {  // wave-uniform
                     const long long row_px = wave_px + (long long)y * lv.out_w;
-                    if constexpr (!kStreamBlockRows) {
-                        if (cs_out) {
-                            float* __restrict__ crow = cs_out + row_px;
-                            if (out_lane) __builtin_nontemporal_store(cw[1][1], crow + lane);
-                        }
+                    if (cs_out) {
+                        float* __restrict__ crow = cs_out + row_px;
+                        if (out_lane) __builtin_nontemporal_store(cw[1][1], crow + lane);
                     }
                     if (end_out) {
                         float acc[K];
@@ -730,13 +673,6 @@ __global__ __launch_bounds__(64 * kFusedWaves) void gray_stream_kernel(const flo
                                 for (int k = 0; k < K; ++k) po[lane * K + k] = acc[k];
                             }
                         }
-                    }
-                }
-                if constexpr (kStreamBlockRows) {
-                    if (((i - 12) & 3) == 0 && i >= 12) {   // rows 4 g ... 4 g + 3 of both maps are parked: wave w writes row 4 g + w
-                        __syncthreads();
-                        stream_flush_rows<NR>(s_rows, (i - 12) >> 2, wave, lane, y0, tx * kFusedTW, lv.out_h, lv.out_w, pyr + base_px,
-                                              cs_out ? cs_out + base_px : nullptr);
                     }
                 }
             }
