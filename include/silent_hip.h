@@ -197,7 +197,8 @@ int silent_profile_elapsed_ms(silent_ctx* ctx, float* ms, int64_t* pixels);
 /* Kernel-selection knobs for tests and A/B timing (no reference counterpart: the reference has one code path).
  * Every context starts from the environment variables SILENT_GRAY_OPTS / SILENT_RGB_OPTS / SILENT_PYRAMID_OPTS, read
  * once in silent_create; silent_set_tuning changes a knob of one context afterwards.  Bits -- GRAY: 1 XCD-aware tile
- * order, 2 32-row filter tiles, 8 32-row fused tiles, 16 no single-read stream kernel, 32 XCD order in the stream kernel;
+ * order, 16 no single-read stream kernel, 32 XCD order in the stream kernel (2 and 8 selected 32-row tiles until round 5: slower in
+ * every A/B, the instantiations are gone and the bits are ignored);
  * RGB: 1 dense weights, 2 no two-group form, 8 no short tiles, 16 the one-pixel-per-lane chain kernel (default: two pixels
  * per lane on packed f32, same bits), 32 no sparse keypoint tail, 64 no symmetric forms (the two-group instantiation of the pair
  * kernel, bit-identical to the one-pixel kernel), 128 16-byte stores of orient / line_end where rows are 16-byte aligned (same bits as the default

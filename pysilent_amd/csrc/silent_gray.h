@@ -176,7 +176,11 @@ __global__ __launch_bounds__(256) void gray_line_end_kernel(const float* __restr
 // Same wave-autonomous streaming structure as gray_line_end_kernel, with the 5-tap smoother in front: the
 // level is never re-read from HBM by the filter pass.  Each stage costs halo lanes (2 + 1 + 1 per side):
 // 56 of the 64 lanes produce outputs; a tile is 224 columns x 16 rows and streams 24 source rows.
-constexpr int kFusedCols = 56;
+#ifndef SILENT_FUSED_COLS
+#define SILENT_FUSED_COLS 56
+#endif
+constexpr int kFusedCols = SILENT_FUSED_COLS;
+static_assert(kFusedCols >= 16 && kFusedCols <= 56 && kFusedCols % 4 == 0, "64 lanes = output columns + 4 halo lanes per side");
 #ifndef SILENT_FUSED_WAVES
 #define SILENT_FUSED_WAVES 4
 #endif

@@ -15,9 +15,10 @@ static int launch_gray(silent_ctx* ctx, const char* who, const float* pyr, const
     if (n_orient != 3 && n_orient != 4 && n_orient != 8)
         return fail(ctx, SILENT_E_UNSUPPORTED, std::string(who) + ": n_orient must be 3, 4 or 8");
     // development knob for interleaved A/B timing (scripts/ab_gray.py): bit0 XCD-aware tile order (measured
-    // 7 % slower, off), bit1 32-row tiles (3 % slower, off), bit2 non-temporal stores (no effect, off)
+    // 7 % slower, off), bit2 non-temporal stores (no effect, off).  (Bit1 selected 32-row tiles until round 5: 3 % slower in every
+    // A/B and 145 - 156 SGPR spills; the instantiations are gone since round 6, the bit is ignored.)
     const unsigned opts = ctx->tune[SILENT_TUNE_GRAY];
-    const int th = (opts & 2u) ? 32 : kGrayTH;
+    const int th = kGrayTH;
     LevelTab tab;
     long long blocks;
     TRY(build_level_tab(ctx, who, levels, n_levels, n_frames, kGrayTW, th, &tab, &blocks, skip));
@@ -28,15 +29,9 @@ static int launch_gray(silent_ctx* ctx, const char* who, const float* pyr, const
     if (end_bank) std::memcpy(w.end, end_bank, sizeof(float) * 9 * n_orient);
 #define GRAY_LAUNCH(K_, R_) \
     hipLaunchKernelGGL((gray_line_end_kernel<K_, R_>), dim3((unsigned)blocks), dim3(256), 0, s, pyr, cs_out, end_out, tab, w, clip_hi, opts)
-    if (th == 32) {
-        if (n_orient == 3) GRAY_LAUNCH(3, 32);
-        else if (n_orient == 4) GRAY_LAUNCH(4, 32);
-        else GRAY_LAUNCH(8, 32);
-    } else {
-        if (n_orient == 3) GRAY_LAUNCH(3, kGrayTH);
-        else if (n_orient == 4) GRAY_LAUNCH(4, kGrayTH);
-        else GRAY_LAUNCH(8, kGrayTH);
-    }
+    if (n_orient == 3) GRAY_LAUNCH(3, kGrayTH);
+    else if (n_orient == 4) GRAY_LAUNCH(4, kGrayTH);
+    else GRAY_LAUNCH(8, kGrayTH);
 #undef GRAY_LAUNCH
     return check_launch(ctx, who);
 }
@@ -68,14 +63,14 @@ static int gray_pass_parts(silent_ctx* ctx, const silent_pyramid_plan* plan, con
     if (n_frames < 1) return fail(ctx, SILENT_E_INVALID, std::string(who) + ": n_frames must be >= 1");
     hipStream_t s = (hipStream_t)stream;
     const PyrTab& pt = plan->tab;
-    const int kopts = (int)ctx->tune[SILENT_TUNE_GRAY];  // A/B knobs: bit3 32-row fused tiles, bit4 disable the stream path
+    const int kopts = (int)ctx->tune[SILENT_TUNE_GRAY];  // A/B knob: bit4 disables the stream path (bit3, 32-row fused tiles, is ignored since round 6)
     const bool stream_path = plan->stream_ok && !(kopts & 16);
     // 1. non-unit levels of the pyramid: by the region kernel, unless the stream kernel of step 2 produces them
     //    from the same single read of the frame; plus the zero fill of canvases larger than their zoomed crop
     if (!(parts & 3u)) return fail(ctx, SILENT_E_INVALID, std::string(who) + ": parts must name step 1 + 2 (bit 0) and / or step 3 (bit 1)");
     if (parts & 1u) TRY(launch_pyramid(ctx, who, plan, frames, n_frames, pyr, s, false, !stream_path));
     // 2. unit levels: pyramid + CS + end in one kernel
-    const int fth = (!stream_path && (kopts & 8)) ? 32 : kFusedTH;
+    const int fth = kFusedTH;
     FusedTab ft;
     std::memset(&ft, 0, sizeof(ft));
     bool is_unit[kMaxLevels] = {false};
@@ -133,15 +128,9 @@ static int gray_pass_parts(silent_ctx* ctx, const silent_pyramid_plan* plan, con
         } else {
 #define FUSED_LAUNCH(K_, R_) \
     hipLaunchKernelGGL((gray_unit_fused_kernel<K_, R_>), dim3((unsigned)blocks), dim3(64 * kFusedWaves), 0, s, frames, pyr, cs_out, end_out, ft, w, clip_hi)
-            if (fth == 32) {
-                if (n_orient == 3) FUSED_LAUNCH(3, 32);
-                else if (n_orient == 4) FUSED_LAUNCH(4, 32);
-                else FUSED_LAUNCH(8, 32);
-            } else {
-                if (n_orient == 3) FUSED_LAUNCH(3, kFusedTH);
-                else if (n_orient == 4) FUSED_LAUNCH(4, kFusedTH);
-                else FUSED_LAUNCH(8, kFusedTH);
-            }
+            if (n_orient == 3) FUSED_LAUNCH(3, kFusedTH);
+            else if (n_orient == 4) FUSED_LAUNCH(4, kFusedTH);
+            else FUSED_LAUNCH(8, kFusedTH);
 #undef FUSED_LAUNCH
         }
         if (ctx->prof_sample) {

@@ -195,10 +195,10 @@ extern "C" float wp_run(void* dst, long long row_bytes, int rows, int images, in
 // 56 pixels x 4K bytes of the K-orientation map (always), and -- flags -- 1: first reads 24 rows of the frame (64 lanes x 4 B each,
 // all requested up front), 2: writes the 56-float run of the CS map (224 B = 1.75 lines), 4: the same for the pyramid's level 0,
 // 8: those 1-channel stores temporal instead of non-temporal, 16: the K-map stores temporal.
-template <int K>
+template <int K, int COLS = 56>
 __global__ __launch_bounds__(256) void wp2_kernel(float* __restrict__ end, float* __restrict__ cs, float* __restrict__ pyr,
                                                   const float* __restrict__ frames, int W, int H, long long map_px_per_frame, int flags) {
-    constexpr int R = 16, COLS = 56;
+    constexpr int R = 16;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int tiles_x = (W + 4 * COLS - 1) / (4 * COLS), tiles_y = (H + R - 1) / R;
     const unsigned bid = blockIdx.x;
@@ -284,15 +284,25 @@ __global__ __launch_bounds__(256) void wp2_kernel(float* __restrict__ end, float
 
 extern "C" float wp2_run(void* end, void* cs, void* pyr, const void* frames, int K, int W, int H, int images, long long map_px_per_frame,
                          int flags, int reps) {
-    const int tiles_x = (W + 223) / 224, tiles_y = (H + 15) / 16;
+    // flags & 128: 64 output columns per wave (every run starts on a 64-byte boundary and is whole 64-byte pieces) instead of 56
+    const int cols = (flags & 128) ? 64 : (flags & 256) ? 48 : 56;   // flags & 256: 48 columns per wave (192-byte runs, 64-byte aligned)
+    const int tiles_x = (W + 4 * cols - 1) / (4 * cols), tiles_y = (H + 15) / 16;
     const unsigned grid = (unsigned)(tiles_x * tiles_y * images);
     hipEvent_t a, b;
     (void)hipEventCreate(&a);
     (void)hipEventCreate(&b);
     for (int i = 0; i < reps + 2; ++i) {
         if (i == 2) (void)hipEventRecord(a, nullptr);
-        if (K == 8) wp2_kernel<8><<<grid, 256>>>((float*)end, (float*)cs, (float*)pyr, (const float*)frames, W, H, map_px_per_frame, flags);
-        else wp2_kernel<4><<<grid, 256>>>((float*)end, (float*)cs, (float*)pyr, (const float*)frames, W, H, map_px_per_frame, flags);
+        if (flags & 256) {
+            if (K == 8) wp2_kernel<8, 48><<<grid, 256>>>((float*)end, (float*)cs, (float*)pyr, (const float*)frames, W, H, map_px_per_frame, flags);
+            else wp2_kernel<4, 48><<<grid, 256>>>((float*)end, (float*)cs, (float*)pyr, (const float*)frames, W, H, map_px_per_frame, flags);
+        } else if (flags & 128) {
+            if (K == 8) wp2_kernel<8, 64><<<grid, 256>>>((float*)end, (float*)cs, (float*)pyr, (const float*)frames, W, H, map_px_per_frame, flags);
+            else wp2_kernel<4, 64><<<grid, 256>>>((float*)end, (float*)cs, (float*)pyr, (const float*)frames, W, H, map_px_per_frame, flags);
+        } else {
+            if (K == 8) wp2_kernel<8><<<grid, 256>>>((float*)end, (float*)cs, (float*)pyr, (const float*)frames, W, H, map_px_per_frame, flags);
+            else wp2_kernel<4><<<grid, 256>>>((float*)end, (float*)cs, (float*)pyr, (const float*)frames, W, H, map_px_per_frame, flags);
+        }
     }
     (void)hipEventRecord(b, nullptr);
     hipError_t e = hipEventSynchronize(b);
