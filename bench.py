@@ -765,8 +765,8 @@ def run_rank(args):
     torch.cuda.synchronize(dev)
     tune_pipeline(pipe, frames, False if args.one_stream else overlap_policy(world), placement_policy() and not args.no_placement)
     # a marker in the kernel trace: everything the tuners launched (losing placements, candidate stream pairs) lies BEFORE this
-    # one-microsecond busy_wait_kernel -- scripts/summarize_profile.py computes the per-kernel statistics over what follows it
-    pipe.ctx.check(pipe._lib.silent_busy_wait_dev(pipe.ctx.handle, 1, pipe._stream()))
+    # trace_marker_kernel -- scripts/summarize_profile.py computes the per-kernel statistics over what follows it
+    pipe.ctx.check(pipe._lib.silent_trace_marker_dev(pipe.ctx.handle, pipe._stream()))
     torch.cuda.synchronize(dev)
 
     settle_run, settle_ms = settle(torch, pipe, frames, dev)

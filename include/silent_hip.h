@@ -95,6 +95,9 @@ int silent_synchronize(silent_ctx* ctx, silent_stream stream);
  * uses to find out whether two streams really run side by side (pysilent_amd.pipeline.pick_concurrent_stream).  No
  * counterpart in the reference (it has one stream: tf.device('/device:GPU:0'), recognition_testing.py:64). */
 int silent_busy_wait_dev(silent_ctx* ctx, unsigned microseconds, silent_stream stream);
+/* One empty kernel named trace_marker_kernel on `stream`: a mark in a rocprofv3 kernel trace (bench.py puts it between its tuners
+ * and the measured steps; scripts/summarize_profile.py reads the statistics behind it).  No counterpart in the reference. */
+int silent_trace_marker_dev(silent_ctx* ctx, silent_stream stream);
 
 /* ---------------------------------------------------------------------------- a-1 pyramid
  * Replaces image_to_zoom_tensor, slam_recognition/util/zoom/from_image.py:10-69: per level a crop of

@@ -91,6 +91,7 @@ _SIGNATURES = {
     "silent_memcpy_d2h": [_vp, _vp, _vp, _sz, _vp],
     "silent_synchronize": [_vp, _vp],
     "silent_busy_wait_dev": [_vp, _u, _vp],
+    "silent_trace_marker_dev": [_vp, _vp],
     "silent_pyramid_plan_create": [_vp, _i, _i, _i, C.POINTER(PyrLevel), _i, C.POINTER(_vp)],
     "silent_pyramid_plan_destroy": [_vp],
     "silent_pyramid": [_vp, _vp, _fp, _i, _fp],

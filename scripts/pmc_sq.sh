@@ -8,8 +8,8 @@ OUT=$REPO/gpurun_out/pmc_$TAG
 mkdir -p $OUT
 export TMPDIR=/tmp
 cd /tmp
-rocprofv3 --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_INSTS_VALU SQ_ACTIVE_INST_LDS SQ_WAVES GRBM_GUI_ACTIVE --output-format csv -d $OUT/p1 -o p1 -- python3 $REPO/bench.py --steps 2 --warmup 1 --no-cpu-baseline "$@" > $OUT/p1.log 2>&1 || exit 1
-rocprofv3 --pmc SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_ACTIVE_INST_VMEM SQ_ACTIVE_INST_SCA SQ_LDS_BANK_CONFLICT SQ_WAIT_INST_LDS --output-format csv -d $OUT/p2 -o p2 -- python3 $REPO/bench.py --steps 2 --warmup 1 --no-cpu-baseline "$@" > $OUT/p2.log 2>&1 || exit 1
+rocprofv3 --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_INSTS_VALU SQ_ACTIVE_INST_LDS SQ_WAVES --output-format csv -d $OUT/p1 -o p1 -- python3 $REPO/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-latency --no-ingest "$@" > $OUT/p1.log 2>&1 || exit 1
+rocprofv3 --pmc SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_ACTIVE_INST_VMEM SQ_ACTIVE_INST_SCA SQ_LDS_BANK_CONFLICT SQ_WAIT_INST_LDS --output-format csv -d $OUT/p2 -o p2 -- python3 $REPO/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-latency --no-ingest "$@" > $OUT/p2.log 2>&1 || exit 1
 python3 - <<PY
 import csv, glob, collections
 for p in ("p1", "p2"):

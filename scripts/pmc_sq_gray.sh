@@ -14,7 +14,7 @@ P3="SQ_INST_LEVEL_VMEM SQ_INST_LEVEL_LDS SQ_ACTIVE_INST_VMEM SQ_INST_CYCLES_VMEM
 i=0
 for P in "$P1" "$P2" "$P3"; do
   i=$((i+1))
-  rocprofv3 --pmc $P --kernel-include-regex gray_stream --output-format csv -d $OUT/p$i -o p$i -- python3 $REPO/bench.py --steps 4 --warmup 2 --no-cpu-baseline --no-side-workloads "$@" > $OUT/p$i.log 2>&1 || exit 1
+  rocprofv3 --pmc $P --kernel-include-regex gray_stream --output-format csv -d $OUT/p$i -o p$i -- python3 $REPO/bench.py --steps 4 --warmup 2 --no-cpu-baseline --no-latency --no-ingest --no-side-workloads "$@" > $OUT/p$i.log 2>&1 || exit 1
 done
 python3 - <<PY
 import csv, glob, collections

@@ -3,7 +3,7 @@
 set -o pipefail
 WL=${1:-reference_layout}
 REPO=$(pwd); OUT=$REPO/gpurun_out/pmc_walk_$WL; mkdir -p $OUT; export TMPDIR=/tmp; cd /tmp
-rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_INSTS_VALU SQ_WAVES GRBM_GUI_ACTIVE --output-format csv -d $OUT/p1 -o p1 -- python3 $REPO/scripts/walk_only.py $WL > $OUT/p1.log 2>&1 || exit 1
+rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_INSTS_VALU SQ_WAVES --output-format csv -d $OUT/p1 -o p1 -- python3 $REPO/scripts/walk_only.py $WL > $OUT/p1.log 2>&1 || exit 1
 rocprofv3 --pmc SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_ACTIVE_INST_VMEM SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_LDS SQ_INSTS_SMEM --output-format csv -d $OUT/p2 -o p2 -- python3 $REPO/scripts/walk_only.py $WL > $OUT/p2.log 2>&1 || exit 1
 rocprofv3 --pmc SQ_WAIT_INST_LDS SQ_INST_CYCLES_SALU SQ_WAIT_ANY SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_FLAT_LDS_ONLY SQ_INSTS_GDS SQ_WAVES_EQ_64 --output-format csv -d $OUT/p3 -o p3 -- python3 $REPO/scripts/walk_only.py $WL > $OUT/p3.log 2>&1
 python3 - <<PY

@@ -43,8 +43,11 @@ P = os.path.join(root, "gpurun_out", "prof_" + median)
 # over the launches AFTER that marker (what the step runs with); the tool's table is kept as kernel_stats_all_launches.csv.
 shutil.copy(os.path.join(P, "trace", "trace_kernel_stats.csv"), os.path.join(out, "kernel_stats_all_launches.csv"))
 trace_rows = sorted(csv.DictReader(open(os.path.join(P, "trace", "trace_kernel_trace.csv"))), key=lambda r: int(r["Start_Timestamp"]))
-marks = [i for i, r in enumerate(trace_rows) if "busy_wait_kernel" in r["Kernel_Name"]]
-after = trace_rows[marks[-1] + 1:] if marks else trace_rows
+# (the FIRST trace_marker_kernel: side workloads of the same process set markers of their own later on)
+marks = [i for i, r in enumerate(trace_rows) if "trace_marker_kernel" in r["Kernel_Name"]]
+if not marks:
+    sys.exit("summarize_profile: no trace_marker_kernel in %s -- not a trace of this revision's bench.py" % P)
+after = trace_rows[marks[0] + 1:]
 agg = collections.OrderedDict()
 for r in after:
     agg.setdefault(r["Kernel_Name"], []).append(int(r["End_Timestamp"]) - int(r["Start_Timestamp"]))
@@ -57,6 +60,8 @@ with open(os.path.join(out, "kernel_stats.csv"), "w") as fh:
         sd = (sum((x - mean) ** 2 for x in v) / len(v)) ** 0.5
         w.writerow([k, len(v), sum(v), "%.6f" % mean, "%.6f" % (100.0 * sum(v) / tot), min(v), max(v), "%.6f" % sd])
 dom_after = [d for k, v in agg.items() if kernel_sub in k for d in v]
+if len(dom_after) < 20:
+    sys.exit("summarize_profile: only %d launches of %s behind the marker (the timed steps alone are more): wrong trace or wrong kernel" % (len(dom_after), kernel_sub))
 if dom_after:
     per_run[median] = (sum(dom_after) / len(dom_after) / 1e3, per_run[median][1])
 try:
