@@ -358,3 +358,44 @@ def test_staging_copy_splits_a_batch_over_threads():
         dst = torch.zeros_like(src)
         P._staging_copy(dst, src, min_bytes=0, workers=4)
         assert torch.equal(dst, src)
+
+
+def test_bench_line_carries_every_config_in_flat_keys_and_a_last_summary():
+    """a reader who keeps only the headline keys (the driver's record keeps ``config``'s scalars) or only the tail
+    of the line still finds every BASELINE config: flat ``config.side_*`` scalars, the first draw beside the tuned step, and one
+    compact ``summary`` string as the LAST key of the JSON line."""
+    import json
+    import os
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import bench
+
+    def wl(ms, frac, first):
+        return {"ms_per_step": ms, "whole_pass_frac_of_hbm_peak": frac, "dominant_kernel_frac_of_hbm_peak": frac + 0.05,
+                "placement_tuning": {"tries_ms": [first, ms], "chosen_ms": ms}}
+
+    out = {"ms_per_step": 0.97, "config": {"workload": "1080p gray, 5-level pyramid", "whole_pass_frac_of_hbm_peak": 0.707,
+                                            "placement_tuning": {"tries_ms": [0.998, 0.97], "chosen_ms": 0.97}},
+           "roofline": {"kernel": "gray_stream_kernel<4>", "avg_launch_ms": 0.777, "frac": 0.626, "traffic": 4435420275},
+           "latency": {"640x480": {"native_ms_p50": 0.38, "native_views_ms_p50": 0.23, "native_in_place_ms_p50": 0.21, "gpu_busy_ms": 0.18}},
+           "other_workloads": {k: wl(1.0 + 0.1 * i, 0.3 + 0.05 * i, 1.2 + 0.1 * i) for i, k in enumerate(bench.SIDE_KEYS)},
+           "cpu_baseline": None}
+    out["other_workloads"]["config3_dense_tail"] = wl(1.6, 0.3, 1.7)           # not a BASELINE config: stays out of the summary
+    bench.record_side(out)
+    cfg = out["config"]
+    assert cfg["first_draw_ms"] == 0.998 and cfg["chosen_ms"] == 0.97
+    for i, k in enumerate(bench.SIDE_KEYS):
+        assert cfg["side_%s_ms" % k] == out["other_workloads"][k]["ms_per_step"]
+        assert cfg["side_%s_first_draw_ms" % k] == out["other_workloads"][k]["placement_tuning"]["tries_ms"][0]
+        assert cfg["side"][k] == [cfg["side_%s_ms" % k], cfg["side_%s_frac" % k], cfg["side_%s_first_draw_ms" % k]]
+    assert "side_config3_dense_tail_ms" not in cfg
+    assert cfg["latency_480p_ms"] == 0.38 and cfg["latency_480p_views_ms"] == 0.23 and cfg["latency_480p_in_place_ms"] == 0.21
+    assert list(out)[-1] == "summary" and len(out["summary"]) <= 1500 and out["summary"].startswith("SUMMARY")
+    for k in ("config3 ", "config5 ", "reference_layout ", "reference_layout_gray ", "first draw 0.998", "latency 640x480", "frac 0.6260"):
+        assert k in out["summary"], k
+    assert json.loads(json.dumps(out))["summary"] == out["summary"] and json.dumps(out).rstrip("}").endswith('"')
+    # a run without side workloads / latency (N > 1, --no-side-workloads): the keys that exist, nothing else, no exception
+    bare = {"ms_per_step": 1.0, "config": {"workload": "w", "whole_pass_frac_of_hbm_peak": 0.5, "placement_tuning": None},
+            "roofline": {"kernel": "k", "avg_launch_ms": 0.8, "frac": 0.6, "traffic": None}, "latency": None, "other_workloads": None}
+    bench.record_side(bare)
+    assert bare["config"]["first_draw_ms"] is None and bare["config"]["side"] == {} and "first draw None" in bare["summary"]
