@@ -167,6 +167,21 @@ def test_placement_tuning_keeps_the_results(mode):
     assert abs(torch.cuda.mem_get_info()[0] - free0) < 256 << 20
     with pytest.raises(ValueError):
         LineEndPipeline((h, w), mode=mode, n_levels=4, batch=B, placement="yes", **kw)
+    # a map the tuner drew is a silent_malloc block wrapped as a tensor: the block lives exactly as long as the tensor (and its views)
+    import gc
+    import weakref
+    t = a._raw_tensor(a.pyr)
+    owner = weakref.ref([o for o in gc.get_objects() if type(o).__name__ == "_RawBlock" and o.ptr == t.data_ptr()][0])
+    view = t[16:32]
+    del t
+    gc.collect()
+    assert owner() is not None and owner().ptr != 0               # the view keeps the storage, the storage keeps the block
+    view.fill_(3.0)
+    torch.cuda.synchronize()
+    assert float(view.sum()) == 48.0
+    del view
+    gc.collect()
+    assert owner() is None                                        # ... and silent_free ran with the last reference
     a.close()
 
 
