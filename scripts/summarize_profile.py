@@ -28,10 +28,18 @@ os.makedirs(out, exist_ok=True)
 
 
 def stats_of(run):
-    p = os.path.join(root, "gpurun_out", "prof_" + run, "trace", "trace_kernel_stats.csv")
-    rows = list(csv.DictReader(open(p)))
-    dom = [r for r in rows if kernel_sub in r["Name"]]
-    return (float(dom[0]["AverageNs"]) / 1e3 if dom else float("nan")), rows
+    """Average duration (us) of the dominant kernel over the launches BEHIND bench.py's trace marker (the tuner's draws lie in front
+    of it), and rocprofv3's own table over every launch."""
+    d = os.path.join(root, "gpurun_out", "prof_" + run, "trace")
+    rows = list(csv.DictReader(open(os.path.join(d, "trace_kernel_stats.csv"))))
+    tr = sorted(csv.DictReader(open(os.path.join(d, "trace_kernel_trace.csv"))), key=lambda r: int(r["Start_Timestamp"]))
+    marks = [i for i, r in enumerate(tr) if "trace_marker_kernel" in r["Kernel_Name"]]
+    if not marks:
+        sys.exit("summarize_profile: no trace_marker_kernel in %s -- not a trace of this revision's bench.py" % d)
+    dom = [int(r["End_Timestamp"]) - int(r["Start_Timestamp"]) for r in tr[marks[0] + 1:] if kernel_sub in r["Kernel_Name"]]
+    if len(dom) < 20:
+        sys.exit("summarize_profile: only %d launches of %s behind the marker in %s" % (len(dom), kernel_sub, d))
+    return sum(dom) / len(dom) / 1e3, rows
 
 
 per_run = {r: stats_of(r) for r in runs}
