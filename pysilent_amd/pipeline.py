@@ -423,6 +423,8 @@ class LineEndPipeline(object):
         if frames is None:
             frames = torch.randint(0, 256, (self.batch,) + self.frame_shape, device=self.tdev).to(torch.float32)
         t_start = time.perf_counter()
+        self.wait()                                # (an overlapped step still in flight on the side streams: order it, then let it finish)
+        torch.cuda.synchronize(self.tdev)
         if len(self._pyrs) < 2:
             self._pyrs.append(torch.empty_like(self._pyrs[0]))
         self.overlap = False
