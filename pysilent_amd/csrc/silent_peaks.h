@@ -1005,14 +1005,17 @@ struct CellTab {
 };
 
 // cell (j, i) of one H x W map v: total of the box, and its centroid (0 / 0 = NaN in an empty cell, like the reference)
-__device__ __forceinline__ void centroid_cell(const float* __restrict__ v, int H, int W, int y_first, int x_first, int rh, int rw, int j, int i,
-                                              float* tot_out, float* cx, float* cy) {
+// (load(y, x): the map's value at a pixel -- a plain array for the per-op kernel, the displayer's tail computes value / 255 and the
+// nearest-neighbour resize on the fly there)
+template <class Load>
+__device__ __forceinline__ void centroid_cell_of(Load load, int H, int W, int y_first, int x_first, int rh, int rw, int j, int i,
+                                                 float* tot_out, float* cx, float* cy) {
     const int y0 = max(y_first + j * rh, 0), y1 = min(y_first + j * rh + rh, H);
     const int x0 = max(x_first + i * rw, 0), x1 = min(x_first + i * rw + rw, W);
     float tot = 0.0f, sx = 0.0f, sy = 0.0f;
     for (int y = y0; y < y1; ++y)
         for (int x = x0; x < x1; ++x) {
-            const float val = v[(long long)y * W + x];
+            const float val = load(y, x);
             sx = __fadd_rn(sx, __fmul_rn((float)x, val));   // ind_tens * value, then the box sum (float32)
             sy = __fadd_rn(sy, __fmul_rn((float)y, val));
             const float half = __fmul_rn(val, 0.5f);        // value tiled to 2 channels times the 1/2 tap
@@ -1021,6 +1024,10 @@ __device__ __forceinline__ void centroid_cell(const float* __restrict__ v, int H
     *tot_out = tot;
     *cx = sx / tot;
     *cy = sy / tot;
+}
+__device__ __forceinline__ void centroid_cell(const float* __restrict__ v, int H, int W, int y_first, int x_first, int rh, int rw, int j, int i,
+                                              float* tot_out, float* cx, float* cy) {
+    centroid_cell_of([&](int y, int x) { return v[(long long)y * W + x]; }, H, W, y_first, x_first, rh, rw, j, i, tot_out, cx, cy);
 }
 
 __global__ __launch_bounds__(256) void centroid_cells_kernel(const float* __restrict__ value, const LevelTab tab,
@@ -1217,48 +1224,48 @@ struct DispTail {
     AffineP by255, imp, inv, x255;
     BoostP bp;
     const float* value;                            // [L, h, w]
-    float *g, *im2n;                               // value / 255; resized value / 255
+    float *g, *im2n;                               // (value / 255; resized value / 255: intermediates of the per-op path, not written here since round 6)
     float *cxy, *cxy2, *tot1;                      // centroids of both maps [cells][2]; cell totals of the first
     float *imp_out, *m;                            // importances; importances ** energy
     float *energy;                                 // [L, ch, cw] state, advanced in place
     float *out1, *out2, *out3, *update;            // 255 - dist * 255 (both maps), fired * 255, update_importances
 };
 
-// g = value / 255 on the full map; im2n = resize_nearest(value) / 255 on the half map
-__global__ __launch_bounds__(256) void disp_prep_kernel(const DispTail t) {
-    const long long px = (long long)t.L * t.h * t.w, px2 = (long long)t.L * t.h2 * t.w2;
-    const long long gid = (long long)blockIdx.x * 256 + threadIdx.x;
-    if (gid < px) {
-        t.g[gid] = affine_px(t.value[gid], t.by255);
-    } else if (gid < px + px2) {
-        const long long q = gid - px;
-        const int f = (int)(q / ((long long)t.h2 * t.w2)), p = (int)(q - (long long)f * t.h2 * t.w2);
-        const int y = p / t.w2, x = p - y * t.w2;
-        const int sy = min((int)floorf(__fmul_rn((float)y, t.yscale_r)), t.h - 1);
-        const int sx = min((int)floorf(__fmul_rn((float)x, t.xscale_r)), t.w - 1);
-        t.im2n[q] = affine_px(t.value[((long long)f * t.h + sy) * t.w + sx], t.by255);
-    }
-}
-
-// the centroid cells of both maps
+// Round 6: TWO launches instead of four (each costs ~5 us on the critical path of a camera frame).
+// (1) the centroid cells of both maps with value / 255 and the nearest-neighbour resize computed on the fly (the per-op path's
+//     affine_clip + resize_nearest + affine_clip kernels wrote them to memory first: same operations on the same floats), and for
+//     the cells of the first map the importances (total_pool * 255 / 4 clipped to [1, 256], - 1) and importances ** energy.
 __global__ __launch_bounds__(256) void disp_cells_kernel(const DispTail t) {
     const long long c1 = (long long)t.L * t.ch * t.cw, c2 = (long long)t.L * t.ch2 * t.cw2;
     const long long gid = (long long)blockIdx.x * 256 + threadIdx.x;
     if (gid < c1) {
         const int f = (int)(gid / ((long long)t.ch * t.cw)), r = (int)(gid - (long long)f * t.ch * t.cw);
-        centroid_cell(t.g + (long long)f * t.h * t.w, t.h, t.w, t.y_first, t.x_first, t.rh, t.rw, r / t.cw, r % t.cw, &t.tot1[gid],
-                      &t.cxy[gid * 2], &t.cxy[gid * 2 + 1]);
+        const float* __restrict__ v = t.value + (long long)f * t.h * t.w;
+        float tot;
+        centroid_cell_of([&](int y, int x) { return affine_px(v[(long long)y * t.w + x], t.by255); }, t.h, t.w, t.y_first, t.x_first, t.rh, t.rw,
+                         r / t.cw, r % t.cw, &tot, &t.cxy[gid * 2], &t.cxy[gid * 2 + 1]);
+        t.tot1[gid] = tot;
+        const float imp = affine_px(tot, t.imp);
+        t.imp_out[gid] = imp;
+        t.m[gid] = (float)pow((double)imp, (double)t.energy[gid]);          // boost_power_kernel
     } else if (gid < c1 + c2) {
         const long long q = gid - c1;
         const int f = (int)(q / ((long long)t.ch2 * t.cw2)), r = (int)(q - (long long)f * t.ch2 * t.cw2);
+        const float* __restrict__ v = t.value + (long long)f * t.h * t.w;
         float tot;
-        centroid_cell(t.im2n + (long long)f * t.h2 * t.w2, t.h2, t.w2, t.y_first2, t.x_first2, t.rh, t.rw, r / t.cw2, r % t.cw2, &tot,
-                      &t.cxy2[q * 2], &t.cxy2[q * 2 + 1]);
+        centroid_cell_of(
+            [&](int y, int x) {
+                const int sy = min((int)floorf(__fmul_rn((float)y, t.yscale_r)), t.h - 1);
+                const int sx = min((int)floorf(__fmul_rn((float)x, t.xscale_r)), t.w - 1);
+                return affine_px(v[(long long)sy * t.w + sx], t.by255);
+            },
+            t.h2, t.w2, t.y_first2, t.x_first2, t.rh, t.rw, r / t.cw2, r % t.cw2, &tot, &t.cxy2[q * 2], &t.cxy2[q * 2 + 1]);
     }
 }
 
-// 255 - dist * 255 of both maps, the importances (total_pool * 255 / 4 clipped to [1, 256], - 1) and importances ** energy
-__global__ __launch_bounds__(256) void disp_dist_kernel(const DispTail t) {
+// (2) 255 - dist * 255 of both maps, and -- beside them, it needs nothing of theirs -- boost_update_kernel + fired * 255
+//     (C channels: 3 with bp.visualize) on the cells
+__global__ __launch_bounds__(256) void disp_dist_boost_kernel(const DispTail t) {
     const long long px = (long long)t.L * t.h * t.w, px2 = (long long)t.L * t.h2 * t.w2, c1 = (long long)t.L * t.ch * t.cw;
     const long long gid = (long long)blockIdx.x * 256 + threadIdx.x;
     if (gid < px) {
@@ -1272,25 +1279,15 @@ __global__ __launch_bounds__(256) void disp_dist_kernel(const DispTail t) {
         t.out2[q] = affine_px(d, t.inv);
     } else if (gid < px + px2 + c1) {
         const long long q = gid - px - px2;
-        const float v = affine_px(t.tot1[q], t.imp);
-        t.imp_out[q] = v;
-        t.m[q] = (float)pow((double)v, (double)t.energy[q]);          // boost_power_kernel
-    }
-}
-
-// boost_update_kernel + fired * 255 (C channels: 3 with bp.visualize)
-__global__ __launch_bounds__(256) void disp_boost_kernel(const DispTail t) {
-    const long long c1 = (long long)t.L * t.ch * t.cw;
-    const long long gid = (long long)blockIdx.x * 256 + threadIdx.x;
-    if (gid >= c1) return;
-    const int f = (int)(gid / ((long long)t.ch * t.cw)), p = (int)(gid - (long long)f * t.ch * t.cw);
-    float f_out, e_out;
-    t.energy[gid] = boost_update_px(t.m + (long long)f * t.ch * t.cw, t.ch, t.cw, p, t.imp_out[gid], t.energy[gid], t.bp, &f_out, &e_out);
-    const int C = t.bp.visualize ? 3 : 1;
-    const float shown = affine_px(f_out, t.x255);
-    for (int c = 0; c < C; ++c) {
-        t.out3[gid * C + c] = shown;
-        t.update[gid * C + c] = e_out;
+        const int f = (int)(q / ((long long)t.ch * t.cw)), p = (int)(q - (long long)f * t.ch * t.cw);
+        float f_out, e_out;
+        t.energy[q] = boost_update_px(t.m + (long long)f * t.ch * t.cw, t.ch, t.cw, p, t.imp_out[q], t.energy[q], t.bp, &f_out, &e_out);
+        const int C = t.bp.visualize ? 3 : 1;
+        const float shown = affine_px(f_out, t.x255);
+        for (int c = 0; c < C; ++c) {
+            t.out3[q * C + c] = shown;
+            t.update[q * C + c] = e_out;
+        }
     }
 }
 

@@ -674,10 +674,8 @@ int displayer_tail(silent_ctx* ctx, int L, int h, int w, int rh, int rw, int h2,
     t.value = value; t.g = g; t.im2n = im2n; t.tot1 = tot1; t.imp_out = imp; t.energy = energy;
     t.out1 = out1; t.out2 = out2; t.out3 = out3; t.update = update;
     auto grid = [](long long n) { return dim3((unsigned)((n + 255) / 256)); };
-    hipLaunchKernelGGL(disp_prep_kernel, grid(px + px2), dim3(256), 0, s, t);
     hipLaunchKernelGGL(disp_cells_kernel, grid(cells + cells2), dim3(256), 0, s, t);
-    hipLaunchKernelGGL(disp_dist_kernel, grid(px + px2 + cells), dim3(256), 0, s, t);
-    hipLaunchKernelGGL(disp_boost_kernel, grid(cells), dim3(256), 0, s, t);
+    hipLaunchKernelGGL(disp_dist_boost_kernel, grid(px + px2 + cells), dim3(256), 0, s, t);
     return check_launch(ctx, who);
 }
 

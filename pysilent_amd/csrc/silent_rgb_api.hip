@@ -258,11 +258,18 @@ int rgb_chain_tile_height(const silent_ctx* ctx, const silent_extent* levels, in
         for (int l = 0; l < n_levels; ++l)
             tiles90 += (long long)((levels[l].w + tw - 1) / tw) * ((levels[l].h + kRgbTH - 1) / kRgbTH);
         const bool model = tiles90 * n_frames < 2 * resident;
-        for (int cand = kRgbTHMin; model && cand <= kRgbTHMax; cand += 2) {
+        // Round 6: launches far below one round (a camera frame: 2 - 4 levels of 192 x 288 = a few hundred tiles on a chip that
+        // holds 1536) are pure latency -- one wave's row walk, th + 14 steps of about a microsecond -- and the pair kernel has no
+        // chunking that ties the tile height to kRgbTHMin: down to 4 rows while the launch stays within a QUARTER of a round
+        // (measured on the application graph, 640 x 480: chain 44 -> 24 us, frame 0.2085 -> 0.1873 ms at 4 rows; 2 rows 0.1904,
+        // 6: 0.1898, 8: 0.1918, 12: 0.2013; profiles/r06_experiments.txt 8).  Fuller launches keep kRgbTHMin: there the rows a
+        // tile re-reads (14 per tile) cost bandwidth and issue slots, not just latency.
+        for (int cand = pair_kernel ? 4 : kRgbTHMin; model && cand <= kRgbTHMax; cand += 2) {
             long long tiles = 0;
             for (int l = 0; l < n_levels; ++l)
                 tiles += (long long)((levels[l].w + tw - 1) / tw) * ((levels[l].h + cand - 1) / cand);
             tiles *= n_frames;
+            if (cand < kRgbTHMin && tiles * 4 > resident) continue;
             const long long cost = ((tiles + resident - 1) / resident) * (cand + 2 * kRgbHalo);
             if (best < 0 || cost < best) {
                 best = cost;
