@@ -71,22 +71,30 @@ static int displayer_enqueue(silent_displayer* d, int slot) {
     silent_stream s = (silent_stream)d->stream;
     const int L = d->L;
     const silent_extent lev = {d->h, d->w};
-    HIP_TRY(d->owner, hipMemcpyAsync(d->d_raw, d->h_in, d->in_bytes, hipMemcpyHostToDevice, d->stream));
+    // Round 6, zero copy at both ends.  The pinned buffers are device-accessible (hipHostMalloc: mapped, coherent): a uint8 camera
+    // frame is read by the cast kernel straight from the pinned input buffer (no upload node), and the six results are WRITTEN by
+    // the kernels that produce them straight into the pinned result slot -- posted writes over the link, beside the arithmetic --
+    // instead of one 3.55 MB download behind the last kernel (64 of the frame's 151 us at 640 x 480).
+    float* const out = d->h_out[slot];
     // np.asarray(frame, dtype=float32) (:141)
-    if (d->prm.frame_dtype != SILENT_DT_F32)
-        TRY(silent_cast_interleave_dev(c, d->d_raw, d->prm.frame_dtype, (size_t)d->prm.frame_h * d->prm.frame_w, 3, 0, 3, d->d_frame, 3, 0, s));
+    if (d->prm.frame_dtype != SILENT_DT_F32) {
+        TRY(silent_cast_interleave_dev(c, d->h_in, d->prm.frame_dtype, (size_t)d->prm.frame_h * d->prm.frame_w, 3, 0, 3, d->d_frame, 3, 0, s));
+    } else {
+        // (float32 frames: the walk re-reads halo columns and rows -- from device memory, behind one upload)
+        HIP_TRY(d->owner, hipMemcpyAsync(d->d_raw, d->h_in, d->in_bytes, hipMemcpyHostToDevice, d->stream));
+    }
     // zoom.from_image (:142)
     TRY(silent_pyramid_dev(c, d->plan, d->prm.frame_dtype == SILENT_DT_F32 ? (const float*)d->d_raw : d->d_frame, 1, d->d_pyr, s));
     // rgc -> rgby -> orientation -> line-end -> clip -> pad_inwards; get_value_from_color (:69-77): the pyramid's levels are the batch
     silent_rgb_chain_params cp = d->prm.chain;
     cp.rgc = d->kernels; cp.rgby = d->kernels + 81; cp.stripe = d->kernels + 162; cp.end = d->kernels + 243; cp.blur = d->kernels + 324;
-    TRY(silent_rgb_line_end_dev(c, d->d_pyr, &lev, 1, L, &cp, d->d_orient, d->d_line, d->d_value, s));
+    TRY(silent_rgb_line_end_dev(c, d->d_pyr, &lev, 1, L, &cp, out + d->out_off[0], out + d->out_off[5], d->d_value, s));
     // centroids of gray / 255 (:79-80), importances (:81); the same on the nearest-neighbour half-size map (:82-84); get_boosting
     // (:86, advances energy_values); what the reference fetches (:99-100): 255 - centroids * 255 (both), fired * 255, update --
-    // fifteen launches of the per-op path (affine, centroid cells / dist, resize, boost power / update) as four (silent_peaks.h, DispTail)
+    // fifteen launches of the per-op path (affine, centroid cells / dist, resize, boost power / update) as two (silent_peaks.h, DispTail)
     TRY(displayer_tail(c, L, d->h, d->w, d->prm.centroid_region_h, d->prm.centroid_region_w, d->hh, d->hw, &d->prm.boosting, d->d_value,
-                       d->d_g, d->d_im2n, d->d_tot1, d->d_imp, d->d_energy, d->d_out1, d->d_out2, d->d_out3, d->d_update, d->stream));
-    HIP_TRY(d->owner, hipMemcpyAsync(d->h_out[slot], d->d_results, d->out_total * 4, hipMemcpyDeviceToHost, d->stream));
+                       d->d_g, d->d_im2n, d->d_tot1, d->d_imp, d->d_energy, out + d->out_off[1], out + d->out_off[2], out + d->out_off[3],
+                       out + d->out_off[4], d->stream));
     return SILENT_OK;
 }
 
@@ -120,6 +128,9 @@ SILENT_EXPORT int silent_displayer_create(silent_ctx* ctx, const silent_displaye
     int rc = silent_create(ctx->device, &d->ctx);
     if (rc != SILENT_OK) return fail(ctx, rc, std::string(who) + ": " + silent_last_error(nullptr));
     for (int i = 0; i < SILENT_TUNE_COUNT; ++i) d->ctx->tune[i] = ctx->tune[i];
+    // the chain kernel writes orient / line_end straight into pinned host memory here: 16-byte stores (knob bit 7, same bits as
+    // the 12-byte form, same speed into device memory) make better use of the link (in-place p50 0.174 -> 0.166 ms at 640 x 480)
+    d->ctx->tune[SILENT_TUNE_RGB] |= 128u;
     rc = silent_pyramid_plan_create(d->ctx, p->frame_h, p->frame_w, 3, levels, n_levels, &d->plan);
     if (rc != SILENT_OK) return fail(ctx, rc, std::string(who) + ": " + silent_last_error(d->ctx));
     d->L = n_levels;
