@@ -472,8 +472,8 @@ int silent_rgb_line_end_dev(silent_ctx* ctx, const float* pyr, const silent_exte
  *   0 orient [L,h,w,3]   1 255 - centroids * 255 [L,h,w,1]   2 255 - centroids2 * 255 [L,h2,w2,1] (h2 = int(h / e ** .5))
  *   3 fired * 255 [L,ch,cw,C]   4 update_importances [L,ch,cw,C]   5 padded line_end [L,h,w,3]      (ch = ceil(h / region_h);
  *                                                                                      C = 3 with boosting.visualize, else 1)
- * The reference pays a feed, a session.run and six fetches per frame; the displayer replays ONE HIP graph per frame (upload,
- * ~20 kernels, download) on a stream of its own and owns every buffer, a private context and the boosting state
+ * The reference pays a feed, a session.run and six fetches per frame; the displayer replays ONE HIP graph per frame (five kernels
+ * that read the pinned input buffer and write the pinned result slot themselves: no copy node) on a stream of its own and owns every buffer, a private context and the boosting state
  * (energy_values, :56; 8 everywhere at creation).  levels: the host's geometry of image_to_zoom_tensor (from_image.py:45-64),
  * every level on the same canvas extent.  Not thread-safe; frames of one camera must come to one displayer, in order. */
 typedef struct silent_displayer silent_displayer;

@@ -26,13 +26,12 @@ struct silent_displayer {
     // device
     void* slab = nullptr;
     void* d_raw = nullptr;
-    float *d_frame = nullptr, *d_pyr = nullptr, *d_orient = nullptr, *d_line = nullptr, *d_value = nullptr, *d_g = nullptr, *d_tot1 = nullptr,
-          *d_imp = nullptr, *d_im2n = nullptr, *d_update = nullptr, *d_energy = nullptr, *d_out1 = nullptr, *d_out2 = nullptr, *d_out3 = nullptr;
+    float *d_frame = nullptr, *d_pyr = nullptr, *d_value = nullptr, *d_tot1 = nullptr, *d_imp = nullptr, *d_energy = nullptr;
     // pinned host: the frame, and two result slots (the results of step n stay valid until step n + 2)
     void* h_in = nullptr;
     float* h_out[2] = {nullptr, nullptr};
     size_t out_floats[6] = {0, 0, 0, 0, 0, 0}, out_off[6] = {0, 0, 0, 0, 0, 0}, out_total = 0;   // (offsets / total in floats, 64-byte steps)
-    float* d_results = nullptr;           // the six results back to back on the device, in the layout of a host slot: ONE download
+    // (round 6: the six results have no device copy any more -- the kernels write them into the pinned slot, displayer_enqueue)
     int slot = 0;
     long long steps = 0;
 };
@@ -93,7 +92,7 @@ static int displayer_enqueue(silent_displayer* d, int slot) {
     // (:86, advances energy_values); what the reference fetches (:99-100): 255 - centroids * 255 (both), fired * 255, update --
     // fifteen launches of the per-op path (affine, centroid cells / dist, resize, boost power / update) as two (silent_peaks.h, DispTail)
     TRY(displayer_tail(c, L, d->h, d->w, d->prm.centroid_region_h, d->prm.centroid_region_w, d->hh, d->hw, &d->prm.boosting, d->d_value,
-                       d->d_g, d->d_im2n, d->d_tot1, d->d_imp, d->d_energy, out + d->out_off[1], out + d->out_off[2], out + d->out_off[3],
+                       nullptr, nullptr, d->d_tot1, d->d_imp, d->d_energy, out + d->out_off[1], out + d->out_off[2], out + d->out_off[3],
                        out + d->out_off[4], d->stream));
     return SILENT_OK;
 }
@@ -145,30 +144,23 @@ SILENT_EXPORT int silent_displayer_create(silent_ctx* ctx, const silent_displaye
     const size_t px = (size_t)d->L * d->h * d->w, cells = (size_t)d->L * d->ch * d->cw, px2 = (size_t)d->L * d->hh * d->hw;
     const int vis = p->boosting.visualize ? 3 : 1;
     d->in_bytes = (size_t)p->frame_h * p->frame_w * 3 * dt_size(p->frame_dtype);
-    // the six results first, back to back in 64-byte steps: the device block and a host slot share one layout
+    // the six results back to back in 64-byte steps: the layout of a pinned host slot
     const size_t outs[6] = {px * 3, px, px2, cells * vis, cells * vis, px * 3};
     for (int i = 0; i < 6; ++i) {
         d->out_floats[i] = outs[i];
         d->out_off[i] = d->out_total;
         d->out_total += (outs[i] + 15) / 16 * 16;
     }
-    const size_t want[] = {d->out_total * 4, d->in_bytes, (size_t)p->frame_h * p->frame_w * 12, px * 12, px * 4, px * 4, cells * 4, cells * 4, px2 * 4,
-                           cells * 4};
+    (void)px2;
+    const size_t want[] = {d->in_bytes, (size_t)p->frame_h * p->frame_w * 12, px * 12, px * 4, cells * 4, cells * 4, cells * 4};
     size_t total = 0;
     for (size_t b : want) total += align_up(b);
     HIP_TRY(ctx, hipMalloc(&d->slab, total));
     char* at = (char*)d->slab;
     auto take = [&](size_t b) { char* r = at; at += align_up(b); return r; };
-    d->d_results = (float*)take(want[0]);
-    d->d_orient = d->d_results + d->out_off[0];
-    d->d_out1 = d->d_results + d->out_off[1];
-    d->d_out2 = d->d_results + d->out_off[2];
-    d->d_out3 = d->d_results + d->out_off[3];
-    d->d_update = d->d_results + d->out_off[4];
-    d->d_line = d->d_results + d->out_off[5];
-    d->d_raw = take(want[1]);
-    float** f[] = {&d->d_frame, &d->d_pyr, &d->d_value, &d->d_g, &d->d_tot1, &d->d_imp, &d->d_im2n, &d->d_energy};
-    for (size_t i = 0; i < sizeof(f) / sizeof(f[0]); ++i) *f[i] = (float*)take(want[i + 2]);
+    d->d_raw = take(want[0]);
+    float** f[] = {&d->d_frame, &d->d_pyr, &d->d_value, &d->d_tot1, &d->d_imp, &d->d_energy};
+    for (size_t i = 0; i < sizeof(f) / sizeof(f[0]); ++i) *f[i] = (float*)take(want[i + 1]);
     HIP_TRY(ctx, hipHostMalloc(&d->h_in, d->in_bytes, hipHostMallocDefault));
     for (float*& hp : d->h_out) HIP_TRY(ctx, hipHostMalloc((void**)&hp, d->out_total * 4, hipHostMallocDefault));
     HIP_TRY(ctx, hipStreamCreateWithFlags(&d->stream, hipStreamNonBlocking));

@@ -644,7 +644,8 @@ SILENT_EXPORT int silent_resize_nearest_dev(silent_ctx* ctx, const float* in, co
 }
 
 // ------------------------------------------------------------------------------------------ the displayer's fused tail
-// (silent_displayer_api.hip) value [L, h, w] -> the four small results + the advanced state, in five launches (silent_peaks.h, DispTail)
+// (silent_displayer_api.hip) value [L, h, w] -> the four small results + the advanced state, in two launches (silent_peaks.h, DispTail);
+// g / im2n: unused since round 6 (value / 255 and its resize are computed on the fly), may be NULL
 int displayer_tail(silent_ctx* ctx, int L, int h, int w, int rh, int rw, int h2, int w2, const silent_boosting_params* boost, const float* value,
                    float* g, float* im2n, float* tot1, float* imp, float* energy, float* out1, float* out2, float* out3, float* update,
                    hipStream_t s) {
