@@ -579,7 +579,10 @@ static bool walk3_plan(const silent_ctx* ctx, const silent_pyramid_plan* plan, i
         w.strips_x = (w.out_w + kW3NC * px - 1) / (kW3NC * px);
         strip_rows += (long long)w.strips_x * w.out_h;
     }
-    const long long target = std::max<long long>(32, (2 * strip_rows * n_frames + 7 * resident - 1) / (7 * resident));   // rows per segment
+    // (round 6: a launch that stays within a quarter of the chip even in 8-row segments -- a single camera frame -- is pure latency,
+    // one block's walk of segment rows + 8: 8-row segments there, profiles/r06_experiments.txt 8)
+    const long long min_rows = (strip_rows * n_frames + 7) / 8 * 4 <= resident ? 8 : 32;
+    const long long target = std::max<long long>(min_rows, (2 * strip_rows * n_frames + 7 * resident - 1) / (7 * resident));   // rows per segment
     long long block0 = 0;
     for (int pi = 0; pi < wa->n_plans; ++pi) {
         Walk3Plan& w = wa->plan[pi];
