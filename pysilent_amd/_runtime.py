@@ -649,8 +649,10 @@ class FrameDisplayer(object):
         #: ``np.copyto``) and passes it to ``step`` is uploaded without the staging copy
         self.frame_buffer = np.frombuffer(buf, self.dtype).reshape(self.frame_shape)
 
-    def step(self, frame, copy=False):
-        """frame: [H, W, 3] ndarray of the displayer's dtype.  Returns the six float32 arrays -- ``copy=False`` (the zero-copy form):
+    def step(self, frame, copy=False, timing=False):
+        """frame: [H, W, 3] ndarray of the displayer's dtype.  ``timing``: also measure the device time of the frame (``gpu_ms``; HIP events
+        around the graph and a stream synchronisation instead of the poll of the frame's completion word: ~0.02 ms more wall time).
+        Returns the six float32 arrays -- ``copy=False`` (the zero-copy form):
         VIEWS of the displayer's pinned result slot, valid until the second next step (two slots alternate) and, like
         ``frame_buffer``, only while the displayer is open (``close`` defers the free while such views are alive);
         ``copy=True``: fresh arrays, like the reference's session.run (recognition_testing.py:132)."""
@@ -659,8 +661,9 @@ class FrameDisplayer(object):
         if not isinstance(frame, np.ndarray) or frame.dtype != self.dtype or tuple(frame.shape) != self.frame_shape:
             raise ValueError("frame must be a %s ndarray of shape %s" % (self.dtype, self.frame_shape,))
         f = frame if frame.flags["C_CONTIGUOUS"] else np.ascontiguousarray(frame)
-        self.ctx.check(self._lib.silent_displayer_step(self.handle, C.c_void_p(f.ctypes.data), self._res, C.byref(self._ms)))
-        self.gpu_ms = float(self._ms.value)
+        self.ctx.check(self._lib.silent_displayer_step(self.handle, C.c_void_p(f.ctypes.data), self._res, C.byref(self._ms) if timing else None))
+        if timing:
+            self.gpu_ms = float(self._ms.value)
         out = []
         if copy:
             # ONE copy of the whole slot (the six results lie back to back, 64-byte steps), then views of the copy

@@ -5,6 +5,8 @@
 // kernel nodes (every one a kernel of the other translation units, enqueued through their *_dev entry points while the stream
 // captures), a download node.  The object owns its buffers, its stream, a context of its own (nobody else regrows the workspace
 // the graph's nodes point into) and the boosting state (energy_values, recognition_testing.py:56).
+#include <chrono>
+
 #include "silent_internal.h"
 
 using namespace silent;
@@ -34,6 +36,11 @@ struct silent_displayer {
     // (round 6: the six results have no device copy any more -- the kernels write them into the pinned slot, displayer_enqueue)
     int slot = 0;
     long long steps = 0;
+    // completion signal (round 6): a one-thread kernel behind the last one stores the number of completed frames into h_flag (pinned host
+    // memory); a step that does not ask for the device time polls it instead of synchronising the stream
+    unsigned long long* d_seq = nullptr;
+    unsigned long long* h_flag = nullptr;
+    unsigned long long frames_signalled = 0;   // what h_flag will read once every launched frame has completed
 };
 
 static size_t dt_size(int dt) {
@@ -56,6 +63,7 @@ static void displayer_free(silent_displayer* d) {
         if (e) (void)hipEventDestroy(e);
     if (d->stream) (void)hipStreamDestroy(d->stream);
     if (d->slab) (void)hipFree(d->slab);
+    if (d->h_flag) (void)hipHostFree((void*)d->h_flag);
     if (d->h_in) (void)hipHostFree(d->h_in);
     for (float* p : d->h_out)
         if (p) (void)hipHostFree(p);
@@ -93,7 +101,7 @@ static int displayer_enqueue(silent_displayer* d, int slot) {
     // fifteen launches of the per-op path (affine, centroid cells / dist, resize, boost power / update) as two (silent_peaks.h, DispTail)
     TRY(displayer_tail(c, L, d->h, d->w, d->prm.centroid_region_h, d->prm.centroid_region_w, d->hh, d->hw, &d->prm.boosting, d->d_value,
                        nullptr, nullptr, d->d_tot1, d->d_imp, d->d_energy, out + d->out_off[1], out + d->out_off[2], out + d->out_off[3],
-                       out + d->out_off[4], d->stream));
+                       out + d->out_off[4], d->stream, d->d_seq, d->h_flag));
     return SILENT_OK;
 }
 
@@ -152,7 +160,7 @@ SILENT_EXPORT int silent_displayer_create(silent_ctx* ctx, const silent_displaye
         d->out_total += (outs[i] + 15) / 16 * 16;
     }
     (void)px2;
-    const size_t want[] = {d->in_bytes, (size_t)p->frame_h * p->frame_w * 12, px * 12, px * 4, cells * 4, cells * 4, cells * 4};
+    const size_t want[] = {d->in_bytes, (size_t)p->frame_h * p->frame_w * 12, px * 12, px * 4, cells * 4, cells * 4, cells * 4, 64};
     size_t total = 0;
     for (size_t b : want) total += align_up(b);
     HIP_TRY(ctx, hipMalloc(&d->slab, total));
@@ -161,6 +169,13 @@ SILENT_EXPORT int silent_displayer_create(silent_ctx* ctx, const silent_displaye
     d->d_raw = take(want[0]);
     float** f[] = {&d->d_frame, &d->d_pyr, &d->d_value, &d->d_tot1, &d->d_imp, &d->d_energy};
     for (size_t i = 0; i < sizeof(f) / sizeof(f[0]); ++i) *f[i] = (float*)take(want[i + 1]);
+    {
+        char* sig = take(64);
+        HIP_TRY(ctx, hipMemset(sig, 0, 64));
+        d->d_seq = (unsigned long long*)sig;
+    }
+    HIP_TRY(ctx, hipHostMalloc((void**)&d->h_flag, 64, hipHostMallocDefault));
+    *d->h_flag = 0;
     HIP_TRY(ctx, hipHostMalloc(&d->h_in, d->in_bytes, hipHostMallocDefault));
     for (float*& hp : d->h_out) HIP_TRY(ctx, hipHostMalloc((void**)&hp, d->out_total * 4, hipHostMallocDefault));
     HIP_TRY(ctx, hipStreamCreateWithFlags(&d->stream, hipStreamNonBlocking));
@@ -213,14 +228,14 @@ SILENT_EXPORT int silent_displayer_step(silent_displayer* d, const void* frame_h
     if (frame_host != d->h_in) std::memmove(d->h_in, frame_host, d->in_bytes);
     const int slot = d->slot;
     d->ctx->err.clear();
-    HIP_TRY(ctx, hipEventRecord(d->ev[0], d->stream));
+    if (gpu_ms) HIP_TRY(ctx, hipEventRecord(d->ev[0], d->stream));
     if (d->steps == 0) {
         // the first frame runs eagerly: the private context's workspace grows to its final size outside any capture
         const int rc = displayer_enqueue(d, slot);
         if (rc != SILENT_OK) return displayer_fail(d, rc, who);
     } else {
         if (!d->exec[slot]) {
-            // the same sequence under stream capture, once per result slot (the download nodes point into the slot)
+            // the same sequence under stream capture, once per result slot (the kernels' output pointers point into the slot)
             HIP_TRY(ctx, hipStreamBeginCapture(d->stream, hipStreamCaptureModeRelaxed));
             const int rc = displayer_enqueue(d, slot);
             hipGraph_t g = nullptr;
@@ -239,9 +254,33 @@ SILENT_EXPORT int silent_displayer_step(silent_displayer* d, const void* frame_h
         }
         HIP_TRY(ctx, hipGraphLaunch(d->exec[slot], d->stream));
     }
-    HIP_TRY(ctx, hipEventRecord(d->ev[1], d->stream));
-    HIP_TRY(ctx, hipStreamSynchronize(d->stream));
-    if (gpu_ms) HIP_TRY(ctx, hipEventElapsedTime(gpu_ms, d->ev[0], d->ev[1]));
+    ++d->frames_signalled;                       // one more frame in the queue: its signal kernel will store this number into h_flag
+    if (gpu_ms) {
+        HIP_TRY(ctx, hipEventRecord(d->ev[1], d->stream));
+        HIP_TRY(ctx, hipStreamSynchronize(d->stream));
+        HIP_TRY(ctx, hipEventElapsedTime(gpu_ms, d->ev[0], d->ev[1]));
+    } else {
+        // Nobody asked for the device time: wait for the frame's own completion word in pinned memory (a one-thread kernel behind
+        // the last one writes it; the results are in the same kind of memory, stored by kernels that have ended) instead of a stream synchronisation --
+        // the driver's wake-up costs more than the last two kernels of a 640 x 480 frame.  Bounded: after 20 ms the stream is
+        // synchronised the ordinary way (a faulting kernel never signals; the error then surfaces there).
+        const unsigned long long want = d->frames_signalled;
+        const auto t_end = std::chrono::steady_clock::now() + std::chrono::milliseconds(20);
+        bool seen = false;
+#ifdef SILENT_HOST_ONLY
+        for (unsigned spin = 0; spin < 1; ++spin) {        // (no device behind the sanitizer build: nothing will ever signal)
+#else
+        for (unsigned spin = 0;; ++spin) {
+#endif
+            if (__atomic_load_n(d->h_flag, __ATOMIC_ACQUIRE) >= want) {
+                seen = true;
+                break;
+            }
+            __builtin_ia32_pause();
+            if ((spin & 1023u) == 1023u && std::chrono::steady_clock::now() > t_end) break;
+        }
+        if (!seen) HIP_TRY(ctx, hipStreamSynchronize(d->stream));
+    }
     for (int i = 0; i < 6; ++i) results[i] = d->h_out[slot] + d->out_off[i];
     d->slot ^= 1;
     ++d->steps;

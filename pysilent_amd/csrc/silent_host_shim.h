@@ -86,6 +86,7 @@ void __hipUnregisterFatBinary(void**) {}
 #define hipMalloc(p, n) silent_host::Malloc((void**)(p), (n))
 #define hipFree(p) silent_host::Free((void*)(p))
 #define hipMemcpy(d, s, n, kind) silent_host::Memcpy((void*)(d), (const void*)(s), (n))
+#define hipMemset(d, v, n) (std::memset((void*)(d), (v), (n)), hipSuccess)
 #define hipMemcpyAsync(d, s, n, kind, stream) silent_host::Memcpy((void*)(d), (const void*)(s), (n))
 #define hipStreamSynchronize(s) ((void)(s), hipSuccess)
 #define hipStreamIsCapturing(s, st) ((void)(s), *(st) = hipStreamCaptureStatusNone, hipSuccess)

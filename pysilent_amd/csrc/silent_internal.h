@@ -161,7 +161,7 @@ int rgb_chain_launch(silent_ctx* ctx, const char* who, const float* pyr, const s
                      const silent_rgb_chain_params* p, float* orient_out, float* line_end_out, float* value_out, unsigned* mm,
                      bool* mm_done, silent_stream stream, const silent::SumTab* st = nullptr, float* sum = nullptr,
                      int* nan_flags = nullptr);
-// (silent_peaks_api.hip) the tail of the displayer's graph after the chain, fused into four launches (silent_peaks.h, DispTail)
+// (silent_peaks_api.hip) the tail of the displayer's graph after the chain, fused into two launches (silent_peaks.h, DispTail); seq / flag: the completion signal
 int displayer_tail(silent_ctx* ctx, int L, int h, int w, int rh, int rw, int h2, int w2, const silent_boosting_params* boost, const float* value,
                    float* g, float* im2n, float* tot1, float* imp, float* energy, float* out1, float* out2, float* out3, float* update,
-                   hipStream_t s);
+                   hipStream_t s, unsigned long long* seq = nullptr, unsigned long long* flag = nullptr);

@@ -1229,6 +1229,10 @@ struct DispTail {
     float *imp_out, *m;                            // importances; importances ** energy
     float *energy;                                 // [L, ch, cw] state, advanced in place
     float *out1, *out2, *out3, *update;            // 255 - dist * 255 (both maps), fired * 255, update_importances
+    // completion signal (NULL: none): disp_signal_kernel, one thread behind the last kernel, bumps *seq and stores it to *flag -- a
+    // word in pinned host memory the caller polls instead of paying a stream synchronisation (silent_displayer_step)
+    unsigned long long* seq;                       // frames completed (device)
+    unsigned long long* flag;                      // = *seq, in pinned host memory
 };
 
 // Round 6: TWO launches instead of four (each costs ~5 us on the critical path of a camera frame).
@@ -1288,6 +1292,17 @@ __global__ __launch_bounds__(256) void disp_dist_boost_kernel(const DispTail t) 
             t.out3[q * C + c] = shown;
             t.update[q * C + c] = e_out;
         }
+    }
+}
+
+// The frame's completion word.  A kernel of its own BEHIND the last one: the kernels in front have ended, their stores (some of them
+// into pinned host memory) are visible system-wide.  (Counting finished blocks inside the last kernel, with a system-scope fence per
+// block, made that kernel wait for the link 700 times: + 60 us per frame, measured.)
+__global__ __launch_bounds__(64) void disp_signal_kernel(unsigned long long* seq, unsigned long long* flag) {
+    if (threadIdx.x == 0) {
+        const unsigned long long n = *seq + 1;
+        *seq = n;
+        __hip_atomic_store(flag, n, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
     }
 }
 

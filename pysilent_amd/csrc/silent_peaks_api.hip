@@ -648,7 +648,7 @@ SILENT_EXPORT int silent_resize_nearest_dev(silent_ctx* ctx, const float* in, co
 // g / im2n: unused since round 6 (value / 255 and its resize are computed on the fly), may be NULL
 int displayer_tail(silent_ctx* ctx, int L, int h, int w, int rh, int rw, int h2, int w2, const silent_boosting_params* boost, const float* value,
                    float* g, float* im2n, float* tot1, float* imp, float* energy, float* out1, float* out2, float* out3, float* update,
-                   hipStream_t s) {
+                   hipStream_t s, unsigned long long* seq, unsigned long long* flag) {
     const char* who = "silent_displayer_step";
     DispTail t;
     std::memset(&t, 0, sizeof(t));
@@ -674,9 +674,11 @@ int displayer_tail(silent_ctx* ctx, int L, int h, int w, int rh, int rw, int h2,
     t.m = t.cxy2 + cells2 * 2;
     t.value = value; t.g = g; t.im2n = im2n; t.tot1 = tot1; t.imp_out = imp; t.energy = energy;
     t.out1 = out1; t.out2 = out2; t.out3 = out3; t.update = update;
+    t.seq = seq; t.flag = flag;
     auto grid = [](long long n) { return dim3((unsigned)((n + 255) / 256)); };
     hipLaunchKernelGGL(disp_cells_kernel, grid(cells + cells2), dim3(256), 0, s, t);
     hipLaunchKernelGGL(disp_dist_boost_kernel, grid(px + px2 + cells), dim3(256), 0, s, t);
+    if (flag) hipLaunchKernelGGL(disp_signal_kernel, dim3(1), dim3(64), 0, s, seq, flag);
     return check_launch(ctx, who);
 }
 
