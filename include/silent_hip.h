@@ -499,6 +499,12 @@ int silent_displayer_shape(const silent_displayer* d, int32_t* shape7, size_t* o
  * one stores the frame count into pinned host memory, the host polls it (bounded: after 20 ms it synchronises the stream the
  * ordinary way, where a failed launch surfaces) -- which is ~0.02 ms less wall time per frame. */
 int silent_displayer_step(silent_displayer* d, const void* frame_host, const float** results, float* gpu_ms);
+/* More result slots, for callers that hand the results out zero-copy and must not overwrite what somebody still holds (the reference's
+ * session.run returns fresh arrays, recognition_testing.py:132): silent_displayer_add_slot allocates one more pinned slot (numbers 0 and
+ * 1 exist from creation: silent_displayer_step alternates between those two), silent_displayer_step_slot is silent_displayer_step
+ * into a slot of the caller's choice -- one nobody references any more (pysilent_amd._runtime.FrameDisplayer keeps the books). */
+int silent_displayer_add_slot(silent_displayer* d, int* slot_index);
+int silent_displayer_step_slot(silent_displayer* d, const void* frame_host, int slot, const float** results, float* gpu_ms);
 /* The displayer's pinned input buffer: a capture loop that writes the camera frame THERE and passes this pointer to
  * silent_displayer_step skips the staging copy (6 MB per 1080p frame).  A frame_host that overlaps the buffer at another
  * offset is moved into place (memmove). */

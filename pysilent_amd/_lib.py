@@ -149,6 +149,8 @@ _SIGNATURES = {
     "silent_displayer_destroy": [_vp],
     "silent_displayer_shape": [_vp, C.POINTER(C.c_int32), C.POINTER(_sz)],
     "silent_displayer_step": [_vp, _vp, C.POINTER(_vp), C.POINTER(_f)],
+    "silent_displayer_add_slot": [_vp, C.POINTER(_i)],
+    "silent_displayer_step_slot": [_vp, _vp, _i, C.POINTER(_vp), C.POINTER(_f)],
     "silent_displayer_input": [_vp, C.POINTER(_vp), C.POINTER(_sz)],
     "silent_displayer_get_state": [_vp, _fp],
     "silent_displayer_set_state": [_vp, _fp],

@@ -649,23 +649,40 @@ class FrameDisplayer(object):
         #: ``np.copyto``) and passes it to ``step`` is uploaded without the staging copy
         self.frame_buffer = np.frombuffer(buf, self.dtype).reshape(self.frame_shape)
 
-    def step(self, frame, copy=False, timing=False):
-        """frame: [H, W, 3] ndarray of the displayer's dtype.  ``timing``: also measure the device time of the frame (``gpu_ms``; HIP events
-        around the graph and a stream synchronisation instead of the poll of the frame's completion word: ~0.02 ms more wall time).
-        Returns the six float32 arrays -- ``copy=False`` (the zero-copy form):
-        VIEWS of the displayer's pinned result slot, valid until the second next step (two slots alternate) and, like
-        ``frame_buffer``, only while the displayer is open (``close`` defers the free while such views are alive);
-        ``copy=True``: fresh arrays, like the reference's session.run (recognition_testing.py:132)."""
+    #: result slots a displayer may hold for ``step(hold=True)`` before it falls back to copying (3.55 MB each at 640 x 480)
+    MAX_HELD_SLOTS = 8
+
+    def step(self, frame, copy=False, timing=False, hold=False):
+        """frame: [H, W, 3] ndarray of the displayer's dtype.  Returns the six float32 arrays, in one of three ways:
+
+        ``hold=True`` -- what ``LineEndDisplayer.callback`` hands out: arrays that stay valid FOR AS LONG AS THEY ARE REFERENCED, like the
+        fresh arrays of the reference's session.run (recognition_testing.py:132), without a copy: the frame is stepped into a pinned
+        result slot nobody references any more (the displayer keeps weak references to what it handed out; slots are added on demand,
+        at most MAX_HELD_SLOTS); when every slot is still held the frame goes through the two alternating slots and is COPIED out.
+        ``copy=False`` (default) -- the raw form: views of one of two alternating slots, valid until the second next raw step.
+        ``copy=True`` -- fresh arrays by one memcpy of the slot.
+        All views (and ``frame_buffer``) keep the displayer alive; ``close`` defers the free while they exist.
+        ``timing``: also measure the device time of the frame (``gpu_ms``; HIP events around the graph and a stream synchronisation
+        instead of the poll of the frame's completion word: ~0.02 ms more wall time)."""
         if not getattr(self, "handle", None):
             raise RuntimeError("the displayer is closed")
         if not isinstance(frame, np.ndarray) or frame.dtype != self.dtype or tuple(frame.shape) != self.frame_shape:
             raise ValueError("frame must be a %s ndarray of shape %s" % (self.dtype, self.frame_shape,))
         f = frame if frame.flags["C_CONTIGUOUS"] else np.ascontiguousarray(frame)
-        self.ctx.check(self._lib.silent_displayer_step(self.handle, C.c_void_p(f.ctypes.data), self._res, C.byref(self._ms) if timing else None))
+        ms = C.byref(self._ms) if timing else None
+        slot = None
+        if hold:
+            slot = self._free_slot()
+            if slot is None:
+                copy = True                     # every slot is still referenced by somebody: this frame is copied out
+        if slot is None:
+            self.ctx.check(self._lib.silent_displayer_step(self.handle, C.c_void_p(f.ctypes.data), self._res, ms))
+        else:
+            self.ctx.check(self._lib.silent_displayer_step_slot(self.handle, C.c_void_p(f.ctypes.data), slot, self._res, ms))
         if timing:
             self.gpu_ms = float(self._ms.value)
         out = []
-        if copy:
+        if copy and slot is None:
             # ONE copy of the whole slot (the six results lie back to back, 64-byte steps), then views of the copy
             ptrs = [int(p) for p in self._res]
             total = (max(ptrs) - min(ptrs)) // 4 + int(np.prod(self.shapes[ptrs.index(max(ptrs))]))
@@ -674,14 +691,30 @@ class FrameDisplayer(object):
                 o = (ptr - min(ptrs)) // 4
                 out.append(whole[o:o + int(np.prod(sh))].reshape(sh))
             return out
+        refs = self._exports if slot is None else self._held[slot]
         for ptr, sh in zip(self._res, self.shapes):
             buf = (C.c_float * int(np.prod(sh))).from_address(ptr)
             buf._owner = self               # the views keep the displayer (and with it the pinned slot) alive
-            self._exports.append(weakref.ref(buf))
+            refs.append(weakref.ref(buf))
             out.append(np.frombuffer(buf, np.float32).reshape(sh))
         if len(self._exports) > 64:
             self._exports = [r for r in self._exports if r() is not None]
         return out
+
+    def _free_slot(self):
+        """A held-results slot (numbers 2, 3, ...: 0 and 1 are the raw alternating pair) nobody references any more; a new one while
+        fewer than MAX_HELD_SLOTS exist; None when all are taken."""
+        held = self.__dict__.setdefault("_held", {})
+        for slot, refs in held.items():
+            if not any(r() is not None for r in refs):
+                del refs[:]
+                return slot
+        if len(held) >= self.MAX_HELD_SLOTS:
+            return None
+        idx = C.c_int(-1)
+        self.ctx.check(self._lib.silent_displayer_add_slot(self.handle, C.byref(idx)))
+        held[int(idx.value)] = []
+        return int(idx.value)
 
     def get_state(self):
         st = np.empty(self.state_shape, np.float32)
@@ -703,7 +736,8 @@ class FrameDisplayer(object):
             return
         fb = self.__dict__.pop("frame_buffer", None)      # our own reference to the input view does not count
         del fb
-        if any(r() is not None for r in getattr(self, "_exports", ())):
+        live = list(getattr(self, "_exports", ())) + [r for refs in getattr(self, "_held", {}).values() for r in refs]
+        if any(r() is not None for r in live):
             self._deferred, self.handle = self.handle, C.c_void_p()
             return
         self._lib.silent_displayer_destroy(self.handle)

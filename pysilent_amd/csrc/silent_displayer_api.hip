@@ -6,6 +6,7 @@
 // captures), a download node.  The object owns its buffers, its stream, a context of its own (nobody else regrows the workspace
 // the graph's nodes point into) and the boosting state (energy_values, recognition_testing.py:56).
 #include <chrono>
+#include <vector>
 
 #include "silent_internal.h"
 
@@ -18,8 +19,8 @@ struct silent_displayer {
     silent_ctx* ctx = nullptr;            // private context: workspace of the graph's nodes
     silent_pyramid_plan* plan = nullptr;
     hipStream_t stream = nullptr;
-    hipGraph_t graph[2] = {nullptr, nullptr};        // one per result slot (the download nodes point into the slot)
-    hipGraphExec_t exec[2] = {nullptr, nullptr};
+    std::vector<hipGraph_t> graph;        // one per result slot (the kernels' output pointers point into the slot)
+    std::vector<hipGraphExec_t> exec;
     hipEvent_t ev[2] = {nullptr, nullptr};
     silent_displayer_params prm{};
     float kernels[4 * 81 + 441];          // private copy of the chain's constant kernels (the caller's arrays may go away)
@@ -29,9 +30,11 @@ struct silent_displayer {
     void* slab = nullptr;
     void* d_raw = nullptr;
     float *d_frame = nullptr, *d_pyr = nullptr, *d_value = nullptr, *d_tot1 = nullptr, *d_imp = nullptr, *d_energy = nullptr;
-    // pinned host: the frame, and two result slots (the results of step n stay valid until step n + 2)
+    // pinned host: the frame, and the result slots -- two at creation (silent_displayer_step alternates between them: the results of
+    // step n stay valid until step n + 2), more on demand (silent_displayer_add_slot / silent_displayer_step_slot: a caller that hands
+    // the results out zero-copy steps into a slot nobody holds any more)
     void* h_in = nullptr;
-    float* h_out[2] = {nullptr, nullptr};
+    std::vector<float*> h_out;
     size_t out_floats[6] = {0, 0, 0, 0, 0, 0}, out_off[6] = {0, 0, 0, 0, 0, 0}, out_total = 0;   // (offsets / total in floats, 64-byte steps)
     // (round 6: the six results have no device copy any more -- the kernels write them into the pinned slot, displayer_enqueue)
     int slot = 0;
@@ -177,7 +180,13 @@ SILENT_EXPORT int silent_displayer_create(silent_ctx* ctx, const silent_displaye
     HIP_TRY(ctx, hipHostMalloc((void**)&d->h_flag, 64, hipHostMallocDefault));
     *d->h_flag = 0;
     HIP_TRY(ctx, hipHostMalloc(&d->h_in, d->in_bytes, hipHostMallocDefault));
-    for (float*& hp : d->h_out) HIP_TRY(ctx, hipHostMalloc((void**)&hp, d->out_total * 4, hipHostMallocDefault));
+    for (int k = 0; k < 2; ++k) {
+        float* hp = nullptr;
+        HIP_TRY(ctx, hipHostMalloc((void**)&hp, d->out_total * 4, hipHostMallocDefault));
+        d->h_out.push_back(hp);
+        d->graph.push_back(nullptr);
+        d->exec.push_back(nullptr);
+    }
     HIP_TRY(ctx, hipStreamCreateWithFlags(&d->stream, hipStreamNonBlocking));
     for (hipEvent_t& e : d->ev) HIP_TRY(ctx, hipEventCreate(&e));
     // initialize_boosting: 8 everywhere (boosting.py:6-7, recognition_testing.py:56)
@@ -218,15 +227,49 @@ static int displayer_fail(silent_displayer* d, int rc, const char* who) {
 // frame_host: the camera frame [frame_h, frame_w, 3] of the dtype the displayer was created for.  results[0 .. 5]: pointers INTO
 // the displayer's pinned result slot (layouts: silent_displayer_shape), valid until the second next step.  gpu_ms (may be NULL):
 // device time of the frame, upload to download, from events around the graph.  Synchronous.
-SILENT_EXPORT int silent_displayer_step(silent_displayer* d, const void* frame_host, const float** results, float* gpu_ms) try {
-    if (!d) return fail(nullptr, SILENT_E_INVALID, "silent_displayer_step: displayer is NULL");
+// One more pinned result slot (its graph is captured the first time a frame is stepped into it); *slot_index: its number.
+SILENT_EXPORT int silent_displayer_add_slot(silent_displayer* d, int* slot_index) try {
+    if (!d || !slot_index) return fail(d ? d->owner : nullptr, SILENT_E_INVALID, "silent_displayer_add_slot: NULL pointer");
     silent_ctx* ctx = d->owner;
     NEED_CTX(ctx);
-    const char* who = "silent_displayer_step";
+    if (d->h_out.size() >= 64) return fail(ctx, SILENT_E_INVALID, "silent_displayer_add_slot: at most 64 result slots");
+    float* hp = nullptr;
+    HIP_TRY(ctx, hipHostMalloc((void**)&hp, d->out_total * 4, hipHostMallocDefault));
+    d->h_out.push_back(hp);
+    d->graph.push_back(nullptr);
+    d->exec.push_back(nullptr);
+    *slot_index = (int)d->h_out.size() - 1;
+    return SILENT_OK;
+} catch (...) {
+    return on_exception(d ? d->owner : nullptr, "silent_displayer_add_slot");
+}
+
+static int displayer_step_slot(silent_displayer* d, const void* frame_host, int slot, const float** results, float* gpu_ms, const char* who);
+
+SILENT_EXPORT int silent_displayer_step(silent_displayer* d, const void* frame_host, const float** results, float* gpu_ms) try {
+    if (!d) return fail(nullptr, SILENT_E_INVALID, "silent_displayer_step: displayer is NULL");
+    const int rc = displayer_step_slot(d, frame_host, d->slot, results, gpu_ms, "silent_displayer_step");
+    if (rc == SILENT_OK) d->slot ^= 1;
+    return rc;
+} catch (...) {
+    return on_exception(d ? d->owner : nullptr, "silent_displayer_step");
+}
+
+SILENT_EXPORT int silent_displayer_step_slot(silent_displayer* d, const void* frame_host, int slot, const float** results, float* gpu_ms) try {
+    if (!d) return fail(nullptr, SILENT_E_INVALID, "silent_displayer_step_slot: displayer is NULL");
+    if (slot < 0 || slot >= (int)d->h_out.size())
+        return fail(d->owner, SILENT_E_INVALID, "silent_displayer_step_slot: no such result slot (silent_displayer_add_slot)");
+    return displayer_step_slot(d, frame_host, slot, results, gpu_ms, "silent_displayer_step_slot");
+} catch (...) {
+    return on_exception(d ? d->owner : nullptr, "silent_displayer_step_slot");
+}
+
+static int displayer_step_slot(silent_displayer* d, const void* frame_host, int slot, const float** results, float* gpu_ms, const char* who) {
+    silent_ctx* ctx = d->owner;
+    NEED_CTX(ctx);
     if (!frame_host || !results) return fail(ctx, SILENT_E_INVALID, std::string(who) + ": NULL pointer");
     // (a capture loop may grab INTO silent_displayer_input; a frame that is a view at an offset into that buffer overlaps it: memmove)
     if (frame_host != d->h_in) std::memmove(d->h_in, frame_host, d->in_bytes);
-    const int slot = d->slot;
     d->ctx->err.clear();
     if (gpu_ms) HIP_TRY(ctx, hipEventRecord(d->ev[0], d->stream));
     if (d->steps == 0) {
@@ -282,11 +325,8 @@ SILENT_EXPORT int silent_displayer_step(silent_displayer* d, const void* frame_h
         if (!seen) HIP_TRY(ctx, hipStreamSynchronize(d->stream));
     }
     for (int i = 0; i < 6; ++i) results[i] = d->h_out[slot] + d->out_off[i];
-    d->slot ^= 1;
     ++d->steps;
     return SILENT_OK;
-} catch (...) {
-    return on_exception(d ? d->owner : nullptr, "silent_displayer_step");
 }
 
 // The displayer's pinned input buffer (frame_h x frame_w x 3 of the frame dtype): a frame written there and passed to

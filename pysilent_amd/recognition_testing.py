@@ -27,9 +27,10 @@ class LineEndDisplayer(PyramidDisplayer):
     def __init__(self, n_dimensions=2, use_graph=False, native=True, **argv):
         """``native`` (default): ``callback`` hands the camera frame to ONE library call (silent_displayer_step: upload, cast,
         pyramid, the whole graph, download -- a HIP graph replayed per frame, buffers and boosting state owned by the library;
-        _runtime.FrameDisplayer).  Like the reference's session.run (recognition_testing.py:132) ``callback`` returns FRESH
-        arrays; ``callback(frame, copy=False)`` returns views of a pinned result slot instead, valid until the second next
-        frame (0.03 ms less per 640 x 480 frame).  ``native=False``: the
+        _runtime.FrameDisplayer).  Like the reference's session.run (recognition_testing.py:132) ``callback`` returns arrays that
+        are the caller's for as long as it holds them -- without a copy: the frame is computed into a pinned result slot nobody
+        references any more (``FrameDisplayer.step(hold=True)``; up to eight slots, then copies).  ``callback(frame, copy=False)``
+        returns the raw views of two alternating slots instead, valid until the second next frame.  ``native=False``: the
         per-op path below (``run`` / ``run_device`` always take it: they start from a pyramid, not from a frame).
         ``use_graph`` (per-op path): capture the ~20 launches of one frame into a HIP graph the first time a pyramid shape is
         seen and replay it per frame (torch.cuda.CUDAGraph is only the capture / replay plumbing; every node is one
@@ -163,7 +164,7 @@ class LineEndDisplayer(PyramidDisplayer):
         import torch
         if self.native and isinstance(frame, np.ndarray) and frame.ndim == 3 and frame.shape[2] == 3 and self.output_colors == 3 \
                 and frame.dtype.name in _runtime.FrameDisplayer._DT:
-            tensors = self._native_for(frame).step(frame, copy=copy)
+            tensors = self._native_for(frame).step(frame, hold=bool(copy))
             return [frame] + [[tensors[x][y] for y in range(len(tensors[x]))] for x in range(6)]
         # frame -> GPU once; the zoom pyramid stays on the device between from_image and the graph
         dev = torch.device("cuda", self.device_index)

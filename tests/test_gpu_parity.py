@@ -647,8 +647,7 @@ def test_line_end_displayer_results_outlive_frames_shape_changes_and_close(rt):
     from pysilent_amd.recognition_testing import LineEndDisplayer
     disp = LineEndDisplayer(output_size=(96, 64))
     f0 = structured_frame(80, 150, 230, 3)
-    kept = disp.callback(f0)                                   # fresh arrays
-    assert all(lev.flags["OWNDATA"] or lev.base is not None and lev.base.flags["OWNDATA"] for lev in kept[1])
+    kept = disp.callback(f0)                                   # the caller's for as long as it holds them (a pinned slot of their own)
     want = [np.stack(kept[i]).copy() for i in range(1, 7)]
     views = disp.callback(f0 * 0 + 7.0, copy=False)            # views of a pinned slot (another state step: other values)
     want_views = [np.stack(views[i]).copy() for i in range(1, 7)]
@@ -681,6 +680,24 @@ def test_line_end_displayer_results_outlive_frames_shape_changes_and_close(rt):
     again = fresh.callback(f0)
     for i in range(6):
         np.testing.assert_array_equal(np.stack(again[1 + i]), want[i])
+    # the slot pool: results that are dropped give their slot back (a long run needs two or three slots, not one per frame) ...
+    fd = fresh._native[1]
+    for step in range(20):
+        r = fresh.callback(structured_frame(100 + step, 150, 230, 3))
+    assert 1 <= len(fd._held) <= 3
+    # ... and a consumer that keeps EVERYTHING gets copies once MAX_HELD_SLOTS slots are taken: still every frame's own values
+    per_op = LineEndDisplayer(output_size=(96, 64), native=False)
+    per_op.callback(f0)                                        # (compiles the pyramid shape; the state is set next)
+    per_op.set_state(fresh.get_state())
+    hoard, wants = [], []
+    for step in range(fd.MAX_HELD_SLOTS + 4):
+        fr = structured_frame(200 + step, 150, 230, 3)
+        hoard.append(fresh.callback(fr))
+        wants.append([np.stack(x) for x in per_op.callback(fr)[1:]])
+    assert len(fd._held) == fd.MAX_HELD_SLOTS
+    for got, want_f in zip(hoard, wants):
+        for i in range(6):
+            np.testing.assert_array_equal(np.stack(got[1 + i]), want_f[i])
 
 
 # ----------------------------------------------------------------------------- RGB chain
