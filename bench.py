@@ -482,8 +482,8 @@ def latency_record():
             rec["%s_ms_p50" % label] = round(float(np.percentile(ts, 50)), 4)
             rec["%s_ms_p99" % label] = round(float(np.percentile(ts, 99)), 4)
             if label == "native":
-                # callback(copy=False): views of the pinned result slot instead of fresh arrays (the reference's session.run
-                # returns fresh arrays, and so does callback by default: the copy is one memcpy of the slot)
+                # callback(copy=False): the raw views of two alternating pinned slots (valid until the second next frame) instead of
+                # callback's default, arrays the caller may keep (a pinned slot nobody references any more; no copy either)
                 ts = []
                 for i in range(n):
                     t0 = time.perf_counter()
@@ -639,7 +639,7 @@ def record_side(out):
                                                      100 * cfg["whole_pass_frac_of_hbm_peak"], cfg["first_draw_ms"])]
     parts += ["%s %.4f ms %.1f%% (first draw %s)" % (k, v[0], 100 * v[1], v[2]) for k, v in side.items()]
     if lat:
-        parts.append("latency 640x480 p50: %.4f ms fresh arrays, %.4f views, %.4f in place, GPU busy %.4f" % (
+        parts.append("latency 640x480 p50: %.4f ms callback (arrays the caller may keep), %.4f raw views, %.4f in place, GPU busy %.4f" % (
             lat.get("native_ms_p50", 0), lat.get("native_views_ms_p50", 0), lat.get("native_in_place_ms_p50", 0), lat.get("gpu_busy_ms", 0)))
     r = out["roofline"]
     parts.append("roofline %s %.4f ms frac %.4f traffic %s" % (r["kernel"], r["avg_launch_ms"], r["frac"], r["traffic"]))
