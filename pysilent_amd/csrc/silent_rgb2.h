@@ -41,9 +41,6 @@ constexpr int kRgb2Cols = 128 - 2 * kRgb2Halo;   // 112 output columns per wave
 constexpr int kRgb2Waves = RGB2_WAVES;          // waves side by side in a block
 constexpr int kRgb2TW = kRgb2Waves * kRgb2Cols;
 constexpr int kRgb2RowHalo = 7;                  // rows above / below a tile (same as silent_rgb.h)
-#ifndef RGB2_MM_WAVES
-#define RGB2_MM_WAVES 3   // waves / SIMD the extrema (MM) and 16-byte-store (ST4) instantiations are compiled for (149 VGPRs; 4 = 128)
-#endif
 #ifndef RGB2_STORE_AUX
 #define RGB2_STORE_AUX 2
 #endif
@@ -472,7 +469,7 @@ __device__ __forceinline__ float relu_max3_poisoned(float v, float u) {   // u: 
 // fast as the 12-byte form (0.806 vs 0.804 ms per config-3 launch): not the default.
 template <unsigned RGC_PAIRS, bool STRIPE_SUM, unsigned RGBY_A, unsigned END_A0, unsigned END_A1, unsigned END_A2, bool MM = false, bool SYM = false,
           bool ST4 = false>
-__global__ __launch_bounds__(64 * kRgb2Waves) __attribute__((amdgpu_waves_per_eu((MM || ST4) ? RGB2_MM_WAVES : 4, 8))) void rgb_line_end2_kernel(const Rgb2Args args) {
+__global__ __launch_bounds__(64 * kRgb2Waves) __attribute__((amdgpu_waves_per_eu((MM || ST4) ? 3 : 4, 8))) void rgb_line_end2_kernel(const Rgb2Args args) {
     typedef Rgb2Layout<RGC_PAIRS, STRIPE_SUM, RGBY_A != kDense, END_A0 != kDense, SYM> L;
     static_assert(L::blocks * kRgb2Blk <= kRgb2StreamMax, "stream fits its kernarg array");
     static_assert((RGC_PAIRS & 0x1ffu) == 0x1ffu || (RGC_PAIRS & 0x1ffu) == 0x111u, "rgc: dense or channel-diagonal");
