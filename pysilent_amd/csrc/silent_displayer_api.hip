@@ -224,9 +224,6 @@ static int displayer_fail(silent_displayer* d, int rc, const char* who) {
     return rc;
 }
 
-// frame_host: the camera frame [frame_h, frame_w, 3] of the dtype the displayer was created for.  results[0 .. 5]: pointers INTO
-// the displayer's pinned result slot (layouts: silent_displayer_shape), valid until the second next step.  gpu_ms (may be NULL):
-// device time of the frame, upload to download, from events around the graph.  Synchronous.
 // One more pinned result slot (its graph is captured the first time a frame is stepped into it); *slot_index: its number.
 SILENT_EXPORT int silent_displayer_add_slot(silent_displayer* d, int* slot_index) try {
     if (!d || !slot_index) return fail(d ? d->owner : nullptr, SILENT_E_INVALID, "silent_displayer_add_slot: NULL pointer");
@@ -246,6 +243,9 @@ SILENT_EXPORT int silent_displayer_add_slot(silent_displayer* d, int* slot_index
 
 static int displayer_step_slot(silent_displayer* d, const void* frame_host, int slot, const float** results, float* gpu_ms, const char* who);
 
+// frame_host: the camera frame [frame_h, frame_w, 3] of the dtype the displayer was created for.  results[0 .. 5]: pointers INTO
+// the displayer's pinned result slot (layouts: silent_displayer_shape), valid until the second next step (slots 0 and 1 alternate).
+// gpu_ms (may be NULL): device time of the frame from events around the graph.  Synchronous.
 SILENT_EXPORT int silent_displayer_step(silent_displayer* d, const void* frame_host, const float** results, float* gpu_ms) try {
     if (!d) return fail(nullptr, SILENT_E_INVALID, "silent_displayer_step: displayer is NULL");
     const int rc = displayer_step_slot(d, frame_host, d->slot, results, gpu_ms, "silent_displayer_step");
