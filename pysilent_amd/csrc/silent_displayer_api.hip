@@ -25,6 +25,7 @@ struct silent_displayer {
     silent_displayer_params prm{};
     float kernels[4 * 81 + 441];          // private copy of the chain's constant kernels (the caller's arrays may go away)
     int L = 0, h = 0, w = 0, ch = 0, cw = 0, hh = 0, hw = 0;
+    int cast_y0 = 0, cast_x0 = 0, cast_h = 0, cast_w = 0;   // the rectangle of the frame the pyramid reads (union of the levels' crops + margin)
     size_t in_bytes = 0;
     // device
     void* slab = nullptr;
@@ -88,7 +89,9 @@ static int displayer_enqueue(silent_displayer* d, int slot) {
     float* const out = d->h_out[slot];
     // np.asarray(frame, dtype=float32) (:141)
     if (d->prm.frame_dtype != SILENT_DT_F32) {
-        TRY(silent_cast_interleave_dev(c, d->h_in, d->prm.frame_dtype, (size_t)d->prm.frame_h * d->prm.frame_w, 3, 0, 3, d->d_frame, 3, 0, s));
+        // (only the rectangle the pyramid reads: the union of the levels' crops, about half of the frame in the reference's layout;
+        // the rest of d_frame stays 0 from creation)
+        TRY(cast_rect_launch(c, d->h_in, d->prm.frame_dtype, d->prm.frame_w, 3, d->cast_y0, d->cast_x0, d->cast_h, d->cast_w, d->d_frame, d->stream));
     } else {
         // (float32 frames: the walk re-reads halo columns and rows -- from device memory, behind one upload)
         HIP_TRY(d->owner, hipMemcpyAsync(d->d_raw, d->h_in, d->in_bytes, hipMemcpyHostToDevice, d->stream));
@@ -143,6 +146,19 @@ SILENT_EXPORT int silent_displayer_create(silent_ctx* ctx, const silent_displaye
     d->ctx->tune[SILENT_TUNE_RGB] |= 128u;
     rc = silent_pyramid_plan_create(d->ctx, p->frame_h, p->frame_w, 3, levels, n_levels, &d->plan);
     if (rc != SILENT_OK) return fail(ctx, rc, std::string(who) + ": " + silent_last_error(d->ctx));
+    {
+        // union of the crops the levels resample, + a margin for the walk's ring halo / alignment slack (read, never used), clipped
+        int y0 = p->frame_h, x0 = p->frame_w, y1 = 0, x1 = 0;
+        for (int l = 0; l < n_levels; ++l) {
+            y0 = std::min(y0, levels[l].src_y0);
+            x0 = std::min(x0, levels[l].src_x0);
+            y1 = std::max(y1, levels[l].src_y0 + levels[l].src_h);
+            x1 = std::max(x1, levels[l].src_x0 + levels[l].src_w);
+        }
+        y0 = std::max(0, y0 - 8); x0 = std::max(0, x0 - 16);
+        y1 = std::min(p->frame_h, y1 + 8); x1 = std::min(p->frame_w, x1 + 16);
+        d->cast_y0 = y0; d->cast_x0 = x0; d->cast_h = std::max(1, y1 - y0); d->cast_w = std::max(1, x1 - x0);
+    }
     d->L = n_levels;
     d->h = levels[0].out_h;
     d->w = levels[0].out_w;
@@ -177,6 +193,7 @@ SILENT_EXPORT int silent_displayer_create(silent_ctx* ctx, const silent_displaye
         HIP_TRY(ctx, hipMemset(sig, 0, 64));
         d->d_seq = (unsigned long long*)sig;
     }
+    HIP_TRY(ctx, hipMemset(d->d_frame, 0, (size_t)p->frame_h * p->frame_w * 12));   // what the cast never writes reads as 0
     HIP_TRY(ctx, hipHostMalloc((void**)&d->h_flag, 64, hipHostMallocDefault));
     *d->h_flag = 0;
     HIP_TRY(ctx, hipHostMalloc(&d->h_in, d->in_bytes, hipHostMallocDefault));

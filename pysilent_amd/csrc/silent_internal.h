@@ -161,6 +161,8 @@ int rgb_chain_launch(silent_ctx* ctx, const char* who, const float* pyr, const s
                      const silent_rgb_chain_params* p, float* orient_out, float* line_end_out, float* value_out, unsigned* mm,
                      bool* mm_done, silent_stream stream, const silent::SumTab* st = nullptr, float* sum = nullptr,
                      int* nan_flags = nullptr);
+// (silent_peaks_api.hip) the widening cast of a rectangle of an interleaved frame (the displayer: the part of the frame its pyramid reads)
+int cast_rect_launch(silent_ctx* ctx, const void* in, int in_dtype, int W, int C, int y0, int x0, int h, int w, float* out, hipStream_t s);
 // (silent_peaks_api.hip) the tail of the displayer's graph after the chain, fused into two launches (silent_peaks.h, DispTail); seq / flag: the completion signal
 int displayer_tail(silent_ctx* ctx, int L, int h, int w, int rh, int rw, int h2, int w2, const silent_boosting_params* boost, const float* value,
                    float* g, float* im2n, float* tot1, float* imp, float* energy, float* out1, float* out2, float* out3, float* update,

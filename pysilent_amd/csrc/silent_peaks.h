@@ -1183,6 +1183,20 @@ __global__ __launch_bounds__(256) void cast_interleave_kernel(const T* __restric
     }
 }
 
+// The same cast for a RECTANGLE of an interleaved [H][W][C] frame (rows y0 .. y0 + h, columns x0 .. x0 + w), written to the same
+// positions of the float32 frame: the displayer converts only the part of a camera frame its pyramid reads (the union of the
+// reference layout's centre crops is about half of the frame -- half of the bytes that cross the link when the frame is read straight
+// from pinned host memory).
+template <class T>
+__global__ __launch_bounds__(256) void cast_rect_kernel(const T* __restrict__ in, float* __restrict__ out, int W, int C, int y0, int x0, int h, int w) {
+    const long long row_n = (long long)w * C, total = row_n * h;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+        const long long r = i / row_n;
+        const long long at = ((long long)(y0 + r) * W + x0) * C + (i - r * row_n);
+        out[at] = (float)in[at];
+    }
+}
+
 // tf.image.resize_nearest_neighbor (TF1, align_corners = False): src = min(floor(dst * float32(in / out)), in - 1).
 // ``tab`` describes the OUTPUT maps; the input level l has extents (ih[l], iw[l]) at in_off[l] of a frame of in_px.
 struct ResizeTab {

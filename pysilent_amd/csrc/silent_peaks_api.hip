@@ -613,6 +613,28 @@ SILENT_EXPORT int silent_cast_interleave_dev(silent_ctx* ctx, const void* in, in
     return on_exception(ctx, "silent_cast_interleave_dev");
 }
 
+// (silent_displayer_api.hip) np.asarray(frame, float32) for the rectangle of the frame the displayer's pyramid reads
+int cast_rect_launch(silent_ctx* ctx, const void* in, int in_dtype, int W, int C, int y0, int x0, int h, int w, float* out, hipStream_t s) {
+    const char* who = "silent_displayer_step";
+    if (!in || !out || h < 1 || w < 1) return fail(ctx, SILENT_E_INVALID, std::string(who) + ": bad cast rectangle");
+    const long long total = (long long)h * w * C;
+    const unsigned grid = (unsigned)std::min<long long>((total + 255) / 256, 256ll * 64);
+#define CAST_CASE(DT, T) \
+    case DT: hipLaunchKernelGGL(cast_rect_kernel<T>, dim3(grid), dim3(256), 0, s, (const T*)in, out, W, C, y0, x0, h, w); break
+    switch (in_dtype) {
+        CAST_CASE(SILENT_DT_U8, unsigned char);
+        CAST_CASE(SILENT_DT_F32, float);
+        CAST_CASE(SILENT_DT_F64, double);
+        CAST_CASE(SILENT_DT_I32, int);
+        CAST_CASE(SILENT_DT_U16, unsigned short);
+        CAST_CASE(SILENT_DT_I16, short);
+        CAST_CASE(SILENT_DT_I64, long long);
+        default: return fail(ctx, SILENT_E_UNSUPPORTED, std::string(who) + ": frame dtype");
+    }
+#undef CAST_CASE
+    return check_launch(ctx, who);
+}
+
 SILENT_EXPORT int silent_resize_nearest_dev(silent_ctx* ctx, const float* in, const silent_extent* in_levels,
                                             int n_levels, int n_frames, int channels, const silent_extent* out_levels,
                                             float* out, silent_stream stream) try {

@@ -638,6 +638,26 @@ def test_line_end_displayer_three_frames(rt, kernels):
         disp.run_camera()
 
 
+@pytest.mark.parametrize("shape", [(480, 640), (1080, 1920), (333, 517)])
+def test_line_end_displayer_camera_geometry_native_equals_per_op(rt, shape):
+    """The application graph at the reference's own geometry (camera frames, output_size (288, 192), zoom e ** .5 -- what bench.py's
+    latency record times): the native displayer reads only the rectangle of the uint8 frame its pyramid needs, straight from pinned
+    host memory, and its kernels write the pinned result slot themselves -- every fetched tensor and the state bit-identical to the
+    per-op path over four different frames (a pixel used from outside that rectangle, or a result not yet landed, would show)."""
+    from pysilent_amd.recognition_testing import LineEndDisplayer
+    h, w = shape
+    native, per_op = LineEndDisplayer(), LineEndDisplayer(native=False)
+    rng = np.random.default_rng(5)
+    for step in range(4):
+        frame = rng.integers(0, 256, (h, w, 3)).astype(np.uint8)
+        if step == 2:
+            frame[:] = structured_frame(7, h, w, 3).clip(0, 255).astype(np.uint8)
+        a, b = native.callback(frame), per_op.callback(frame)
+        for i in range(1, 7):
+            np.testing.assert_array_equal(np.stack(a[i]), np.stack(b[i]), err_msg="frame %d, output %d" % (step, i))
+        np.testing.assert_array_equal(native.get_state(), per_op.get_state())
+
+
 def test_line_end_displayer_results_outlive_frames_shape_changes_and_close(rt):
     """like the reference's session.run (recognition_testing.py:132-144) ``callback`` returns FRESH arrays -- a consumer
     (the reference's asynchronous display loop) may keep them over any number of frames; the zero-copy views (``copy=False``,
