@@ -658,6 +658,31 @@ def test_line_end_displayer_camera_geometry_native_equals_per_op(rt, shape):
         np.testing.assert_array_equal(native.get_state(), per_op.get_state())
 
 
+@pytest.mark.parametrize("seed", range(10))
+def test_line_end_displayer_random_geometries_native_equals_per_op(rt, seed):
+    """Random camera geometries through the native application graph (zero copy at both ends, only the crop union of the frame is
+    converted, tiny-launch tile heights / segment heights) against the per-op path: frame sizes, output sizes, zoom ratios and frame
+    dtypes drawn at random; every fetched tensor and the state bit for bit over three frames, raw views and held arrays alike."""
+    from pysilent_amd.recognition_testing import LineEndDisplayer
+    rng = np.random.default_rng(1000 + seed)
+    ow, oh = int(rng.integers(12, 80)) * 4, int(rng.integers(24, 200))
+    ratio = float(rng.choice([1.3, 2 ** .5, 1.5, np.e ** .5, 2.0]))
+    h = int(oh * ratio ** rng.uniform(0.6, 2.6)) + int(rng.integers(1, 9))
+    w = (int(ow * ratio ** rng.uniform(0.6, 2.6)) + int(rng.integers(1, 9)) + 3) // 4 * 4
+    dtype = [np.uint8, np.uint8, np.float32, np.uint16, np.float64][int(rng.integers(0, 5))]
+    kw = dict(output_size=(ow, oh), zoom_ratio=ratio)
+    native, per_op = LineEndDisplayer(**kw), LineEndDisplayer(native=False, **kw)
+    for step in range(3):
+        frame = rng.integers(0, 256, (h, w, 3)).astype(dtype)
+        a = native.callback(frame, copy=bool(step & 1))
+        b = per_op.callback(frame)
+        assert native._native is not None, "the native path must take camera frames of this dtype"
+        for i in range(1, 7):
+            np.testing.assert_array_equal(np.stack(a[i]), np.stack(b[i]),
+                                          err_msg="%dx%d %s -> %dx%d ratio %.3f, frame %d, output %d" % (w, h, np.dtype(dtype).name, ow, oh, ratio, step, i))
+        np.testing.assert_array_equal(native.get_state(), per_op.get_state())
+
+
 def test_line_end_displayer_results_outlive_frames_shape_changes_and_close(rt):
     """like the reference's session.run (recognition_testing.py:132-144) ``callback`` returns FRESH arrays -- a consumer
     (the reference's asynchronous display loop) may keep them over any number of frames; the zero-copy views (``copy=False``,
